@@ -1,0 +1,156 @@
+"""Synthetic benchmark clouds.
+
+A table plane plus K random primitives (spheres, boxes, cylinders) resting on it,
+seen by one depth camera at the origin looking down -z from 0.8 m.  Points are
+the camera-facing surface samples snapped to a 3 mm lattice and de-duplicated
+(what Cloud::voxelizeCloud(0.003) leaves of a dense scan, candidates_generator.cpp:24-26);
+normals are the analytic outward normals (they face the camera by construction),
+stored float32 like the reference stores PCL normals (cloud.cpp:531-532).
+
+Deterministic for a given (seed, num_points): numpy RandomState legacy streams.
+"""
+import numpy as np
+
+VOXEL = 0.003
+TABLE_Z = -0.8
+
+
+def _snap(points):
+    return np.round(points / VOXEL).astype(np.int64)
+
+
+def _sphere(rng, c, r, n):
+    v = rng.randn(n, 3)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return c + r * v, v
+
+
+def _box(rng, c, half, n):
+    # c = centre, half = half extents; uniform over the 6 faces by area
+    areas = np.array([half[1] * half[2], half[1] * half[2], half[0] * half[2], half[0] * half[2], half[0] * half[1], half[0] * half[1]])
+    face = rng.choice(6, size=n, p=areas / areas.sum())
+    uv = rng.rand(n, 3) * 2.0 - 1.0
+    p = uv * half
+    nrm = np.zeros((n, 3))
+    ax = face // 2
+    sign = np.where(face % 2 == 0, 1.0, -1.0)
+    p[np.arange(n), ax] = sign * half[ax]
+    nrm[np.arange(n), ax] = sign
+    return c + p, nrm
+
+
+def _cylinder(rng, c, r, h, n):
+    # axis along z, centre c, radius r, height h: side + top cap
+    a_side, a_cap = 2 * np.pi * r * h, np.pi * r * r
+    is_side = rng.rand(n) < a_side / (a_side + a_cap)
+    th = rng.rand(n) * 2 * np.pi
+    z = (rng.rand(n) - 0.5) * h
+    rr = r * np.sqrt(rng.rand(n))
+    p = np.stack([np.where(is_side, r, rr) * np.cos(th), np.where(is_side, r, rr) * np.sin(th), np.where(is_side, z, h / 2)], 1)
+    nrm = np.stack([np.where(is_side, np.cos(th), 0.0), np.where(is_side, np.sin(th), 0.0), np.where(is_side, 0.0, 1.0)], 1)
+    return c + p, nrm
+
+
+def make_cloud(seed=1234, num_points=30000, clutter=False):
+    """Returns dict(xyz f32 [P,3], normals f32 [P,3], cam_source i32 [1,P],
+    view_points f64 [1,3], is_object bool [P])."""
+    rng = np.random.RandomState(seed)
+    area = num_points * VOXEL * VOXEL  # target visible surface area
+    extent = np.sqrt(area) * (0.55 if not clutter else 0.6)  # half-size of the object region
+    # number of primitives: roughly 45 % of the points on objects
+    K = max(4, int(round(0.45 * area / 0.008)))
+    pts, nrms = [], []
+    for _ in range(K):
+        kind = rng.randint(3)
+        cx, cy = (rng.rand(2) * 2 - 1) * extent
+        lift = rng.rand() * (0.12 if clutter else 0.0)
+        if kind == 0:
+            r = 0.02 + 0.03 * rng.rand()
+            c = np.array([cx, cy, TABLE_Z + r + lift])
+            n = int(4 * np.pi * r * r / (VOXEL * VOXEL) * 4)
+            p, nr = _sphere(rng, c, r, n)
+        elif kind == 1:
+            half = (0.03 + 0.07 * rng.rand(3)) / 2
+            c = np.array([cx, cy, TABLE_Z + half[2] + lift])
+            a = 8 * (half[0] * half[1] + half[0] * half[2] + half[1] * half[2])
+            n = int(a / (VOXEL * VOXEL) * 4)
+            p, nr = _box(rng, c, half, n)
+            # random yaw
+            yaw = rng.rand() * np.pi
+            R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+            p = (p - c) @ R.T + c
+            nr = nr @ R.T
+        else:
+            r = 0.02 + 0.02 * rng.rand()
+            h = 0.05 + 0.07 * rng.rand()
+            c = np.array([cx, cy, TABLE_Z + h / 2 + lift])
+            n = int((2 * np.pi * r * h + np.pi * r * r) / (VOXEL * VOXEL) * 4)
+            p, nr = _cylinder(rng, c, r, h, n)
+        facing = np.einsum("ij,ij->i", nr, -p) > 0.05 * np.linalg.norm(p, axis=1)  # camera at the origin
+        pts.append(p[facing])
+        nrms.append(nr[facing])
+    p = np.concatenate(pts)
+    nr = np.concatenate(nrms)
+    key = _snap(p)
+    _, first = np.unique(key, axis=0, return_index=True)
+    first.sort()
+    key, nr = key[first], nr[first]
+    n_obj_max = int(0.6 * num_points)
+    if len(key) > n_obj_max:
+        keep = np.sort(rng.permutation(len(key))[:n_obj_max])
+        key, nr = key[keep], nr[keep]
+    n_obj = len(key)
+    # table: lattice nodes by increasing distance from the patch centre, skipping
+    # nodes already taken by an object, until the cloud has exactly num_points
+    n_tab = num_points - n_obj
+    m = int(np.ceil(np.sqrt(n_tab * 1.2) / 2)) + 4
+    gi, gj = np.meshgrid(np.arange(-m, m + 1), np.arange(-m, m + 1), indexing="ij")
+    gi, gj = gi.ravel(), gj.ravel()
+    order = np.lexsort((gj, gi, gi * gi + gj * gj))
+    tz = int(round(TABLE_Z / VOXEL))
+    tkey = np.stack([gi[order], gj[order], np.full(len(order), tz)], 1)
+    taken = set(map(tuple, key[key[:, 2] == tz]))
+    if taken:
+        free = np.array([tuple(k) not in taken for k in tkey])
+        tkey = tkey[free]
+    tkey = tkey[:n_tab]
+    assert len(tkey) == n_tab
+    tn = np.tile(np.array([0.0, 0.0, 1.0]), (n_tab, 1))
+    key = np.concatenate([key, tkey])
+    nr = np.concatenate([nr, tn])
+    is_obj = np.concatenate([np.ones(n_obj, bool), np.zeros(n_tab, bool)])
+    perm = rng.permutation(len(key))
+    key, nr, is_obj = key[perm], nr[perm], is_obj[perm]
+    xyz = (key.astype(np.float64) * VOXEL).astype(np.float32)
+    P = len(xyz)
+    return dict(xyz=np.ascontiguousarray(xyz), normals=np.ascontiguousarray(nr.astype(np.float32)),
+                cam_source=np.ones((1, P), np.int32), view_points=np.zeros((1, 3)), is_object=is_obj, seed=seed)
+
+
+def sample_indices(cloud, num_samples, seed=None):
+    """First S entries of a seeded permutation of the object (non-plane) points."""
+    rng = np.random.RandomState((cloud["seed"] if seed is None else seed) + 7919)
+    obj = np.flatnonzero(cloud["is_object"])
+    return np.ascontiguousarray(rng.permutation(obj)[:num_samples].astype(np.int32))
+
+
+def lenet_weights(channels=15, seed=42, real=None):
+    """LeNet parameters in the reference's file layouts (eigen_classifier.cpp:28-50).
+    `real`: optional dict with the reference's conv1/conv2/ip2 parameters; ip1
+    (500x7200, missing from the reference snapshot) is always N(0, 0.005^2), seed 42."""
+    rng = np.random.RandomState(seed)
+    w = dict(
+        f1w=(rng.randn(7200 * 500) * 0.005).astype(np.float32),
+        c1w=(rng.randn(20 * channels * 25) * 0.05).astype(np.float32),
+        c1b=(rng.randn(20) * 0.05).astype(np.float32),
+        c2w=(rng.randn(50 * 500) * 0.02).astype(np.float32),
+        c2b=(rng.randn(50) * 0.02).astype(np.float32),
+        f1b=(rng.randn(500) * 0.0023).astype(np.float32),
+        f2w=(rng.randn(2 * 500) * 0.05).astype(np.float32),
+        f2b=(rng.randn(2) * 0.01).astype(np.float32),
+    )
+    if real is not None:
+        for k in ("c1w", "c1b", "c2w", "c2b", "f1b", "f2w", "f2b"):
+            if k in real and real[k].size == w[k].size:
+                w[k] = np.ascontiguousarray(real[k], np.float32).ravel()
+    return w

@@ -1,0 +1,157 @@
+/*
+ * gpd_hip.h — C-ABI of libgpd_hip.so, the MI355X (gfx950) implementation of the
+ * GPD hot path: candidate search -> grasp image -> LeNet score.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes.  Host buffers are
+ * owned by the caller, device memory is owned by the context.  One context per
+ * device; a context is not thread-safe (the reference's GraspDetector is not
+ * either: grasp_detector.cpp:192-328 is called from one thread).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * the reference tree).  Return value: 0 on success, <0 on error
+ * (gpd_hip_last_error() gives the text).  Nothing throws across the boundary.
+ */
+#ifndef GPD_HIP_H_
+#define GPD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPD_MAX_SLOTS 24 /* num_hand_axes * num_orientations upper bound */
+
+/* Error codes (negative). */
+#define GPD_OK 0
+#define GPD_ERR_INVALID (-1)   /* bad argument                                   */
+#define GPD_ERR_HIP (-2)       /* a HIP runtime call failed                      */
+#define GPD_ERR_CAPACITY (-3)  /* a neighbourhood exceeded the LDS list capacity */
+#define GPD_ERR_STATE (-4)     /* call order violated (no cloud / no weights)    */
+
+/*
+ * Parameters of the path.  Field names follow the reference's cfg keys:
+ * hand geometry  — cfg/hand_geometry.cfg:8-12, candidate/hand_geometry.cpp:25-30
+ * image geometry — cfg/image_geometry_15channels.cfg:8-12, descriptor/image_geometry.cpp:24-28
+ * search         — grasp_detector.cpp:67-86 (HandSearch::Parameters)
+ * filter         — grasp_detector.cpp:158-174
+ */
+typedef struct gpd_params {
+  double finger_width;        /* 0.01 */
+  double hand_outer_diameter; /* 0.12 */
+  double hand_depth;          /* 0.06 */
+  double hand_height;         /* 0.02 */
+  double init_bite;           /* 0.01 */
+  double volume_width;        /* 0.10 */
+  double volume_depth;        /* 0.06 */
+  double volume_height;       /* 0.02 */
+  double nn_radius_frames;    /* nn_radius, 0.01 */
+  double friction_coeff;      /* 20 */
+  double min_aperture;        /* 0.0 */
+  double max_aperture;        /* 0.085 */
+  double workspace_grasps[6]; /* -1 1 -1 1 -1 1 */
+  int32_t image_size;         /* 60 (only 60 is supported, as eigen_classifier.cpp:12) */
+  int32_t image_num_channels; /* 3, 12 or 15 */
+  int32_t num_orientations;   /* 8 */
+  int32_t num_finger_placements; /* 10 */
+  int32_t num_hand_axes;      /* 1 */
+  int32_t hand_axes[3];       /* {2} */
+  int32_t deepen_hand;        /* 1 */
+  int32_t min_viable;         /* 6 */
+} gpd_params;
+
+/*
+ * One grasp candidate = candidate::Hand (include/gpd/candidate/hand.h:80-277,
+ * candidate/hand.cpp:24-45) flattened to POD.  `frame` is row-major; its columns
+ * are approach | binormal | axis (hand.h getApproach/getBinormal/getAxis).
+ */
+typedef struct gpd_hand {
+  double sample[3];
+  double frame[9];
+  double position[3];
+  double top, bottom, center; /* closing box, hand.h BoundingBox */
+  double grasp_width;
+  float score;
+  int32_t finger_placement_index; /* -1 when no feasible placement exists */
+  int32_t set_index;              /* hand set = sample that produced it     */
+  int32_t slot;                   /* axis_i * num_orientations + angle_i    */
+  uint8_t valid;                  /* HandSet::is_valid_                     */
+  uint8_t half_antipodal, full_antipodal;
+  uint8_t pad_[5];
+} gpd_hand;
+
+typedef struct gpd_hip_ctx gpd_hip_ctx;
+
+/* Fill `p` with the defaults of cfg/eigen_params.cfg + cfg/hand_geometry.cfg +
+ * cfg/image_geometry_15channels.cfg. */
+void gpd_hip_default_params(gpd_params *p);
+
+/* Create a context on HIP device `device`.  Replaces the constructor work of
+ * GraspDetector (grasp_detector.cpp:5-190) that sizes the path. */
+int gpd_hip_create(int device, const gpd_params *params, gpd_hip_ctx **out);
+void gpd_hip_destroy(gpd_hip_ctx *ctx);
+const char *gpd_hip_last_error(void);
+
+/* LeNet parameters, raw float32 exactly as the files read by
+ * EigenClassifier::EigenClassifier (net/eigen_classifier.cpp:28-50):
+ * conv1 [20][C*25] row-major, conv2 [50][500] row-major, ip1 column-major
+ * 500 x 7200 over the pixel-major flatten (eigen_classifier.cpp:103-107,
+ * dense_layer.cpp:7), ip2 column-major 2 x 500.  Copied to the device once. */
+int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels,
+                              const float *conv1_w, const float *conv1_b,
+                              const float *conv2_w, const float *conv2_b,
+                              const float *ip1_w, const float *ip1_b,
+                              const float *ip2_w, const float *ip2_b);
+
+/* Replaces Classifier::classifyImages (net/classifier.h:70-71,
+ * eigen_classifier.cpp:59-79).  images: n contiguous 60x60xC u8 HWC images
+ * (cv::Mat CV_8UC(C) layout); scores[i] = logit1 - logit0.
+ * images == NULL scores the images left on the device by gpd_hip_images. */
+int gpd_hip_score(gpd_hip_ctx *ctx, const uint8_t *images, int n, float *scores);
+
+/* Upload the processed cloud: what HandSearch::searchHands and
+ * ImageGenerator::createImages read from util::Cloud (hand_search.cpp:28-31,
+ * 160-165; image_generator.cpp:24-29): float32 xyz (AoS), float32 normals
+ * (AoS), camera source n_cams x P (row per camera, 0/1), view points 3 doubles
+ * per camera. */
+int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normals,
+                         int num_points, const int32_t *cam_source, int num_cams,
+                         const double *view_points);
+
+/* Replaces CandidatesGenerator::generateGraspCandidateSets ->
+ * HandSearch::searchHands (candidates_generator.cpp:62-69, hand_search.cpp:24-64)
+ * for samples given by index (Cloud::getSampleIndices).  Writes
+ * num_sets * num_slots hands (set-major, slot-minor; num_slots = num_hand_axes *
+ * num_orientations); samples without a frame neighbourhood are dropped before
+ * sets are numbered (frame_estimator.cpp:24-29).  hands must hold
+ * num_samples * num_slots records. */
+int gpd_hip_search(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples,
+                   gpd_hand *hands, int *num_sets);
+
+/* Replaces ImageGenerator::createImages (image_generator.cpp:17-99) for hand
+ * sets produced by gpd_hip_search (optionally after the host workspace filter,
+ * grasp_detector.cpp:334-398, which clears `valid`).  One image per valid hand
+ * in set-major, slot-minor order; sets without a valid hand are skipped like
+ * filterGraspsWorkspace drops them.  images (may be NULL: keep on device) holds
+ * n_cand * 60*60*C bytes HWC.  cand_index (may be NULL) receives for each image
+ * the index into `hands`. */
+int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets,
+                   uint8_t *images, int32_t *cand_index, int *num_candidates);
+
+/* Fused path used by GraspDetector::detectGrasps steps 1-4
+ * (grasp_detector.cpp:222-273): search, workspace/aperture filter, images,
+ * scores; everything stays on the device between the stages.  hands receives
+ * num_samples*num_slots records with `score` set on the valid ones. */
+int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples,
+                   gpd_hand *hands, int *num_sets, int *num_candidates);
+
+/* Stage times of the last call in milliseconds (HIP events on the context's
+ * stream): [0] search, [1] images (incl. shadow), [2] score.  The counterpart
+ * of the RUNTIMES printout, grasp_detector.cpp:313-320. */
+int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPD_HIP_H_ */
