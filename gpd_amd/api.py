@@ -1,0 +1,177 @@
+"""ctypes binding of libgpd_hip.so (include/gpd_hip.h) — the product path.
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this
+raises.  The Python layer only marshals numpy arrays into the C-ABI.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpd_hip.so")
+_LIB = None
+
+# numpy mirror of `gpd_hand` (include/gpd_hip.h)
+HAND_DTYPE = np.dtype([
+    ("sample", "<f8", (3,)), ("frame", "<f8", (9,)), ("position", "<f8", (3,)),
+    ("top", "<f8"), ("bottom", "<f8"), ("center", "<f8"), ("grasp_width", "<f8"),
+    ("score", "<f4"), ("finger_placement_index", "<i4"), ("set_index", "<i4"), ("slot", "<i4"),
+    ("valid", "u1"), ("half_antipodal", "u1"), ("full_antipodal", "u1"), ("pad_", "u1", (5,)),
+], align=False)
+
+
+class Params(C.Structure):
+    """Mirror of `gpd_params` (include/gpd_hip.h)."""
+    _fields_ = [
+        ("finger_width", C.c_double), ("hand_outer_diameter", C.c_double), ("hand_depth", C.c_double),
+        ("hand_height", C.c_double), ("init_bite", C.c_double), ("volume_width", C.c_double),
+        ("volume_depth", C.c_double), ("volume_height", C.c_double), ("nn_radius_frames", C.c_double),
+        ("friction_coeff", C.c_double), ("min_aperture", C.c_double), ("max_aperture", C.c_double),
+        ("workspace_grasps", C.c_double * 6), ("image_size", C.c_int32), ("image_num_channels", C.c_int32),
+        ("num_orientations", C.c_int32), ("num_finger_placements", C.c_int32), ("num_hand_axes", C.c_int32),
+        ("hand_axes", C.c_int32 * 3), ("deepen_hand", C.c_int32), ("min_viable", C.c_int32),
+    ]
+
+
+class GpdHipError(RuntimeError):
+    pass
+
+
+EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
+           "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
+           "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times"]
+
+
+def build():
+    """Compile libgpd_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise GpdHipError("libgpd_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                              "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.gpd_hip_last_error.restype = C.c_char_p
+        L.gpd_hip_create.argtypes = [C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.gpd_hip_destroy.argtypes = [C.c_void_p]
+        L.gpd_hip_destroy.restype = None
+        L.gpd_hip_set_lenet_weights.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        L.gpd_hip_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.gpd_hip_upload_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.gpd_hip_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.gpd_hip_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.gpd_hip_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
+        L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def default_params(channels=15):
+    p = Params()
+    lib().gpd_hip_default_params(C.byref(p))
+    p.image_num_channels = channels
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One gpd_hip_ctx: owns the device copy of the cloud, the LeNet weights and all scratch."""
+
+    def __init__(self, params=None, device=0):
+        self.params = params if params is not None else default_params()
+        self._h = C.c_void_p()
+        self._check(lib().gpd_hip_create(int(device), C.byref(self.params), C.byref(self._h)))
+        self.n_slots = self.params.num_hand_axes * self.params.num_orientations
+
+    def _check(self, rc):
+        if rc != 0:
+            raise GpdHipError("libgpd_hip error %d: %s" % (rc, lib().gpd_hip_last_error().decode()))
+
+    def close(self):
+        if self._h:
+            lib().gpd_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_lenet_weights(self, w):
+        arrs = [np.ascontiguousarray(w[k], np.float32) for k in ("c1w", "c1b", "c2w", "c2b", "f1w", "f1b", "f2w", "f2b")]
+        ch = self.params.image_num_channels
+        assert arrs[0].size == 20 * ch * 25, "conv1 weights do not match image_num_channels"
+        self._check(lib().gpd_hip_set_lenet_weights(self._h, ch, *[_ptr(a) for a in arrs]))
+
+    def score(self, images=None, n=None):
+        """Classifier::classifyImages; images [n,60,60,C] u8, or None to score the device images."""
+        if images is not None:
+            images = np.ascontiguousarray(images, np.uint8)
+            n = images.shape[0]
+        out = np.zeros(n, np.float32)
+        self._check(lib().gpd_hip_score(self._h, _ptr(images), n, _ptr(out)))
+        return out
+
+    def upload_cloud(self, xyz, normals, cam_source=None, view_points=None):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        normals = np.ascontiguousarray(normals, np.float32)
+        P = len(xyz)
+        cam = np.ones((1, P), np.int32) if cam_source is None else np.ascontiguousarray(cam_source, np.int32).reshape(-1, P)
+        vp = np.zeros((1, 3)) if view_points is None else np.ascontiguousarray(view_points, np.float64).reshape(-1, 3)
+        self._check(lib().gpd_hip_upload_cloud(self._h, _ptr(xyz), _ptr(normals), P, _ptr(cam), cam.shape[0], _ptr(vp)))
+
+    def search(self, sample_indices):
+        """generateGraspCandidateSets -> hands[n_sets, n_slots]."""
+        si = np.ascontiguousarray(sample_indices, np.int32)
+        hands = np.zeros((len(si), self.n_slots), HAND_DTYPE)
+        ns = C.c_int(0)
+        self._check(lib().gpd_hip_search(self._h, _ptr(si), len(si), _ptr(hands), C.byref(ns)))
+        return hands[: ns.value].copy()
+
+    def images(self, hands, download=True):
+        """ImageGenerator::createImages -> (images[n,60,60,C] or None, cand_index[n])."""
+        hands = np.ascontiguousarray(hands)
+        nv = int(hands["valid"].astype(bool).sum())
+        Cn = self.params.image_num_channels
+        img = np.zeros((nv, 60, 60, Cn), np.uint8) if download else None
+        cand = np.zeros(max(nv, 1), np.int32)
+        n = C.c_int(0)
+        self._check(lib().gpd_hip_images(self._h, _ptr(hands), hands.shape[0], _ptr(img), _ptr(cand), C.byref(n)))
+        assert n.value == nv
+        return img, cand[:nv]
+
+    def detect(self, sample_indices):
+        """detectGrasps steps 1-4 -> (hands[n_sets, n_slots] with scores, n_candidates)."""
+        si = np.ascontiguousarray(sample_indices, np.int32)
+        hands = np.zeros((len(si), self.n_slots), HAND_DTYPE)
+        ns, nc = C.c_int(0), C.c_int(0)
+        self._check(lib().gpd_hip_detect(self._h, _ptr(si), len(si), _ptr(hands), C.byref(ns), C.byref(nc)))
+        return hands[: ns.value].copy(), nc.value
+
+    def stage_ms(self):
+        ms = np.zeros(3, np.float32)
+        self._check(lib().gpd_hip_last_stage_ms(self._h, _ptr(ms)))
+        return ms
+
+    def replay(self, stages=3):
+        """Re-run images (1) and/or LeNet (2) on the device-resident candidate list (async)."""
+        self._check(lib().gpd_hip_replay(self._h, int(stages)))
+
+    def replay_times(self, n_scores=0):
+        """Synchronise -> (image_ms_sum, lenet_ms_sum, launches, scores or None)."""
+        ms = np.zeros(2, np.float32)
+        n = C.c_int(0)
+        sc = np.zeros(n_scores, np.float32) if n_scores else None
+        self._check(lib().gpd_hip_replay_times(self._h, _ptr(ms), C.byref(n), _ptr(sc)))
+        return float(ms[0]), float(ms[1]), n.value, sc

@@ -1,0 +1,106 @@
+// Internal declarations shared by the HIP translation units of libgpd_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/gpd_hip.h"
+
+namespace gpd {
+
+constexpr int kImg = 60;            // image_size (eigen_classifier.cpp:12)
+constexpr int kPix = kImg * kImg;   // 3600
+constexpr int kFc1In = 7200;        // 50 * 12 * 12
+constexpr int kFc1Out = 500;
+
+// ---- LeNet (lenet.hip) ----------------------------------------------------
+struct LeNetWeights {
+  int channels = 0;
+  float *c1w = nullptr, *c1b = nullptr, *c2w = nullptr, *c2b = nullptr;
+  float *f1w = nullptr, *f1b = nullptr, *f2w = nullptr, *f2b = nullptr;
+};
+
+struct LeNetScratch {
+  int capacity = 0;        // images per chunk
+  float *pool1 = nullptr;  // [cap][20][28][28]
+  float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
+  float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
+};
+
+// Scores n images (device pointer, HWC u8) into d_scores (device). Async on stream.
+hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *d_images, int n, float *d_scores,
+                         hipStream_t stream);
+hipError_t lenet_scratch_reserve(LeNetScratch &s, int n);
+void lenet_scratch_free(LeNetScratch &s);
+
+void set_error(const char *fmt, ...);
+
+// ---- Cloud (search.hip) -----------------------------------------------------
+// Device copy of what the path reads from util::Cloud, as SoA for coalesced streaming.
+constexpr int kMaxCams = 8;
+struct Cloud {
+  int num_points = 0, num_cams = 0, capacity = 0;
+  uint64_t generation = 0;            // bumped by every upload
+  float *px = nullptr, *py = nullptr, *pz = nullptr;
+  float *nx = nullptr, *ny = nullptr, *nz = nullptr;
+  int32_t *cam_source = nullptr;      // [num_cams][num_points]
+  float *staging = nullptr;           // AoS upload buffer, 6 floats per point
+  double view_points[3 * kMaxCams] = {0};
+};
+hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
+                        const double *view_points, hipStream_t stream);
+void cloud_free(Cloud &c);
+
+// ---- Candidate search (search.hip) -----------------------------------------------
+struct SearchState {
+  int num_samples = 0, capacity_samples = 0;
+  int nn_cap = 0;                     // entries per neighbourhood list (8192 or 16384)
+  uint64_t cloud_generation = 0;
+  int32_t *d_sample_idx = nullptr;    // [S]
+  int32_t *d_counts = nullptr;        // [S][8]: N_hands, N_images, k_frames, total found, seen by camera 0
+  int32_t *d_nn_idx = nullptr;        // [S][nn_cap] sorted by (d2, index)
+  float *d_nn = nullptr;              // [S][6][nn_cap] gathered px,py,pz,nx,ny,nz in that order
+  double *d_frames = nullptr;         // [S][12] sample, normal, binormal, curvature
+  double *d_centers = nullptr;        // [S][3] mean of the image neighbourhood
+  gpd_hand *d_hands = nullptr;        // [S][slots]
+  std::vector<int32_t> h_counts;      // host copy of d_counts
+  std::vector<int32_t> h_set_sample;  // set -> sample slot
+  std::vector<double> h_samples;      // [S][3] sample coordinates (to validate hands passed to images)
+};
+int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, int S, hipStream_t stream);
+int search_download(const gpd_params &p, SearchState &s, gpd_hand *hands, int *num_sets, hipStream_t stream);
+void search_free(SearchState &s);
+
+// GraspDetector::filterGraspsWorkspace (grasp_detector.cpp:334-398) on the host.
+void filter_workspace_host(const gpd_params &p, gpd_hand *hands, int num_sets);
+
+// ---- Grasp images (images.hip) ---------------------------------------------------
+struct ImageState {
+  int num_candidates = 0;
+  int capacity = 0;                   // images
+  uint8_t *d_images = nullptr;        // [n][60][60][C]
+  gpd_hand *d_hands = nullptr;        // candidate hand records
+  int32_t *d_cand_meta = nullptr;     // [n][4]: sample slot, N_images, lcg offset lo, hi
+  int32_t *d_status = nullptr;        // error flags from the kernel
+  int cap_hands = 0;
+};
+int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageState &im, const gpd_hand *hands, int num_sets,
+               int32_t *cand_index, hipStream_t stream);
+int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool check);
+void images_free(ImageState &im);
+
+// Host-side constants of the path (host_math.cpp), computed with libm exactly as the
+// reference computes them on the host.
+struct HostConsts {
+  double rot[GPD_MAX_SLOTS][9];  // Ry(pi) * R_axis(angle) factors: see host_math.cpp
+  double rot_binormal[9];        // AngleAxisd(pi, UnitY)
+  double finger_spacing[32];     // 2 * num_finger_placements
+  double deepen_depths[32];
+  int num_deepen;
+  double cos_friction;
+  double nn_radius_hands, nn_radius_images;
+};
+void host_consts(const gpd_params &p, HostConsts &h);
+
+}  // namespace gpd

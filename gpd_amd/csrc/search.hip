@@ -1,0 +1,893 @@
+// Candidate search on gfx950: radius neighbourhoods, local frames, hand evaluation.
+//
+// Replaces HandSearch::searchHands / evalHands (candidate/hand_search.cpp:24-64,
+// 144-188), FrameEstimator::calculateFrame (candidate/frame_estimator.cpp:66-86),
+// LocalFrame::findAverageNormalAxis (candidate/local_frame.cpp:14-41),
+// HandSet::evalHandSet/evalHands (candidate/hand_set.cpp:31-116), FingerHand
+// (candidate/finger_hand.cpp:6-184), Hand::construct (candidate/hand.cpp:24-45),
+// HandSet::modifyCandidate/labelHypothesis (hand_set.cpp:235-261) and
+// Antipodal::evaluateGrasp (candidate/antipodal.cpp:10-96).
+//
+// neighbourhood_kernel   one workgroup per sample: streams the whole cloud (SoA,
+//     coalesced) instead of walking PCL's k-d tree, collects (d2, index) keys with
+//     d2 < r_hands^2 in LDS, bitonic-sorts them — FLANN's (distance, index) order —
+//     and writes the sorted neighbourhood gathered as SoA.  The 0.10 m image
+//     neighbourhood and the 0.01 m frame neighbourhood are prefixes of this list
+//     (same query point, same float d2, same sort).  Lane 0 then forms
+//     M = sum n n^T in neighbour order and runs the 3x3 symmetric QR eigensolver
+//     (Eigen's SelfAdjointEigenSolver algorithm, fp64, unfused).
+// hand_eval_kernel       one workgroup per (sample, orientation): five order-free
+//     reductions over the neighbourhood (finger collision masks, deepen masks,
+//     closing region, antipodal extremes, antipodal counts).  The reference's
+//     cropByHandHeight quirk (point_list.cpp:44-55 pads with copies of column 0)
+//     is reproduced by a ghost point with multiplicity N-k.
+//
+// All fp64 expressions are evaluated unfused, left to right (-ffp-contract=off),
+// exactly as oracle/gpd_oracle.cpp defines them.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "gpd_internal.h"
+
+namespace gpd {
+
+#define HIP_RET(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return GPD_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// Cloud upload: AoS (caller layout) -> SoA planes.
+// ---------------------------------------------------------------------------
+__global__ void split_soa_kernel(const float *__restrict__ xyz, const float *__restrict__ nrm, int n, float *px, float *py,
+                                 float *pz, float *nx, float *ny, float *nz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  px[i] = xyz[3 * i];
+  py[i] = xyz[3 * i + 1];
+  pz[i] = xyz[3 * i + 2];
+  nx[i] = nrm[3 * i];
+  ny[i] = nrm[3 * i + 1];
+  nz[i] = nrm[3 * i + 2];
+}
+
+void cloud_free(Cloud &c) {
+  void *ptrs[] = {c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.cam_source, c.staging};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  c = Cloud();
+}
+
+hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
+                        const double *view_points, hipStream_t stream) {
+  if (num_cams > kMaxCams) return hipErrorInvalidValue;
+  hipError_t e;
+  if (n > c.capacity || num_cams > c.num_cams) {
+    uint64_t gen = c.generation;
+    cloud_free(c);
+    c.generation = gen;
+    float **planes[] = {&c.px, &c.py, &c.pz, &c.nx, &c.ny, &c.nz};
+    for (float **p : planes)
+      if ((e = hipMalloc(p, (size_t)n * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMalloc(&c.cam_source, (size_t)n * num_cams * sizeof(int32_t))) != hipSuccess) return e;
+    if ((e = hipMalloc(&c.staging, (size_t)n * 6 * sizeof(float))) != hipSuccess) return e;
+    c.capacity = n;
+  }
+  c.num_points = n;
+  c.num_cams = num_cams;
+  c.generation++;
+  std::memcpy(c.view_points, view_points, sizeof(double) * 3 * num_cams);
+  if ((e = hipMemcpyAsync(c.staging, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(c.staging + (size_t)n * 3, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, stream)) !=
+      hipSuccess)
+    return e;
+  if ((e = hipMemcpyAsync(c.cam_source, cam_source, (size_t)n * num_cams * sizeof(int32_t), hipMemcpyHostToDevice, stream)) !=
+      hipSuccess)
+    return e;
+  split_soa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c.staging, c.staging + (size_t)n * 3, n, c.px, c.py, c.pz, c.nx, c.ny,
+                                                         c.nz);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return hipStreamSynchronize(stream);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 symmetric eigensolver, fp64: scale, closed-form tridiagonalisation, implicit
+// QR with Wilkinson shift, ascending sort — the algorithm of Eigen's
+// SelfAdjointEigenSolver<Matrix3d>::compute (used at local_frame.cpp:17-21).
+// Q is row-major, columns are eigenvectors.
+// ---------------------------------------------------------------------------
+__device__ inline void givens(double p, double q, double &c, double &s) {
+  if (q == 0.0) {
+    c = p < 0 ? -1.0 : 1.0;
+    s = 0.0;
+  } else if (p == 0.0) {
+    c = 0.0;
+    s = q < 0 ? 1.0 : -1.0;
+  } else if (fabs(p) > fabs(q)) {
+    double t = q / p;
+    double u = sqrt(1.0 + t * t);
+    if (p < 0) u = -u;
+    c = 1.0 / u;
+    s = -t * c;
+  } else {
+    double t = p / q;
+    double u = sqrt(1.0 + t * t);
+    if (q < 0) u = -u;
+    s = -1.0 / u;
+    c = -t * s;
+  }
+}
+
+__device__ inline double hypot_pos(double x, double y) {
+  x = fabs(x);
+  y = fabs(y);
+  double p = fmax(x, y);
+  if (p == 0.0) return 0.0;
+  double qp = fmin(y, x) / p;
+  return p * sqrt(1.0 + qp * qp);
+}
+
+__device__ void eigen3(double m00, double m10, double m11, double m20, double m21, double m22, double *eval, double *Q) {
+  double scale = fmax(fmax(fmax(fabs(m00), fabs(m10)), fmax(fabs(m11), fabs(m20))), fmax(fabs(m21), fabs(m22)));
+  if (scale == 0.0) scale = 1.0;
+  m00 /= scale;
+  m10 /= scale;
+  m11 /= scale;
+  m20 /= scale;
+  m21 /= scale;
+  m22 /= scale;
+  double diag[3], sub[2];
+  diag[0] = m00;
+  const double v1norm2 = m20 * m20;
+  if (v1norm2 <= DBL_MIN) {
+    diag[1] = m11;
+    diag[2] = m22;
+    sub[0] = m10;
+    sub[1] = m21;
+    Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = 1; Q[5] = 0; Q[6] = 0; Q[7] = 0; Q[8] = 1;
+  } else {
+    const double beta = sqrt(m10 * m10 + v1norm2);
+    const double invBeta = 1.0 / beta;
+    const double m01 = m10 * invBeta;
+    const double m02 = m20 * invBeta;
+    const double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+    diag[1] = m11 + m02 * q;
+    diag[2] = m22 - m02 * q;
+    sub[0] = beta;
+    sub[1] = m21 - m01 * q;
+    Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = m01; Q[5] = m02; Q[6] = 0; Q[7] = m02; Q[8] = -m01;
+  }
+  int end = 2, start = 0, iter = 0;
+  const double precision_inv = 1.0 / DBL_EPSILON;
+  while (end > 0) {
+    for (int i = start; i < end; i++) {
+      if (fabs(sub[i]) < DBL_MIN) {
+        sub[i] = 0.0;
+      } else {
+        const double ss = precision_inv * sub[i];
+        if (ss * ss <= (fabs(diag[i]) + fabs(diag[i + 1]))) sub[i] = 0.0;
+      }
+    }
+    while (end > 0 && sub[end - 1] == 0.0) end--;
+    if (end <= 0) break;
+    iter++;
+    if (iter > 90) break;
+    start = end - 1;
+    while (start > 0 && sub[start - 1] != 0.0) start--;
+    const double td = (diag[end - 1] - diag[end]) * 0.5;
+    const double e = sub[end - 1];
+    double mu = diag[end];
+    if (td == 0.0) {
+      mu -= fabs(e);
+    } else if (e != 0.0) {
+      const double e2 = e * e;
+      const double h = hypot_pos(td, e);
+      if (e2 == 0.0)
+        mu -= e / ((td + (td > 0.0 ? h : -h)) / e);
+      else
+        mu -= e2 / (td + (td > 0.0 ? h : -h));
+    }
+    double x = diag[start] - mu;
+    double z = sub[start];
+    for (int k = start; k < end && z != 0.0; k++) {
+      double c, s;
+      givens(x, z, c, s);
+      const double sdk = s * diag[k] + c * sub[k];
+      const double dkp1 = s * sub[k] + c * diag[k + 1];
+      diag[k] = c * (c * diag[k] - s * sub[k]) - s * (c * sub[k] - s * diag[k + 1]);
+      diag[k + 1] = s * sdk + c * dkp1;
+      sub[k] = c * sdk - s * dkp1;
+      if (k > start) sub[k - 1] = c * sub[k - 1] - s * z;
+      x = sub[k];
+      if (k < end - 1) {
+        z = -s * sub[k + 1];
+        sub[k + 1] = c * sub[k + 1];
+      }
+      for (int i = 0; i < 3; i++) {
+        const double xi = Q[3 * i + k], yi = Q[3 * i + k + 1];
+        Q[3 * i + k] = c * xi - s * yi;
+        Q[3 * i + k + 1] = s * xi + c * yi;
+      }
+    }
+  }
+  for (int i = 0; i < 2; i++) {
+    int k = 0;
+    for (int j = 1; j < 3 - i; j++)
+      if (diag[i + j] < diag[i + k]) k = j;
+    if (k > 0) {
+      double t = diag[i];
+      diag[i] = diag[k + i];
+      diag[k + i] = t;
+      for (int r = 0; r < 3; r++) {
+        t = Q[3 * r + i];
+        Q[3 * r + i] = Q[3 * r + k + i];
+        Q[3 * r + k + i] = t;
+      }
+    }
+  }
+  for (int i = 0; i < 3; i++) eval[i] = diag[i] * scale;
+}
+
+// ---------------------------------------------------------------------------
+// neighbourhood_kernel
+// ---------------------------------------------------------------------------
+struct NbParams {
+  const float *px, *py, *pz, *nx, *ny, *nz;
+  int num_points;
+  const int32_t *sample_idx;
+  float r2_hands, r2_images, r2_frames;
+  int cap;  // power of two
+  int32_t *counts;  // [S][8]: N_hands, N_images, k_frames, found, seen_by_cam0, -, -, -
+  int32_t *nn_idx;
+  float *nn;
+  double *frames;
+  double *centers;  // [S][3] mean of the image neighbourhood (hand_set.cpp:131-133)
+  const int32_t *cam_source;
+};
+
+__global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
+  __shared__ int s_count;
+  __shared__ int s_bounds[2];
+  __shared__ int s_seen;
+  __shared__ double s_center[3];
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int sidx = P.sample_idx[s];
+  const float qx = P.px[sidx], qy = P.py[sidx], qz = P.pz[sidx];
+  if (tid == 0) {
+    s_count = 0;
+    s_bounds[0] = 0;
+    s_bounds[1] = 0;
+    s_seen = 0;
+  }
+  __syncthreads();
+  // 1. stream the cloud; FLANN L2_Simple<float>: d2 accumulated over x,y,z, strict <
+  const int n_iter = (P.num_points + 255) / 256;
+  for (int it = 0; it < n_iter; it++) {
+    const int i = it * 256 + tid;
+    bool hit = false;
+    float d2 = 0.f;
+    if (i < P.num_points) {
+      float d = qx - P.px[i];
+      d2 += d * d;
+      d = qy - P.py[i];
+      d2 += d * d;
+      d = qz - P.pz[i];
+      d2 += d * d;
+      hit = d2 < P.r2_hands;
+    }
+    const unsigned long long ballot = __ballot(hit);
+    if (ballot) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
+      base = __shfl(base, 0);
+      if (hit) {
+        const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
+        if (pos < P.cap) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+      }
+    }
+  }
+  __syncthreads();
+  const int found = s_count;
+  const int n = found < P.cap ? found : P.cap;
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = n + tid; i < m; i += 256) s_keys[i] = ~0ull;
+  __syncthreads();
+  // 2. bitonic sort ascending by (d2 bits, index); non-negative floats order as unsigned
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (m >> 1); t += 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = s_keys[lo], b = s_keys[hi];
+        if ((a > b) == up) {
+          s_keys[lo] = b;
+          s_keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // 3. prefix lengths of the image and frame neighbourhoods
+  const unsigned ri = __float_as_uint(P.r2_images), rf = __float_as_uint(P.r2_frames);
+  for (int t = tid; t < n; t += 256) {
+    const unsigned d = (unsigned)(s_keys[t] >> 32);
+    const unsigned dn = (t + 1 < n) ? (unsigned)(s_keys[t + 1] >> 32) : 0xffffffffu;
+    if (d < ri && dn >= ri) s_bounds[0] = t + 1;
+    if (d < rf && dn >= rf) s_bounds[1] = t + 1;
+  }
+  __syncthreads();
+  // 4. sorted index list + gathered SoA neighbourhood.  Each key slot is then reused
+  //    for (px, py) of its entry so that the centre sum below reads LDS.
+  int32_t *oi = P.nn_idx + (size_t)s * P.cap;
+  float *on = P.nn + (size_t)s * 6 * P.cap;
+  const int n_img = s_bounds[0];
+  int seen = 0;
+  for (int t = tid; t < n; t += 256) {
+    const int i = (int)(unsigned)(s_keys[t] & 0xffffffffull);
+    oi[t] = i;
+    const float x = P.px[i], y = P.py[i];
+    on[0 * P.cap + t] = x;
+    on[1 * P.cap + t] = y;
+    on[2 * P.cap + t] = P.pz[i];
+    on[3 * P.cap + t] = P.nx[i];
+    on[4 * P.cap + t] = P.ny[i];
+    on[5 * P.cap + t] = P.nz[i];
+    if (t < n_img) seen |= P.cam_source[i];
+    s_keys[t] = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
+  }
+  if (__ballot(seen != 0) && lane == 0) atomicOr(&s_seen, 1);
+  __threadfence_block();
+  __syncthreads();
+  // 4b. centre of the image neighbourhood: sequential fp64 sums in neighbour order
+  //     (HandSet::calculateShadow, hand_set.cpp:131-133), one lane per coordinate.
+  if (tid == 64 || tid == 128) {
+    const int sh = (tid == 128) ? 32 : 0;
+    double acc = 0.0;
+    for (int t = 0; t < n_img; t++) acc += (double)__uint_as_float((unsigned)(s_keys[t] >> sh));
+    s_center[tid == 128 ? 1 : 0] = acc;
+  }
+  __syncthreads();
+  for (int t = tid; t < n_img; t += 256) s_keys[t] = __float_as_uint(on[2 * P.cap + t]);
+  __syncthreads();
+  if (tid == 64) {
+    double acc = 0.0;
+    for (int t = 0; t < n_img; t++) acc += (double)__uint_as_float((unsigned)s_keys[t]);
+    s_center[2] = acc;
+  }
+  // 5. local frame (local_frame.cpp:14-41), sequential sums in neighbour order
+  if (tid == 0) {
+    const int kf = s_bounds[1];
+    P.counts[8 * s + 0] = n;
+    P.counts[8 * s + 1] = s_bounds[0];
+    P.counts[8 * s + 2] = kf;
+    P.counts[8 * s + 3] = found;
+    double *f = P.frames + 12 * (size_t)s;
+    f[0] = (double)qx;
+    f[1] = (double)qy;
+    f[2] = (double)qz;
+    if (kf > 0) {
+      double m00 = 0, m10 = 0, m11 = 0, m20 = 0, m21 = 0, m22 = 0, a0 = 0, a1 = 0, a2 = 0;
+      for (int t = 0; t < kf; t++) {
+        const double n0 = (double)on[3 * P.cap + t], n1 = (double)on[4 * P.cap + t], n2 = (double)on[5 * P.cap + t];
+        m00 += n0 * n0;
+        m10 += n1 * n0;
+        m11 += n1 * n1;
+        m20 += n2 * n0;
+        m21 += n2 * n1;
+        m22 += n2 * n2;
+        a0 += n0;
+        a1 += n1;
+        a2 += n2;
+      }
+      double ev[3], Q[9];
+      eigen3(m00, m10, m11, m20, m21, m22, ev, Q);
+      int mn = 0, mx = 0;
+      for (int i = 1; i < 3; i++) {
+        if (ev[i] < ev[mn]) mn = i;
+        if (ev[i] > ev[mx]) mx = i;
+      }
+      double curv[3], nor[3];
+      for (int r = 0; r < 3; r++) {
+        curv[r] = Q[3 * r + mn];
+        nor[r] = Q[3 * r + mx];
+      }
+      const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+      a0 /= nrm;
+      a1 /= nrm;
+      a2 /= nrm;
+      const double dot = a0 * nor[0] + a1 * nor[1] + a2 * nor[2];
+      if (dot < 0)
+        for (int r = 0; r < 3; r++) nor[r] *= -1.0;
+      f[3] = nor[0];
+      f[4] = nor[1];
+      f[5] = nor[2];
+      f[6] = curv[1] * nor[2] - curv[2] * nor[1];
+      f[7] = curv[2] * nor[0] - curv[0] * nor[2];
+      f[8] = curv[0] * nor[1] - curv[1] * nor[0];
+      f[9] = curv[0];
+      f[10] = curv[1];
+      f[11] = curv[2];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    P.counts[8 * s + 4] = s_seen;
+    const int ni = s_bounds[0];
+    for (int r = 0; r < 3; r++) P.centers[3 * (size_t)s + r] = ni > 0 ? s_center[r] / (double)ni : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// hand_eval_kernel
+// ---------------------------------------------------------------------------
+struct HandConsts {
+  double rot[GPD_MAX_SLOTS][9];
+  double rot_binormal[9];
+  double spacing[32];
+  double depths[32];
+  int num_deepen;
+  int nfp;  // num_finger_placements
+  int slots;
+  int deepen;
+  int min_viable;
+  double cos_friction;
+  double fw, hand_depth, hand_height, init_bite;
+};
+
+struct HandParams {
+  const int32_t *counts;
+  const float *nn;
+  const double *frames;
+  int cap;
+  gpd_hand *hands;
+};
+
+__device__ inline void mat3mul(const double *a, const double *b, double *c) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) c[3 * i + j] = a[3 * i + 0] * b[0 + j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+// Block-wide helpers (256 threads = 4 waves).
+__device__ inline unsigned block_or(unsigned v, unsigned *s_tmp) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_tmp[0] | s_tmp[1] | s_tmp[2] | s_tmp[3];
+}
+__device__ inline double block_min(double v, double *s_tmp) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmin(fmin(s_tmp[0], s_tmp[1]), fmin(s_tmp[2], s_tmp[3]));
+}
+__device__ inline double block_max(double v, double *s_tmp) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(s_tmp[0], s_tmp[1]), fmax(s_tmp[2], s_tmp[3]));
+}
+__device__ inline long long block_sum(long long v, long long *s_tmp) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+// The list FingerHand sees: in-height points (z in (-h, h)) followed by the ghost
+// (column 0) with multiplicity N-k.  Iterates entries e in [0, N]; e == N is the
+// ghost.  Returns false when the entry is not part of the list.
+struct ListCtx {
+  const float *nn;
+  int cap, N;
+  double FR[9];
+  double sample[3];
+  double hand_height;
+  int ghost_mult;  // N - k (valid after pass 0)
+};
+__device__ inline bool list_entry(const ListCtx &L, int e, double t[3], double tn[3], int &mult) {
+  const int i = (e == L.N) ? 0 : e;
+  const double c0 = (double)L.nn[0 * L.cap + i] - L.sample[0];
+  const double c1 = (double)L.nn[1 * L.cap + i] - L.sample[1];
+  const double c2 = (double)L.nn[2 * L.cap + i] - L.sample[2];
+  const double n0 = (double)L.nn[3 * L.cap + i], n1 = (double)L.nn[4 * L.cap + i], n2 = (double)L.nn[5 * L.cap + i];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    t[r] = L.FR[0 + r] * c0 + L.FR[3 + r] * c1 + L.FR[6 + r] * c2;
+    tn[r] = L.FR[0 + r] * n0 + L.FR[3 + r] * n1 + L.FR[6 + r] * n2;
+  }
+  if (e == L.N) {
+    mult = L.ghost_mult;
+    return L.ghost_mult > 0;
+  }
+  mult = 1;
+  return t[2] > -1.0 * L.hand_height && t[2] < L.hand_height;
+}
+
+__constant__ HandConsts c_hand;
+
+__global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
+  __shared__ unsigned s_u[4];
+  __shared__ double s_d[4];
+  __shared__ long long s_l[4];
+  const HandConsts &K = c_hand;
+  const int s = blockIdx.x / K.slots;
+  const int slot = blockIdx.x - s * K.slots;
+  const int tid = threadIdx.x;
+  const int N = P.counts[8 * s + 0];
+  const int kf = P.counts[8 * s + 2];
+  gpd_hand *H = P.hands + (size_t)s * K.slots + slot;
+  const double *fr = P.frames + 12 * (size_t)s;
+  if (kf == 0 || N == 0) {  // no frame: the sample is dropped on the host
+    if (tid == 0) {
+      gpd_hand z;
+      memset(&z, 0, sizeof(z));
+      z.finger_placement_index = -1;
+      z.slot = slot;
+      *H = z;
+    }
+    return;
+  }
+  ListCtx L;
+  L.nn = P.nn + (size_t)s * 6 * P.cap;
+  L.cap = P.cap;
+  L.N = N;
+  L.hand_height = K.hand_height;
+  // frame_ << normal, binormal, curvature (hand_set.cpp:39-40); frame_rot = frame_ * RB * R (:72)
+  double F[9], FRB[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    L.sample[r] = fr[r];
+    F[3 * r + 0] = fr[3 + r];
+    F[3 * r + 1] = fr[6 + r];
+    F[3 * r + 2] = fr[9 + r];
+  }
+  mat3mul(F, K.rot_binormal, FRB);
+  mat3mul(FRB, K.rot[slot], L.FR);
+  L.ghost_mult = 0;
+
+  const int nfp = K.nfp;
+  const double bite = K.init_bite;
+  const double bottom0 = bite - K.hand_depth;
+  // ---- pass 0+1: height count, finger collision masks at init_bite (finger_hand.cpp:26-73)
+  long long kin = 0;
+  for (int e = tid; e < N; e += 256) {
+    double t[3], tn[3];
+    int mult;
+    if (list_entry(L, e, t, tn, mult)) kin++;
+  }
+  const long long k = block_sum(kin, s_l);
+  L.ghost_mult = N - (int)k;
+  unsigned blocked = 0, flags = 0;  // flags bit0: some x<bite, bit1: some x<bottom
+  for (int e = tid; e <= N; e += 256) {
+    double t[3], tn[3];
+    int mult;
+    if (!list_entry(L, e, t, tn, mult)) continue;
+    if (t[0] < bite) {
+      flags |= 1u;
+      if (t[0] < bottom0) flags |= 2u;
+      for (int i = 0; i < 2 * nfp; i++)
+        if (t[1] > K.spacing[i] && t[1] < K.spacing[i] + K.fw) blocked |= 1u << i;
+    }
+  }
+  blocked = block_or(blocked, s_u);
+  flags = block_or(flags, s_u);
+  unsigned fingers = 0;
+  if ((flags & 1u) && !(flags & 2u)) fingers = ~blocked & ((1u << (2 * nfp)) - 1u);
+  unsigned hand = fingers & (fingers >> nfp) & ((1u << nfp) - 1u);
+
+  double top = bite, bottom = bottom0, center = 0.0;
+  int fidx = hand ? (__ffs(hand) - 1) : -1;
+  bool valid = false;
+  double width = 0.0;
+  int label = 0;
+  if (hand) {
+    // chooseMiddleHand (finger_hand.cpp:89-105): idx[ceil(m/2) - 1]
+    const int mcount = __popc(hand);
+    const int want = (mcount + 1) / 2 - 1;
+    int mid = -1, seen = 0;
+    for (int i = 0; i < nfp; i++)
+      if (hand & (1u << i)) {
+        if (seen == want) {
+          mid = i;
+          break;
+        }
+        seen++;
+      }
+    if (K.deepen) {
+      // ---- pass 2: deepenHand (finger_hand.cpp:107-139) for all depths at once
+      unsigned m_any = 0, m_back = 0, m_blk = 0;
+      const double sl = K.spacing[mid], sr = K.spacing[nfp + mid];
+      for (int e = tid; e <= N; e += 256) {
+        double t[3], tn[3];
+        int mult;
+        if (!list_entry(L, e, t, tn, mult)) continue;
+        const bool blk = (t[1] > sl && t[1] < sl + K.fw) || (t[1] > sr && t[1] < sr + K.fw);
+        for (int j = 0; j < K.num_deepen; j++) {
+          const double d = K.depths[j];
+          if (t[0] < d) {
+            m_any |= 1u << j;
+            if (t[0] < d - K.hand_depth) m_back |= 1u << j;
+            if (blk) m_blk |= 1u << j;
+          }
+        }
+      }
+      m_any = block_or(m_any, s_u);
+      m_back = block_or(m_back, s_u);
+      m_blk = block_or(m_blk, s_u);
+      for (int j = 0; j < K.num_deepen; j++) {
+        const bool ok = (m_any >> j & 1u) && !(m_back >> j & 1u) && !(m_blk >> j & 1u);
+        if (!ok) break;
+        top = K.depths[j];
+        bottom = K.depths[j] - K.hand_depth;
+      }
+      hand = 1u << mid;
+    }
+    // ---- pass 3: computePointsInClosingRegion (finger_hand.cpp:141-171)
+    const double left = K.spacing[mid] + K.fw;
+    const double right = K.spacing[nfp + mid];
+    const double center_c = 0.5 * (left + right);
+    double ymin = DBL_MAX, ymax = -DBL_MAX;
+    unsigned any_c = 0;
+    for (int e = tid; e <= N; e += 256) {
+      double t[3], tn[3];
+      int mult;
+      if (!list_entry(L, e, t, tn, mult)) continue;
+      if (t[0] > bottom && t[0] < top && t[1] > left && t[1] < right) {
+        any_c = 1;
+        ymin = fmin(ymin, t[1]);
+        ymax = fmax(ymax, t[1]);
+      }
+    }
+    any_c = block_or(any_c, s_u);
+    if (any_c) {
+      valid = true;
+      center = center_c;
+      fidx = __ffs(hand) - 1;
+      ymin = block_min(ymin, s_d);
+      ymax = block_max(ymax, s_d);
+      width = ymax - ymin;
+      // ---- pass 4+5: Antipodal::evaluateGrasp (antipodal.cpp:10-96), lateral 1, forward 0, vertical 2
+      const double min_x = ymin + 0.003, max_x = ymax - 0.003;
+      double lx0 = DBL_MAX, lx1 = -DBL_MAX, lz0 = DBL_MAX, lz1 = -DBL_MAX;
+      double rx0 = DBL_MAX, rx1 = -DBL_MAX, rz0 = DBL_MAX, rz1 = -DBL_MAX;
+      unsigned lr = 0;
+      for (int e = tid; e <= N; e += 256) {
+        double t[3], tn[3];
+        int mult;
+        if (!list_entry(L, e, t, tn, mult)) continue;
+        if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
+        const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
+        const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
+        if (ln > K.cos_friction && t[1] < min_x) {
+          lr |= 1u;
+          lx0 = fmin(lx0, t[0]);
+          lx1 = fmax(lx1, t[0]);
+          lz0 = fmin(lz0, t[2]);
+          lz1 = fmax(lz1, t[2]);
+        }
+        if (rn > K.cos_friction && t[1] > max_x) {
+          lr |= 2u;
+          rx0 = fmin(rx0, t[0]);
+          rx1 = fmax(rx1, t[0]);
+          rz0 = fmin(rz0, t[2]);
+          rz1 = fmax(rz1, t[2]);
+        }
+      }
+      lr = block_or(lr, s_u);
+      if (lr) label = 1;
+      if (lr == 3u) {
+        lx0 = block_min(lx0, s_d);
+        lx1 = block_max(lx1, s_d);
+        lz0 = block_min(lz0, s_d);
+        lz1 = block_max(lz1, s_d);
+        rx0 = block_min(rx0, s_d);
+        rx1 = block_max(rx1, s_d);
+        rz0 = block_min(rz0, s_d);
+        rz1 = block_max(rz1, s_d);
+        const double top_y = fmin(lx1, rx1), bot_y = fmax(lx0, rx0);
+        const double top_z = fmin(lz1, rz1), bot_z = fmax(lz0, rz0);
+        long long nl = 0, nr = 0;
+        for (int e = tid; e <= N; e += 256) {
+          double t[3], tn[3];
+          int mult;
+          if (!list_entry(L, e, t, tn, mult)) continue;
+          if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
+          const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
+          const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
+          const bool inb = t[0] >= bot_y && t[0] <= top_y && t[2] >= bot_z && t[2] <= top_z;
+          if (ln > K.cos_friction && t[1] < min_x && inb) nl += mult;
+          if (rn > K.cos_friction && t[1] > max_x && inb) nr += mult;
+        }
+        nl = block_sum(nl, s_l);
+        nr = block_sum(nr, s_l);
+        if (nl >= K.min_viable && nr >= K.min_viable) label = 2;
+      }
+    } else {
+      // closing region empty: the hand keeps what Hand() saw before deepening (hand_set.cpp:89-109)
+      top = bite;
+      bottom = bottom0;
+      center = 0.0;
+      fidx = __ffs(fingers & (fingers >> nfp) & ((1u << nfp) - 1u)) - 1;
+    }
+  }
+  if (tid == 0) {
+    gpd_hand h;
+    memset(&h, 0, sizeof(h));
+#pragma unroll
+    for (int r = 0; r < 3; r++) h.sample[r] = L.sample[r];
+#pragma unroll
+    for (int i = 0; i < 9; i++) h.frame[i] = L.FR[i];
+    h.top = top;
+    h.bottom = bottom;
+    h.center = center;
+    // Hand::calculateGraspPositions (hand.cpp:41-45)
+#pragma unroll
+    for (int r = 0; r < 3; r++) h.position[r] = (L.FR[3 * r + 0] * bottom + L.FR[3 * r + 1] * center + L.FR[3 * r + 2] * 0.0) + L.sample[r];
+    h.grasp_width = width;
+    h.finger_placement_index = fidx;
+    h.set_index = s;
+    h.slot = slot;
+    h.valid = valid ? 1 : 0;
+    h.half_antipodal = label >= 1;
+    h.full_antipodal = label == 2;
+    *H = h;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+void search_free(SearchState &s) {
+  void *ptrs[] = {s.d_sample_idx, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  s = SearchState();
+}
+
+static int search_reserve(SearchState &s, int S, int cap, int slots) {
+  if (S <= s.capacity_samples && cap == s.nn_cap) return GPD_OK;
+  const int newS = S > s.capacity_samples ? S : s.capacity_samples;
+  search_free(s);
+  HIP_RET(hipMalloc(&s.d_sample_idx, (size_t)newS * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&s.d_counts, (size_t)newS * 8 * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&s.d_nn_idx, (size_t)newS * cap * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&s.d_nn, (size_t)newS * 6 * cap * sizeof(float)));
+  HIP_RET(hipMalloc(&s.d_frames, (size_t)newS * 12 * sizeof(double)));
+  HIP_RET(hipMalloc(&s.d_centers, (size_t)newS * 3 * sizeof(double)));
+  HIP_RET(hipMalloc(&s.d_hands, (size_t)newS * slots * sizeof(gpd_hand)));
+  s.capacity_samples = newS;
+  s.nn_cap = cap;
+  return GPD_OK;
+}
+
+static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, int S, int cap,
+                              hipStream_t stream) {
+  NbParams np;
+  np.px = c.px; np.py = c.py; np.pz = c.pz; np.nx = c.nx; np.ny = c.ny; np.nz = c.nz;
+  np.num_points = c.num_points;
+  np.sample_idx = s.d_sample_idx;
+  // pcl::KdTreeFLANN::radiusSearch passes (float)(radius*radius) to FLANN
+  np.r2_hands = (float)(hc.nn_radius_hands * hc.nn_radius_hands);
+  np.r2_images = (float)(hc.nn_radius_images * hc.nn_radius_images);
+  np.r2_frames = (float)(p.nn_radius_frames * p.nn_radius_frames);
+  np.cap = cap;
+  np.counts = s.d_counts;
+  np.nn_idx = s.d_nn_idx;
+  np.nn = s.d_nn;
+  np.frames = s.d_frames;
+  np.centers = s.d_centers;
+  np.cam_source = c.cam_source;
+  const size_t lds = (size_t)cap * sizeof(unsigned long long);
+  HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  neighbourhood_kernel<<<S, 256, lds, stream>>>(np);
+  HIP_RET(hipGetLastError());
+  s.h_counts.resize((size_t)S * 8);
+  HIP_RET(hipMemcpyAsync(s.h_counts.data(), s.d_counts, (size_t)S * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipStreamSynchronize(stream));
+  return GPD_OK;
+}
+
+int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, int S, hipStream_t stream) {
+  const int slots = p.num_hand_axes * p.num_orientations;
+  HostConsts hc;
+  host_consts(p, hc);
+  if (hc.nn_radius_images > hc.nn_radius_hands || p.nn_radius_frames > hc.nn_radius_hands) {
+    set_error("search: image/frame radius larger than the hand-search radius is not supported");
+    return GPD_ERR_INVALID;
+  }
+  int cap = s.nn_cap ? s.nn_cap : 8192;
+  int rc = search_reserve(s, S, cap, slots);
+  if (rc) return rc;
+  HIP_RET(hipMemcpyAsync(s.d_sample_idx, sample_idx, (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  for (;;) {
+    rc = run_neighbourhoods(p, c, s, hc, S, cap, stream);
+    if (rc) return rc;
+    int worst = 0;
+    for (int i = 0; i < S; i++) worst = s.h_counts[8 * i + 3] > worst ? s.h_counts[8 * i + 3] : worst;
+    if (worst <= cap) break;
+    if (cap >= 16384) {
+      set_error("search: a neighbourhood holds %d points, more than the LDS list capacity 16384", worst);
+      return GPD_ERR_CAPACITY;
+    }
+    cap = 16384;  // 128 KB of LDS per workgroup
+    rc = search_reserve(s, S, cap, slots);
+    if (rc) return rc;
+    HIP_RET(hipMemcpyAsync(s.d_sample_idx, sample_idx, (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  }
+  HandConsts hk;
+  std::memset(&hk, 0, sizeof(hk));
+  std::memcpy(hk.rot, hc.rot, sizeof(hk.rot));
+  std::memcpy(hk.rot_binormal, hc.rot_binormal, sizeof(hk.rot_binormal));
+  std::memcpy(hk.spacing, hc.finger_spacing, sizeof(hk.spacing));
+  std::memcpy(hk.depths, hc.deepen_depths, sizeof(hk.depths));
+  hk.num_deepen = hc.num_deepen;
+  hk.nfp = p.num_finger_placements;
+  hk.slots = slots;
+  hk.deepen = p.deepen_hand;
+  hk.min_viable = p.min_viable;
+  hk.cos_friction = hc.cos_friction;
+  hk.fw = p.finger_width;
+  hk.hand_depth = p.hand_depth;
+  hk.hand_height = p.hand_height;
+  hk.init_bite = p.init_bite;
+  HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_hand), &hk, sizeof(hk), 0, hipMemcpyHostToDevice, stream));
+  HandParams hp;
+  hp.counts = s.d_counts;
+  hp.nn = s.d_nn;
+  hp.frames = s.d_frames;
+  hp.cap = cap;
+  hp.hands = s.d_hands;
+  hand_eval_kernel<<<S * slots, 256, 0, stream>>>(hp);
+  HIP_RET(hipGetLastError());
+  s.num_samples = S;
+  s.cloud_generation = c.generation;
+  return GPD_OK;
+}
+
+int search_download(const gpd_params &p, SearchState &s, gpd_hand *hands, int *num_sets, hipStream_t stream) {
+  const int slots = p.num_hand_axes * p.num_orientations;
+  const int S = s.num_samples;
+  std::vector<gpd_hand> tmp((size_t)S * slots);
+  HIP_RET(hipMemcpyAsync(tmp.data(), s.d_hands, tmp.size() * sizeof(gpd_hand), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipStreamSynchronize(stream));
+  // drop samples without a frame neighbourhood before numbering sets (frame_estimator.cpp:24-29)
+  s.h_set_sample.clear();
+  s.h_samples.clear();
+  int ns = 0;
+  for (int i = 0; i < S; i++) {
+    if (s.h_counts[8 * i + 2] == 0) continue;
+    for (int j = 0; j < slots; j++) {
+      gpd_hand h = tmp[(size_t)i * slots + j];
+      h.set_index = ns;
+      hands[(size_t)ns * slots + j] = h;
+    }
+    s.h_set_sample.push_back(i);
+    for (int r = 0; r < 3; r++) s.h_samples.push_back(tmp[(size_t)i * slots].sample[r]);
+    ns++;
+  }
+  *num_sets = ns;
+  return GPD_OK;
+}
+
+}  // namespace gpd

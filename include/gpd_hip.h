@@ -151,6 +151,18 @@ int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samp
  * of the RUNTIMES printout, grasp_detector.cpp:313-320. */
 int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]);
 
+/* Re-run stage 3 (stages & 1: grasp images) and/or stage 4 (stages & 2: LeNet) on the
+ * candidate list that the last gpd_hip_images / gpd_hip_detect left resident on the
+ * device — what calling ImageGenerator::createImages + Classifier::classifyImages
+ * again on the same hand sets does (grasp_detector.cpp:261-273), without host hops.
+ * Asynchronous on the context's stream; each call is bracketed by HIP events. */
+int gpd_hip_replay(gpd_hip_ctx *ctx, int stages);
+
+/* Synchronise; ms[0] / ms[1] = summed HIP-event time of the image / LeNet stage over the
+ * gpd_hip_replay calls since the last query, *launches = their number; scores (may be
+ * NULL) receives the scores of the last replay. */
+int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1180,7 +1180,7 @@ int gpd_oracle_images(const gpd_params *P, const float *xyz, const float *normal
       if (C == 15 && !nbrs[k].empty()) {
         Lcg rng{0};
         rng.jump(lcg_off[k]);
-        calculateShadow(xyz, np, cam_source, n_cams, view_points, nbrs[k], 0.10, rng, shadow);
+        calculateShadow(xyz, np, cam_source, n_cams, view_points, nbrs[k], radius, rng, shadow);  // shadow_length_ (image_15_channels_strategy.h:70-75)
       }
       size_t o = img_off[k];
       for (int j = 0; j < n_slots; j++) {
