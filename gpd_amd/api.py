@@ -41,7 +41,7 @@ class GpdHipError(RuntimeError):
 
 EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
-           "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times"]
+           "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats"]
 
 
 def build():
@@ -68,6 +68,7 @@ def lib():
         L.gpd_hip_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
+        L.gpd_hip_last_images_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         _LIB = L
     return _LIB
@@ -175,3 +176,8 @@ class Context:
         sc = np.zeros(n_scores, np.float32) if n_scores else None
         self._check(lib().gpd_hip_replay_times(self._h, _ptr(ms), C.byref(n), _ptr(sc)))
         return float(ms[0]), float(ms[1]), n.value, sc
+
+    def images_stats(self):
+        out = np.zeros(4, np.int64)
+        self._check(lib().gpd_hip_last_images_stats(self._h, _ptr(out)))
+        return dict(candidates=int(out[0]), sets=int(out[1]), sum_set_ni=int(out[2]), sum_cand_ni=int(out[3]))

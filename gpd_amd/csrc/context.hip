@@ -367,6 +367,15 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
   return GPD_OK;
 }
 
+int gpd_hip_last_images_stats(gpd_hip_ctx *ctx, long long out[4]) {
+  if (!ctx || !out) return GPD_ERR_INVALID;
+  out[0] = ctx->images.num_candidates;
+  out[1] = ctx->images.stat_sets;
+  out[2] = ctx->images.stat_sum_set_ni;
+  out[3] = ctx->images.stat_sum_cand_ni;
+  return GPD_OK;
+}
+
 int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]) {
   if (!ctx || !ms) return GPD_ERR_INVALID;
   for (int i = 0; i < 3; i++) ms[i] = ctx->stage_ms[i];

@@ -84,6 +84,7 @@ struct ImageState {
   int32_t *d_cand_meta = nullptr;     // [n][4]: sample slot, N_images, lcg offset lo, hi
   int32_t *d_status = nullptr;        // error flags from the kernel
   int cap_hands = 0;
+  long long stat_sets = 0, stat_sum_set_ni = 0, stat_sum_cand_ni = 0;  // for the algorithmic byte count
 };
 int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageState &im, const gpd_hand *hands, int num_sets,
                int32_t *cand_index, hipStream_t stream);

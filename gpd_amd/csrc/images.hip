@@ -550,6 +550,9 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   std::vector<gpd_hand> cand;
   std::vector<int32_t> meta;
   unsigned long long lcg = 0;
+  im.stat_sets = 0;
+  im.stat_sum_set_ni = 0;
+  im.stat_sum_cand_ni = 0;
   for (int si = 0; si < num_sets; si++) {
     int nv = 0;
     for (int j = 0; j < slots; j++) nv += hands[(size_t)si * slots + j].valid ? 1 : 0;
@@ -574,6 +577,9 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
       meta.push_back(seen ? (int32_t)(lcg >> 32) : -1);
     }
     if (C == 15 && seen) lcg += (unsigned long long)Ni * 33ull;
+    im.stat_sets++;
+    im.stat_sum_set_ni += Ni;
+    im.stat_sum_cand_ni += (long long)Ni * nv;
   }
   const int n = (int)cand.size();
   im.num_candidates = n;

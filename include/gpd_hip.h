@@ -151,6 +151,11 @@ int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samp
  * of the RUNTIMES printout, grasp_detector.cpp:313-320. */
 int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]);
 
+/* Sizes of the last gpd_hip_images call, for the algorithmic byte count of SURVEY §8d:
+ * out[0] candidates, out[1] live hand sets, out[2] sum over live sets of the image
+ * neighbourhood size N_i, out[3] sum over candidates of N_i. */
+int gpd_hip_last_images_stats(gpd_hip_ctx *ctx, long long out[4]);
+
 /* Re-run stage 3 (stages & 1: grasp images) and/or stage 4 (stages & 2: LeNet) on the
  * candidate list that the last gpd_hip_images / gpd_hip_detect left resident on the
  * device — what calling ImageGenerator::createImages + Classifier::classifyImages

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Turns the rocprofv3 rocpd databases written by profiles/run_profile.sh into the text
+summary committed under profiles/ (per-kernel count / total / average duration, and the
+FETCH_SIZE / WRITE_SIZE PMC sums per kernel).
+
+usage: python profiles/summarize.py gpurun_out/prof_<tag> > profiles/<tag>_rocprof_summary.txt
+"""
+import os
+import sqlite3
+import sys
+
+
+def kernel_stats(db):
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                     "from kernels group by name order by sum(end-start) desc").fetchall()
+    return rows
+
+
+def counter_stats(db):
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    rows = c.execute("select %s, counter_name, count(*), sum(value), avg(value) from counters_collection "
+                     "group by %s, counter_name order by sum(value) desc" % (name_col, name_col)).fetchall()
+    return rows
+
+
+def main():
+    d = sys.argv[1]
+    print("# rocprofv3 summary of %s" % d)
+    st = os.path.join(d, "stats", "bench_results.db")
+    if os.path.exists(st):
+        print("\n## kernel-trace --stats  (bench.py --steps 10 --warmup 2; + first pass => 13 launches of each stage)")
+        print("%-70s %6s %12s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us"))
+        tot = 0.0
+        rows = kernel_stats(st)
+        for name, n, total, avg, mn, mx in rows:
+            tot += total
+        for name, n, total, avg, mn, mx in rows:
+            print("%-70s %6d %12.1f %12.2f %12.2f %12.2f  %5.1f%%" % (name[:70], n, total / 1e3, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * total / tot))
+    for sub, label in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        db = os.path.join(d, sub, "bench_results.db")
+        if not os.path.exists(db):
+            continue
+        print("\n## --pmc %s  (bench.py --steps 3 --warmup 1 => 5 launches; raw counter units = KiB as rocprofv3 reports them;" % label)
+        print("##   per MI355X_MICROARCH.md §HBM FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950)")
+        print("%-70s %-12s %6s %16s %16s" % ("kernel", "counter", "calls", "sum", "avg_per_launch"))
+        for name, cn, n, s, a in counter_stats(db):
+            print("%-70s %-12s %6d %16.1f %16.1f" % (str(name)[:70], cn, n, s, a))
+
+
+if __name__ == "__main__":
+    main()
