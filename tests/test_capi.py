@@ -1,0 +1,57 @@
+"""The C-ABI library loads and exports every symbol include/gpd_hip.h declares (no GPU calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gpd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpd_hip_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gpd_amd import api
+    L = api.lib()
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), "libgpd_hip.so does not export " + n
+    assert sorted(api.EXPORTS) == names
+
+
+def test_default_params_match_reference_cfg():
+    from gpd_amd import api
+    p = api.default_params()
+    # cfg/hand_geometry.cfg:8-12, cfg/image_geometry_15channels.cfg:8-12, cfg/eigen_params.cfg:34-42
+    assert (p.finger_width, p.hand_outer_diameter, p.hand_depth, p.hand_height, p.init_bite) == (0.01, 0.12, 0.06, 0.02, 0.01)
+    assert (p.volume_width, p.volume_depth, p.volume_height, p.image_size, p.image_num_channels) == (0.10, 0.06, 0.02, 60, 15)
+    assert (p.num_orientations, p.num_finger_placements, p.num_hand_axes, p.hand_axes[0], p.deepen_hand) == (8, 10, 1, 2, 1)
+    assert (p.friction_coeff, p.min_viable, p.max_aperture) == (20.0, 6, 0.085)
+
+
+def test_no_gpu_means_error_not_fallback():
+    """Without a GPU the product must fail loudly: no CPU path behind the C-ABI."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    from gpd_amd import api
+    try:
+        api.Context(api.default_params())
+    except api.GpdHipError as e:
+        assert "libgpd_hip error" in str(e)
+    else:
+        raise AssertionError("Context() succeeded without a GPU")
+
+
+def test_product_does_not_reference_the_oracle():
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "gpd_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(d, f)).read()
+                if re.search(r"import oracle|from oracle|libgpd_oracle|gpd_oracle_", txt):
+                    bad.append(f)
+    assert not bad, bad
