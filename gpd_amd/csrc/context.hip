@@ -42,7 +42,8 @@ struct gpd_hip_ctx {
   SearchState search;
   ImageState images;
   // staging for gpd_hip_score with host images
-  uint8_t *d_img_in = nullptr;
+  uint8_t *d_img_in = nullptr;      // HWC images handed to gpd_hip_score
+  uint8_t *d_img_planar = nullptr;  // their planar copy
   size_t d_img_in_bytes = 0;
   float *d_scores = nullptr;
   int d_scores_cap = 0;
@@ -139,6 +140,7 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
   search_free(ctx->search);
   images_free(ctx->images);
   if (ctx->d_img_in) (void)hipFree(ctx->d_img_in);
+  if (ctx->d_img_planar) (void)hipFree(ctx->d_img_planar);
   if (ctx->d_scores) (void)hipFree(ctx->d_scores);
   for (auto &e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
@@ -193,13 +195,17 @@ int gpd_hip_score(gpd_hip_ctx *ctx, const uint8_t *images, int n, float *scores)
   if (images) {
     if (bytes > ctx->d_img_in_bytes) {
       if (ctx->d_img_in) (void)hipFree(ctx->d_img_in);
+      if (ctx->d_img_planar) (void)hipFree(ctx->d_img_planar);
       ctx->d_img_in = nullptr;
+      ctx->d_img_planar = nullptr;
       ctx->d_img_in_bytes = 0;
       HIP_TRY(hipMalloc(&ctx->d_img_in, bytes));
+      HIP_TRY(hipMalloc(&ctx->d_img_planar, bytes));
       ctx->d_img_in_bytes = bytes;
     }
     HIP_TRY(hipMemcpyAsync(ctx->d_img_in, images, bytes, hipMemcpyHostToDevice, ctx->stream));
-    d_img = ctx->d_img_in;
+    HIP_TRY(hwc_to_planar(ctx->d_img_in, ctx->d_img_planar, n, ctx->lenet.channels, ctx->stream));
+    d_img = ctx->d_img_planar;
   } else {
     if (n != ctx->images.num_candidates || !ctx->images.d_images) {
       set_error("gpd_hip_score: no device images for n=%d (gpd_hip_images produced %d)", n, ctx->images.num_candidates);
@@ -272,10 +278,16 @@ int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets, uint8_
   if (rc) return rc;
   HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
   *num_candidates = ctx->images.num_candidates;
-  if (images && ctx->images.num_candidates > 0)
-    HIP_TRY(hipMemcpyAsync(images, ctx->images.d_images,
+  if (images && ctx->images.num_candidates > 0) {
+    // the caller wants cv::Mat-layout pixels: planar -> HWC on the device, then one copy
+    const size_t bytes = (size_t)ctx->images.capacity * kPix * ctx->params.image_num_channels;
+    if (!ctx->images.d_images_hwc) HIP_TRY(hipMalloc(&ctx->images.d_images_hwc, bytes));
+    HIP_TRY(planar_to_hwc(ctx->images.d_images, ctx->images.d_images_hwc, ctx->images.num_candidates,
+                          ctx->params.image_num_channels, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(images, ctx->images.d_images_hwc,
                            (size_t)ctx->images.num_candidates * kPix * ctx->params.image_num_channels, hipMemcpyDeviceToHost,
                            ctx->stream));
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipEventElapsedTime(&ctx->stage_ms[1], ctx->ev[0], ctx->ev[1]));
   return GPD_OK;

@@ -28,7 +28,7 @@ struct LeNetScratch {
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
 };
 
-// Scores n images (device pointer, HWC u8) into d_scores (device). Async on stream.
+// Scores n images (device pointer, planar u8 [n][C][3600]) into d_scores (device). Async on stream.
 hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *d_images, int n, float *d_scores,
                          hipStream_t stream);
 hipError_t lenet_scratch_reserve(LeNetScratch &s, int n);
@@ -79,7 +79,8 @@ void filter_workspace_host(const gpd_params &p, gpd_hand *hands, int num_sets);
 struct ImageState {
   int num_candidates = 0;
   int capacity = 0;                   // images
-  uint8_t *d_images = nullptr;        // [n][60][60][C]
+  uint8_t *d_images = nullptr;        // planar [n][C][60][60]
+  uint8_t *d_images_hwc = nullptr;    // [n][60][60][C], only when the caller downloads pixels
   gpd_hand *d_hands = nullptr;        // candidate hand records
   int32_t *d_cand_meta = nullptr;     // [n][4]: sample slot, N_images, lcg offset lo, hi
   int32_t *d_status = nullptr;        // error flags from the kernel
@@ -89,6 +90,9 @@ struct ImageState {
 int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageState &im, const gpd_hand *hands, int num_sets,
                int32_t *cand_index, hipStream_t stream);
 int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool check);
+hipError_t planar_to_hwc(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream);
+hipError_t hwc_to_planar(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream);
+void image_cell_thresholds(double len, double *out);  // 61 doubles
 void images_free(ImageState &im);
 
 // Host-side constants of the path (host_math.cpp), computed with libm exactly as the

@@ -20,8 +20,18 @@
 //
 // The 33*N LCG draws of a hand set are regenerated per candidate by jump-ahead
 // (hand_set.cpp:263-266 is an affine map mod 2^32), so no per-set voxel list is stored.
+//
+// Cell indices floor((x/len)/(1/60)) (image_strategy.cpp:92-102) are monotone in x, so
+// they are looked up in a table of exact double thresholds computed on the host with the
+// same IEEE divisions — bit-identical to dividing, without fp64 divisions in the kernel.
+// Only the depth value that enters a pixel's running mean is actually divided.
+//
+// Device images are planar u8 [n][C][60][60]; the cv::Mat HWC layout of the reference
+// interface is produced by planar_to_hwc_kernel when the caller asks for the pixels.
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gpd_internal.h"
@@ -37,9 +47,11 @@ namespace gpd {
     }                                                                                       \
   } while (0)
 
-constexpr int IMG_THREADS = 512;
-constexpr int PLACE_CAP = 8192;  // in-box points / shadow voxels per candidate
-constexpr int VDIM = 46;         // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
+constexpr int IMG_THREADS = 1024;
+constexpr int IMG_WAVES = IMG_THREADS / 64;
+constexpr int PT_CAP = 2048;  // in-box points per candidate
+constexpr int SH_CAP = 8192;  // in-box shadow voxels per candidate
+constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
 constexpr int VBITS = VDIM * VDIM * VDIM;
 constexpr int VWORDS = (VBITS + 31) / 32;
 
@@ -50,6 +62,9 @@ struct ImgConsts {
   double shadow_length, voxel, voxel_mult, rand_inv;
   int num_shadow;
   uint32_t stride_a, stride_c;  // LCG jump by IMG_THREADS * num_shadow draws
+  double len[3];                // box extent per hand axis: vol_depth, vol_width, dbl_h
+  double inv_cell[3];           // approximate cells per metre (first guess only)
+  double thr[3][kImg + 1];      // thr[a][k] = smallest x with floor((x/len[a])/(1/60)) >= k
 };
 __constant__ ImgConsts c_img;
 
@@ -59,54 +74,78 @@ struct ImgParams {
   const double *centers;
   const gpd_hand *hands;  // one per candidate
   const int32_t *meta;    // [n][4]: sample slot, N_images, lcg offset lo, hi (hi < 0: no shadow)
-  uint8_t *images;
+  uint8_t *images;        // planar [n][C][3600]
   int32_t *status;
+  unsigned long long *dbg;  // profiling aid (GPD_IMG_TIMING=1): per-phase cycle sums
 };
 
 struct Box {
   double F[9];
   double sample[3];
-  double bottom, center;
+  double off[3];  // x_a = t_a - off[a]: bottom, center - half_od, -vol_height
+  double lo[3], hi[3];
 };
 
-// ImageStrategy::transformToUnitImage / findPointsInUnitImage / transformPointsToUnitImage
-// (image_strategy.cpp:32-90): rotate into the hand frame, strict box test, unit cube.
-__device__ inline bool to_unit(const Box &B, double w0, double w1, double w2, double u[3]) {
-  const ImgConsts &K = c_img;
-  const double c0 = w0 - B.sample[0], c1 = w1 - B.sample[1], c2 = w2 - B.sample[2];
-  const double t0 = B.F[0] * c0 + B.F[3] * c1 + B.F[6] * c2;
-  const double t1 = B.F[1] * c0 + B.F[4] * c1 + B.F[7] * c2;
-  const double t2 = B.F[2] * c0 + B.F[5] * c1 + B.F[8] * c2;
-  if ((t0 > B.bottom) && (t0 < B.bottom + K.vol_depth) && (t1 > B.center - K.half_od) && (t1 < B.center + K.half_od) &&
-      (t2 > -1.0 * K.vol_height) && (t2 < K.vol_height)) {
-    u[0] = (t0 - B.bottom) / K.vol_depth;
-    u[1] = (t1 - (B.center - K.half_od)) / K.vol_width;
-    u[2] = (t2 + K.vol_height) / K.dbl_h;
-    return true;
-  }
-  return false;
-}
+struct SmemPts {
+  double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
+  float a[3][PT_CAP];   // |normal| in the hand frame
+  uint32_t key[PT_CAP]; // cx | cy << 6 | cz << 12 | neighbour rank << 18
+};
+struct SmemSh {
+  uint32_t bits[VWORDS];
+  uint32_t lin[SH_CAP];     // set bits inside the box, ascending
+  uint32_t cells3[SH_CAP];  // cx | cy << 6 | cz << 12
+};
+struct Smem {
+  union {
+    SmemPts p;
+    SmemSh s;
+  } u;
+  float raster[3][kPix];  // cell-index order (row flip applied at the store)
+  uint32_t cells[kPix];   // (segment start << 16) | count; reused as the f32 depth plane
+  uint16_t place[SH_CAP];
+  double thr[3][kImg + 1];
+  float red_f[2 * IMG_WAVES];
+  int red_i[IMG_WAVES];
+  int vorg[3];
+  int counter;
+  int flag;
+};
 
-// ImageStrategy::findCellIndices (image_strategy.cpp:92-102)
-__device__ inline int cell_index(double ua, double ub) {
-  const double cellsize = 1.0 / (double)kImg;
-  int v = (int)floor(ua / cellsize);
-  int h = (int)floor(ub / cellsize);
-  v = v < kImg - 1 ? v : kImg - 1;
-  h = h < kImg - 1 ? h : kImg - 1;
+// hand-frame coordinates of a world point: t = F^T (w - sample)  (image_strategy.cpp:36-40)
+__device__ inline void to_hand(const Box &B, double w0, double w1, double w2, double t[3]) {
+  const double c0 = w0 - B.sample[0], c1 = w1 - B.sample[1], c2 = w2 - B.sample[2];
+  t[0] = B.F[0] * c0 + B.F[3] * c1 + B.F[6] * c2;
+  t[1] = B.F[1] * c0 + B.F[4] * c1 + B.F[7] * c2;
+  t[2] = B.F[2] * c0 + B.F[5] * c1 + B.F[8] * c2;
+}
+// findPointsInUnitImage (image_strategy.cpp:53-70): strict box test
+__device__ inline bool in_box(const Box &B, const double t[3]) {
+  return (t[0] > B.lo[0]) && (t[0] < B.hi[0]) && (t[1] > B.lo[1]) && (t[1] < B.hi[1]) && (t[2] > B.lo[2]) && (t[2] < B.hi[2]);
+}
+// min(floor(((t - off)/len)/(1/60)), 59) by exact thresholds (see file header)
+__device__ inline int cell_coord(const Smem &S, int axis, double x) {
+  int k = (int)(x * c_img.inv_cell[axis]);
+  k = k < 0 ? 0 : (k > kImg - 1 ? kImg - 1 : k);
+  while (k > 0 && x < S.thr[axis][k]) k--;
+  while (k < kImg - 1 && x >= S.thr[axis][k + 1]) k++;
+  return k;
+}
+__device__ inline uint32_t cells_of(const Smem &S, const Box &B, const double t[3]) {
+  const int cx = cell_coord(S, 0, t[0] - B.off[0]);
+  const int cy = cell_coord(S, 1, t[1] - B.off[1]);
+  const int cz = cell_coord(S, 2, t[2] - B.off[2]);
+  return (uint32_t)cx | ((uint32_t)cy << 6) | ((uint32_t)cz << 12);
+}
+// projections by cumulative row swaps 0<->2 then 1<->2: (x,y,z), (z,y,x), (z,x,y);
+// cell = horizontal + 60 * vertical (image_strategy.cpp:92-102)
+__device__ inline int cell_of_key(uint32_t key, int pr) {
+  const int cx = key & 63, cy = (key >> 6) & 63, cz = (key >> 12) & 63;
+  const int v = pr == 0 ? cx : cz;
+  const int h = pr == 2 ? cx : cy;
   return h + v * kImg;
 }
-
-// projections by cumulative row swaps 0<->2 then 1<->2: (x,y,z), (z,y,x), (z,x,y)
-__device__ inline void project(int pr, const double u[3], double &a, double &b, double &d) {
-  if (pr == 0) {
-    a = u[0]; b = u[1]; d = u[2];
-  } else if (pr == 1) {
-    a = u[2]; b = u[1]; d = u[0];
-  } else {
-    a = u[2]; b = u[0]; d = u[1];
-  }
-}
+__device__ inline int depth_axis(int pr) { return pr == 0 ? 2 : (pr == 1 ? 0 : 1); }
 
 __device__ inline uint32_t lcg_step(uint32_t &s) {  // HandSet::fastrand (hand_set.cpp:263-266)
   s = 214013u * s + 2531011u;
@@ -126,29 +165,33 @@ __device__ inline uint32_t lcg_jump(uint32_t s, unsigned long long n) {
   return A * s + Cc;
 }
 
-template <class T>
-__device__ inline T wave_sum(T v) {
+// block-wide exclusive scan of one int per thread; returns the exclusive prefix, total in *total
+__device__ inline int block_excl_scan(Smem &S, int v, int *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int x = __shfl_up(incl, o);
+    if (lane >= o) incl += x;
+  }
+  __syncthreads();
+  if (lane == 63) S.red_i[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < IMG_WAVES; w++) {
+    const int x = S.red_i[w];
+    if (w < wave) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + incl - v;
 }
-
-struct Smem {
-  uint32_t cells[kPix];        // (segment start << 16) | count
-  float raster[kPix * 3];
-  uint32_t place[PLACE_CAP];
-  uint32_t bits[VWORDS];
-  float red_f[2 * (IMG_THREADS / 64)];
-  int red_i[IMG_THREADS / 64];
-  int vorg[3];
-  int flag;
-};
 
 // exclusive scan of cells[].count into the start field; returns the total
 __device__ int scan_cells(Smem &S) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;  // 8
+  constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;  // 4
   int c[PER];
   int sum = 0;
 #pragma unroll
@@ -157,22 +200,8 @@ __device__ int scan_cells(Smem &S) {
     c[k] = i < kPix ? (int)(S.cells[i] & 0xffffu) : 0;
     sum += c[k];
   }
-  int incl = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o);
-    if (lane >= o) incl += v;
-  }
-  __syncthreads();
-  if (lane == 63) S.red_i[wave] = incl;
-  __syncthreads();
-  int base = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < IMG_THREADS / 64; w++) {
-    if (w < wave) base += S.red_i[w];
-    total += S.red_i[w];
-  }
-  int run = base + incl - sum;
+  int total;
+  int run = block_excl_scan(S, sum, &total);
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const int i = tid * PER + k;
@@ -183,45 +212,43 @@ __device__ int scan_cells(Smem &S) {
   return total;
 }
 
-__device__ inline void sort_segment(uint32_t *p, int n) {
-  for (int i = 1; i < n; i++) {
-    const uint32_t v = p[i];
-    int j = i - 1;
-    while (j >= 0 && p[j] > v) {
-      p[j + 1] = p[j];
-      j--;
-    }
-    p[j + 1] = v;
-  }
-}
-
 // 3x3 rect max-dilate (border ignored), NORM_MINMAX to [0,1], u8 = round-half-even(v*255)
 // (image_strategy.cpp:144-153, 178-187, 221-230; cv::dilate / cv::normalize / convertTo).
+// planes are in cell-index order (cell row = 59 - image row; the 3x3 window is symmetric);
+// each thread owns groups of 4 consecutive pixels and stores them as one dword.
 template <int NCH>
-__device__ void finalize_channels(Smem &S, uint8_t *out, int C, int ch_off) {
+__device__ void finalize_channels(Smem &S, const float *planes, uint8_t *out) {
   const int tid = threadIdx.x;
-  constexpr int N = kPix * NCH;
-  constexpr int PER = (N + IMG_THREADS - 1) / IMG_THREADS;
-  float d[PER];
+  constexpr int GROUPS = NCH * kImg * (kImg / 4);  // 900 per plane
+  constexpr int PER = (GROUPS + IMG_THREADS - 1) / IMG_THREADS;
+  float d[PER][4];
   float mn = FLT_MAX, mx = -FLT_MAX;
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    const int e = tid + k * IMG_THREADS;
-    d[k] = 0.f;
-    if (e < N) {
-      const int pix = e / NCH, ch = e - pix * NCH;
-      const int r = pix / kImg, c = pix - r * kImg;
-      float m = -FLT_MAX;
+    const int g = tid + k * IMG_THREADS;
+    if (g < GROUPS) {
+      const int ch = g / 900, rem = g - ch * 900;
+      const int r = rem / 15, c0 = (rem - r * 15) * 4;
+      const float *pl = planes + ch * kPix;
+      float cm[6];  // column maxima over the 3 rows for columns c0-1 .. c0+4
 #pragma unroll
-      for (int dr = -1; dr <= 1; dr++)
-#pragma unroll
-        for (int dc = -1; dc <= 1; dc++) {
-          const int rr = r + dr, cc = c + dc;
-          if (rr >= 0 && rr < kImg && cc >= 0 && cc < kImg) m = fmaxf(m, S.raster[(rr * kImg + cc) * NCH + ch]);
+      for (int j = 0; j < 6; j++) {
+        const int cc = c0 - 1 + j;
+        float m = -FLT_MAX;
+        if (cc >= 0 && cc < kImg) {
+          m = pl[r * kImg + cc];
+          if (r > 0) m = fmaxf(m, pl[(r - 1) * kImg + cc]);
+          if (r < kImg - 1) m = fmaxf(m, pl[(r + 1) * kImg + cc]);
         }
-      d[k] = m;
-      mn = fminf(mn, m);
-      mx = fmaxf(mx, m);
+        cm[j] = m;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float v = fmaxf(fmaxf(cm[j], cm[j + 1]), cm[j + 2]);
+        d[k][j] = v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+      }
     }
   }
 #pragma unroll
@@ -238,7 +265,7 @@ __device__ void finalize_channels(Smem &S, uint8_t *out, int C, int ch_off) {
   mn = S.red_f[0];
   mx = S.red_f[1];
 #pragma unroll
-  for (int w = 1; w < IMG_THREADS / 64; w++) {
+  for (int w = 1; w < IMG_WAVES; w++) {
     mn = fminf(mn, S.red_f[2 * w]);
     mx = fmaxf(mx, S.red_f[2 * w + 1]);
   }
@@ -248,24 +275,67 @@ __device__ void finalize_channels(Smem &S, uint8_t *out, int C, int ch_off) {
   const float fs = (float)scale, fb = (float)shift;
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    const int e = tid + k * IMG_THREADS;
-    if (e < N) {
-      const int pix = e / NCH, ch = e - pix * NCH;
-      const float v = d[k] * fs + fb;
-      const float u = v * 255.0f + 0.0f;
-      float r = rintf(u);
-      r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
-      out[(size_t)pix * C + ch_off + ch] = (uint8_t)(int)r;
+    const int g = tid + k * IMG_THREADS;
+    if (g < GROUPS) {
+      const int ch = g / 900, rem = g - ch * 900;
+      const int r = rem / 15, c0 = (rem - r * 15) * 4;
+      uint32_t packed = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float v = d[k][j] * fs + fb;
+        const float u = v * 255.0f + 0.0f;
+        float q = rintf(u);
+        q = q < 0.f ? 0.f : (q > 255.f ? 255.f : q);
+        packed |= (uint32_t)(int)q << (8 * j);
+      }
+      // image row = 59 - cell row (image_strategy.cpp:128-129)
+      *reinterpret_cast<uint32_t *>(out + (size_t)ch * kPix + (kImg - 1 - r) * kImg + c0) = packed;
     }
   }
   __syncthreads();
 }
 
+__device__ inline void sort_u16(uint16_t *p, int n) {
+  for (int i = 1; i < n; i++) {
+    const uint16_t v = p[i];
+    int j = i - 1;
+    while (j >= 0 && p[j] > v) {
+      p[j + 1] = p[j];
+      j--;
+    }
+    p[j + 1] = v;
+  }
+}
+// sort entry indices by the neighbour rank stored in key[] (rank = key >> 18)
+__device__ inline void sort_by_rank(uint16_t *p, int n, const uint32_t *key) {
+  for (int i = 1; i < n; i++) {
+    const uint16_t v = p[i];
+    const uint32_t kv = key[v] >> 18;
+    int j = i - 1;
+    while (j >= 0 && (key[p[j]] >> 18) > kv) {
+      p[j + 1] = p[j];
+      j--;
+    }
+    p[j + 1] = v;
+  }
+}
+
+#define TICK(k)                                                     \
+  do {                                                              \
+    if (P.dbg && tid == 0) {                                        \
+      const unsigned long long now_ = __builtin_readcyclecounter(); \
+      atomicAdd(&P.dbg[k], now_ - t_last);                          \
+      t_last = now_;                                                \
+    }                                                               \
+  } while (0)
+
 __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   __shared__ Smem S;
+  unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
   const int cand = blockIdx.x;
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const gpd_hand &H = P.hands[cand];
   const int slot_s = P.meta[4 * cand + 0];
   const int N = P.meta[4 * cand + 1];
@@ -278,21 +348,35 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   for (int i = 0; i < 9; i++) B.F[i] = H.frame[i];
 #pragma unroll
   for (int i = 0; i < 3; i++) B.sample[i] = H.sample[i];
-  B.bottom = H.bottom;
-  B.center = H.center;
-  if (tid == 0) S.flag = 0;
-
-  // ---- shadow voxel bitset (15 channels): HandSet::calculateShadow for one camera ----
+  // bounds exactly as findPointsInUnitImage / transformPointsToUnitImage evaluate them
+  B.off[0] = H.bottom;
+  B.off[1] = H.center - K.half_od;
+  B.off[2] = -K.vol_height;  // (t2 + height) == t2 - (-height)
+  B.lo[0] = H.bottom;
+  B.hi[0] = H.bottom + K.vol_depth;
+  B.lo[1] = H.center - K.half_od;
+  B.hi[1] = H.center + K.half_od;
+  B.lo[2] = -1.0 * K.vol_height;
+  B.hi[2] = K.vol_height;
+  for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
+  if (tid == 0) {
+    S.flag = 0;
+    S.counter = 0;
+  }
   const bool with_shadow = (K.C == 15);
+
+  // =====================================================================
+  // Shadow channels first (their LDS is reused by the point phase).
+  // =====================================================================
   if (with_shadow) {
-    for (int w = tid; w < VWORDS; w += IMG_THREADS) S.bits[w] = 0u;
+    for (int w = tid; w < VWORDS; w += IMG_THREADS) S.u.s.bits[w] = 0u;
     if (tid == 0) {
       // voxel AABB of the image box: corners sample + F * (bx, by, bz)
       double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX};
       for (int k = 0; k < 8; k++) {
-        const double bx = (k & 1) ? B.bottom + K.vol_depth : B.bottom;
-        const double by = (k & 2) ? B.center + K.half_od : B.center - K.half_od;
-        const double bz = (k & 4) ? K.vol_height : -K.vol_height;
+        const double bx = (k & 1) ? B.hi[0] : B.lo[0];
+        const double by = (k & 2) ? B.hi[1] : B.lo[1];
+        const double bz = (k & 4) ? B.hi[2] : B.lo[2];
         for (int r = 0; r < 3; r++) {
           const double w = B.sample[r] + B.F[3 * r + 0] * bx + B.F[3 * r + 1] * by + B.F[3 * r + 2] * bz;
           lo[r] = fmin(lo[r], w);
@@ -301,9 +385,9 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       for (int r = 0; r < 3; r++) S.vorg[r] = (int)floor(lo[r] * K.voxel_mult) - 1;
     }
     __syncthreads();
+    const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
+    // ---- HandSet::calculateShadowForCamera (hand_set.cpp:202-233), one camera
     if (off_hi >= 0 && N > 0) {
-      const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
-      // shadow_vec = shadow_length * (center - view_point) / norm (hand_set.cpp:147-150)
       const double *cen = P.centers + 3 * (size_t)slot_s;
       double vec[3];
       for (int r = 0; r < 3; r++) vec[r] = cen[r] - K.view_point[r];
@@ -320,12 +404,13 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
           const int vx = (int)((p0 + t * vec[0]) * K.voxel_mult);
           const int vy = (int)((p1 + t * vec[1]) * K.voxel_mult);
           const int vz = (int)((p2 + t * vec[2]) * K.voxel_mult);
-          double u[3];
-          if (to_unit(B, (double)vx * K.voxel, (double)vy * K.voxel, (double)vz * K.voxel, u)) {
+          double th[3];
+          to_hand(B, (double)vx * K.voxel, (double)vy * K.voxel, (double)vz * K.voxel, th);
+          if (in_box(B, th)) {
             const int ix = vx - x0, iy = vy - y0, iz = vz - z0;
             if ((unsigned)ix < (unsigned)VDIM && (unsigned)iy < (unsigned)VDIM && (unsigned)iz < (unsigned)VDIM) {
               const int bit = (ix * VDIM + iy) * VDIM + iz;
-              atomicOr(&S.bits[bit >> 5], 1u << (bit & 31));
+              atomicOr(&S.u.s.bits[bit >> 5], 1u << (bit & 31));
             } else {
               bad = 1;
             }
@@ -335,51 +420,175 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       }
       if (bad) atomicOr(&S.flag, 1);
     }
+    __syncthreads();
+    TICK(0);
+    // ---- ordered list of the set bits + their three cell coordinates
+    constexpr int WPT = (VWORDS + IMG_THREADS - 1) / IMG_THREADS;  // words per thread, contiguous
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < WPT; k++) {
+      const int w = tid * WPT + k;
+      if (w < VWORDS) cnt += __popc(S.u.s.bits[w]);
+    }
+    int n_sh;
+    int pos = block_excl_scan(S, cnt, &n_sh);
+    if (n_sh > SH_CAP) {
+      if (tid == 0) atomicOr(&S.flag, 4);
+    }
+    for (int k = 0; k < WPT; k++) {
+      const int w = tid * WPT + k;
+      if (w >= VWORDS) break;
+      uint32_t bits = S.u.s.bits[w];
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        if (pos < SH_CAP) S.u.s.lin[pos] = (uint32_t)(w * 32 + b);
+        pos++;
+      }
+    }
+    __syncthreads();
+    const int ns = n_sh < SH_CAP ? n_sh : SH_CAP;
+    for (int k = tid; k < ns; k += IMG_THREADS) {
+      const int lin = (int)S.u.s.lin[k];
+      const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
+      double th[3];
+      to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
+      S.u.s.cells3[k] = cells_of(S, B, th);
+    }
+    __syncthreads();
+    TICK(1);
+    for (int pr = 0; pr < 3; pr++) {
+      // ---- createShadowImage (image_strategy.cpp:192-233)
+      for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
+      __syncthreads();
+      for (int k = tid; k < ns; k += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(S.u.s.cells3[k], pr)], 1u);
+      __syncthreads();
+      scan_cells(S);
+      for (int k = tid; k < ns; k += IMG_THREADS) {
+        const uint32_t old = atomicAdd(&S.cells[cell_of_key(S.u.s.cells3[k], pr)], 1u);
+        S.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)k;
+      }
+      __syncthreads();
+      TICK(2);
+      const int da = depth_axis(pr);
+      float lmax = -FLT_MAX;
+      int lany = 0;
+      for (int c = tid; c < kPix; c += IMG_THREADS) {
+        const uint32_t w = S.cells[c];
+        const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
+        float v = 0.f;
+        if (cn > 0) {
+          sort_u16(&S.place[start], cn);
+          float fc = 0.f;
+          for (int e = 0; e < cn; e++) {
+            const int lin = (int)S.u.s.lin[S.place[start + e]];
+            const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
+            const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
+                         c2 = (double)(iz + z0) * K.voxel - B.sample[2];
+            const double td = B.F[da] * c0 + B.F[3 + da] * c1 + B.F[6 + da] * c2;
+            const double d = (td - B.off[da]) / K.len[da];
+            fc = (float)((double)fc + 1.0);
+            v = (float)((double)v + (d - (double)v) * (1.0 / (double)fc));
+          }
+          lmax = fmaxf(lmax, v);
+          lany = 1;
+        }
+        S.raster[0][c] = v;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        lany |= __shfl_xor(lany, o);
+      }
+      __syncthreads();
+      if (lane == 0) {
+        S.red_f[tid >> 6] = lmax;
+        S.red_i[tid >> 6] = lany;
+      }
+      __syncthreads();
+      float gmax = -FLT_MAX;
+      int gany = 0;
+#pragma unroll
+      for (int w = 0; w < IMG_WAVES; w++) {
+        gmax = fmaxf(gmax, S.red_f[w]);
+        gany |= S.red_i[w];
+      }
+      // minMaxLoc with mask -> max (0 if the mask is empty); image = max_img - image
+      const double mxd = gany ? (double)gmax : 0.0;
+      __syncthreads();
+      for (int c = tid; c < kPix; c += IMG_THREADS) {
+        const float m = (S.cells[c] & 0xffffu) ? (float)mxd : 0.0f;
+        S.raster[0][c] = m - S.raster[0][c];
+      }
+      __syncthreads();
+      TICK(3);
+      finalize_channels<1>(S, &S.raster[0][0], out + (size_t)(pr * K.per + 4) * kPix);
+      TICK(4);
+    }
+  }
+
+  // =====================================================================
+  // Point channels: normals (3) and depth (1) per projection.
+  // =====================================================================
+  __syncthreads();
+  for (int i0 = 0; i0 < N; i0 += IMG_THREADS) {
+    const int i = i0 + tid;
+    double t[3] = {0, 0, 0};
+    bool in = false;
+    if (i < N) {
+      to_hand(B, (double)nn[0 * P.cap + i], (double)nn[1 * P.cap + i], (double)nn[2 * P.cap + i], t);
+      in = in_box(B, t);
+    }
+    const unsigned long long ballot = __ballot(in);
+    if (ballot) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&S.counter, __popcll(ballot));
+      base = __shfl(base, 0);
+      if (in) {
+        const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
+        if (e < PT_CAP) {
+          const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
+          S.u.p.t[0][e] = t[0];
+          S.u.p.t[1][e] = t[1];
+          S.u.p.t[2][e] = t[2];
+          S.u.p.a[0][e] = (float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2);
+          S.u.p.a[1][e] = (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2);
+          S.u.p.a[2][e] = (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2);
+          S.u.p.key[e] = cells_of(S, B, t) | ((uint32_t)i << 18);
+        }
+      }
+    }
   }
   __syncthreads();
-
+  const int n_box_all = S.counter;
+  if (n_box_all > PT_CAP && tid == 0) atomicOr(&S.flag, 2);
+  const int nb = n_box_all < PT_CAP ? n_box_all : PT_CAP;
+  TICK(5);
   for (int pr = 0; pr < K.nproj; pr++) {
-    const int ch0 = pr * K.per;
-    // ---- points: counting sort by pixel ----
     for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
     __syncthreads();
-    for (int i = tid; i < N; i += IMG_THREADS) {
-      double u[3];
-      if (to_unit(B, (double)nn[0 * P.cap + i], (double)nn[1 * P.cap + i], (double)nn[2 * P.cap + i], u)) {
-        double a, b, d;
-        project(pr, u, a, b, d);
-        atomicAdd(&S.cells[cell_index(a, b)], 1u);
-      }
+    for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(S.u.p.key[e], pr)], 1u);
+    __syncthreads();
+    scan_cells(S);
+    for (int e = tid; e < nb; e += IMG_THREADS) {
+      const uint32_t old = atomicAdd(&S.cells[cell_of_key(S.u.p.key[e], pr)], 1u);
+      S.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)e;
     }
     __syncthreads();
-    const int total = scan_cells(S);
-    if (total > PLACE_CAP) {
-      if (tid == 0) atomicOr(&S.flag, 2);
-    }
-    for (int i = tid; i < N; i += IMG_THREADS) {
-      double u[3];
-      if (to_unit(B, (double)nn[0 * P.cap + i], (double)nn[1 * P.cap + i], (double)nn[2 * P.cap + i], u)) {
-        double a, b, d;
-        project(pr, u, a, b, d);
-        const uint32_t old = atomicAdd(&S.cells[cell_index(a, b)], 1u);
-        const uint32_t slot = (old >> 16) + (old & 0xffffu);
-        if (slot < PLACE_CAP) S.place[slot] = (uint32_t)i;
-      }
-    }
-    __syncthreads();
-    // ---- normals (image_strategy.cpp:124-156): pixel owner walks its segment in neighbour order
+    TICK(6);
+    // ---- createNormalsImage + createDepthImage (image_strategy.cpp:124-190): the pixel owner
+    //      walks its segment in neighbour order
+    const int da = depth_axis(pr);
     for (int c = tid; c < kPix; c += IMG_THREADS) {
       const uint32_t w = S.cells[c];
-      const int cnt = (int)(w & 0xffffu), start = (int)(w >> 16);
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (cnt > 0 && start + cnt <= PLACE_CAP) {
-        sort_segment(&S.place[start], cnt);
-        for (int e = 0; e < cnt; e++) {
-          const int i = (int)S.place[start + e];
-          const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
-          const float a0 = (float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2);
-          const float a1 = (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2);
-          const float a2 = (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2);
+      const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, pix = 0.f;
+      if (cn > 0) {
+        sort_by_rank(&S.place[start], cn, S.u.p.key);
+        float avg = 0.f, fc = 0.f;
+        for (int q = 0; q < cn; q++) {
+          const int e = S.place[start + q];
+          const float a0 = S.u.p.a[0][e], a1 = S.u.p.a[1][e], a2 = S.u.p.a[2][e];
           if (v0 == 0.f && v1 == 0.f && v2 == 0.f) {
             v0 = a0;
             v1 = a1;
@@ -392,139 +601,90 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
             v1 = v1 + (float)((double)d1 * inv);
             v2 = v2 + (float)((double)d2 * inv);
           }
+          const double d = (S.u.p.t[da][e] - B.off[da]) / K.len[da];
+          fc = (float)((double)fc + 1.0);
+          avg = (float)((double)avg + (d - (double)avg) * (1.0 / (double)fc));
         }
+        pix = (float)(1.0 - (double)avg);
       }
-      const int row = kImg - 1 - c / kImg, col = c % kImg;
-      float *px = &S.raster[(row * kImg + col) * 3];
-      px[0] = v0;
-      px[1] = v1;
-      px[2] = v2;
+      S.raster[0][c] = v0;
+      S.raster[1][c] = v1;
+      S.raster[2][c] = v2;
+      S.cells[c] = __float_as_uint(pix);  // the depth plane, in place of the segment table
     }
     __syncthreads();
-    finalize_channels<3>(S, out, K.C, ch0);
-    // ---- depth (image_strategy.cpp:158-190)
-    if (K.C >= 12) {
-      for (int c = tid; c < kPix; c += IMG_THREADS) {
-        const uint32_t w = S.cells[c];
-        const int cnt = (int)(w & 0xffffu), start = (int)(w >> 16);
-        float pix = 0.f;
-        if (cnt > 0 && start + cnt <= PLACE_CAP) {
-          float avg = 0.f, cn = 0.f;
-          for (int e = 0; e < cnt; e++) {
-            const int i = (int)S.place[start + e];
-            double u[3], a, b, d;
-            to_unit(B, (double)nn[0 * P.cap + i], (double)nn[1 * P.cap + i], (double)nn[2 * P.cap + i], u);
-            project(pr, u, a, b, d);
-            cn = (float)((double)cn + 1.0);
-            avg = (float)((double)avg + (d - (double)avg) * (1.0 / (double)cn));
-          }
-          pix = (float)(1.0 - (double)avg);
-        }
-        const int row = kImg - 1 - c / kImg, col = c % kImg;
-        S.raster[row * kImg + col] = pix;
-      }
-      __syncthreads();
-      finalize_channels<1>(S, out, K.C, ch0 + 3);
-    }
-    // ---- shadow (image_strategy.cpp:192-233) over the voxel bitset in index order
-    if (with_shadow) {
-      const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
-      for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
-      __syncthreads();
-      for (int wd = tid; wd < VWORDS; wd += IMG_THREADS) {
-        uint32_t bits = S.bits[wd];
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          const int lin = wd * 32 + b;
-          const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
-          double u[3], a, bb, d;
-          to_unit(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, u);
-          project(pr, u, a, bb, d);
-          atomicAdd(&S.cells[cell_index(a, bb)], 1u);
-        }
-      }
-      __syncthreads();
-      const int tot_s = scan_cells(S);
-      if (tot_s > PLACE_CAP) {
-        if (tid == 0) atomicOr(&S.flag, 4);
-      }
-      for (int wd = tid; wd < VWORDS; wd += IMG_THREADS) {
-        uint32_t bits = S.bits[wd];
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          const int lin = wd * 32 + b;
-          const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
-          double u[3], a, bb, d;
-          to_unit(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, u);
-          project(pr, u, a, bb, d);
-          const uint32_t old = atomicAdd(&S.cells[cell_index(a, bb)], 1u);
-          const uint32_t slot = (old >> 16) + (old & 0xffffu);
-          if (slot < PLACE_CAP) S.place[slot] = (uint32_t)lin;
-        }
-      }
-      __syncthreads();
-      float lmax = -FLT_MAX;
-      int lany = 0;
-      for (int c = tid; c < kPix; c += IMG_THREADS) {
-        const uint32_t w = S.cells[c];
-        const int cnt = (int)(w & 0xffffu), start = (int)(w >> 16);
-        float v = 0.f;
-        if (cnt > 0 && start + cnt <= PLACE_CAP) {
-          sort_segment(&S.place[start], cnt);
-          float cn = 0.f;
-          for (int e = 0; e < cnt; e++) {
-            const int lin = (int)S.place[start + e];
-            const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
-            double u[3], a, bb, d;
-            to_unit(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, u);
-            project(pr, u, a, bb, d);
-            cn = (float)((double)cn + 1.0);
-            v = (float)((double)v + (d - (double)v) * (1.0 / (double)cn));
-          }
-          lmax = fmaxf(lmax, v);
-          lany = 1;
-        }
-        const int row = kImg - 1 - c / kImg, col = c % kImg;
-        S.raster[row * kImg + col] = v;
-        S.raster[kPix + row * kImg + col] = cnt > 0 ? 1.f : 0.f;  // nonzero mask
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        lany |= __shfl_xor(lany, o);
-      }
-      __syncthreads();
-      if ((tid & 63) == 0) {
-        S.red_f[tid >> 6] = lmax;
-        S.red_i[tid >> 6] = lany;
-      }
-      __syncthreads();
-      float gmax = -FLT_MAX;
-      int gany = 0;
-#pragma unroll
-      for (int w = 0; w < IMG_THREADS / 64; w++) {
-        gmax = fmaxf(gmax, S.red_f[w]);
-        gany |= S.red_i[w];
-      }
-      // minMaxLoc with mask -> max (0 if the mask is empty); image = max_img - image
-      const double mxd = gany ? (double)gmax : 0.0;
-      __syncthreads();
-      for (int p = tid; p < kPix; p += IMG_THREADS) {
-        const float m = S.raster[kPix + p] != 0.f ? (float)mxd : 0.0f;
-        S.raster[p] = m - S.raster[p];
-      }
-      __syncthreads();
-      finalize_channels<1>(S, out, K.C, ch0 + 4);
-    }
+    TICK(7);
+    finalize_channels<3>(S, &S.raster[0][0], out + (size_t)(pr * K.per) * kPix);
+    if (K.C >= 12) finalize_channels<1>(S, reinterpret_cast<const float *>(S.cells), out + (size_t)(pr * K.per + 3) * kPix);
+    TICK(8);
   }
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
 
+// planar [n][C][3600] <-> HWC [n][3600][C] (cv::Mat CV_8UC(C), the reference's image layout)
+__global__ void planar_to_hwc_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int C, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t per = (size_t)kPix * C;
+  const size_t img = i / per, r = i - img * per;
+  const int pix = (int)(r / C), c = (int)(r - (size_t)pix * C);
+  dst[i] = src[img * per + (size_t)c * kPix + pix];
+}
+__global__ void hwc_to_planar_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int C, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t per = (size_t)kPix * C;
+  const size_t img = i / per, r = i - img * per;
+  const int c = (int)(r / kPix), pix = (int)(r - (size_t)c * kPix);
+  dst[i] = src[img * per + (size_t)pix * C + c];
+}
+hipError_t planar_to_hwc(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream) {
+  const size_t total = (size_t)n * kPix * C;
+  if (!total) return hipSuccess;
+  planar_to_hwc_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(src, dst, C, total);
+  return hipGetLastError();
+}
+hipError_t hwc_to_planar(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream) {
+  const size_t total = (size_t)n * kPix * C;
+  if (!total) return hipSuccess;
+  hwc_to_planar_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(src, dst, C, total);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+// smallest positive double x with floor((x/len)/(1.0/60)) >= k — the exact image of the
+// reference's cell formula (image_strategy.cpp:92-102 applied to transformPointsToUnitImage's
+// quotient, :72-90), found by bisection on the bit pattern with the same IEEE operations.
+static double cell_threshold(double len, int k) {
+  const double cellsize = 1.0 / (double)kImg;
+  auto f = [&](double x) { return std::floor((x / len) / cellsize) >= (double)k; };
+  uint64_t lo = 0, hi;  // f(bits lo) false, f(bits hi) true
+  double top = len * 2.0;
+  std::memcpy(&hi, &top, sizeof(hi));
+  while (hi - lo > 1) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    double x;
+    std::memcpy(&x, &mid, sizeof(x));
+    if (f(x))
+      hi = mid;
+    else
+      lo = mid;
+  }
+  double x;
+  std::memcpy(&x, &hi, sizeof(x));
+  return x;
+}
+
+void image_cell_thresholds(double len, double *out) {
+  out[0] = 0.0;
+  for (int k = 1; k < kImg; k++) out[k] = cell_threshold(len, k);
+  out[kImg] = DBL_MAX;
+}
+
 void images_free(ImageState &im) {
-  void *ptrs[] = {im.d_images, im.d_hands, im.d_cand_meta, im.d_status};
+  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   im = ImageState();
@@ -585,10 +745,11 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   im.num_candidates = n;
   if (n == 0) return GPD_OK;
   if (n > im.capacity) {
-    if (im.d_images) (void)hipFree(im.d_images);
-    if (im.d_hands) (void)hipFree(im.d_hands);
-    if (im.d_cand_meta) (void)hipFree(im.d_cand_meta);
+    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta};
+    for (void *q : ptrs)
+      if (q) (void)hipFree(q);
     im.d_images = nullptr;
+    im.d_images_hwc = nullptr;
     im.d_hands = nullptr;
     im.d_cand_meta = nullptr;
     im.capacity = 0;
@@ -618,6 +779,13 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   k.voxel_mult = 1.0 / 0.003;
   k.rand_inv = 1.0 / 32767.0;
   k.num_shadow = (int)std::floor(k.shadow_length / k.voxel);
+  k.len[0] = k.vol_depth;
+  k.len[1] = k.vol_width;
+  k.len[2] = k.dbl_h;
+  for (int a = 0; a < 3; a++) {
+    k.inv_cell[a] = (double)kImg / k.len[a];
+    image_cell_thresholds(k.len[a], k.thr[a]);
+  }
   {  // affine map of IMG_THREADS * num_shadow LCG steps
     uint32_t a = 214013u, cc = 2531011u, A = 1u, Cc = 0u;
     unsigned long long nsteps = (unsigned long long)IMG_THREADS * (unsigned)k.num_shadow;
@@ -633,7 +801,8 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
     k.stride_a = A;
     k.stride_c = Cc;
   }
-  HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_img), &k, sizeof(k), 0, hipMemcpyHostToDevice, stream));
+  HIP_RET(hipStreamSynchronize(stream));
+  HIP_RET(hipMemcpyToSymbol(HIP_SYMBOL(c_img), &k, sizeof(k), 0, hipMemcpyHostToDevice));
   return images_launch(s, im, stream, true);
 }
 
@@ -649,15 +818,34 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
   ip.meta = im.d_cand_meta;
   ip.images = im.d_images;
   ip.status = im.d_status;
+  static unsigned long long *d_dbg = nullptr;
+  ip.dbg = nullptr;
+  if (getenv("GPD_IMG_TIMING")) {
+    if (!d_dbg) HIP_RET(hipMalloc(&d_dbg, 16 * sizeof(unsigned long long)));
+    HIP_RET(hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), stream));
+    ip.dbg = d_dbg;
+  }
   grasp_image_kernel<<<n, IMG_THREADS, 0, stream>>>(ip);
   HIP_RET(hipGetLastError());
+  if (ip.dbg) {
+    unsigned long long h[16];
+    HIP_RET(hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+    static const char *names[9] = {"shadow_gen",  "sh_list_cells",   "sh_count_place", "sh_walk",  "sh_final",
+                                   "pts_collect", "pts_count_place", "pts_walk",       "pts_final"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 9; i++) tot += h[i];
+    for (int i = 0; i < 9; i++)
+      fprintf(stderr, "[img-timing] %-16s %10.1f kcycles/cand  %5.1f%%\n", names[i], (double)h[i] / n / 1e3,
+              100.0 * h[i] / (double)tot);
+  }
   if (!check) return GPD_OK;
   int32_t status = 0;
   HIP_RET(hipMemcpyAsync(&status, im.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   HIP_RET(hipStreamSynchronize(stream));
   if (status) {
     set_error("images: kernel capacity exceeded (flags %d: 1 voxel AABB, 2 in-box points > %d, 4 shadow voxels > %d)", status,
-              PLACE_CAP, PLACE_CAP);
+              PT_CAP, SH_CAP);
     return GPD_ERR_CAPACITY;
   }
   return GPD_OK;

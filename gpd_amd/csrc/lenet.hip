@@ -10,7 +10,7 @@
 // used for FC1 is bitwise such a chain (cdna_hip_programming.md §3).
 //
 // Kernels:
-//   conv1_pool   u8 HWC image -> LDS (planar u8) -> direct 5x5 conv, weights as
+//   conv1_pool   planar u8 image -> LDS -> direct 5x5 conv, weights as
 //                wave-uniform scalars, 2x2 max-pool fused        -> pool1 [n][20][28][28]
 //   conv2_pool   pool1 plane set in LDS (62.7 KB) -> direct conv + pool, output in the
 //                reference's flatten order j = pixel*50 + channel -> flat  [n][7200]
@@ -32,16 +32,10 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(const uint8_t *__restri
   __shared__ __attribute__((aligned(16))) uint8_t s_in[C * kPix];  // planar [c][y][x]
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(images + (size_t)img * kPix * C);
-  for (int i = tid; i < kPix * C / 4; i += 256) {
-    uint32_t v = src[i];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      int e = 4 * i + q;
-      int pix = e / C, c = e - pix * C;
-      s_in[c * kPix + pix] = (uint8_t)(v >> (8 * q));
-    }
-  }
+  // planar u8 image [C][60][60] -> LDS, 16 bytes per lane
+  const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)img * kPix * C);
+  uint4 *dst = reinterpret_cast<uint4 *>(s_in);
+  for (int i = tid; i < kPix * C / 16; i += 256) dst[i] = src[i];
   __syncthreads();
   const int fg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
