@@ -65,6 +65,8 @@ struct ImgConsts {
   double len[3];                // box extent per hand axis: vol_depth, vol_width, dbl_h
   double inv_cell[3];           // approximate cells per metre (first guess only)
   double thr[3][kImg + 1];      // thr[a][k] = smallest x with floor((x/len[a])/(1/60)) >= k
+  double inv_len[3];            // RN(1/len[a]) for the division by a constant below
+  int true_div;                 // 1: the host self-check of div_len failed for these extents, divide for real
 };
 __constant__ ImgConsts c_img;
 
@@ -105,6 +107,7 @@ struct Smem {
   uint32_t cells[kPix];   // (segment start << 16) | count; reused as the f32 depth plane
   uint16_t place[SH_CAP];
   double thr[3][kImg + 1];
+  double recip[256];  // 1.0 / k
   float red_f[2 * IMG_WAVES];
   int red_i[IMG_WAVES];
   int vorg[3];
@@ -146,6 +149,23 @@ __device__ inline int cell_of_key(uint32_t key, int pr) {
   return h + v * kImg;
 }
 __device__ inline int depth_axis(int pr) { return pr == 0 ? 2 : (pr == 1 ? 0 : 1); }
+
+// x / len[axis], correctly rounded, without a division: q = x*y, r = x - len*q (exact, FMA),
+// q' = q + r*y with y = RN(1/len) (Markstein).  Bit-identical to the IEEE quotient for the
+// image extents; images_run() checks that on the host and falls back to a real division.
+__device__ inline double div_len(double x, int axis) {
+  const ImgConsts &K = c_img;
+  if (K.true_div) return x / K.len[axis];
+  const double y = K.inv_len[axis];
+  const double q = x * y;
+  const double r = __builtin_fma(-K.len[axis], q, x);
+  return __builtin_fma(r, y, q);
+}
+// 1.0 / (double)count for the running means (image_strategy.cpp:170, 206)
+__device__ inline double recip_count(const double *tab, float fc) {
+  const int k = (int)fc;
+  return k < 256 ? tab[k] : 1.0 / (double)fc;
+}
 
 __device__ inline uint32_t lcg_step(uint32_t &s) {  // HandSet::fastrand (hand_set.cpp:263-266)
   s = 214013u * s + 2531011u;
@@ -359,6 +379,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   B.lo[2] = -1.0 * K.vol_height;
   B.hi[2] = K.vol_height;
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
+  for (int i = tid; i < 256; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
   if (tid == 0) {
     S.flag = 0;
     S.counter = 0;
@@ -396,11 +417,33 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       const unsigned long long off = ((unsigned long long)(uint32_t)off_hi << 32) | off_lo;
       uint32_t state = lcg_jump(0u, off + (unsigned long long)tid * (unsigned)K.num_shadow);
       int bad = 0;
+      // conservative f32 pre-test: a draw whose f32 position is outside the box grown by one
+      // voxel diagonal (the voxel point is within 3 mm per axis of the draw) cannot pass the
+      // exact f64 test below, so most draws never reach it.
+      float Ff[9], sf[3], vf[3], lof[3], hif[3];
+      const float grow = 0.0054f;
+      for (int q = 0; q < 9; q++) Ff[q] = (float)B.F[q];
+      for (int q = 0; q < 3; q++) {
+        sf[q] = (float)B.sample[q];
+        vf[q] = (float)vec[q];
+        lof[q] = (float)B.lo[q] - grow;
+        hif[q] = (float)B.hi[q] + grow;
+      }
       for (int i = tid; i < N; i += IMG_THREADS) {
-        const double p0 = (double)nn[0 * P.cap + i], p1 = (double)nn[1 * P.cap + i], p2 = (double)nn[2 * P.cap + i];
+        const float pf0 = nn[0 * P.cap + i], pf1 = nn[1 * P.cap + i], pf2 = nn[2 * P.cap + i];
+        const double p0 = (double)pf0, p1 = (double)pf1, p2 = (double)pf2;
+        const float cf0 = pf0 - sf[0], cf1 = pf1 - sf[1], cf2 = pf2 - sf[2];
+        // hand-frame start and direction of the shadow ray, f32
+        const float b0 = Ff[0] * cf0 + Ff[3] * cf1 + Ff[6] * cf2, d0 = Ff[0] * vf[0] + Ff[3] * vf[1] + Ff[6] * vf[2];
+        const float b1 = Ff[1] * cf0 + Ff[4] * cf1 + Ff[7] * cf2, d1 = Ff[1] * vf[0] + Ff[4] * vf[1] + Ff[7] * vf[2];
+        const float b2 = Ff[2] * cf0 + Ff[5] * cf1 + Ff[8] * cf2, d2 = Ff[2] * vf[0] + Ff[5] * vf[1] + Ff[8] * vf[2];
         uint32_t st = state;
         for (int k = 0; k < K.num_shadow; k++) {
-          const double t = (double)(int)lcg_step(st) * K.rand_inv;
+          const int rnd = (int)lcg_step(st);
+          const float tf = (float)rnd * (1.0f / 32767.0f);
+          const float h0 = b0 + tf * d0, h1 = b1 + tf * d1, h2 = b2 + tf * d2;
+          if (!(h0 > lof[0] && h0 < hif[0] && h1 > lof[1] && h1 < hif[1] && h2 > lof[2] && h2 < hif[2])) continue;
+          const double t = (double)rnd * K.rand_inv;
           const int vx = (int)((p0 + t * vec[0]) * K.voxel_mult);
           const int vy = (int)((p1 + t * vec[1]) * K.voxel_mult);
           const int vz = (int)((p2 + t * vec[2]) * K.voxel_mult);
@@ -486,9 +529,9 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
             const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
                          c2 = (double)(iz + z0) * K.voxel - B.sample[2];
             const double td = B.F[da] * c0 + B.F[3 + da] * c1 + B.F[6 + da] * c2;
-            const double d = (td - B.off[da]) / K.len[da];
+            const double d = div_len(td - B.off[da], da);
             fc = (float)((double)fc + 1.0);
-            v = (float)((double)v + (d - (double)v) * (1.0 / (double)fc));
+            v = (float)((double)v + (d - (double)v) * recip_count(S.recip, fc));
           }
           lmax = fmaxf(lmax, v);
           lany = 1;
@@ -601,9 +644,9 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
             v1 = v1 + (float)((double)d1 * inv);
             v2 = v2 + (float)((double)d2 * inv);
           }
-          const double d = (S.u.p.t[da][e] - B.off[da]) / K.len[da];
+          const double d = div_len(S.u.p.t[da][e] - B.off[da], da);
           fc = (float)((double)fc + 1.0);
-          avg = (float)((double)avg + (d - (double)avg) * (1.0 / (double)fc));
+          avg = (float)((double)avg + (d - (double)avg) * recip_count(S.recip, fc));
         }
         pix = (float)(1.0 - (double)avg);
       }
@@ -782,9 +825,24 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   k.len[0] = k.vol_depth;
   k.len[1] = k.vol_width;
   k.len[2] = k.dbl_h;
+  k.true_div = 0;
   for (int a = 0; a < 3; a++) {
     k.inv_cell[a] = (double)kImg / k.len[a];
     image_cell_thresholds(k.len[a], k.thr[a]);
+    k.inv_len[a] = 1.0 / k.len[a];
+    // self-check of div_len(): the FMA sequence must reproduce the IEEE quotient
+    uint64_t rs = 88172645463325252ull;
+    for (int i = 0; i < 200000 && !k.true_div; i++) {
+      rs ^= rs << 13;
+      rs ^= rs >> 7;
+      rs ^= rs << 17;
+      double x = (double)(rs >> 11) * (1.0 / 9007199254740992.0) * k.len[a];
+      if (i & 1) x = (double)(float)x;
+      if (i < kImg) x = k.thr[a][i];
+      const double q = x * k.inv_len[a];
+      const double r = std::fma(-k.len[a], q, x);
+      if (std::fma(r, k.inv_len[a], q) != x / k.len[a]) k.true_div = 1;
+    }
   }
   {  // affine map of IMG_THREADS * num_shadow LCG steps
     uint32_t a = 214013u, cc = 2531011u, A = 1u, Cc = 0u;

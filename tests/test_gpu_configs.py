@@ -1,0 +1,161 @@
+"""BASELINE.json configs on the GPU against the oracle (configs[1..4]) plus edge cases and
+error behaviour of the C-ABI.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from gpd_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(C):
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden", "lenet%d_params.npz" % C)
+    return synth.lenet_weights(C, real=dict(np.load(g)) if os.path.exists(g) else None)
+
+
+def _full_compare(oracle_mod, cl, si, C, max_cand=None):
+    w = _weights(C)
+    ctx = api.Context(api.default_params(C))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+        hands, n_cand = ctx.detect(si)
+        p = oracle_mod.default_params(C)
+        ohands, on_cand, _ = oracle_mod.detect(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, w)
+        assert n_cand == on_cand
+        assert np.array_equal(hands["valid"], ohands["valid"])
+        v = ohands["valid"].astype(bool)
+        for f in ("finger_placement_index", "half_antipodal", "full_antipodal"):
+            assert np.array_equal(hands[f][v], ohands[f][v]), f
+        for f in ("frame", "position", "top", "bottom", "center", "grasp_width"):
+            assert np.allclose(hands[f][v], ohands[f][v], rtol=1e-12, atol=1e-15), f
+        err = np.abs(hands["score"][v] - ohands["score"][v]).max()
+        assert err <= 1e-4, err
+        return n_cand, float(err)
+    finally:
+        ctx.close()
+
+
+def test_config2_30k_cloud_5000_candidates(oracle_mod, cloud30k):
+    """configs[1]: single 30k-point cloud, ~5000 candidates, 15 channels, full oracle comparison."""
+    si = synth.sample_indices(cloud30k, 2200)
+    n, err = _full_compare(oracle_mod, cloud30k, si, 15)
+    assert n > 4500
+
+
+@pytest.mark.parametrize("C", [3, 12])
+def test_config3_other_image_geometries(oracle_mod, cloud30k, C):
+    """configs[2]: 3- and 12-channel geometries on the same cloud."""
+    si = synth.sample_indices(cloud30k, 500)
+    n, err = _full_compare(oracle_mod, cloud30k, si, C)
+    assert n > 1000
+
+
+def test_config4_dense_clutter_300k(oracle_mod):
+    """configs[3]: 300k-point clutter cloud, tens of thousands of candidates (single-GPU stress)."""
+    cl = synth.make_cloud(1234, 300000, clutter=True)
+    si = synth.sample_indices(cl, 9000)
+    n, err = _full_compare(oracle_mod, cl, si, 15)
+    assert n > 25000
+
+
+def test_config5_batch_of_clouds_one_context(oracle_mod):
+    """configs[4] on one GPU: independent clouds through one context, results independent of order."""
+    w = _weights(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        p = oracle_mod.default_params(15)
+        first = None
+        for cid in (0, 1, 2, 0):
+            cl = synth.make_cloud(1234 + cid, 30000)
+            si = synth.sample_indices(cl, 120)
+            ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+            hands, n = ctx.detect(si)
+            oh, on, _ = oracle_mod.detect(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, w)
+            assert n == on and np.array_equal(hands["valid"], oh["valid"])
+            v = oh["valid"].astype(bool)
+            assert np.abs(hands["score"][v] - oh["score"][v]).max() <= 1e-4
+            if cid == 0:
+                if first is None:
+                    first = hands.copy()
+                else:  # the shadow LCG restarts per cloud: same cloud -> same bytes
+                    assert first.tobytes() == hands.tobytes()
+    finally:
+        ctx.close()
+
+
+def test_replay_is_idempotent_and_matches_detect(cloud30k):
+    w = _weights(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"], cloud30k["view_points"])
+        si = synth.sample_indices(cloud30k, 300)
+        hands, n = ctx.detect(si)
+        want = hands["score"][hands["valid"].astype(bool)]
+        for _ in range(3):
+            ctx.replay(3)
+        _, _, launches, sc = ctx.replay_times(n_scores=n)
+        assert launches == 3 and np.array_equal(sc, want)
+    finally:
+        ctx.close()
+
+
+def test_edge_cases_and_errors(oracle_mod, cloud30k):
+    w = _weights(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        with pytest.raises(api.GpdHipError):  # no cloud yet
+            ctx.search(np.array([0], np.int32))
+        with pytest.raises(api.GpdHipError):  # no weights yet
+            ctx.score(np.zeros((1, 60, 60, 15), np.uint8))
+        ctx.set_lenet_weights(w)
+        assert len(ctx.score(np.zeros((0, 60, 60, 15), np.uint8))) == 0
+        # all-zero / all-255 images
+        img = np.zeros((2, 60, 60, 15), np.uint8)
+        img[1] = 255
+        assert np.array_equal(ctx.score(img), oracle_mod.lenet(img, w))
+        ctx.upload_cloud(cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"], cloud30k["view_points"])
+        assert ctx.search(np.zeros(0, np.int32)).shape == (0, 8)
+        with pytest.raises(api.GpdHipError):  # index out of range
+            ctx.search(np.array([len(cloud30k["xyz"])], np.int32))
+        # a table point has no graspable geometry: a set without valid hands yields no image
+        tab = np.flatnonzero(~cloud30k["is_object"])[:3].astype(np.int32)
+        hands = ctx.search(tab)
+        oh = oracle_mod.search(oracle_mod.default_params(15), cloud30k["xyz"], cloud30k["normals"], tab)
+        assert np.array_equal(hands["valid"], oh["valid"])
+        hands["valid"] = 0
+        img, cand = ctx.images(hands)
+        assert img.shape[0] == 0 and len(cand) == 0
+        # a single sample
+        one = synth.sample_indices(cloud30k, 1)
+        h1, n1 = ctx.detect(one)
+        o1, on1, _ = oracle_mod.detect(oracle_mod.default_params(15), cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"],
+                                       cloud30k["view_points"], one, w)
+        assert n1 == on1 and np.array_equal(h1["valid"], o1["valid"])
+        # weights of the wrong geometry are refused
+        with pytest.raises(AssertionError):
+            ctx.set_lenet_weights(_weights(3))
+    finally:
+        ctx.close()
+
+
+def test_tiny_cloud(oracle_mod):
+    """A cloud smaller than one workgroup's stride and a sample whose neighbourhood is the whole cloud."""
+    rng = np.random.RandomState(3)
+    xyz = (np.round(rng.rand(50, 3) * 0.02 / 0.003) * 0.003).astype(np.float32)
+    xyz = np.unique(xyz, axis=0)
+    nrm = rng.randn(len(xyz), 3)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    ctx = api.Context(api.default_params(12))
+    try:
+        ctx.upload_cloud(xyz, nrm)
+        si = np.arange(min(5, len(xyz)), dtype=np.int32)
+        hands = ctx.search(si)
+        oh = oracle_mod.search(oracle_mod.default_params(12), xyz, nrm, si)
+        assert np.array_equal(hands["valid"], oh["valid"])
+        assert np.allclose(hands["frame"], oh["frame"], rtol=1e-12, atol=1e-15)
+    finally:
+        ctx.close()
