@@ -18,6 +18,7 @@ constexpr int kFc1Out = 500;
 struct LeNetWeights {
   int channels = 0;
   float *c1w = nullptr, *c1b = nullptr, *c2w = nullptr, *c2b = nullptr;
+  float *c1wt = nullptr, *c2wt = nullptr;  // k-major copies [K][F] for the implicit-GEMM A operand
   float *f1w = nullptr, *f1b = nullptr, *f2w = nullptr, *f2b = nullptr;
 };
 

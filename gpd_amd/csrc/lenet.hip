@@ -10,10 +10,11 @@
 // used for FC1 is bitwise such a chain (cdna_hip_programming.md §3).
 //
 // Kernels:
-//   conv1_pool   planar u8 image -> LDS -> direct 5x5 conv, weights as
-//                wave-uniform scalars, 2x2 max-pool fused        -> pool1 [n][20][28][28]
-//   conv2_pool   pool1 plane set in LDS (62.7 KB) -> direct conv + pool, output in the
-//                reference's flatten order j = pixel*50 + channel -> flat  [n][7200]
+//   conv1_mfma   planar u8 images + k-major weights in LDS -> implicit GEMM on f32 MFMA,
+//                2x2 max-pool fused                              -> pool1 [n][20][28][28]
+//   conv2_mfma   pool1 plane set in LDS (62.7 KB), weights streamed in channel-pair chunks,
+//                implicit GEMM + pool, output in the reference's flatten order
+//                j = pixel*50 + channel                          -> flat  [n][7200]
 //   fc1_mfma     [500 x 7200] x [7200 x n] on v_mfma_f32_32x32x2_f32, + bias, ReLU
 //                                                               -> fc1t  [500][n]
 //   fc2_score    2 x 500 chains per image, score = y1 - y0       -> scores[n]
@@ -24,130 +25,202 @@ namespace gpd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------
-// conv1 + pool1.  One workgroup per image, wave w <-> filters 5w..5w+4.
+// Convolutions as implicit GEMMs on v_mfma_f32_32x32x2_f32:  D[f][pix] = sum_k W[f][k] X[k][pix],
+// k = c*25 + kh*5 + kw ascending — the MFMA accumulates k, k+1 in order, so each output is
+// still the oracle's fmaf chain (cdna_hip_programming.md §3, "bit-for-bit a k-ordered chain").
+//   A operand (lane l): W[f = l&31][k0 + (l>>5)]   (weights, k-major copy in LDS, rows >= F read
+//                                                    a clamped row and their outputs are dropped)
+//   B operand (lane l): X[k0 + (l>>5)][pix = l&31] (image/pool1 planes in LDS)
+//   D (lane l, reg r):  pixel l&31, filter (r&3) + 8*(r>>2) + 4*(l>>5)
+// A pixel tile is 4 rows x 8 columns of conv outputs, so the 2x2 max-pool is two lane
+// exchanges (xor 1, xor 8).  max(a_i + b) == max(a_i) + b (rounding is monotone).
 // ---------------------------------------------------------------------------
+__device__ inline int tap_offset(int k_rel, int plane, int row_stride) {  // k_rel in [0, 50): (channel, kh, kw) of a channel pair
+  const int c = k_rel / 25, tap = k_rel - c * 25;
+  return c * plane + (tap / 5) * row_stride + tap % 5;
+}
+
+__device__ inline f32x16 pool_lanes(f32x16 v) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    float x = v[r];
+    x = fmaxf(x, __shfl_xor(x, 1));
+    x = fmaxf(x, __shfl_xor(x, 8));
+    v[r] = x;
+  }
+  return v;
+}
+
+// conv1 + pool1.  Two images per workgroup (8 waves = 2 per SIMD: the second wave's MFMAs fill
+// the issue gaps of the first), weights [K][20] f32 + both u8 images in LDS.  The compiler
+// hoists each lane's 188 weight values into registers across the tile loop.
+// (Tried on MI355X and slower: one wave per SIMD with two accumulators, and explicit operand
+// prefetch groups pinned with sched_barrier — DESIGN.md §9.)
+constexpr int C1_THREADS = 512;
 template <int C>
-__global__ __launch_bounds__(256) void conv1_pool_kernel(const uint8_t *__restrict__ images, const float *__restrict__ w,
-                                                         const float *__restrict__ b, float *__restrict__ out, int n) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_in[C * kPix];  // planar [c][y][x]
-  const int img = blockIdx.x;
+__global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wt,
+                                                                const float *__restrict__ bias, float *__restrict__ out, int n) {
+  constexpr int K = 25 * C, KP = (K + 1) & ~1;
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
+  __shared__ __attribute__((aligned(16))) float s_w[KP * 20];
   const int tid = threadIdx.x;
-  // planar u8 image [C][60][60] -> LDS, 16 bytes per lane
-  const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)img * kPix * C);
-  uint4 *dst = reinterpret_cast<uint4 *>(s_in);
-  for (int i = tid; i < kPix * C / 16; i += 256) dst[i] = src[i];
+  const int img0 = blockIdx.x * 2;
+  for (int q = 0; q < 2; q++) {
+    const int img = min(img0 + q, n - 1);
+    const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)img * kPix * C);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_img[q]);
+    for (int i = tid; i < kPix * C / 16; i += C1_THREADS) dst[i] = src[i];
+  }
+  for (int i = tid; i < KP * 20; i += C1_THREADS) s_w[i] = i < K * 20 ? wt[i] : 0.f;
   __syncthreads();
-  const int fg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const float *__restrict__ wf = w + (size_t)fg * 5 * C * 25;
-  for (int chunk = 0; chunk < 13; chunk++) {
-    const int p = chunk * 64 + lane;
-    const bool act = p < 784;
-    const int pp = act ? p : 0;
-    const int py = pp / 28, px = pp - py * 28;
-    float acc[5][4];
+  const int half = lane >> 5, j = lane & 31;
+  const int fcl = j < 20 ? j : 19;
+  for (int t = wave; t < 2 * 98; t += C1_THREADS / 64) {
+    const int q = t / 98, tt = t - q * 98;
+    const int ty = tt / 7, tx = tt - ty * 7;
+    const uint8_t *xin = s_img[q] + (4 * ty + (j >> 3)) * kImg + 8 * tx + (j & 7);
+    f32x16 acc;
 #pragma unroll
-    for (int f = 0; f < 5; f++)
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int cp = 0; cp < C / 2; cp++) {
+      const uint8_t *xc = xin + cp * 2 * kPix;
+      const float *wc = s_w + cp * 50 * 20 + fcl;
 #pragma unroll
-      for (int q = 0; q < 4; q++) acc[f][q] = 0.f;
-    const uint8_t *base = s_in + (2 * py) * kImg + 2 * px;
-    for (int c = 0; c < C; c++) {
-      float patch[6][6];
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          uint16_t v = *reinterpret_cast<const uint16_t *>(base + c * kPix + r * kImg + 2 * q);
-          patch[r][2 * q] = (float)(v & 0xff);
-          patch[r][2 * q + 1] = (float)(v >> 8);
-        }
-      }
-#pragma unroll
-      for (int kh = 0; kh < 5; kh++) {
-#pragma unroll
-        for (int kw = 0; kw < 5; kw++) {
-#pragma unroll
-          for (int f = 0; f < 5; f++) {
-            const float wv = wf[(f * C + c) * 25 + kh * 5 + kw];
-            acc[f][0] = __builtin_fmaf(wv, patch[kh][kw], acc[f][0]);
-            acc[f][1] = __builtin_fmaf(wv, patch[kh][kw + 1], acc[f][1]);
-            acc[f][2] = __builtin_fmaf(wv, patch[kh + 1][kw], acc[f][2]);
-            acc[f][3] = __builtin_fmaf(wv, patch[kh + 1][kw + 1], acc[f][3]);
-          }
-        }
+      for (int p = 0; p < 25; p++) {
+        const int boff = half ? tap_offset(2 * p + 1, kPix, kImg) : tap_offset(2 * p, kPix, kImg);
+        const float a = wc[(2 * p + half) * 20];
+        const float b = (float)xc[boff];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
     }
-    if (act) {
+    if (C & 1) {  // last channel: 25 taps = 12 pairs + one tap paired with the zero row k = K
+      const uint8_t *xc = xin + (C - 1) * kPix;
+      const float *wc = s_w + (C - 1) * 25 * 20 + fcl;
 #pragma unroll
-      for (int f = 0; f < 5; f++) {
-        // max(a_i + b) == max(a_i) + b: rounding is monotone
-        float m = fmaxf(fmaxf(acc[f][0], acc[f][1]), fmaxf(acc[f][2], acc[f][3])) + b[fg * 5 + f];
-        out[((size_t)img * 20 + fg * 5 + f) * 784 + p] = m;
+      for (int p = 0; p < 13; p++) {
+        const int k_rel = 2 * p + half;  // 0..25
+        const int kk = k_rel < 25 ? k_rel : 24;
+        const int boff = (kk / 5) * kImg + kk % 5;
+        const float a = wc[k_rel * 20];
+        const float b = (float)xc[boff];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+    }
+    acc = pool_lanes(acc);
+    const int img = img0 + q;
+    if (img < n && !(j & 1) && !(j & 8)) {
+      const int py = 2 * ty + (j >> 4), px = 4 * tx + ((j & 7) >> 1);
+      float *o = out + (size_t)img * 20 * 784 + py * 28 + px;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (f < 20) o[f * 784] = acc[r] + bias[f];
       }
     }
   }
 }
 
-// ---------------------------------------------------------------------------
-// conv2 + pool2.  One workgroup per image; a wave task = (filter group of 5,
-// 64-pixel chunk of the 144 pooled pixels); 30 tasks over 4 waves.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv2_pool_kernel(const float *__restrict__ pool1, const float *__restrict__ w,
-                                                         const float *__restrict__ b, float *__restrict__ flat, int n) {
+// conv2 + pool2.  One image per workgroup (4 waves).  The 100 KB of weights do not fit next to
+// the 62.7 KB input planes, so K is walked in channel-pair chunks (50 taps x 50 filters = 10 KB,
+// double-buffered) and every wave keeps its 9 (pixel tile, filter tile) accumulators live across
+// the chunks — k still ascends within each accumulator.
+__global__ __launch_bounds__(256) void conv2_mfma_kernel(const float *__restrict__ pool1, const float *__restrict__ wt,
+                                                         const float *__restrict__ bias, float *__restrict__ flat, int n) {
   __shared__ __attribute__((aligned(16))) float s_in[20 * 784];
+  __shared__ __attribute__((aligned(16))) float s_w[2][50 * 50];
   const int img = blockIdx.x;
   const int tid = threadIdx.x;
-  const float4 *src = reinterpret_cast<const float4 *>(pool1 + (size_t)img * 20 * 784);
-  float4 *dst = reinterpret_cast<float4 *>(s_in);
-  for (int i = tid; i < 20 * 784 / 4; i += 256) dst[i] = src[i];
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(pool1 + (size_t)img * 20 * 784);
+    float4 *dst = reinterpret_cast<float4 *>(s_in);
+    for (int i = tid; i < 20 * 784 / 4; i += 256) dst[i] = src[i];
+    for (int i = tid; i < 2500; i += 256) s_w[0][i] = wt[i];
+  }
   __syncthreads();
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  for (int task = wv; task < 30; task += 4) {
-    const int fg = task / 3, chunk = task - fg * 3;
-    const int p = chunk * 64 + lane;
-    const bool act = p < 144;
-    const int pp = act ? p : 0;
-    const int py = pp / 12, px = pp - py * 12;
-    const float *__restrict__ wf = w + (size_t)fg * 5 * 500;
-    float acc[5][4];
+  const int half = lane >> 5, j = lane & 31;
+  int xoff[9], woff[9];
+  f32x16 acc[9];
 #pragma unroll
-    for (int f = 0; f < 5; f++)
+  for (int q = 0; q < 9; q++) {
+    const int pi = wave * 9 + q;  // 36 (pixel tile, filter tile) pairs per image
+    const int pt = pi >> 1, ft = pi & 1;
+    const int ty = pt / 3, tx = pt - ty * 3;
+    xoff[q] = (4 * ty + (j >> 3)) * 28 + 8 * tx + (j & 7);
+    const int f = ft * 32 + j;
+    woff[q] = f < 50 ? f : 49;
 #pragma unroll
-      for (int q = 0; q < 4; q++) acc[f][q] = 0.f;
-    const float *base = s_in + (2 * py) * 28 + 2 * px;
-    for (int c = 0; c < 20; c++) {
-      float patch[6][6];
+    for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+  }
+  for (int cp = 0; cp < 10; cp++) {
+    const int cur = cp & 1;
+    float nxt[10];
+    if (cp + 1 < 10) {
 #pragma unroll
-      for (int r = 0; r < 6; r++) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          float2 v = *reinterpret_cast<const float2 *>(base + c * 784 + r * 28 + 2 * q);
-          patch[r][2 * q] = v.x;
-          patch[r][2 * q + 1] = v.y;
-        }
-      }
-#pragma unroll
-      for (int kh = 0; kh < 5; kh++) {
-#pragma unroll
-        for (int kw = 0; kw < 5; kw++) {
-#pragma unroll
-          for (int f = 0; f < 5; f++) {
-            const float wvv = wf[f * 500 + c * 25 + kh * 5 + kw];
-            acc[f][0] = __builtin_fmaf(wvv, patch[kh][kw], acc[f][0]);
-            acc[f][1] = __builtin_fmaf(wvv, patch[kh][kw + 1], acc[f][1]);
-            acc[f][2] = __builtin_fmaf(wvv, patch[kh + 1][kw], acc[f][2]);
-            acc[f][3] = __builtin_fmaf(wvv, patch[kh + 1][kw + 1], acc[f][3]);
-          }
-        }
+      for (int u = 0; u < 10; u++) {
+        const int i = tid + u * 256;
+        nxt[u] = i < 2500 ? wt[(cp + 1) * 2500 + i] : 0.f;
       }
     }
-    if (act) {
+    const float *xc = s_in + cp * 2 * 784;
+    const float *wc = s_w[cur];
+    // operands of step p+1 are requested before the nine MFMAs of step p are issued
+    float a_cur[9], b_cur[9], a_nxt[9], b_nxt[9];
+    {
+      const int boff = half ? tap_offset(1, 784, 28) : tap_offset(0, 784, 28);
 #pragma unroll
-      for (int f = 0; f < 5; f++) {
-        float m = fmaxf(fmaxf(acc[f][0], acc[f][1]), fmaxf(acc[f][2], acc[f][3])) + b[fg * 5 + f];
-        // flatten: j = pixel*50 + channel (eigen_classifier.cpp:103-107)
-        flat[(size_t)img * kFc1In + p * 50 + fg * 5 + f] = m;
+      for (int q = 0; q < 9; q++) {
+        a_cur[q] = wc[half * 50 + woff[q]];
+        b_cur[q] = xc[xoff[q] + boff];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 25; p++) {
+      if (p + 1 < 25) {
+        const int boff = half ? tap_offset(2 * p + 3, 784, 28) : tap_offset(2 * p + 2, 784, 28);
+        const float *wrow = wc + (2 * p + 2 + half) * 50;
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+          a_nxt[q] = wrow[woff[q]];
+          b_nxt[q] = xc[xoff[q] + boff];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // next step's LDS reads stay ahead of this step's MFMAs
+#pragma unroll
+      for (int q = 0; q < 9; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q], b_cur[q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        a_cur[q] = a_nxt[q];
+        b_cur[q] = b_nxt[q];
+      }
+    }
+    if (cp + 1 < 10) {
+#pragma unroll
+      for (int u = 0; u < 10; u++) {
+        const int i = tid + u * 256;
+        if (i < 2500) s_w[cur ^ 1][i] = nxt[u];
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 9; q++) {
+    const int pi = wave * 9 + q;
+    const int pt = pi >> 1, ft = pi & 1;
+    const int ty = pt / 3, tx = pt - ty * 3;
+    f32x16 v = pool_lanes(acc[q]);
+    if (!(j & 1) && !(j & 8)) {
+      const int py = 2 * ty + (j >> 4), px = 4 * tx + ((j & 7) >> 1);
+      // flatten: index = pixel*50 + channel (eigen_classifier.cpp:103-107)
+      float *o = flat + (size_t)img * kFc1In + (py * 12 + px) * 50;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int f = ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (f < 50) o[f] = v[r] + bias[f];
       }
     }
   }
@@ -249,12 +322,12 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     const int m = (n - off < kChunk) ? (n - off) : kChunk;
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
     switch (w.channels) {
-      case 15: conv1_pool_kernel<15><<<m, 256, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m); break;
-      case 12: conv1_pool_kernel<12><<<m, 256, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m); break;
-      case 3: conv1_pool_kernel<3><<<m, 256, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m); break;
+      case 15: conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1b, s.pool1, m); break;
+      case 12: conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1b, s.pool1, m); break;
+      case 3: conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1b, s.pool1, m); break;
       default: return hipErrorInvalidValue;
     }
-    conv2_pool_kernel<<<m, 256, 0, stream>>>(s.pool1, w.c2w, w.c2b, s.flat, m);
+    conv2_mfma_kernel<<<m, 256, 0, stream>>>(s.pool1, w.c2wt, w.c2b, s.flat, m);
     dim3 g((kFc1Out + FC_BU - 1) / FC_BU, (m + FC_BM - 1) / FC_BM);
     fc1_mfma_kernel<<<g, 256, 0, stream>>>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity);
     fc2_score_kernel<<<(m + 255) / 256, 256, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
