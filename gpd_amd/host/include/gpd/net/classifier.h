@@ -1,0 +1,56 @@
+// net::Classifier — the reference's plugin surface (net/classifier.h:52-81) with a HIP back-end.
+// cv::Mat is absent here; `Image` carries what classifyImages reads from it (rows, cols,
+// channels, data pointer, continuity; eigen_classifier.cpp:64-74, 130-149).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+struct gpd_hip_ctx;
+
+namespace gpd {
+namespace net {
+
+struct Image {  // stand-in for cv::Mat CV_8UC(C), HWC interleaved
+  int rows = 0, cols = 0, channels_ = 0;
+  std::vector<uint8_t> data;
+  bool continuous = true;
+  Image() {}
+  Image(int r, int c, int ch) : rows(r), cols(c), channels_(ch), data((size_t)r * c * ch, 0) {}
+  bool isContinuous() const { return continuous; }
+  int channels() const { return channels_; }
+};
+
+class Classifier {
+ public:
+  enum class Device : uint8_t { eCPU = 0, eGPU = 1, eVPU = 2, eFPGA = 3 };
+  virtual ~Classifier() {}
+  // weights_file: the parameter directory ending in '/', as for EigenClassifier
+  // (eigen_classifier.cpp:28-50).  Only Device::eGPU exists in this build: asking for another
+  // device prints an error and returns nullptr (there is no CPU path behind this interface).
+  static std::shared_ptr<Classifier> create(const std::string &model_file, const std::string &weights_file,
+                                            Device device = Device::eGPU, int batch_size = 1);
+  virtual std::vector<float> classifyImages(const std::vector<std::unique_ptr<Image>> &image_list) = 0;
+  virtual int getBatchSize() const = 0;
+};
+
+class HipClassifier : public Classifier {
+ public:
+  HipClassifier(const std::string &model_file, const std::string &weights_file, Classifier::Device device, int batch_size);
+  ~HipClassifier() override;
+  std::vector<float> classifyImages(const std::vector<std::unique_ptr<Image>> &image_list) override;
+  int getBatchSize() const override { return batch_size_; }
+  bool ok() const { return ctx_ != nullptr && loaded_; }
+  // raw float32 parameter file -> vector (EigenClassifier::readBinaryFileIntoVector, :185-204)
+  static std::vector<float> readBinaryFileIntoVector(const std::string &location);
+
+ private:
+  gpd_hip_ctx *ctx_ = nullptr;
+  bool loaded_ = false;
+  int channels_ = 0;
+  int batch_size_ = 1;
+};
+
+}  // namespace net
+}  // namespace gpd

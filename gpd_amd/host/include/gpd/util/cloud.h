@@ -1,0 +1,43 @@
+// util::Cloud — the part of the reference's PCL wrapper that the hot path reads
+// (util/cloud.h: getCloudProcessed, getNormals, getCameraSource, getViewPoints,
+// getSampleIndices/setSampleIndices, subsample).  Preprocessing (voxelise, normal
+// estimation) is out of scope: clouds arrive with normals.
+#pragma once
+#include <string>
+#include <vector>
+
+namespace gpd {
+namespace util {
+
+class Cloud {
+ public:
+  Cloud() {}
+  // xyz / normals: 3 floats per point; camera_source: n_cams x P (0/1); view_points: 3 doubles per camera
+  Cloud(const std::vector<float> &xyz, const std::vector<float> &normals, const std::vector<int> &camera_source,
+        const std::vector<double> &view_points);
+  // ASCII PCD with FIELDS x y z [normal_x normal_y normal_z ...] (pcl::io::loadPCDFile, cloud.cpp:643-660)
+  Cloud(const std::string &filename, const std::vector<double> &view_points);
+
+  size_t size() const { return xyz_.size() / 3; }
+  bool hasNormals() const { return normals_.size() == xyz_.size() && !xyz_.empty(); }
+  const std::vector<float> &getCloudProcessed() const { return xyz_; }
+  const std::vector<float> &getNormals() const { return normals_; }
+  const std::vector<int> &getCameraSource() const { return camera_source_; }
+  const std::vector<double> &getViewPoints() const { return view_points_; }
+  int numCameras() const { return (int)(view_points_.size() / 3); }
+  const std::vector<int> &getSampleIndices() const { return sample_indices_; }
+  void setSampleIndices(const std::vector<int> &idx) { sample_indices_ = idx; }
+  void setNormals(const std::vector<float> &normals) { normals_ = normals; }
+  // Cloud::subsample (cloud.cpp:350-405) draws with pcl::RandomSample (time-seeded); here a
+  // seeded Fisher-Yates permutation so runs are reproducible.
+  void subsample(int num_samples, unsigned seed = 0);
+
+ private:
+  std::vector<float> xyz_, normals_;
+  std::vector<int> camera_source_;
+  std::vector<double> view_points_;
+  std::vector<int> sample_indices_;
+};
+
+}  // namespace util
+}  // namespace gpd

@@ -1,0 +1,539 @@
+// Host side of the drop-in: util::ConfigFile, util::Cloud, net::HipClassifier,
+// gpd::GraspDetector — the reference's classes re-hosted on libgpd_hip.so (include/gpd_hip.h).
+// Error convention of the reference: print + empty result (grasp_detector.cpp:201-205, 227-229).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <numeric>
+
+#include "gpd/grasp_detector.h"
+#include "gpd/util/config_file.h"
+
+namespace gpd {
+
+// ------------------------------------------------------------------ util::ConfigFile
+namespace util {
+
+static std::string trim(const std::string &s) {
+  const char *ws = " \t\r\n";
+  size_t a = s.find_first_not_of(ws);
+  if (a == std::string::npos) return "";
+  size_t b = s.find_last_not_of(ws);
+  return s.substr(a, b - a + 1);
+}
+
+bool ConfigFile::ExtractKeys() {  // config_file.cpp:76-104
+  std::ifstream file(fName_.c_str());
+  if (!file) {
+    std::cout << "Config file " + fName_ + " could not be found!\n";
+    return false;
+  }
+  std::string line;
+  size_t lineNo = 0;
+  while (std::getline(file, line)) {
+    lineNo++;
+    size_t hash = line.find('#');
+    if (hash != std::string::npos) line.erase(hash);
+    if (trim(line).empty()) continue;
+    size_t eq = line.find('=');
+    if (eq == std::string::npos) {
+      std::cout << "CFG: Bad format for line: " << lineNo << "\n";
+      continue;
+    }
+    std::string key = trim(line.substr(0, eq)), val = trim(line.substr(eq + 1));
+    if (key.empty()) {
+      std::cout << "CFG: Bad format for line: " << lineNo << "\n";
+      continue;
+    }
+    if (!keyExists(key)) contents_[key] = val;  // first definition wins, as the reference's map insert
+  }
+  return true;
+}
+
+std::string ConfigFile::getValueOfKeyAsString(const std::string &key, const std::string &defaultValue) const {
+  auto it = contents_.find(key);
+  return it == contents_.end() ? defaultValue : it->second;
+}
+std::vector<double> ConfigFile::getValueOfKeyAsStdVectorDouble(const std::string &key, const std::string &defaultValue) const {
+  std::stringstream ss(getValueOfKeyAsString(key, defaultValue));
+  std::vector<double> v;
+  double x;
+  while (ss >> x) v.push_back(x);
+  return v;
+}
+std::vector<int> ConfigFile::getValueOfKeyAsStdVectorInt(const std::string &key, const std::string &defaultValue) const {
+  std::stringstream ss(getValueOfKeyAsString(key, defaultValue));
+  std::vector<int> v;
+  double x;  // the reference parses ints through a double as well (config_file.cpp:154-167)
+  while (ss >> x) v.push_back((int)x);
+  return v;
+}
+
+// ------------------------------------------------------------------ util::Cloud
+Cloud::Cloud(const std::vector<float> &xyz, const std::vector<float> &normals, const std::vector<int> &camera_source,
+             const std::vector<double> &view_points)
+    : xyz_(xyz), normals_(normals), camera_source_(camera_source), view_points_(view_points) {
+  if (camera_source_.empty()) camera_source_.assign(size() * std::max(1, numCameras()), 1);
+}
+
+Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points) : view_points_(view_points) {
+  std::ifstream f(filename.c_str());
+  if (!f) {
+    printf("Couldn't read .pcd file: %s\n", filename.c_str());
+    return;
+  }
+  std::string line;
+  std::vector<std::string> fields;
+  bool ascii = false;
+  while (std::getline(f, line)) {
+    std::stringstream ss(line);
+    std::string tag;
+    ss >> tag;
+    if (tag == "FIELDS") {
+      std::string x;
+      while (ss >> x) fields.push_back(x);
+    } else if (tag == "DATA") {
+      std::string kind;
+      ss >> kind;
+      ascii = (kind == "ascii");
+      break;
+    }
+  }
+  if (!ascii) {
+    printf("Only ASCII .pcd files are supported: %s\n", filename.c_str());
+    return;
+  }
+  int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
+  for (int i = 0; i < (int)fields.size(); i++) {
+    if (fields[i] == "x") ix = i;
+    if (fields[i] == "y") iy = i;
+    if (fields[i] == "z") iz = i;
+    if (fields[i] == "normal_x") inx = i;
+    if (fields[i] == "normal_y") iny = i;
+    if (fields[i] == "normal_z") inz = i;
+  }
+  if (ix < 0 || iy < 0 || iz < 0) {
+    printf("PCD file has no x y z fields: %s\n", filename.c_str());
+    return;
+  }
+  std::vector<double> row(fields.size());
+  while (std::getline(f, line)) {
+    std::stringstream ss(line);
+    bool good = true;
+    for (size_t i = 0; i < fields.size(); i++)
+      if (!(ss >> row[i])) good = false;
+    if (!good || row[ix] != row[ix] || row[iy] != row[iy] || row[iz] != row[iz]) continue;  // removeNans
+    xyz_.push_back((float)row[ix]);
+    xyz_.push_back((float)row[iy]);
+    xyz_.push_back((float)row[iz]);
+    if (inx >= 0 && iny >= 0 && inz >= 0) {
+      normals_.push_back((float)row[inx]);
+      normals_.push_back((float)row[iny]);
+      normals_.push_back((float)row[inz]);
+    }
+  }
+  if (view_points_.empty()) view_points_.assign(3, 0.0);
+  camera_source_.assign(size() * numCameras(), 1);
+}
+
+void Cloud::subsample(int num_samples, unsigned seed) {
+  const int n = (int)size();
+  if (num_samples <= 0 || n == 0) return;
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  uint64_t s = 0x9E3779B97F4A7C15ull ^ seed;
+  const int m = std::min(num_samples, n);
+  for (int i = 0; i < m; i++) {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    std::swap(idx[i], idx[i + (int)(s % (uint64_t)(n - i))]);
+  }
+  idx.resize(m);
+  sample_indices_ = idx;
+}
+
+}  // namespace util
+
+// ------------------------------------------------------------------ candidate::Hand
+namespace candidate {
+void Hand::print() const {  // hand.cpp:66-79
+  auto p = getPosition(), a = getApproach(), b = getBinormal(), x = getAxis();
+  printf("position: %g %g %g\napproach: %g %g %g\nbinormal: %g %g %g\naxis: %g %g %g\nscore: %g\n", p[0], p[1], p[2], a[0], a[1],
+         a[2], b[0], b[1], b[2], x[0], x[1], x[2], getScore());
+  printf("full-antipodal: %d\nhalf-antipodal: %d\nclosing box:\n bottom: %g\n top: %g\n center: %g\n", isFullAntipodal(),
+         isHalfAntipodal(), getBottom(), getTop(), getCenter());
+}
+}  // namespace candidate
+
+// ------------------------------------------------------------------ net::Classifier
+namespace net {
+
+std::shared_ptr<Classifier> Classifier::create(const std::string &model_file, const std::string &weights_file, Device device,
+                                               int batch_size) {
+  if (device != Device::eGPU) {
+    printf("ERROR: this build only has the HIP classifier (device = 1); no CPU back-end is linked.\n");
+    return nullptr;
+  }
+  auto c = std::make_shared<HipClassifier>(model_file, weights_file, device, batch_size);
+  if (!c->ok()) return nullptr;
+  return c;
+}
+
+std::vector<float> HipClassifier::readBinaryFileIntoVector(const std::string &location) {
+  std::vector<float> vals;
+  std::ifstream file(location.c_str(), std::ios::binary | std::ios::in);
+  if (!file.is_open()) {
+    std::cout << "ERROR: Cannot open file: " << location << "!\n";
+    return vals;
+  }
+  float x;
+  while (file.read(reinterpret_cast<char *>(&x), sizeof(float))) vals.push_back(x);
+  return vals;
+}
+
+HipClassifier::HipClassifier(const std::string &, const std::string &weights_file, Classifier::Device, int batch_size)
+    : batch_size_(batch_size) {
+  const std::string &dir = weights_file;
+  auto c1w = readBinaryFileIntoVector(dir + "conv1_weights.bin"), c1b = readBinaryFileIntoVector(dir + "conv1_biases.bin");
+  auto c2w = readBinaryFileIntoVector(dir + "conv2_weights.bin"), c2b = readBinaryFileIntoVector(dir + "conv2_biases.bin");
+  auto f1w = readBinaryFileIntoVector(dir + "ip1_weights.bin"), f1b = readBinaryFileIntoVector(dir + "ip1_biases.bin");
+  auto f2w = readBinaryFileIntoVector(dir + "ip2_weights.bin"), f2b = readBinaryFileIntoVector(dir + "ip2_biases.bin");
+  if (c1w.size() % 500 != 0 || c1w.empty() || c1b.size() != 20 || c2w.size() != 25000 || c2b.size() != 50 ||
+      f1w.size() != 3600000 || f1b.size() != 500 || f2w.size() != 1000 || f2b.size() != 2) {
+    printf("ERROR: LeNet parameter files in %s are missing or have unexpected sizes\n", dir.c_str());
+    return;
+  }
+  channels_ = (int)(c1w.size() / 500);
+  gpd_params p;
+  gpd_hip_default_params(&p);
+  p.image_num_channels = channels_;
+  if (gpd_hip_create(0, &p, &ctx_) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    ctx_ = nullptr;
+    return;
+  }
+  if (gpd_hip_set_lenet_weights(ctx_, channels_, c1w.data(), c1b.data(), c2w.data(), c2b.data(), f1w.data(), f1b.data(), f2w.data(),
+                                f2b.data()) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return;
+  }
+  loaded_ = true;
+}
+
+HipClassifier::~HipClassifier() {
+  if (ctx_) gpd_hip_destroy(ctx_);
+}
+
+std::vector<float> HipClassifier::classifyImages(const std::vector<std::unique_ptr<Image>> &image_list) {
+  std::vector<float> out(image_list.size(), 0.f);
+  if (!ok()) return out;
+  const size_t bytes = (size_t)60 * 60 * channels_;
+  std::vector<uint8_t> batch;
+  std::vector<size_t> where;
+  batch.reserve(image_list.size() * bytes);
+  for (size_t i = 0; i < image_list.size(); i++) {
+    const Image &im = *image_list[i];
+    // non-continuous images are skipped and keep score 0 (eigen_classifier.cpp:68)
+    if (!im.isContinuous() || im.rows != 60 || im.cols != 60 || im.channels() != channels_ || im.data.size() != bytes) continue;
+    batch.insert(batch.end(), im.data.begin(), im.data.end());
+    where.push_back(i);
+  }
+  std::vector<float> s(where.size());
+  if (!where.empty() && gpd_hip_score(ctx_, batch.data(), (int)where.size(), s.data()) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return out;
+  }
+  for (size_t k = 0; k < where.size(); k++) out[where[k]] = s[k];
+  return out;
+}
+
+}  // namespace net
+
+// ------------------------------------------------------------------ GraspDetector
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static std::string dir_of(const std::string &path) {
+  size_t s = path.find_last_of('/');
+  return s == std::string::npos ? std::string("./") : path.substr(0, s + 1);
+}
+// cfg paths are relative to the working directory in the reference; also try the cfg file's own directory
+static std::string resolve(const std::string &p, const std::string &cfg_dir) {
+  if (p.empty() || p[0] == '/') return p;
+  std::ifstream a(p.c_str());
+  if (a.good()) return p;
+  return cfg_dir + p;
+}
+
+GraspDetector::GraspDetector(const std::string &config_filename) {
+  util::ConfigFile config_file(config_filename);
+  if (!config_file.ExtractKeys()) return;
+  const std::string cfg_dir = dir_of(config_filename);
+  gpd_hip_default_params(&params_);
+  // hand geometry (grasp_detector.cpp:13-19, hand_geometry.cpp:22-30)
+  std::string hg = config_file.getValueOfKeyAsString("hand_geometry_filename", "");
+  util::ConfigFile hand_cfg(hg == "0" || hg.empty() ? config_filename : resolve(hg, cfg_dir));
+  hand_cfg.ExtractKeys();
+  params_.finger_width = hand_cfg.getValueOfKey<double>("finger_width", 0.01);
+  params_.hand_outer_diameter = hand_cfg.getValueOfKey<double>("hand_outer_diameter", 0.12);
+  params_.hand_depth = hand_cfg.getValueOfKey<double>("hand_depth", 0.06);
+  params_.hand_height = hand_cfg.getValueOfKey<double>("hand_height", 0.02);
+  params_.init_bite = hand_cfg.getValueOfKey<double>("init_bite", 0.01);
+  // candidate generation (grasp_detector.cpp:47-88)
+  num_samples_ = config_file.getValueOfKey<int>("num_samples", 1000);
+  params_.nn_radius_frames = config_file.getValueOfKey<double>("nn_radius", 0.01);
+  params_.num_orientations = config_file.getValueOfKey<int>("num_orientations", 8);
+  params_.num_finger_placements = config_file.getValueOfKey<int>("num_finger_placements", 10);
+  params_.deepen_hand = config_file.getValueOfKey<bool>("deepen_hand", true) ? 1 : 0;
+  std::vector<int> axes = config_file.getValueOfKeyAsStdVectorInt("hand_axes", "2");
+  params_.num_hand_axes = (int)std::min<size_t>(axes.size(), 3);
+  for (int i = 0; i < params_.num_hand_axes; i++) params_.hand_axes[i] = axes[i];
+  params_.friction_coeff = config_file.getValueOfKey<double>("friction_coeff", 20.0);
+  params_.min_viable = config_file.getValueOfKey<int>("min_viable", 6);
+  // image geometry (grasp_detector.cpp:120-127, image_geometry.cpp:21-29)
+  std::string ig = config_file.getValueOfKeyAsString("image_geometry_filename", "");
+  util::ConfigFile img_cfg(ig == "0" || ig.empty() ? config_filename : resolve(ig, cfg_dir));
+  img_cfg.ExtractKeys();
+  params_.volume_width = img_cfg.getValueOfKey<double>("volume_width", 0.10);
+  params_.volume_depth = img_cfg.getValueOfKey<double>("volume_depth", 0.06);
+  params_.volume_height = img_cfg.getValueOfKey<double>("volume_height", 0.02);
+  params_.image_size = img_cfg.getValueOfKey<int>("image_size", 60);
+  params_.image_num_channels = img_cfg.getValueOfKey<int>("image_num_channels", 15);
+  // filtering and selection (grasp_detector.cpp:157-185)
+  workspace_grasps_ = config_file.getValueOfKeyAsStdVectorDouble("workspace_grasps", "-1 1 -1 1 -1 1");
+  workspace_grasps_.resize(6, 0.0);
+  for (int i = 0; i < 6; i++) params_.workspace_grasps[i] = workspace_grasps_[i];
+  params_.min_aperture = config_file.getValueOfKey<double>("min_aperture", 0.0);
+  params_.max_aperture = config_file.getValueOfKey<double>("max_aperture", 0.085);
+  num_selected_ = config_file.getValueOfKey<int>("num_selected", 100);
+  printf("============ CANDIDATE GENERATION ============\n");
+  printf("num_samples: %d\nnn_radius: %3.2f\nnum_orientations: %d\nnum_finger_placements: %d\ndeepen_hand: %s\n", num_samples_,
+         params_.nn_radius_frames, params_.num_orientations, params_.num_finger_placements, params_.deepen_hand ? "true" : "false");
+  printf("==============================================\n");
+  if (gpd_hip_create(config_file.getValueOfKey<int>("hip_device", 0), &params_, &ctx_) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    ctx_ = nullptr;
+    return;
+  }
+  // classifier (grasp_detector.cpp:129-145): weights_file is the parameter directory
+  std::string weights_file = config_file.getValueOfKeyAsString("weights_file", "");
+  if (!weights_file.empty()) {
+    const std::string dir = resolve(weights_file, cfg_dir);
+    typedef net::HipClassifier HC;
+    auto c1w = HC::readBinaryFileIntoVector(dir + "conv1_weights.bin"), c1b = HC::readBinaryFileIntoVector(dir + "conv1_biases.bin");
+    auto c2w = HC::readBinaryFileIntoVector(dir + "conv2_weights.bin"), c2b = HC::readBinaryFileIntoVector(dir + "conv2_biases.bin");
+    auto f1w = HC::readBinaryFileIntoVector(dir + "ip1_weights.bin"), f1b = HC::readBinaryFileIntoVector(dir + "ip1_biases.bin");
+    auto f2w = HC::readBinaryFileIntoVector(dir + "ip2_weights.bin"), f2b = HC::readBinaryFileIntoVector(dir + "ip2_biases.bin");
+    const size_t want_c1 = (size_t)20 * 25 * params_.image_num_channels;
+    if (c1w.size() == want_c1 && c1b.size() == 20 && c2w.size() == 25000 && c2b.size() == 50 && f1w.size() == 3600000 &&
+        f1b.size() == 500 && f2w.size() == 1000 && f2b.size() == 2 &&
+        gpd_hip_set_lenet_weights(ctx_, params_.image_num_channels, c1w.data(), c1b.data(), c2w.data(), c2b.data(), f1w.data(),
+                                  f1b.data(), f2w.data(), f2b.data()) == GPD_OK) {
+      has_classifier_ = true;
+    } else {
+      printf("ERROR: could not load the LeNet parameters from %s\n", dir.c_str());
+    }
+    printf("============ CLASSIFIER ======================\nweights_file: %s\n==============================================\n",
+           dir.c_str());
+  }
+}
+
+GraspDetector::~GraspDetector() {
+  if (ctx_) gpd_hip_destroy(ctx_);
+}
+
+void GraspDetector::preprocessPointCloud(util::Cloud &cloud) {
+  if (cloud.getSampleIndices().empty()) cloud.subsample(num_samples_);
+}
+
+bool GraspDetector::upload(const util::Cloud &cloud) {
+  if (!ctx_) return false;
+  if (cloud.size() == 0) {
+    printf("ERROR: Point cloud is empty!");
+    return false;
+  }
+  if (!cloud.hasNormals()) {
+    printf("ERROR: the cloud has no normals (normal estimation is outside this build's scope)\n");
+    return false;
+  }
+  if (gpd_hip_upload_cloud(ctx_, cloud.getCloudProcessed().data(), cloud.getNormals().data(), (int)cloud.size(),
+                           cloud.getCameraSource().data(), cloud.numCameras(), cloud.getViewPoints().data()) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return false;
+  }
+  return true;
+}
+
+static std::vector<std::unique_ptr<candidate::HandSet>> to_sets(const std::vector<gpd_hand> &recs, int n_sets, int slots) {
+  std::vector<std::unique_ptr<candidate::HandSet>> sets(n_sets);
+  for (int s = 0; s < n_sets; s++) {
+    sets[s] = std::make_unique<candidate::HandSet>();
+    sets[s]->is_valid_.resize(slots);
+    for (int j = 0; j < slots; j++) {
+      const gpd_hand &r = recs[(size_t)s * slots + j];
+      sets[s]->hands_.push_back(std::make_unique<candidate::Hand>(r));
+      sets[s]->is_valid_[j] = r.valid != 0;
+    }
+    sets[s]->sample_ = {recs[(size_t)s * slots].sample[0], recs[(size_t)s * slots].sample[1], recs[(size_t)s * slots].sample[2]};
+  }
+  return sets;
+}
+
+std::vector<std::unique_ptr<candidate::HandSet>> GraspDetector::generateGraspCandidates(const util::Cloud &cloud) {
+  std::vector<std::unique_ptr<candidate::HandSet>> none;
+  if (!upload(cloud)) return none;
+  const std::vector<int> &idx = cloud.getSampleIndices();
+  if (idx.empty()) {
+    std::cout << "Error: No samples or no indices!\n";  // hand_search.cpp:44-48
+    return none;
+  }
+  const int slots = params_.num_hand_axes * params_.num_orientations;
+  std::vector<gpd_hand> recs(idx.size() * slots);
+  int n_sets = 0;
+  if (gpd_hip_search(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return none;
+  }
+  return to_sets(recs, n_sets, slots);
+}
+
+// grasp_detector.cpp:334-398 (the right_top typo at :360-363 is kept)
+std::vector<std::unique_ptr<candidate::HandSet>> GraspDetector::filterGraspsWorkspace(
+    std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, const std::vector<double> &workspace) const {
+  int remaining = 0;
+  std::vector<std::unique_ptr<candidate::HandSet>> out;
+  printf("Filtering grasps outside of workspace ...\n");
+  for (size_t i = 0; i < hand_set_list.size(); i++) {
+    const auto &hands = hand_set_list[i]->getHands();
+    std::vector<bool> is_valid = hand_set_list[i]->getIsValid();
+    bool any = false;
+    for (size_t j = 0; j < hands.size(); j++) {
+      if (!is_valid[j]) continue;
+      const double half_width = 0.5 * params_.hand_outer_diameter;
+      auto pos = hands[j]->getPosition(), bin = hands[j]->getBinormal(), app = hands[j]->getApproach();
+      bool ok = hands[j]->getGraspWidth() >= params_.min_aperture && hands[j]->getGraspWidth() <= params_.max_aperture;
+      for (int r = 0; r < 3 && ok; r++) {
+        const double lb = pos[r] + half_width * bin[r], rb = pos[r] - half_width * bin[r];
+        const double lt = lb + params_.hand_depth * app[r], rt = lb + params_.hand_depth * app[r];
+        const double ap = pos[r] - 0.05 * app[r];
+        const double mn = std::min({lb, rb, lt, rt, ap}), mx = std::max({lb, rb, lt, rt, ap});
+        ok = mn >= workspace[2 * r] && mx <= workspace[2 * r + 1];
+      }
+      is_valid[j] = ok;
+      if (ok) {
+        remaining++;
+        any = true;
+      }
+    }
+    if (any) {
+      hand_set_list[i]->setIsValid(is_valid);
+      out.push_back(std::move(hand_set_list[i]));
+    }
+  }
+  printf("Number of grasp candidates within workspace and gripper width: %d\n", remaining);
+  return out;
+}
+
+bool GraspDetector::createGraspImages(util::Cloud &cloud, std::vector<std::unique_ptr<candidate::Hand>> &hands_out,
+                                      std::vector<std::unique_ptr<net::Image>> &images_out) {
+  hands_out.clear();
+  images_out.clear();
+  if (!upload(cloud)) return false;
+  const std::vector<int> &idx = cloud.getSampleIndices();
+  const int slots = params_.num_hand_axes * params_.num_orientations;
+  std::vector<gpd_hand> recs(idx.size() * slots);
+  int n_sets = 0, n_cand = 0;
+  if (idx.empty() || gpd_hip_search(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets) != GPD_OK) {
+    printf("ERROR: %s\n", idx.empty() ? "no sample indices" : gpd_hip_last_error());
+    return false;
+  }
+  printf("Generated %d hand sets.\n", n_sets);
+  // workspace / aperture filter on the flat records (same predicate as filterGraspsWorkspace)
+  {
+    auto sets = to_sets(recs, n_sets, slots);
+    std::vector<std::vector<bool>> keep(n_sets, std::vector<bool>(slots, false));
+    for (int s = 0; s < n_sets; s++) sets[s]->sample_[0] = s;  // remember the set number through the move
+    auto filtered = filterGraspsWorkspace(sets, workspace_grasps_);
+    for (auto &hs : filtered) keep[(int)hs->sample_[0]] = hs->getIsValid();
+    for (int s = 0; s < n_sets; s++)
+      for (int j = 0; j < slots; j++) recs[(size_t)s * slots + j].valid = keep[s][j] ? 1 : 0;
+  }
+  const size_t bytes = (size_t)60 * 60 * params_.image_num_channels;
+  size_t nv = 0;
+  for (size_t i = 0; i < (size_t)n_sets * slots; i++) nv += recs[i].valid;
+  std::vector<uint8_t> pix(nv * bytes);
+  std::vector<int32_t> cand(nv);
+  if (gpd_hip_images(ctx_, recs.data(), n_sets, pix.data(), cand.data(), &n_cand) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return false;
+  }
+  for (int k = 0; k < n_cand; k++) {  // order: set-major, slot-minor, valid only (image_generator.cpp:91-98)
+    auto im = std::make_unique<net::Image>(60, 60, params_.image_num_channels);
+    std::memcpy(im->data.data(), pix.data() + (size_t)k * bytes, bytes);
+    images_out.push_back(std::move(im));
+    hands_out.push_back(std::make_unique<candidate::Hand>(recs[cand[k]]));
+  }
+  return true;
+}
+
+std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::selectGrasps(std::vector<std::unique_ptr<candidate::Hand>> &hands) const {
+  printf("Selecting the %d highest scoring grasps ...\n", num_selected_);  // grasp_detector.cpp:405-420
+  int middle = std::min((int)hands.size(), num_selected_);
+  std::partial_sort(hands.begin(), hands.begin() + middle, hands.end(), isScoreGreater);
+  std::vector<std::unique_ptr<candidate::Hand>> out;
+  for (int i = 0; i < middle; i++) {
+    out.push_back(std::move(hands[i]));
+    printf(" grasp #%d, score: %3.4f\n", i, out[i]->getScore());
+  }
+  return out;
+}
+
+std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const util::Cloud &cloud) {
+  const double t0 = now_s();
+  std::vector<std::unique_ptr<candidate::Hand>> hands_out;
+  if (!upload(cloud)) return hands_out;
+  if (!has_classifier_) {
+    printf("ERROR: no classifier weights loaded (cfg key weights_file)\n");
+    return hands_out;
+  }
+  const std::vector<int> &idx = cloud.getSampleIndices();
+  if (idx.empty()) {
+    std::cout << "Error: No samples or no indices!\n";
+    return hands_out;
+  }
+  const int slots = params_.num_hand_axes * params_.num_orientations;
+  std::vector<gpd_hand> recs(idx.size() * slots);
+  int n_sets = 0, n_cand = 0;
+  // steps 1-4 fused on the device (grasp_detector.cpp:222-273)
+  if (gpd_hip_detect(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets, &n_cand) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return hands_out;
+  }
+  printf("Generated %d hand sets.\n", n_sets);
+  float ms[3] = {0, 0, 0};
+  gpd_hip_last_stage_ms(ctx_, ms);
+  std::vector<std::unique_ptr<candidate::Hand>> hands;
+  for (size_t i = 0; i < (size_t)n_sets * slots; i++)
+    if (recs[i].valid) hands.push_back(std::make_unique<candidate::Hand>(recs[i]));
+  // 5. select the highest scoring grasps; 6. clustering is out of scope (min_inliers = 0); 7. sort
+  std::vector<std::unique_ptr<candidate::Hand>> clusters = selectGrasps(hands);
+  std::sort(clusters.begin(), clusters.end(), isScoreGreater);
+  printf("======== Selected grasps ========\n");
+  for (size_t i = 0; i < clusters.size(); i++) std::cout << "Grasp " << i << ": " << clusters[i]->getScore() << "\n";
+  printf("Selected the %d best grasps.\n", (int)clusters.size());
+  runtimes_[0] = ms[0] / 1e3;
+  runtimes_[1] = ms[1] / 1e3;
+  runtimes_[2] = ms[2] / 1e3;
+  runtimes_[3] = now_s() - t0;
+  printf("======== RUNTIMES ========\n 1. Candidate generation: %3.4fs\n 2. Descriptor extraction: %3.4fs\n 3. Classification: %3.4fs\n"
+         "==========\n TOTAL: %3.4fs\n",
+         runtimes_[0], runtimes_[1], runtimes_[2], runtimes_[3]);
+  return clusters;
+}
+
+}  // namespace gpd

@@ -1,0 +1,91 @@
+"""The C++ host layer (gpd_amd/host): GraspDetector / ConfigFile / Cloud / detect_grasps CLI."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gpd_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "gpd_amd", "host", "detect_grasps")
+
+
+def _write_case(tmp, cl, w, num_samples, num_selected, channels=15):
+    params = tmp / "params"
+    params.mkdir()
+    names = dict(c1w="conv1_weights", c1b="conv1_biases", c2w="conv2_weights", c2b="conv2_biases", f1w="ip1_weights",
+                 f1b="ip1_biases", f2w="ip2_weights", f2b="ip2_biases")
+    for k, v in names.items():
+        np.asarray(w[k], "<f4").tofile(str(params / (v + ".bin")))
+    (tmp / "hand_geometry.cfg").write_text("# hand\nfinger_width = 0.01\nhand_outer_diameter = 0.12\nhand_depth = 0.06\n"
+                                           "hand_height = 0.02\ninit_bite = 0.01\n")
+    (tmp / "image_geometry.cfg").write_text("volume_width = 0.10\nvolume_depth = 0.06\nvolume_height = 0.02\nimage_size = 60  \n"
+                                            "image_num_channels = %d  # channels\n" % channels)
+    cfg = tmp / "params.cfg"
+    cfg.write_text("# test config in the format of cfg/eigen_params.cfg\n"
+                   "hand_geometry_filename = hand_geometry.cfg\nimage_geometry_filename = image_geometry.cfg\n"
+                   "weights_file = params/\ndevice = 1\ncamera_position = 0 0 0\n"
+                   "num_samples = %d\nnum_threads = 4\nnn_radius = 0.01\nnum_orientations = 8\nnum_finger_placements = 10\n"
+                   "hand_axes = 2\ndeepen_hand = 1\nfriction_coeff = 20\nmin_viable = 6\nmin_aperture = 0.0\nmax_aperture = 0.085\n"
+                   "workspace_grasps = -1 1 -1 1 -1 1\nmin_inliers = 0\nnum_selected = %d\nplot_normals = 0\n" % (num_samples, num_selected))
+    pcd = tmp / "cloud.pcd"
+    P = len(cl["xyz"])
+    with open(str(pcd), "w") as f:
+        f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z\n"
+                "SIZE 4 4 4 4 4 4\nTYPE F F F F F F\nCOUNT 1 1 1 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA ascii\n" % (P, P))
+        for p, n in zip(cl["xyz"], cl["normals"]):
+            f.write("%.9g %.9g %.9g %.9g %.9g %.9g\n" % (p[0], p[1], p[2], n[0], n[1], n[2]))
+    return cfg, pcd
+
+
+def _subsample_indices(n, m, seed=0):
+    """util::Cloud::subsample of the host layer (xorshift Fisher-Yates), restated."""
+    idx = list(range(n))
+    s = 0x9E3779B97F4A7C15 ^ seed
+    M = (1 << 64) - 1
+    m = min(m, n)
+    for i in range(m):
+        s ^= (s << 13) & M
+        s ^= s >> 7
+        s ^= (s << 17) & M
+        j = i + s % (n - i)
+        idx[i], idx[j] = idx[j], idx[i]
+    return np.array(idx[:m], np.int32)
+
+
+def test_cli_usage_and_no_gpu_fails_loudly(tmp_path):
+    assert os.path.exists(CLI), "run __graft_entry__.build()"
+    out = subprocess.run([CLI], capture_output=True, text=True)
+    assert out.returncode != 0 and "Usage: detect_grasps CONFIG_FILE PCD_FILE" in out.stdout
+    import torch
+    if torch.cuda.is_available():
+        return
+    cl = synth.make_cloud(5, 2000)
+    cfg, pcd = _write_case(tmp_path, cl, synth.lenet_weights(15), 10, 5)
+    out = subprocess.run([CLI, str(cfg), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode != 0 and "ERROR" in out.stdout  # no device -> error, not a CPU result
+
+
+@pytest.mark.gpu
+def test_detect_grasps_cli_matches_oracle(tmp_path, oracle_mod, lenet15_real):
+    cl = synth.make_cloud(99, 12000)
+    cfg, pcd = _write_case(tmp_path, cl, lenet15_real, 150, 20)
+    out = subprocess.run([CLI, str(cfg), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "======== RUNTIMES ========" in out.stdout
+    got = [l.split() for l in out.stdout.splitlines() if l.startswith("GRASP ")]
+    assert len(got) == 20
+    # the PCD is ASCII with 9 significant digits: float32 round-trips exactly
+    si = _subsample_indices(len(cl["xyz"]), 150)
+    p = oracle_mod.default_params(15)
+    hands, n, _ = oracle_mod.detect(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, lenet15_real)
+    v = hands[hands["valid"].astype(bool)]
+    order = np.argsort(-v["score"], kind="stable")[:20]
+    want = v[order]
+    gs = np.array([float(g[1]) for g in got])
+    assert np.abs(gs - want["score"]).max() <= 1e-4
+    assert np.all(np.diff(gs) <= 0)
+    gp = np.array([[float(x) for x in g[2:5]] for g in got])
+    assert np.allclose(gp, want["position"], rtol=1e-12, atol=1e-15)
+    assert [int(g[6]) for g in got] == want["finger_placement_index"].tolist()
