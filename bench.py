@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--points", type=int, default=30000)
     ap.add_argument("--candidates", type=int, default=5000)
     ap.add_argument("--channels", type=int, default=15)
-    ap.add_argument("--cpu-samples", type=int, default=400, help="samples of the CPU-baseline leg (0 disables)")
+    ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,13 +126,14 @@ def main():
                               "achieved_TFLOPs": net_tflops, "frac_f32": net_tflops / F32_PEAK_TFLOPS,
                               "img_per_s": n_cand / net_s},
         }
+        traffic = _pmc_traffic()
         if net_s >= img_s:
             roofline = {"kernel": "lenet_forward (conv1_pool+conv2_pool+fc1_mfma+fc2)", "bound": "mfma",
                         "achieved": net_tflops, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": net_tflops / F32_PEAK_TFLOPS, "traffic": None}
+                        "frac": net_tflops / F32_PEAK_TFLOPS, "traffic": traffic.get("lenet")}
         else:
             roofline = {"kernel": "grasp_image_kernel", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": None}
+                        "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}
         out = {
             "metric": "15-ch grasp candidates scored/sec (imagegen+LeNet)" if C == 15 else "%d-ch grasp candidates scored/sec (imagegen+LeNet)" % C,
             "value": value, "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -141,7 +142,7 @@ def main():
             "config": {"workload": "single %dk-point synthetic cloud per GPU (seed 1234+rank), first %d valid candidates, %d-channel LeNet"
                        % (args.points // 1000, n_cand, C), "points": args.points, "candidates_per_gpu": n_cand,
                        "samples": int(n_samples), "channels": C, "sharding": "one cloud per GPU, no collective"},
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "kernels": kernels, "pmc_traffic": traffic,
             "search": {"samples": int(n_samples), "hand_sets": int(hands.shape[0]), "kernel_ms": search_ms,
                        "wall_ms_incl_download": search_wall * 1e3},
         }
@@ -171,6 +172,23 @@ def _filter_workspace(hands, p):
     for r in range(3):
         ok &= (mn[:, r] >= ws[2 * r]) & (mx[:, r] <= ws[2 * r + 1])
     h["valid"] = (h["valid"].astype(bool) & ok).astype(np.uint8)
+
+
+def _pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, produced by
+    profiles/run_profile.sh + summarize.py --traffic on the same workload).  None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))["kernels"]
+    out = {"source": "profiles/r01_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes; reads x2 per gfx950 note)"}
+    img = [v for k, v in d.items() if "grasp_image_kernel" in k]
+    if img:
+        out["image"] = img[0]["hbm_bytes_per_launch"]
+    net = [v["hbm_bytes_per_launch"] for k, v in d.items() if any(s in k for s in ("conv1", "conv2", "fc1_mfma", "fc2_score"))]
+    if net:
+        out["lenet"] = float(sum(net))
+    return out
 
 
 def _cpu_baseline(cloud, w, C, n_samples):

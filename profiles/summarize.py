@@ -50,5 +50,29 @@ def main():
             print("%-70s %-12s %6d %16.1f %16.1f" % (str(name)[:70], cn, n, s, a))
 
 
+def traffic_json(d, out):
+    """Per-launch HBM traffic of every kernel from the two PMC passes.  FETCH_SIZE / WRITE_SIZE are
+    in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads
+    (MI355X_MICROARCH.md §HBM), so read bytes = 2 * FETCH_SIZE * 1024.  Calibration in this repo:
+    conv1 reads exactly n*C*3600 image bytes with 16-B lanes and FETCH_SIZE reports half of that."""
+    import json
+    res = {}
+    for sub, key in (("pmc_fetch", "fetch_KiB_raw"), ("pmc_write", "write_KiB")):
+        db = os.path.join(d, sub, "bench_results.db")
+        if not os.path.exists(db):
+            continue
+        for name, cn, n, s, a in counter_stats(db):
+            res.setdefault(str(name), {})[key] = a
+    for k, v in res.items():
+        f, w = v.get("fetch_KiB_raw", 0.0), v.get("write_KiB", 0.0)
+        v["read_bytes_corrected"] = 2.0 * f * 1024.0
+        v["write_bytes"] = w * 1024.0
+        v["hbm_bytes_per_launch"] = v["read_bytes_corrected"] + v["write_bytes"]
+    json.dump({"source": d, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 3 and sys.argv[2] == "--traffic":
+        traffic_json(sys.argv[1], sys.argv[3])
+    else:
+        main()
