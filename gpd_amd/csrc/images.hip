@@ -232,6 +232,28 @@ __device__ int scan_cells(Smem &S) {
   return total;
 }
 
+// list of the non-empty cells (ascending) so that the walks give one pixel to one lane in a
+// single pass; returns their number
+__device__ int list_nonempty_cells(Smem &S, uint16_t *nz) {
+  const int tid = threadIdx.x;
+  constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = tid * PER + k;
+    if (i < kPix && (S.cells[i] & 0xffffu)) cnt++;
+  }
+  int total;
+  int pos = block_excl_scan(S, cnt, &total);
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const int i = tid * PER + k;
+    if (i < kPix && (S.cells[i] & 0xffffu)) nz[pos++] = (uint16_t)i;
+  }
+  __syncthreads();
+  return total;
+}
+
 // 3x3 rect max-dilate (border ignored), NORM_MINMAX to [0,1], u8 = round-half-even(v*255)
 // (image_strategy.cpp:144-153, 178-187, 221-230; cv::dilate / cv::normalize / convertTo).
 // planes are in cell-index order (cell row = 59 - image row; the 3x3 window is symmetric);
@@ -516,11 +538,16 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       const int da = depth_axis(pr);
       float lmax = -FLT_MAX;
       int lany = 0;
-      for (int c = tid; c < kPix; c += IMG_THREADS) {
+      uint16_t *nz = reinterpret_cast<uint16_t *>(&S.raster[1][0]);
+      const int n_nz = list_nonempty_cells(S, nz);
+      for (int c = tid; c < kPix; c += IMG_THREADS) S.raster[0][c] = 0.f;
+      __syncthreads();
+      for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
+        const int c = nz[qn];
         const uint32_t w = S.cells[c];
         const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
         float v = 0.f;
-        if (cn > 0) {
+        {
           sort_u16(&S.place[start], cn);
           float fc = 0.f;
           for (int e = 0; e < cn; e++) {
@@ -622,11 +649,23 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     // ---- createNormalsImage + createDepthImage (image_strategy.cpp:124-190): the pixel owner
     //      walks its segment in neighbour order
     const int da = depth_axis(pr);
+    uint16_t *nz = &S.place[PT_CAP];
+    const int n_nz = list_nonempty_cells(S, nz);
     for (int c = tid; c < kPix; c += IMG_THREADS) {
+      if (!(S.cells[c] & 0xffffu)) {
+        S.raster[0][c] = 0.f;
+        S.raster[1][c] = 0.f;
+        S.raster[2][c] = 0.f;
+        S.cells[c] = 0u;  // depth plane: 0.0f
+      }
+    }
+    __syncthreads();
+    for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
+      const int c = nz[qn];
       const uint32_t w = S.cells[c];
       const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
       float v0 = 0.f, v1 = 0.f, v2 = 0.f, pix = 0.f;
-      if (cn > 0) {
+      {
         sort_by_rank(&S.place[start], cn, S.u.p.key);
         float avg = 0.f, fc = 0.f;
         for (int q = 0; q < cn; q++) {
