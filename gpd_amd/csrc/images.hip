@@ -18,8 +18,9 @@
 // over the candidate's voxel AABB: set semantics for free, and walking the bits in index
 // order is the lexicographic voxel order the oracle defines.
 //
-// The 33*N LCG draws of a hand set are regenerated per candidate by jump-ahead
-// (hand_set.cpp:263-266 is an affine map mod 2^32), so no per-set voxel list is stored.
+// The 33*N LCG draws of a hand set are generated once per set by shadow_set_kernel with
+// jump-ahead (hand_set.cpp:263-266 is an affine map mod 2^32) into a bitset around the sample;
+// each candidate extracts the voxels of its own box from it.
 //
 // Cell indices floor((x/len)/(1/60)) (image_strategy.cpp:92-102) are monotone in x, so
 // they are looked up in a table of exact double thresholds computed on the host with the
@@ -54,6 +55,9 @@ constexpr int SH_CAP = 8192;  // in-box shadow voxels per candidate
 constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
 constexpr int VBITS = VDIM * VDIM * VDIM;
 constexpr int VWORDS = (VBITS + 31) / 32;
+constexpr int SD = 88;        // per-set shadow region edge in voxels (2*43 + 1, rounded up)
+constexpr int SR = 43;        // region reach: every image box of a set lies within 0.1233 m of the sample
+constexpr int SETWORDS = SD * SD * SD / 32;
 
 struct ImgConsts {
   double vol_depth, vol_width, vol_height, half_od, dbl_h;
@@ -75,7 +79,8 @@ struct ImgParams {
   int cap;
   const double *centers;
   const gpd_hand *hands;  // one per candidate
-  const int32_t *meta;    // [n][4]: sample slot, N_images, lcg offset lo, hi (hi < 0: no shadow)
+  const int32_t *meta;    // [n][4]: sample slot, N_images, live-set ordinal (< 0: no shadow), -
+  const uint32_t *set_bits;  // [live sets][SETWORDS] shadow voxel bitsets (shadow_set_kernel)
   uint8_t *images;        // planar [n][C][3600]
   int32_t *status;
   unsigned long long *dbg;  // profiling aid (GPD_IMG_TIMING=1): per-phase cycle sums
@@ -381,8 +386,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   const gpd_hand &H = P.hands[cand];
   const int slot_s = P.meta[4 * cand + 0];
   const int N = P.meta[4 * cand + 1];
-  const uint32_t off_lo = (uint32_t)P.meta[4 * cand + 2];
-  const int32_t off_hi = P.meta[4 * cand + 3];
+  const int set_ord = P.meta[4 * cand + 2];
   const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
   uint8_t *out = P.images + (size_t)cand * kPix * K.C;
   Box B;
@@ -429,61 +433,40 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     }
     __syncthreads();
     const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
-    // ---- HandSet::calculateShadowForCamera (hand_set.cpp:202-233), one camera
-    if (off_hi >= 0 && N > 0) {
-      const double *cen = P.centers + 3 * (size_t)slot_s;
-      double vec[3];
-      for (int r = 0; r < 3; r++) vec[r] = cen[r] - K.view_point[r];
-      const double nrm = sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
-      for (int r = 0; r < 3; r++) vec[r] = K.shadow_length * vec[r] / nrm;
-      const unsigned long long off = ((unsigned long long)(uint32_t)off_hi << 32) | off_lo;
-      uint32_t state = lcg_jump(0u, off + (unsigned long long)tid * (unsigned)K.num_shadow);
-      int bad = 0;
-      // conservative f32 pre-test: a draw whose f32 position is outside the box grown by one
-      // voxel diagonal (the voxel point is within 3 mm per axis of the draw) cannot pass the
-      // exact f64 test below, so most draws never reach it.
-      float Ff[9], sf[3], vf[3], lof[3], hif[3];
-      const float grow = 0.0054f;
-      for (int q = 0; q < 9; q++) Ff[q] = (float)B.F[q];
-      for (int q = 0; q < 3; q++) {
-        sf[q] = (float)B.sample[q];
-        vf[q] = (float)vec[q];
-        lof[q] = (float)B.lo[q] - grow;
-        hif[q] = (float)B.hi[q] + grow;
-      }
-      for (int i = tid; i < N; i += IMG_THREADS) {
-        const float pf0 = nn[0 * P.cap + i], pf1 = nn[1 * P.cap + i], pf2 = nn[2 * P.cap + i];
-        const double p0 = (double)pf0, p1 = (double)pf1, p2 = (double)pf2;
-        const float cf0 = pf0 - sf[0], cf1 = pf1 - sf[1], cf2 = pf2 - sf[2];
-        // hand-frame start and direction of the shadow ray, f32
-        const float b0 = Ff[0] * cf0 + Ff[3] * cf1 + Ff[6] * cf2, d0 = Ff[0] * vf[0] + Ff[3] * vf[1] + Ff[6] * vf[2];
-        const float b1 = Ff[1] * cf0 + Ff[4] * cf1 + Ff[7] * cf2, d1 = Ff[1] * vf[0] + Ff[4] * vf[1] + Ff[7] * vf[2];
-        const float b2 = Ff[2] * cf0 + Ff[5] * cf1 + Ff[8] * cf2, d2 = Ff[2] * vf[0] + Ff[5] * vf[1] + Ff[8] * vf[2];
-        uint32_t st = state;
-        for (int k = 0; k < K.num_shadow; k++) {
-          const int rnd = (int)lcg_step(st);
-          const float tf = (float)rnd * (1.0f / 32767.0f);
-          const float h0 = b0 + tf * d0, h1 = b1 + tf * d1, h2 = b2 + tf * d2;
-          if (!(h0 > lof[0] && h0 < hif[0] && h1 > lof[1] && h1 < hif[1] && h2 > lof[2] && h2 < hif[2])) continue;
-          const double t = (double)rnd * K.rand_inv;
-          const int vx = (int)((p0 + t * vec[0]) * K.voxel_mult);
-          const int vy = (int)((p1 + t * vec[1]) * K.voxel_mult);
-          const int vz = (int)((p2 + t * vec[2]) * K.voxel_mult);
+    // ---- the set's shadow voxels (shadow_set_kernel) restricted to this candidate's box:
+    //      walk the AABB rows of the set bitset, exact f64 box test per set voxel
+    if (set_ord >= 0) {
+      const uint32_t *sb = P.set_bits + (size_t)set_ord * SETWORDS;
+      const int ox = (int)floor(B.sample[0] * K.voxel_mult) - SR, oy = (int)floor(B.sample[1] * K.voxel_mult) - SR,
+                oz = (int)floor(B.sample[2] * K.voxel_mult) - SR;
+      const int zlo = z0 - oz;
+      for (int row = tid; row < VDIM * VDIM; row += IMG_THREADS) {
+        const int ix = row / VDIM, iy = row - ix * VDIM;
+        const int sx = x0 + ix - ox, sy = y0 + iy - oy;
+        if ((unsigned)sx >= (unsigned)SD || (unsigned)sy >= (unsigned)SD) continue;
+        const int rowbit = (sx * SD + sy) * SD;
+        // 46 bits starting at rowbit + zlo, clipped to the row [0, SD)
+        const int za = zlo < 0 ? 0 : zlo, zb = (zlo + VDIM < SD) ? zlo + VDIM : SD;
+        if (za >= zb) continue;
+        const int b0 = rowbit + za;
+        const int w0 = b0 >> 5, sh = b0 & 31;
+        const unsigned long long lo64 = (unsigned long long)sb[w0] | ((unsigned long long)(w0 + 1 < SETWORDS ? sb[w0 + 1] : 0u) << 32);
+        const unsigned long long hi = (w0 + 2 < SETWORDS) ? sb[w0 + 2] : 0u;
+        unsigned long long field = (lo64 >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+        const int nbits = zb - za;
+        field &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
+        while (field) {
+          const int t = __ffsll((long long)field) - 1;
+          field &= field - 1;
+          const int iz = za + t - zlo;
           double th[3];
-          to_hand(B, (double)vx * K.voxel, (double)vy * K.voxel, (double)vz * K.voxel, th);
+          to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
           if (in_box(B, th)) {
-            const int ix = vx - x0, iy = vy - y0, iz = vz - z0;
-            if ((unsigned)ix < (unsigned)VDIM && (unsigned)iy < (unsigned)VDIM && (unsigned)iz < (unsigned)VDIM) {
-              const int bit = (ix * VDIM + iy) * VDIM + iz;
-              atomicOr(&S.u.s.bits[bit >> 5], 1u << (bit & 31));
-            } else {
-              bad = 1;
-            }
+            const int bit = (ix * VDIM + iy) * VDIM + iz;
+            atomicOr(&S.u.s.bits[bit >> 5], 1u << (bit & 31));
           }
         }
-        state = K.stride_a * state + K.stride_c;  // advance by IMG_THREADS * num_shadow draws
       }
-      if (bad) atomicOr(&S.flag, 1);
     }
     __syncthreads();
     TICK(0);
@@ -703,6 +686,64 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
 
+// ---------------------------------------------------------------------------
+// shadow_set_kernel: HandSet::calculateShadow / calculateShadowForCamera (hand_set.cpp:118-233)
+// for one camera, once per hand set.  The 33 * N_i LCG draws of the set (stream offset given by
+// the host, hand_set.cpp:263-266) are voxelised into a bitset over the cube of +-43 voxels around
+// the sample, which contains every image box of the set; the candidates then cut their boxes
+// out of it.
+// ---------------------------------------------------------------------------
+struct SetParams {
+  const float *nn;
+  int cap;
+  const double *centers;
+  const double *frames;     // [S][12], sample first
+  const int32_t *set_meta;  // [sets][4]: sample slot, N_images, lcg offset lo, hi
+  uint32_t *set_bits;       // [sets][SETWORDS]
+};
+
+__global__ __launch_bounds__(IMG_THREADS) void shadow_set_kernel(SetParams P) {
+  __shared__ uint32_t bits[SETWORDS];
+  const ImgConsts &K = c_img;
+  const int set = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int slot_s = P.set_meta[4 * set + 0];
+  const int N = P.set_meta[4 * set + 1];
+  const unsigned long long off =
+      ((unsigned long long)(uint32_t)P.set_meta[4 * set + 3] << 32) | (uint32_t)P.set_meta[4 * set + 2];
+  const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
+  for (int w = tid; w < SETWORDS; w += IMG_THREADS) bits[w] = 0u;
+  __syncthreads();
+  const double *smp = P.frames + 12 * (size_t)slot_s;
+  const int ox = (int)floor(smp[0] * K.voxel_mult) - SR, oy = (int)floor(smp[1] * K.voxel_mult) - SR,
+            oz = (int)floor(smp[2] * K.voxel_mult) - SR;
+  // shadow_vec = shadow_length * (center - view_point) / norm (hand_set.cpp:147-150)
+  const double *cen = P.centers + 3 * (size_t)slot_s;
+  double vec[3];
+  for (int r = 0; r < 3; r++) vec[r] = cen[r] - K.view_point[r];
+  const double nrm = sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
+  for (int r = 0; r < 3; r++) vec[r] = K.shadow_length * vec[r] / nrm;
+  uint32_t state = lcg_jump(0u, off + (unsigned long long)tid * (unsigned)K.num_shadow);
+  for (int i = tid; i < N; i += IMG_THREADS) {
+    const double p0 = (double)nn[0 * P.cap + i], p1 = (double)nn[1 * P.cap + i], p2 = (double)nn[2 * P.cap + i];
+    uint32_t st = state;
+    for (int k = 0; k < K.num_shadow; k++) {
+      const double t = (double)(int)lcg_step(st) * K.rand_inv;
+      const int vx = (int)((p0 + t * vec[0]) * K.voxel_mult) - ox;
+      const int vy = (int)((p1 + t * vec[1]) * K.voxel_mult) - oy;
+      const int vz = (int)((p2 + t * vec[2]) * K.voxel_mult) - oz;
+      if ((unsigned)vx < (unsigned)SD && (unsigned)vy < (unsigned)SD && (unsigned)vz < (unsigned)SD) {
+        const int bit = (vx * SD + vy) * SD + vz;
+        atomicOr(&bits[bit >> 5], 1u << (bit & 31));
+      }
+    }
+    state = K.stride_a * state + K.stride_c;  // advance by IMG_THREADS * num_shadow draws
+  }
+  __syncthreads();
+  uint32_t *out = P.set_bits + (size_t)set * SETWORDS;
+  for (int w = tid; w < SETWORDS; w += IMG_THREADS) out[w] = bits[w];
+}
+
 // planar [n][C][3600] <-> HWC [n][3600][C] (cv::Mat CV_8UC(C), the reference's image layout)
 __global__ void planar_to_hwc_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int C, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -766,7 +807,7 @@ void image_cell_thresholds(double len, double *out) {
 }
 
 void images_free(ImageState &im) {
-  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status};
+  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status, im.d_set_meta, im.d_set_bits};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   im = ImageState();
@@ -790,7 +831,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   }
   // candidate list in set-major, slot-minor order; LCG offsets over live sets
   std::vector<gpd_hand> cand;
-  std::vector<int32_t> meta;
+  std::vector<int32_t> meta, set_meta;
   unsigned long long lcg = 0;
   im.stat_sets = 0;
   im.stat_sum_set_ni = 0;
@@ -815,10 +856,16 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
       cand.push_back(h);
       meta.push_back(samp);
       meta.push_back(Ni);
-      meta.push_back((int32_t)(uint32_t)(lcg & 0xffffffffull));
-      meta.push_back(seen ? (int32_t)(lcg >> 32) : -1);
+      meta.push_back((C == 15 && seen && Ni > 0) ? (int32_t)(set_meta.size() / 4) : -1);
+      meta.push_back(0);
     }
-    if (C == 15 && seen) lcg += (unsigned long long)Ni * 33ull;
+    if (C == 15 && seen && Ni > 0) {
+      set_meta.push_back(samp);
+      set_meta.push_back(Ni);
+      set_meta.push_back((int32_t)(uint32_t)(lcg & 0xffffffffull));
+      set_meta.push_back((int32_t)(lcg >> 32));
+      lcg += (unsigned long long)Ni * 33ull;
+    }
     im.stat_sets++;
     im.stat_sum_set_ni += Ni;
     im.stat_sum_cand_ni += (long long)Ni * nv;
@@ -844,6 +891,19 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   HIP_RET(hipMemsetAsync(im.d_status, 0, sizeof(int32_t), stream));
   HIP_RET(hipMemcpyAsync(im.d_hands, cand.data(), (size_t)n * sizeof(gpd_hand), hipMemcpyHostToDevice, stream));
   HIP_RET(hipMemcpyAsync(im.d_cand_meta, meta.data(), (size_t)n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  im.num_shadow_sets = (int)(set_meta.size() / 4);
+  if (im.num_shadow_sets > im.cap_shadow_sets) {
+    if (im.d_set_meta) (void)hipFree(im.d_set_meta);
+    if (im.d_set_bits) (void)hipFree(im.d_set_bits);
+    im.d_set_meta = nullptr;
+    im.d_set_bits = nullptr;
+    im.cap_shadow_sets = 0;
+    HIP_RET(hipMalloc(&im.d_set_meta, (size_t)im.num_shadow_sets * 4 * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&im.d_set_bits, (size_t)im.num_shadow_sets * SETWORDS * sizeof(uint32_t)));
+    im.cap_shadow_sets = im.num_shadow_sets;
+  }
+  if (im.num_shadow_sets)
+    HIP_RET(hipMemcpyAsync(im.d_set_meta, set_meta.data(), set_meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   ImgConsts k;
   std::memset(&k, 0, sizeof(k));
   k.vol_depth = p.volume_depth;
@@ -921,6 +981,18 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     if (!d_dbg) HIP_RET(hipMalloc(&d_dbg, 16 * sizeof(unsigned long long)));
     HIP_RET(hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), stream));
     ip.dbg = d_dbg;
+  }
+  ip.set_bits = im.d_set_bits;
+  if (im.num_shadow_sets > 0) {
+    SetParams sp;
+    sp.nn = s.d_nn;
+    sp.cap = s.nn_cap;
+    sp.centers = s.d_centers;
+    sp.frames = s.d_frames;
+    sp.set_meta = im.d_set_meta;
+    sp.set_bits = im.d_set_bits;
+    shadow_set_kernel<<<im.num_shadow_sets, IMG_THREADS, 0, stream>>>(sp);
+    HIP_RET(hipGetLastError());
   }
   grasp_image_kernel<<<n, IMG_THREADS, 0, stream>>>(ip);
   HIP_RET(hipGetLastError());
