@@ -103,7 +103,7 @@ struct SmemSh {
   uint32_t lin[SH_CAP];     // set bits inside the box, ascending
   uint32_t cells3[SH_CAP];  // cx | cy << 6 | cz << 12
 };
-struct Smem {
+struct __attribute__((aligned(16))) Smem {
   union {
     SmemPts p;
     SmemSh s;
@@ -113,7 +113,7 @@ struct Smem {
   uint16_t place[SH_CAP];
   double thr[3][kImg + 1];
   double recip[256];  // 1.0 / k
-  float red_f[2 * IMG_WAVES];
+  float red_f[4 * IMG_WAVES];
   int red_i[IMG_WAVES];
   int vorg[3];
   int counter;
@@ -261,79 +261,97 @@ __device__ int list_nonempty_cells(Smem &S, uint16_t *nz) {
 
 // 3x3 rect max-dilate (border ignored), NORM_MINMAX to [0,1], u8 = round-half-even(v*255)
 // (image_strategy.cpp:144-153, 178-187, 221-230; cv::dilate / cv::normalize / convertTo).
-// planes are in cell-index order (cell row = 59 - image row; the 3x3 window is symmetric);
-// each thread owns groups of 4 consecutive pixels and stores them as one dword.
-template <int NCH>
-__device__ void finalize_channels(Smem &S, const float *planes, uint8_t *out) {
+// Planes are in cell-index order (cell row = 59 - image row; the 3x3 window is symmetric).
+// NPL planes are finished in one pass; planes with the same norm group share min/max (the three
+// normal channels are normalised jointly, depth/shadow on their own).  Each thread owns groups of
+// 4 consecutive pixels: three 16-byte LDS reads + two edge reads per row (indices clamped to the
+// image: a clamped duplicate cannot change a max), one dword store.
+// planes 0..2 (or 0 alone) start at p012 and are kPix apart; plane 3, if present, is p3 and is
+// normalised on its own; output channels are consecutive planes starting at out.
+template <int NPL>
+__device__ void finalize_planes(Smem &S, const float *p012, const float *p3, uint8_t *out) {
   const int tid = threadIdx.x;
-  constexpr int GROUPS = NCH * kImg * (kImg / 4);  // 900 per plane
+  constexpr int GROUPS = NPL * 900;
   constexpr int PER = (GROUPS + IMG_THREADS - 1) / IMG_THREADS;
   float d[PER][4];
-  float mn = FLT_MAX, mx = -FLT_MAX;
+  float mn[2] = {FLT_MAX, FLT_MAX}, mx[2] = {-FLT_MAX, -FLT_MAX};
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const int g = tid + k * IMG_THREADS;
     if (g < GROUPS) {
       const int ch = g / 900, rem = g - ch * 900;
       const int r = rem / 15, c0 = (rem - r * 15) * 4;
-      const float *pl = planes + ch * kPix;
-      float cm[6];  // column maxima over the 3 rows for columns c0-1 .. c0+4
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        const int cc = c0 - 1 + j;
-        float m = -FLT_MAX;
-        if (cc >= 0 && cc < kImg) {
-          m = pl[r * kImg + cc];
-          if (r > 0) m = fmaxf(m, pl[(r - 1) * kImg + cc]);
-          if (r < kImg - 1) m = fmaxf(m, pl[(r + 1) * kImg + cc]);
-        }
-        cm[j] = m;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float v = fmaxf(fmaxf(cm[j], cm[j + 1]), cm[j + 2]);
-        d[k][j] = v;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+      const float *pl = (ch < 3) ? p012 + ch * kPix : p3;
+      const int rm = r > 0 ? r - 1 : 0, rp = r < kImg - 1 ? r + 1 : kImg - 1;
+      const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + 4 < kImg ? c0 + 4 : kImg - 1;
+      const float4 a = *reinterpret_cast<const float4 *>(pl + rm * kImg + c0);
+      const float4 b = *reinterpret_cast<const float4 *>(pl + r * kImg + c0);
+      const float4 c = *reinterpret_cast<const float4 *>(pl + rp * kImg + c0);
+      const float el = fmaxf(fmaxf(pl[rm * kImg + cl], pl[r * kImg + cl]), pl[rp * kImg + cl]);
+      const float er = fmaxf(fmaxf(pl[rm * kImg + cr], pl[r * kImg + cr]), pl[rp * kImg + cr]);
+      const float m0 = fmaxf(fmaxf(a.x, b.x), c.x), m1 = fmaxf(fmaxf(a.y, b.y), c.y);
+      const float m2 = fmaxf(fmaxf(a.z, b.z), c.z), m3 = fmaxf(fmaxf(a.w, b.w), c.w);
+      d[k][0] = fmaxf(fmaxf(el, m0), m1);
+      d[k][1] = fmaxf(fmaxf(m0, m1), m2);
+      d[k][2] = fmaxf(fmaxf(m1, m2), m3);
+      d[k][3] = fmaxf(fmaxf(m2, m3), er);
+      const float lo = fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3]));
+      const float hi = fmaxf(fmaxf(d[k][0], d[k][1]), fmaxf(d[k][2], d[k][3]));
+      if (ch < 3) {
+        mn[0] = fminf(mn[0], lo);
+        mx[0] = fmaxf(mx[0], hi);
+      } else {
+        mn[1] = fminf(mn[1], lo);
+        mx[1] = fmaxf(mx[1], hi);
       }
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, o));
-    mx = fmaxf(mx, __shfl_xor(mx, o));
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      mn[q] = fminf(mn[q], __shfl_xor(mn[q], o));
+      mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o));
+    }
   }
   __syncthreads();
   if ((tid & 63) == 0) {
-    S.red_f[2 * (tid >> 6)] = mn;
-    S.red_f[2 * (tid >> 6) + 1] = mx;
+    S.red_f[4 * (tid >> 6) + 0] = mn[0];
+    S.red_f[4 * (tid >> 6) + 1] = mx[0];
+    S.red_f[4 * (tid >> 6) + 2] = mn[1];
+    S.red_f[4 * (tid >> 6) + 3] = mx[1];
   }
   __syncthreads();
-  mn = S.red_f[0];
-  mx = S.red_f[1];
+  float fs[2], fb[2];
 #pragma unroll
-  for (int w = 1; w < IMG_WAVES; w++) {
-    mn = fminf(mn, S.red_f[2 * w]);
-    mx = fmaxf(mx, S.red_f[2 * w + 1]);
+  for (int q = 0; q < 2; q++) {
+    float a = S.red_f[2 * q], b = S.red_f[2 * q + 1];
+#pragma unroll
+    for (int w = 1; w < IMG_WAVES; w++) {
+      a = fminf(a, S.red_f[4 * w + 2 * q]);
+      b = fmaxf(b, S.red_f[4 * w + 2 * q + 1]);
+    }
+    const double smin = (double)a, smax = (double)b;
+    const double scale = 1.0 * ((smax - smin) > DBL_EPSILON ? 1.0 / (smax - smin) : 0.0);
+    const double shift = 0.0 - smin * scale;
+    fs[q] = (float)scale;
+    fb[q] = (float)shift;
   }
-  const double smin = (double)mn, smax = (double)mx;
-  const double scale = 1.0 * ((smax - smin) > DBL_EPSILON ? 1.0 / (smax - smin) : 0.0);
-  const double shift = 0.0 - smin * scale;
-  const float fs = (float)scale, fb = (float)shift;
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const int g = tid + k * IMG_THREADS;
     if (g < GROUPS) {
       const int ch = g / 900, rem = g - ch * 900;
       const int r = rem / 15, c0 = (rem - r * 15) * 4;
+      const int q = ch < 3 ? 0 : 1;
       uint32_t packed = 0;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float v = d[k][j] * fs + fb;
+        const float v = d[k][j] * fs[q] + fb[q];
         const float u = v * 255.0f + 0.0f;
-        float q = rintf(u);
-        q = q < 0.f ? 0.f : (q > 255.f ? 255.f : q);
-        packed |= (uint32_t)(int)q << (8 * j);
+        float t = rintf(u);
+        t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+        packed |= (uint32_t)(int)t << (8 * j);
       }
       // image row = 59 - cell row (image_strategy.cpp:128-129)
       *reinterpret_cast<uint32_t *>(out + (size_t)ch * kPix + (kImg - 1 - r) * kImg + c0) = packed;
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       }
       __syncthreads();
       TICK(3);
-      finalize_channels<1>(S, &S.raster[0][0], out + (size_t)(pr * K.per + 4) * kPix);
+      finalize_planes<1>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per + 4) * kPix);
       TICK(4);
     }
   }
@@ -679,8 +697,10 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     }
     __syncthreads();
     TICK(7);
-    finalize_channels<3>(S, &S.raster[0][0], out + (size_t)(pr * K.per) * kPix);
-    if (K.C >= 12) finalize_channels<1>(S, reinterpret_cast<const float *>(S.cells), out + (size_t)(pr * K.per + 3) * kPix);
+    if (K.C >= 12)
+      finalize_planes<4>(S, &S.raster[0][0], reinterpret_cast<const float *>(S.cells), out + (size_t)(pr * K.per) * kPix);
+    else
+      finalize_planes<3>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per) * kPix);
     TICK(8);
   }
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
