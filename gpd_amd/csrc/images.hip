@@ -437,17 +437,19 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     for (int w = tid; w < VWORDS; w += IMG_THREADS) S.u.s.bits[w] = 0u;
     if (tid == 0) {
       // voxel AABB of the image box: corners sample + F * (bx, by, bz)
-      double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX};
+      double lo0 = DBL_MAX, lo1 = DBL_MAX, lo2 = DBL_MAX;
+#pragma unroll
       for (int k = 0; k < 8; k++) {
         const double bx = (k & 1) ? B.hi[0] : B.lo[0];
         const double by = (k & 2) ? B.hi[1] : B.lo[1];
         const double bz = (k & 4) ? B.hi[2] : B.lo[2];
-        for (int r = 0; r < 3; r++) {
-          const double w = B.sample[r] + B.F[3 * r + 0] * bx + B.F[3 * r + 1] * by + B.F[3 * r + 2] * bz;
-          lo[r] = fmin(lo[r], w);
-        }
+        lo0 = fmin(lo0, B.sample[0] + B.F[0] * bx + B.F[1] * by + B.F[2] * bz);
+        lo1 = fmin(lo1, B.sample[1] + B.F[3] * bx + B.F[4] * by + B.F[5] * bz);
+        lo2 = fmin(lo2, B.sample[2] + B.F[6] * bx + B.F[7] * by + B.F[8] * bz);
       }
-      for (int r = 0; r < 3; r++) S.vorg[r] = (int)floor(lo[r] * K.voxel_mult) - 1;
+      S.vorg[0] = (int)floor(lo0 * K.voxel_mult) - 1;
+      S.vorg[1] = (int)floor(lo1 * K.voxel_mult) - 1;
+      S.vorg[2] = (int)floor(lo2 * K.voxel_mult) - 1;
     }
     __syncthreads();
     const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
@@ -537,6 +539,11 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       __syncthreads();
       TICK(2);
       const int da = depth_axis(pr);
+      // column `da` of F and the matching offset, selected without indexing the register-resident box
+      const double Fd0 = da == 0 ? B.F[0] : (da == 1 ? B.F[1] : B.F[2]);
+      const double Fd1 = da == 0 ? B.F[3] : (da == 1 ? B.F[4] : B.F[5]);
+      const double Fd2 = da == 0 ? B.F[6] : (da == 1 ? B.F[7] : B.F[8]);
+      const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
       float lmax = -FLT_MAX;
       int lany = 0;
       uint16_t *nz = reinterpret_cast<uint16_t *>(&S.raster[1][0]);
@@ -556,8 +563,8 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
             const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
             const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
                          c2 = (double)(iz + z0) * K.voxel - B.sample[2];
-            const double td = B.F[da] * c0 + B.F[3 + da] * c1 + B.F[6 + da] * c2;
-            const double d = div_len(td - B.off[da], da);
+            const double td = Fd0 * c0 + Fd1 * c1 + Fd2 * c2;
+            const double d = div_len(td - offd, da);
             fc = (float)((double)fc + 1.0);
             v = (float)((double)v + (d - (double)v) * recip_count(S.recip, fc));
           }
@@ -650,6 +657,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     // ---- createNormalsImage + createDepthImage (image_strategy.cpp:124-190): the pixel owner
     //      walks its segment in neighbour order
     const int da = depth_axis(pr);
+    const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
     uint16_t *nz = &S.place[PT_CAP];
     const int n_nz = list_nonempty_cells(S, nz);
     for (int c = tid; c < kPix; c += IMG_THREADS) {
@@ -684,7 +692,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
             v1 = v1 + (float)((double)d1 * inv);
             v2 = v2 + (float)((double)d2 * inv);
           }
-          const double d = div_len(S.u.p.t[da][e] - B.off[da], da);
+          const double d = div_len(S.u.p.t[da][e] - offd, da);
           fc = (float)((double)fc + 1.0);
           avg = (float)((double)avg + (d - (double)avg) * recip_count(S.recip, fc));
         }
