@@ -120,6 +120,15 @@ struct __attribute__((aligned(16))) Smem {
   int flag;
 };
 
+// a workgroup-uniform double moved to scalar registers (the candidate's box is the same for
+// all 1024 lanes; keeping its 21 doubles in SGPRs frees ~40 VGPRs per lane)
+__device__ inline double uniform_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // hand-frame coordinates of a world point: t = F^T (w - sample)  (image_strategy.cpp:36-40)
 __device__ inline void to_hand(const Box &B, double w0, double w1, double w2, double t[3]) {
   const double c0 = w0 - B.sample[0], c1 = w1 - B.sample[1], c2 = w2 - B.sample[2];
@@ -409,19 +418,20 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   uint8_t *out = P.images + (size_t)cand * kPix * K.C;
   Box B;
 #pragma unroll
-  for (int i = 0; i < 9; i++) B.F[i] = H.frame[i];
+  for (int i = 0; i < 9; i++) B.F[i] = uniform_f64(H.frame[i]);
 #pragma unroll
-  for (int i = 0; i < 3; i++) B.sample[i] = H.sample[i];
+  for (int i = 0; i < 3; i++) B.sample[i] = uniform_f64(H.sample[i]);
   // bounds exactly as findPointsInUnitImage / transformPointsToUnitImage evaluate them
-  B.off[0] = H.bottom;
-  B.off[1] = H.center - K.half_od;
-  B.off[2] = -K.vol_height;  // (t2 + height) == t2 - (-height)
-  B.lo[0] = H.bottom;
-  B.hi[0] = H.bottom + K.vol_depth;
-  B.lo[1] = H.center - K.half_od;
-  B.hi[1] = H.center + K.half_od;
-  B.lo[2] = -1.0 * K.vol_height;
-  B.hi[2] = K.vol_height;
+  const double hb = uniform_f64(H.bottom), hc = uniform_f64(H.center);
+  B.off[0] = hb;
+  B.off[1] = uniform_f64(hc - K.half_od);
+  B.off[2] = uniform_f64(-K.vol_height);  // (t2 + height) == t2 - (-height)
+  B.lo[0] = hb;
+  B.hi[0] = uniform_f64(hb + K.vol_depth);
+  B.lo[1] = B.off[1];
+  B.hi[1] = uniform_f64(hc + K.half_od);
+  B.lo[2] = uniform_f64(-1.0 * K.vol_height);
+  B.hi[2] = uniform_f64(K.vol_height);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
   for (int i = tid; i < 256; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
   if (tid == 0) {
