@@ -51,18 +51,26 @@ __device__ inline f32x16 pool_lanes(f32x16 v) {
   return v;
 }
 
-// conv1 + pool1.  Two images per workgroup (8 waves = 2 per SIMD: the second wave's MFMAs fill
-// the issue gaps of the first), weights [K][20] f32 + both u8 images in LDS.  The compiler
-// hoists each lane's 188 weight values into registers across the tile loop.
-// (Tried on MI355X and slower: one wave per SIMD with two accumulators, and explicit operand
-// prefetch groups pinned with sched_barrier — DESIGN.md §9.)
-constexpr int C1_THREADS = 512;
+// conv1 + pool1.  Two images per workgroup, 12 waves with two roles that use different pipes:
+//   waves 0-7  filters 0..15 as an implicit GEMM on v_mfma_f32_16x16x4_f32.  A wave owns a band
+//              of two output rows (7 tiles of 2x8 pixels) and keeps the 7 accumulators
+//              independent, so LDS reads and converts slot between MFMAs without stalling them;
+//              20 filters would pad a 32-row MFMA tile to 62 % efficiency, 16 fill it exactly.
+//   waves 8-11 filters 16..19 by direct convolution on the VALU (weights as wave-uniform
+//              scalars, 2x2 pool window per lane), which is idle otherwise.
+// Both are k-ascending fmaf chains (16x16x4 accumulates k..k+3 in order), bias after the pool.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int C1_MFMA_WAVES = 8, C1_VALU_WAVES = 4;
+constexpr int C1_THREADS = 64 * (C1_MFMA_WAVES + C1_VALU_WAVES);
+
 template <int C>
 __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wt,
-                                                                const float *__restrict__ bias, float *__restrict__ out, int n) {
-  constexpr int K = 25 * C, KP = (K + 1) & ~1;
+                                                                const float *__restrict__ w, const float *__restrict__ bias,
+                                                                float *__restrict__ out, int n) {
+  constexpr int K = 25 * C, KP = (K + 3) & ~3, NS = KP / 4;
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
-  __shared__ __attribute__((aligned(16))) float s_w[KP * 20];
+  __shared__ __attribute__((aligned(16))) float s_w[KP * 16];  // [k][16 filters], rows >= K are zero
+  __shared__ uint16_t s_off[KP];                                // byte offset of tap k in an image
   const int tid = threadIdx.x;
   const int img0 = blockIdx.x * 2;
   for (int q = 0; q < 2; q++) {
@@ -71,52 +79,126 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     uint4 *dst = reinterpret_cast<uint4 *>(s_img[q]);
     for (int i = tid; i < kPix * C / 16; i += C1_THREADS) dst[i] = src[i];
   }
-  for (int i = tid; i < KP * 20; i += C1_THREADS) s_w[i] = i < K * 20 ? wt[i] : 0.f;
+  for (int i = tid; i < KP * 16; i += C1_THREADS) {
+    const int k = i >> 4, f = i & 15;
+    s_w[i] = k < K ? wt[k * 20 + f] : 0.f;
+  }
+  for (int k = tid; k < KP; k += C1_THREADS) {
+    const int kk = k < K ? k : K - 1;
+    const int c = kk / 25, tap = kk - c * 25;
+    s_off[k] = (uint16_t)(c * kPix + (tap / 5) * kImg + tap % 5);
+  }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int half = lane >> 5, j = lane & 31;
-  const int fcl = j < 20 ? j : 19;
-  for (int t = wave; t < 2 * 98; t += C1_THREADS / 64) {
-    const int q = t / 98, tt = t - q * 98;
-    const int ty = tt / 7, tx = tt - ty * 7;
-    const uint8_t *xin = s_img[q] + (4 * ty + (j >> 3)) * kImg + 8 * tx + (j & 7);
-    f32x16 acc;
+  if (wave < C1_MFMA_WAVES) {
+    // the matrix waves win issue arbitration; the VALU waves of the same SIMD fill the gaps
+    __builtin_amdgcn_s_setprio(3);
+    const int kq = lane >> 4, j = lane & 15;
+    for (int g = wave; g < 2 * 28; g += C1_MFMA_WAVES) {
+      const int q = g / 28, rp = g - q * 28;
+      const uint8_t *xin = s_img[q] + (2 * rp + (j >> 3)) * kImg + (j & 7);
+      f32x4 acc[7];
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    for (int cp = 0; cp < C / 2; cp++) {
-      const uint8_t *xc = xin + cp * 2 * kPix;
-      const float *wc = s_w + cp * 50 * 20 + fcl;
+      for (int t = 0; t < 7; t++)
 #pragma unroll
-      for (int p = 0; p < 25; p++) {
-        const int boff = half ? tap_offset(2 * p + 1, kPix, kImg) : tap_offset(2 * p, kPix, kImg);
-        const float a = wc[(2 * p + half) * 20];
-        const float b = (float)xc[boff];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
+      // two-deep software pipeline: the bytes of step st+1 and the tap offset of step st+2 are
+      // requested before the seven MFMAs of step st are issued
+      float a_cur = s_w[kq * 16 + j];
+      uint8_t raw_cur[7], raw_nxt[7];
+      {
+        const uint8_t *x0 = xin + s_off[kq];
+#pragma unroll
+        for (int t = 0; t < 7; t++) raw_cur[t] = x0[8 * t];
+      }
+      int off_nxt = s_off[(NS > 1 ? 4 : 0) + kq];
+      for (int st = 0; st < NS; st++) {
+        const int k1 = 4 * (st + 1 < NS ? st + 1 : st) + kq;
+        const int k2 = 4 * (st + 2 < NS ? st + 2 : NS - 1) + kq;
+        const float a_nxt = s_w[k1 * 16 + j];
+        const uint8_t *x1 = xin + off_nxt;
+#pragma unroll
+        for (int t = 0; t < 7; t++) raw_nxt[t] = x1[8 * t];
+        const int off_nn = s_off[k2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 7; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, (float)raw_cur[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+        off_nxt = off_nn;
+#pragma unroll
+        for (int t = 0; t < 7; t++) raw_cur[t] = raw_nxt[t];
+      }
+      const int img = img0 + q;
+#pragma unroll
+      for (int t = 0; t < 7; t++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float x = acc[t][r];
+          x = fmaxf(x, __shfl_xor(x, 1));
+          x = fmaxf(x, __shfl_xor(x, 8));
+          acc[t][r] = x;
+        }
+        if (img < n && !(j & 1) && !(j & 8)) {
+          float *o = out + (size_t)img * 20 * 784 + rp * 28 + 4 * t + ((j & 7) >> 1);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int f = kq * 4 + r;
+            o[f * 784] = acc[t][r] + bias[f];
+          }
+        }
       }
     }
-    if (C & 1) {  // last channel: 25 taps = 12 pairs + one tap paired with the zero row k = K
-      const uint8_t *xc = xin + (C - 1) * kPix;
-      const float *wc = s_w + (C - 1) * 25 * 20 + fcl;
+  } else {
+    // filters 16..19: lane <-> pooled pixel, weights read as scalars in the file layout [f][k]
+    const int vw = wave - C1_MFMA_WAVES;
+    const float *__restrict__ wf = w + (size_t)16 * K;
+    for (int task = vw; task < 2 * 13; task += C1_VALU_WAVES) {
+      const int q = task / 13, chunk = task - q * 13;
+      const int p = chunk * 64 + lane;
+      const bool act = p < 784;
+      const int pp = act ? p : 0;
+      const int py = pp / 28, px = pp - py * 28;
+      float acc[4][4];
 #pragma unroll
-      for (int p = 0; p < 13; p++) {
-        const int k_rel = 2 * p + half;  // 0..25
-        const int kk = k_rel < 25 ? k_rel : 24;
-        const int boff = (kk / 5) * kImg + kk % 5;
-        const float a = wc[k_rel * 20];
-        const float b = (float)xc[boff];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[f][e] = 0.f;
+      const uint8_t *base = s_img[q] + (2 * py) * kImg + 2 * px;
+      for (int c = 0; c < C; c++) {
+        float patch[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+#pragma unroll
+          for (int e = 0; e < 3; e++) {
+            const uint16_t v = *reinterpret_cast<const uint16_t *>(base + c * kPix + r * kImg + 2 * e);
+            patch[r][2 * e] = (float)(v & 0xff);
+            patch[r][2 * e + 1] = (float)(v >> 8);
+          }
+        }
+#pragma unroll
+        for (int kh = 0; kh < 5; kh++) {
+#pragma unroll
+          for (int kw = 0; kw < 5; kw++) {
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+              const float wv = wf[f * K + c * 25 + kh * 5 + kw];
+              acc[f][0] = __builtin_fmaf(wv, patch[kh][kw], acc[f][0]);
+              acc[f][1] = __builtin_fmaf(wv, patch[kh][kw + 1], acc[f][1]);
+              acc[f][2] = __builtin_fmaf(wv, patch[kh + 1][kw], acc[f][2]);
+              acc[f][3] = __builtin_fmaf(wv, patch[kh + 1][kw + 1], acc[f][3]);
+            }
+          }
+        }
       }
-    }
-    acc = pool_lanes(acc);
-    const int img = img0 + q;
-    if (img < n && !(j & 1) && !(j & 8)) {
-      const int py = 2 * ty + (j >> 4), px = 4 * tx + ((j & 7) >> 1);
-      float *o = out + (size_t)img * 20 * 784 + py * 28 + px;
+      const int img = img0 + q;
+      if (act && img < n) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int f = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (f < 20) o[f * 784] = acc[r] + bias[f];
+        for (int f = 0; f < 4; f++) {
+          const float m = fmaxf(fmaxf(acc[f][0], acc[f][1]), fmaxf(acc[f][2], acc[f][3])) + bias[16 + f];
+          out[((size_t)img * 20 + 16 + f) * 784 + p] = m;
+        }
       }
     }
   }
@@ -322,9 +404,9 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     const int m = (n - off < kChunk) ? (n - off) : kChunk;
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
     switch (w.channels) {
-      case 15: conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1b, s.pool1, m); break;
-      case 12: conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1b, s.pool1, m); break;
-      case 3: conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1b, s.pool1, m); break;
+      case 15: conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
+      case 12: conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
+      case 3: conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
       default: return hipErrorInvalidValue;
     }
     conv2_mfma_kernel<<<m, 256, 0, stream>>>(s.pool1, w.c2wt, w.c2b, s.flat, m);
