@@ -103,32 +103,45 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
       for (int t = 0; t < 7; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
-      // two-deep software pipeline: the bytes of step st+1 and the tap offset of step st+2 are
-      // requested before the seven MFMAs of step st are issued
-      float a_cur = s_w[kq * 16 + j];
-      uint8_t raw_cur[7], raw_nxt[7];
+      // three-stage software pipeline per step st: LDS bytes of step st+2 are requested, the
+      // bytes of step st+1 (requested one step ago) are converted, and the seven MFMAs of step
+      // st run on floats converted one step ago — no MFMA waits on a load or a convert.
+      auto off_of = [&](int st) { return (int)s_off[4 * (st < NS ? st : NS - 1) + kq]; };
+      auto w_of = [&](int st) { return s_w[(4 * (st < NS ? st : NS - 1) + kq) * 16 + j]; };
+      float a0 = w_of(0), a1 = w_of(1);
+      float f0[7];
+      uint8_t raw1[7];
       {
-        const uint8_t *x0 = xin + s_off[kq];
+        const uint8_t *x0 = xin + off_of(0), *x1 = xin + off_of(1);
 #pragma unroll
-        for (int t = 0; t < 7; t++) raw_cur[t] = x0[8 * t];
+        for (int t = 0; t < 7; t++) {
+          f0[t] = (float)x0[8 * t];
+          raw1[t] = x1[8 * t];
+        }
       }
-      int off_nxt = s_off[(NS > 1 ? 4 : 0) + kq];
+      int off2 = off_of(2);
       for (int st = 0; st < NS; st++) {
-        const int k1 = 4 * (st + 1 < NS ? st + 1 : st) + kq;
-        const int k2 = 4 * (st + 2 < NS ? st + 2 : NS - 1) + kq;
-        const float a_nxt = s_w[k1 * 16 + j];
-        const uint8_t *x1 = xin + off_nxt;
+        uint8_t raw2[7];
+        float f1[7];
+        const uint8_t *x2 = xin + off2;
 #pragma unroll
-        for (int t = 0; t < 7; t++) raw_nxt[t] = x1[8 * t];
-        const int off_nn = s_off[k2];
+        for (int t = 0; t < 7; t++) raw2[t] = x2[8 * t];
+        const float a2 = w_of(st + 2);
+        const int off3 = off_of(st + 3);
+#pragma unroll
+        for (int t = 0; t < 7; t++) f1[t] = (float)raw1[t];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 7; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, (float)raw_cur[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 7; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, f0[t], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        a_cur = a_nxt;
-        off_nxt = off_nn;
+        a0 = a1;
+        a1 = a2;
+        off2 = off3;
 #pragma unroll
-        for (int t = 0; t < 7; t++) raw_cur[t] = raw_nxt[t];
+        for (int t = 0; t < 7; t++) {
+          f0[t] = f1[t];
+          raw1[t] = raw2[t];
+        }
       }
       const int img = img0 + q;
 #pragma unroll
