@@ -120,6 +120,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
         }
       }
       int off2 = off_of(2);
+#pragma unroll 6
       for (int st = 0; st < NS; st++) {
         uint8_t raw2[7];
         float f1[7];
