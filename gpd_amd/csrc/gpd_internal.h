@@ -84,7 +84,7 @@ struct ImageState {
   uint8_t *d_images_hwc = nullptr;    // [n][60][60][C], only when the caller downloads pixels
   gpd_hand *d_hands = nullptr;        // candidate hand records
   int32_t *d_cand_meta = nullptr;     // [n][4]: sample slot, N_images, shadow-set ordinal, -
-  int32_t *d_set_meta = nullptr;      // [sets][4]: sample slot, N_images, lcg offset lo, hi
+  int32_t *d_set_meta = nullptr;      // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera
   uint32_t *d_set_bits = nullptr;     // [sets][88^3/32] shadow voxel bitsets
   int num_shadow_sets = 0, cap_shadow_sets = 0;
   int32_t *d_status = nullptr;        // error flags from the kernel

@@ -62,7 +62,7 @@ constexpr int SETWORDS = SD * SD * SD / 32;
 struct ImgConsts {
   double vol_depth, vol_width, vol_height, half_od, dbl_h;
   int C, nproj, per;
-  double view_point[3];
+  double view_point[3 * kMaxCams];
   double shadow_length, voxel, voxel_mult, rand_inv;
   int num_shadow;
   uint32_t stride_a, stride_c;  // LCG jump by IMG_THREADS * num_shadow draws
@@ -79,7 +79,7 @@ struct ImgParams {
   int cap;
   const double *centers;
   const gpd_hand *hands;  // one per candidate
-  const int32_t *meta;    // [n][4]: sample slot, N_images, live-set ordinal (< 0: no shadow), -
+  const int32_t *meta;    // [n][4]: sample slot, N_images, first shadow bitset (< 0: no shadow), number of bitsets (cameras)
   const uint32_t *set_bits;  // [live sets][SETWORDS] shadow voxel bitsets (shadow_set_kernel)
   uint8_t *images;        // planar [n][C][3600]
   int32_t *status;
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   const int slot_s = P.meta[4 * cand + 0];
   const int N = P.meta[4 * cand + 1];
   const int set_ord = P.meta[4 * cand + 2];
+  const int set_nb = P.meta[4 * cand + 3];
   const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
   uint8_t *out = P.images + (size_t)cand * kPix * K.C;
   Box B;
@@ -480,9 +481,14 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
         if (za >= zb) continue;
         const int b0 = rowbit + za;
         const int w0 = b0 >> 5, sh = b0 & 31;
-        const unsigned long long lo64 = (unsigned long long)sb[w0] | ((unsigned long long)(w0 + 1 < SETWORDS ? sb[w0 + 1] : 0u) << 32);
-        const unsigned long long hi = (w0 + 2 < SETWORDS) ? sb[w0 + 2] : 0u;
-        unsigned long long field = (lo64 >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+        // several cameras: the shadow is the intersection of their voxel sets (hand_set.cpp:159-172)
+        unsigned long long field = ~0ull;
+        for (int cb = 0; cb < set_nb; cb++) {
+          const uint32_t *sc = sb + (size_t)cb * SETWORDS;
+          const unsigned long long lo64 = (unsigned long long)sc[w0] | ((unsigned long long)(w0 + 1 < SETWORDS ? sc[w0 + 1] : 0u) << 32);
+          const unsigned long long hi = (w0 + 2 < SETWORDS) ? sc[w0 + 2] : 0u;
+          field &= (lo64 >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+        }
         const int nbits = zb - za;
         field &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
         while (field) {
@@ -736,7 +742,7 @@ struct SetParams {
   int cap;
   const double *centers;
   const double *frames;     // [S][12], sample first
-  const int32_t *set_meta;  // [sets][4]: sample slot, N_images, lcg offset lo, hi
+  const int32_t *set_meta;  // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera, -
   uint32_t *set_bits;       // [sets][SETWORDS]
 };
 
@@ -745,10 +751,11 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_set_kernel(SetParams P) {
   const ImgConsts &K = c_img;
   const int set = blockIdx.x;
   const int tid = threadIdx.x;
-  const int slot_s = P.set_meta[4 * set + 0];
-  const int N = P.set_meta[4 * set + 1];
+  const int slot_s = P.set_meta[8 * set + 0];
+  const int N = P.set_meta[8 * set + 1];
   const unsigned long long off =
-      ((unsigned long long)(uint32_t)P.set_meta[4 * set + 3] << 32) | (uint32_t)P.set_meta[4 * set + 2];
+      ((unsigned long long)(uint32_t)P.set_meta[8 * set + 3] << 32) | (uint32_t)P.set_meta[8 * set + 2];
+  const int cam = P.set_meta[8 * set + 4];
   const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
   for (int w = tid; w < SETWORDS; w += IMG_THREADS) bits[w] = 0u;
   __syncthreads();
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_set_kernel(SetParams P) {
   // shadow_vec = shadow_length * (center - view_point) / norm (hand_set.cpp:147-150)
   const double *cen = P.centers + 3 * (size_t)slot_s;
   double vec[3];
-  for (int r = 0; r < 3; r++) vec[r] = cen[r] - K.view_point[r];
+  for (int r = 0; r < 3; r++) vec[r] = cen[r] - K.view_point[3 * cam + r];
   const double nrm = sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
   for (int r = 0; r < 3; r++) vec[r] = K.shadow_length * vec[r] / nrm;
   uint32_t state = lcg_jump(0u, off + (unsigned long long)tid * (unsigned)K.num_shadow);
@@ -859,10 +866,6 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
     set_error("images: hands must come from gpd_hip_search on this context and cloud");
     return GPD_ERR_STATE;
   }
-  if (C == 15 && c.num_cams != 1) {
-    set_error("images: 15-channel shadow supports one camera (got %d)", c.num_cams);
-    return GPD_ERR_INVALID;
-  }
   if (num_sets > (int)s.h_set_sample.size()) {
     set_error("images: %d sets passed, search produced %zu", num_sets, s.h_set_sample.size());
     return GPD_ERR_INVALID;
@@ -886,7 +889,24 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
         return GPD_ERR_STATE;
       }
     const int Ni = s.h_counts[8 * samp + 1];
-    const bool seen = s.h_counts[8 * samp + 4] != 0;
+    const int seen_mask = s.h_counts[8 * samp + 4];
+    // HandSet::calculateShadow (hand_set.cpp:118-185): every camera that sees a neighbourhood point
+    // casts 33*N_i draws, in camera order.  One camera: its set (empty if it sees nothing).  Several:
+    // start from camera 0's set (empty if camera 0 sees nothing) and intersect with the seen others.
+    int first_bits = -1, n_bits = 0;
+    if (C == 15 && Ni > 0) {
+      const bool cam0 = (seen_mask & 1) != 0;
+      for (int cam = 0; cam < c.num_cams; cam++) {
+        if (!(seen_mask >> cam & 1)) continue;
+        if (cam0) {
+          if (first_bits < 0) first_bits = (int)(set_meta.size() / 8);
+          n_bits++;
+          const int32_t row[8] = {samp, Ni, (int32_t)(uint32_t)(lcg & 0xffffffffull), (int32_t)(lcg >> 32), cam, 0, 0, 0};
+          set_meta.insert(set_meta.end(), row, row + 8);
+        }
+        lcg += (unsigned long long)Ni * 33ull;  // the draws are consumed even when the result is discarded
+      }
+    }
     for (int j = 0; j < slots; j++) {
       const gpd_hand &h = hands[(size_t)si * slots + j];
       if (!h.valid) continue;
@@ -894,15 +914,8 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
       cand.push_back(h);
       meta.push_back(samp);
       meta.push_back(Ni);
-      meta.push_back((C == 15 && seen && Ni > 0) ? (int32_t)(set_meta.size() / 4) : -1);
-      meta.push_back(0);
-    }
-    if (C == 15 && seen && Ni > 0) {
-      set_meta.push_back(samp);
-      set_meta.push_back(Ni);
-      set_meta.push_back((int32_t)(uint32_t)(lcg & 0xffffffffull));
-      set_meta.push_back((int32_t)(lcg >> 32));
-      lcg += (unsigned long long)Ni * 33ull;
+      meta.push_back(first_bits);
+      meta.push_back(n_bits);
     }
     im.stat_sets++;
     im.stat_sum_set_ni += Ni;
@@ -929,14 +942,14 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   HIP_RET(hipMemsetAsync(im.d_status, 0, sizeof(int32_t), stream));
   HIP_RET(hipMemcpyAsync(im.d_hands, cand.data(), (size_t)n * sizeof(gpd_hand), hipMemcpyHostToDevice, stream));
   HIP_RET(hipMemcpyAsync(im.d_cand_meta, meta.data(), (size_t)n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  im.num_shadow_sets = (int)(set_meta.size() / 4);
+  im.num_shadow_sets = (int)(set_meta.size() / 8);
   if (im.num_shadow_sets > im.cap_shadow_sets) {
     if (im.d_set_meta) (void)hipFree(im.d_set_meta);
     if (im.d_set_bits) (void)hipFree(im.d_set_bits);
     im.d_set_meta = nullptr;
     im.d_set_bits = nullptr;
     im.cap_shadow_sets = 0;
-    HIP_RET(hipMalloc(&im.d_set_meta, (size_t)im.num_shadow_sets * 4 * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&im.d_set_meta, (size_t)im.num_shadow_sets * 8 * sizeof(int32_t)));
     HIP_RET(hipMalloc(&im.d_set_bits, (size_t)im.num_shadow_sets * SETWORDS * sizeof(uint32_t)));
     im.cap_shadow_sets = im.num_shadow_sets;
   }
@@ -952,7 +965,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   k.C = C;
   k.nproj = (C == 3) ? 1 : 3;
   k.per = (C == 15) ? 5 : (C == 12 ? 4 : 3);
-  for (int r = 0; r < 3; r++) k.view_point[r] = c.view_points[r];
+  for (int r = 0; r < 3 * c.num_cams; r++) k.view_point[r] = c.view_points[r];
   // shadow_length_ = max(volume_depth, volume_height/2, volume_width) (image_15_channels_strategy.h:70-75)
   k.shadow_length = std::fmax(std::fmax(p.volume_depth, p.volume_height / 2.0), p.volume_width);
   k.voxel = 0.003;

@@ -242,12 +242,13 @@ struct NbParams {
   const int32_t *sample_idx;
   float r2_hands, r2_images, r2_frames;
   int cap;  // power of two
-  int32_t *counts;  // [S][8]: N_hands, N_images, k_frames, found, seen_by_cam0, -, -, -
+  int32_t *counts;  // [S][8]: N_hands, N_images, k_frames, found, mask of cameras that see the image neighbourhood, -, -, -
   int32_t *nn_idx;
   float *nn;
   double *frames;
   double *centers;  // [S][3] mean of the image neighbourhood (hand_set.cpp:131-133)
   const int32_t *cam_source;
+  int num_cams;
 };
 
 __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
@@ -342,10 +343,11 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     on[3 * P.cap + t] = P.nx[i];
     on[4 * P.cap + t] = P.ny[i];
     on[5 * P.cap + t] = P.nz[i];
-    if (t < n_img) seen |= P.cam_source[i];
+    if (t < n_img)
+      for (int cam = 0; cam < P.num_cams; cam++) seen |= (P.cam_source[(size_t)cam * P.num_points + i] != 0) << cam;
     s_keys[t] = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
   }
-  if (__ballot(seen != 0) && lane == 0) atomicOr(&s_seen, 1);
+  if (seen) atomicOr(&s_seen, seen);
   __threadfence_block();
   __syncthreads();
   // 4b. centre of the image neighbourhood: sequential fp64 sums in neighbour order
@@ -797,6 +799,7 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.frames = s.d_frames;
   np.centers = s.d_centers;
   np.cam_source = c.cam_source;
+  np.num_cams = c.num_cams;
   const size_t lds = (size_t)cap * sizeof(unsigned long long);
   HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));

@@ -159,3 +159,34 @@ def test_tiny_cloud(oracle_mod):
         assert np.allclose(hands["frame"], oh["frame"], rtol=1e-12, atol=1e-15)
     finally:
         ctx.close()
+
+
+def test_two_cameras_shadow_intersection(oracle_mod, cloud30k):
+    """Two view points: the shadow is the intersection of the per-camera voxel sets
+    (hand_set.cpp:159-172), cameras draw from the LCG in order."""
+    cl = cloud30k
+    P = len(cl["xyz"])
+    cam = np.zeros((2, P), np.int32)
+    cam[0] = cl["xyz"][:, 0] < 0.08      # camera 0 misses one side, camera 1 the other
+    cam[1] = cl["xyz"][:, 0] > -0.08
+    vp = np.array([[0.0, 0.0, 0.0], [0.35, 0.1, 0.05]])
+    si = synth.sample_indices(cl, 150)
+    w = _weights(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(cl["xyz"], cl["normals"], cam, vp)
+        p = oracle_mod.default_params(15)
+        hands = oracle_mod.filter_workspace(p, ctx.search(si))
+        got, gidx = ctx.images(hands)
+        want, widx = oracle_mod.images(p, cl["xyz"], cl["normals"], cam, vp, hands)
+        assert np.array_equal(gidx, widx) and len(gidx) > 100
+        assert np.array_equal(got, want), "differing pixels: %d" % (got != want).sum()
+        # the shadow channels are not trivially empty and differ from the one-camera result
+        assert got[..., 4].any()
+        ctx.upload_cloud(cl["xyz"], cl["normals"], cam[:1], vp[:1])
+        h1 = oracle_mod.filter_workspace(p, ctx.search(si))
+        one, _ = ctx.images(h1)
+        assert not np.array_equal(one[..., 4], got[..., 4])
+    finally:
+        ctx.close()
