@@ -41,7 +41,7 @@ class GpdHipError(RuntimeError):
 
 EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
-           "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats"]
+           "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals"]
 
 
 def build():
@@ -68,6 +68,7 @@ def lib():
         L.gpd_hip_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
+        L.gpd_hip_estimate_normals.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.gpd_hip_last_images_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         _LIB = L
@@ -131,6 +132,7 @@ class Context:
         cam = np.ones((1, P), np.int32) if cam_source is None else np.ascontiguousarray(cam_source, np.int32).reshape(-1, P)
         vp = np.zeros((1, 3)) if view_points is None else np.ascontiguousarray(view_points, np.float64).reshape(-1, 3)
         self._check(lib().gpd_hip_upload_cloud(self._h, _ptr(xyz), _ptr(normals), P, _ptr(cam), cam.shape[0], _ptr(vp)))
+        self._num_points = P
 
     def search(self, sample_indices):
         """generateGraspCandidateSets -> hands[n_sets, n_slots]."""
@@ -181,3 +183,10 @@ class Context:
         out = np.zeros(4, np.int64)
         self._check(lib().gpd_hip_last_images_stats(self._h, _ptr(out)))
         return dict(candidates=int(out[0]), sets=int(out[1]), sum_set_ni=int(out[2]), sum_cand_ni=int(out[3]))
+
+    def estimate_normals(self, radius=0.03):
+        """Cloud::calculateNormals on the uploaded cloud -> f32 [P,3] (also kept on the device)."""
+        P = self._num_points
+        out = np.zeros((P, 3), np.float32)
+        self._check(lib().gpd_hip_estimate_normals(self._h, float(radius), _ptr(out)))
+        return out

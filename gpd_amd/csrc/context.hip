@@ -254,6 +254,19 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
   return GPD_OK;
 }
 
+int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals) {
+  if (!ctx || !normals || !(radius > 0.0)) {
+    set_error("gpd_hip_estimate_normals: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  if (!ctx->cloud.num_points) {
+    set_error("gpd_hip_estimate_normals: no cloud uploaded");
+    return GPD_ERR_STATE;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return normals_run(ctx->cloud, radius, normals, ctx->stream);
+}
+
 int gpd_hip_search(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, gpd_hand *hands, int *num_sets) {
   if (!ctx || !sample_indices || num_samples < 0 || !hands || !num_sets) {
     set_error("gpd_hip_search: bad argument");

@@ -52,6 +52,7 @@ struct Cloud {
 hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
                         const double *view_points, hipStream_t stream);
 void cloud_free(Cloud &c);
+int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream);
 
 // ---- Candidate search (search.hip) -----------------------------------------------
 struct SearchState {

@@ -430,6 +430,186 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
 }
 
 // ---------------------------------------------------------------------------
+// normals_kernel — Cloud::calculateNormals (util/cloud.cpp:451-476): the radius-search normal
+// estimation of calculateNormalsOMP (:497-535, pcl::NormalEstimationOMP) followed by
+// reverseNormals (:573-604).  One workgroup per point: stream the cloud, sort the neighbourhood
+// in FLANN order, centroid and covariance as sequential fp64 sums in that order (one lane per
+// component), 3x3 eigensolver, eigenvector of the smallest eigenvalue, flip towards the view
+// point of the camera that sees the point, then the reference's reversal rule.
+// ---------------------------------------------------------------------------
+constexpr int NRM_CAP = 2048;
+struct NormalsParams {
+  const float *px, *py, *pz;
+  int num_points;
+  const int32_t *cam_source;
+  int num_cams;
+  double view_points[3 * kMaxCams];
+  float r2;
+  float *out;  // AoS [P][3]
+  int32_t *overflow;
+};
+
+__global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
+  __shared__ unsigned long long s_keys[NRM_CAP];
+  __shared__ float s_xyz[3][NRM_CAP];
+  __shared__ int s_count;
+  __shared__ double s_c[3], s_m[6];
+  const int pi = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float qx = P.px[pi], qy = P.py[pi], qz = P.pz[pi];
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  const int n_iter = (P.num_points + 255) / 256;
+  for (int it = 0; it < n_iter; it++) {
+    const int i = it * 256 + tid;
+    bool hit = false;
+    float d2 = 0.f;
+    if (i < P.num_points) {
+      float d = qx - P.px[i];
+      d2 += d * d;
+      d = qy - P.py[i];
+      d2 += d * d;
+      d = qz - P.pz[i];
+      d2 += d * d;
+      hit = d2 < P.r2;
+    }
+    const unsigned long long ballot = __ballot(hit);
+    if (ballot) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
+      base = __shfl(base, 0);
+      if (hit) {
+        const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
+        if (pos < NRM_CAP) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+      }
+    }
+  }
+  __syncthreads();
+  const int found = s_count;
+  if (found > NRM_CAP) {
+    if (tid == 0) atomicMax(P.overflow, found);
+    return;
+  }
+  const int n = found;
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = n + tid; i < m; i += 256) s_keys[i] = ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (m >> 1); t += 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = s_keys[lo], b = s_keys[hi];
+        if ((a > b) == up) {
+          s_keys[lo] = b;
+          s_keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = tid; t < n; t += 256) {
+    const int i = (int)(unsigned)(s_keys[t] & 0xffffffffull);
+    s_xyz[0][t] = P.px[i];
+    s_xyz[1][t] = P.py[i];
+    s_xyz[2][t] = P.pz[i];
+  }
+  __syncthreads();
+  if (tid < 3) {  // centroid, one lane per coordinate
+    double acc = 0.0;
+    for (int t = 0; t < n; t++) acc += (double)s_xyz[tid][t];
+    s_c[tid] = acc / (double)n;
+  }
+  __syncthreads();
+  if (tid < 6) {  // covariance entries 00, 10, 11, 20, 21, 22, one lane each
+    const int a = tid == 0 ? 0 : (tid < 3 ? 1 : 2);
+    const int b = tid == 0 ? 0 : (tid == 1 ? 0 : (tid == 2 ? 1 : tid - 3));
+    const double ca = s_c[a], cb = s_c[b];
+    double acc = 0.0;
+    for (int t = 0; t < n; t++) acc += ((double)s_xyz[a][t] - ca) * ((double)s_xyz[b][t] - cb);
+    s_m[tid] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double ev[3], Q[9];
+    eigen3(s_m[0], s_m[1], s_m[2], s_m[3], s_m[4], s_m[5], ev, Q);
+    int mn = 0;
+    for (int q = 1; q < 3; q++)
+      if (ev[q] < ev[mn]) mn = q;
+    const double nx = Q[mn], ny = Q[3 + mn], nz = Q[6 + mn];
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    for (int cam = 0; cam < P.num_cams; cam++) {  // the last seeing camera wins (cloud.cpp:525-533)
+      if (!P.cam_source[(size_t)cam * P.num_points + pi]) continue;
+      const double *vp = P.view_points + 3 * cam;
+      const double dot = (vp[0] - (double)qx) * nx + (vp[1] - (double)qy) * ny + (vp[2] - (double)qz) * nz;
+      const double sgn = dot < 0 ? -1.0 : 1.0;
+      o0 = (float)(dot < 0 ? -nx : nx);
+      o1 = (float)(dot < 0 ? -ny : ny);
+      o2 = (float)(dot < 0 ? -nz : nz);
+      (void)sgn;
+    }
+    bool needs_reverse = true;  // reverseNormals (cloud.cpp:573-604)
+    for (int cam = 0; cam < P.num_cams && needs_reverse; cam++) {
+      if (P.cam_source[(size_t)cam * P.num_points + pi] != 1) continue;
+      const double *vp = P.view_points + 3 * cam;
+      const double d = (double)o0 * ((double)qx - vp[0]) + (double)o1 * ((double)qy - vp[1]) + (double)o2 * ((double)qz - vp[2]);
+      if (d < 0) needs_reverse = false;
+    }
+    if (needs_reverse) {
+      o0 = (float)((double)o0 * -1.0);
+      o1 = (float)((double)o1 * -1.0);
+      o2 = (float)((double)o2 * -1.0);
+    }
+    P.out[3 * (size_t)pi + 0] = o0;
+    P.out[3 * (size_t)pi + 1] = o1;
+    P.out[3 * (size_t)pi + 2] = o2;
+  }
+}
+
+// Host wrapper: normals of the uploaded cloud (uses its device planes), result to the host and
+// into the context's device copy.
+int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream) {
+  float *d_out = nullptr;
+  int32_t *d_ovf = nullptr;
+  HIP_RET(hipMalloc(&d_out, (size_t)c.num_points * 3 * sizeof(float)));
+  HIP_RET(hipMalloc(&d_ovf, sizeof(int32_t)));
+  HIP_RET(hipMemsetAsync(d_ovf, 0, sizeof(int32_t), stream));
+  HIP_RET(hipMemsetAsync(d_out, 0, (size_t)c.num_points * 3 * sizeof(float), stream));
+  NormalsParams np;
+  np.px = c.px; np.py = c.py; np.pz = c.pz;
+  np.num_points = c.num_points;
+  np.cam_source = c.cam_source;
+  np.num_cams = c.num_cams;
+  std::memcpy(np.view_points, c.view_points, sizeof(np.view_points));
+  np.r2 = (float)(radius * radius);
+  np.out = d_out;
+  np.overflow = d_ovf;
+  normals_kernel<<<c.num_points, 256, 0, stream>>>(np);
+  HIP_RET(hipGetLastError());
+  int32_t ovf = 0;
+  HIP_RET(hipMemcpyAsync(&ovf, d_ovf, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipMemcpyAsync(normals_out, d_out, (size_t)c.num_points * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipStreamSynchronize(stream));
+  int rc = GPD_OK;
+  if (ovf) {
+    set_error("normals: a %.3f m neighbourhood holds %d points, more than the capacity %d", radius, ovf, NRM_CAP);
+    rc = GPD_ERR_CAPACITY;
+  } else {
+    // keep the device copy of the cloud consistent: planes nx, ny, nz
+    split_soa_kernel<<<(c.num_points + 255) / 256, 256, 0, stream>>>(c.staging, d_out, c.num_points, c.px, c.py, c.pz, c.nx, c.ny,
+                                                                       c.nz);
+    HIP_RET(hipGetLastError());
+    HIP_RET(hipStreamSynchronize(stream));
+    c.generation++;
+  }
+  (void)hipFree(d_out);
+  (void)hipFree(d_ovf);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
 // hand_eval_kernel
 // ---------------------------------------------------------------------------
 struct HandConsts {

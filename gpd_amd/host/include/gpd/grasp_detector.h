@@ -19,7 +19,9 @@ class GraspDetector {
   explicit GraspDetector(const std::string &config_filename);
   ~GraspDetector();
   std::vector<std::unique_ptr<candidate::Hand>> detectGrasps(const util::Cloud &cloud);
-  void preprocessPointCloud(util::Cloud &cloud);  // subsample(num_samples) only; see util/cloud.h
+  // CandidatesGenerator::preprocessPointCloud (candidates_generator.cpp:14-37): voxelise (cfg
+  // voxelize/voxel_size), normals on the GPU when the cloud has none (normals_radius), subsample.
+  void preprocessPointCloud(util::Cloud &cloud);
   std::vector<std::unique_ptr<candidate::HandSet>> generateGraspCandidates(const util::Cloud &cloud);
   std::vector<std::unique_ptr<candidate::HandSet>> filterGraspsWorkspace(
       std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, const std::vector<double> &workspace) const;
@@ -40,6 +42,8 @@ class GraspDetector {
   gpd_hip_ctx *ctx_ = nullptr;
   bool has_classifier_ = false;
   int num_samples_ = 1000;
+  bool voxelize_ = true;
+  double voxel_size_ = 0.003, normals_radius_ = 0.03;
   int num_selected_ = 100;
   std::vector<double> workspace_grasps_;
   double runtimes_[4] = {0, 0, 0, 0};

@@ -28,6 +28,9 @@ class Cloud {
   const std::vector<int> &getSampleIndices() const { return sample_indices_; }
   void setSampleIndices(const std::vector<int> &idx) { sample_indices_ = idx; }
   void setNormals(const std::vector<float> &normals) { normals_ = normals; }
+  // Cloud::voxelizeCloud (cloud.cpp:286-348), including what its std::set comparator (cloud.h:105-122,
+  // not an ordering) keeps under libstdc++; drops normals like the reference's preprocessing order does.
+  void voxelizeCloud(float cell_size);
   // Cloud::subsample (cloud.cpp:350-405) draws with pcl::RandomSample (time-seeded); here a
   // seeded Fisher-Yates permutation so runs are reproducible.
   void subsample(int num_samples, unsigned seed = 0);

@@ -7,7 +7,11 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <array>
+#include <cfloat>
+#include <cmath>
 #include <numeric>
+#include <set>
 
 #include "gpd/grasp_detector.h"
 #include "gpd/util/config_file.h"
@@ -137,6 +141,43 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
   }
   if (view_points_.empty()) view_points_.assign(3, 0.0);
   camera_source_.assign(size() * numCameras(), 1);
+}
+
+namespace {
+struct VoxelDiffers {  // UniqueVector4First3Comparator (cloud.h:105-122)
+  bool operator()(const std::array<int, 4> &a, const std::array<int, 4> &b) const {
+    return a[0] != b[0] || a[1] != b[1] || a[2] != b[2];
+  }
+};
+}  // namespace
+
+void Cloud::voxelizeCloud(float cell_size) {
+  const int n = (int)size();
+  if (n == 0) return;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  for (int i = 0; i < n; i++)
+    for (int c = 0; c < 3; c++) mn[c] = std::min(mn[c], xyz_[3 * i + c]);
+  std::set<std::array<int, 4>, VoxelDiffers> bins;
+  for (int i = 0; i < n; i++) {
+    std::array<int, 4> v;
+    for (int c = 0; c < 3; c++) v[c] = (int)std::floor((xyz_[3 * i + c] - mn[c]) / cell_size);
+    v[3] = i;
+    bins.insert(v);
+  }
+  const int cams = numCameras();
+  std::vector<float> out;
+  std::vector<int> cam((size_t)cams * bins.size());
+  size_t k = 0;
+  for (const auto &v : bins) {
+    for (int c = 0; c < 3; c++) out.push_back(mn[c] + cell_size * (float)v[c]);
+    for (int j = 0; j < cams; j++) cam[(size_t)j * bins.size() + k] = camera_source_[(size_t)j * n + v[3]] == 1 ? 1 : 0;
+    k++;
+  }
+  xyz_ = out;
+  camera_source_ = cam;
+  normals_.clear();
+  sample_indices_.clear();
+  printf("Voxelized cloud: %zu\n", size());
 }
 
 void Cloud::subsample(int num_samples, unsigned seed) {
@@ -286,6 +327,9 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   params_.init_bite = hand_cfg.getValueOfKey<double>("init_bite", 0.01);
   // candidate generation (grasp_detector.cpp:47-88)
   num_samples_ = config_file.getValueOfKey<int>("num_samples", 1000);
+  voxelize_ = config_file.getValueOfKey<bool>("voxelize", true);
+  voxel_size_ = config_file.getValueOfKey<double>("voxel_size", 0.003);
+  normals_radius_ = config_file.getValueOfKey<double>("normals_radius", 0.03);
   params_.nn_radius_frames = config_file.getValueOfKey<double>("nn_radius", 0.01);
   params_.num_orientations = config_file.getValueOfKey<int>("num_orientations", 8);
   params_.num_finger_placements = config_file.getValueOfKey<int>("num_finger_placements", 10);
@@ -348,6 +392,22 @@ GraspDetector::~GraspDetector() {
 }
 
 void GraspDetector::preprocessPointCloud(util::Cloud &cloud) {
+  printf("Processing cloud with %zu points.\n", cloud.size());
+  if (!cloud.hasNormals()) {
+    // the reference's order: voxelise, then estimate normals on the voxelised cloud
+    if (voxelize_) cloud.voxelizeCloud((float)voxel_size_);
+    if (ctx_ && cloud.size() > 0) {
+      std::vector<float> zeros(cloud.size() * 3, 0.f), normals(cloud.size() * 3, 0.f);
+      printf("Calculating surface normals ...\n");
+      if (gpd_hip_upload_cloud(ctx_, cloud.getCloudProcessed().data(), zeros.data(), (int)cloud.size(), cloud.getCameraSource().data(),
+                               cloud.numCameras(), cloud.getViewPoints().data()) != GPD_OK ||
+          gpd_hip_estimate_normals(ctx_, normals_radius_, normals.data()) != GPD_OK) {
+        printf("ERROR: %s\n", gpd_hip_last_error());
+        return;
+      }
+      cloud.setNormals(normals);
+    }
+  }
   if (cloud.getSampleIndices().empty()) cloud.subsample(num_samples_);
 }
 

@@ -119,6 +119,12 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
                          int num_points, const int32_t *cam_source, int num_cams,
                          const double *view_points);
 
+/* SURVEY §8f rank 1 (the step that feeds the path its normals): replaces Cloud::calculateNormals
+ * (util/cloud.cpp:451-476) = calculateNormalsOMP (:497-535, radius search, PCA, flip towards the
+ * view point) + reverseNormals (:573-604), on the cloud uploaded last (its normals argument may
+ * be zeros).  normals receives num_points*3 floats and also replaces the device copy. */
+int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals);
+
 /* Replaces CandidatesGenerator::generateGraspCandidateSets ->
  * HandSearch::searchHands (candidates_generator.cpp:62-69, hand_search.cpp:24-64)
  * for samples given by index (Cloud::getSampleIndices).  Writes

@@ -30,7 +30,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <set>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -1259,6 +1261,95 @@ int gpd_oracle_detect(const gpd_params *P, const float *xyz, const float *normal
     times[2] = t3 - t2;
   }
   return 0;
+}
+
+// Cloud::voxelizeCloud (util/cloud.cpp:286-348) without normals.  The reference keys a std::set
+// with UniqueVector4First3Comparator (util/cloud.h:105-122), which returns "the first three
+// elements differ" — not a strict weak ordering, so which points survive depends on the
+// red-black tree of libstdc++'s std::set.  Restated by using std::set with the same predicate
+// (SURVEY §9-K KAT: tutorials/krylon.pcd 4467 -> 3366 points).  out_src: input index kept per voxel.
+struct VoxelDiffers {
+  bool operator()(const std::array<int, 4> &a, const std::array<int, 4> &b) const {
+    for (int i = 0; i < 3; i++)
+      if (a[i] != b[i]) return true;
+    return false;
+  }
+};
+int gpd_oracle_voxelize(const float *xyz, int P, float cell_size, float *out_xyz, int32_t *out_src) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  for (int i = 0; i < P; i++)
+    for (int c = 0; c < 3; c++) mn[c] = std::min(mn[c], xyz[3 * i + c]);
+  std::set<std::array<int, 4>, VoxelDiffers> bins;
+  for (int i = 0; i < P; i++) {
+    std::array<int, 4> v;
+    for (int c = 0; c < 3; c++) v[c] = (int)std::floor((xyz[3 * i + c] - mn[c]) / cell_size);
+    v[3] = i;
+    bins.insert(v);
+  }
+  int n = 0;
+  for (const auto &v : bins) {
+    for (int c = 0; c < 3; c++) out_xyz[3 * n + c] = mn[c] + cell_size * (float)v[c];
+    if (out_src) out_src[n] = v[3];
+    n++;
+  }
+  return n;
+}
+
+// Cloud::calculateNormals (util/cloud.cpp:451-476): pcl::NormalEstimationOMP with a radius search
+// (:497-535) followed by Cloud::reverseNormals (:573-604).  PCL is absent; its semantics restated:
+// neighbours of the point within `radius` among ALL points (FLANN order), covariance of the
+// neighbour coordinates about their centroid, eigenvector of the smallest eigenvalue, flipped
+// towards the view point of the camera that sees the point (flipNormalTowardsViewpoint), stored
+// as float.  Oracle choices (PCL's float accumulators and closed-form eigen33 are unpinned):
+// centroid and covariance as sequential fp64 sums in neighbour order, the same 3x3 QR eigensolver
+// as the local frames.
+void gpd_oracle_normals(const float *xyz, int P, const int32_t *cam_source, int n_cams, const double *view_points, double radius,
+                        float *normals_out) {
+  Grid g;
+  g.build(xyz, P, 0.02f);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < P; i++) {
+    std::vector<Neighbour> nb;
+    radiusSearch(g, xyz + 3 * i, radius, nb);
+    const int k = (int)nb.size();
+    double c[3] = {0, 0, 0};
+    for (int n = 0; n < k; n++)
+      for (int r = 0; r < 3; r++) c[r] += (double)xyz[3 * nb[n].idx + r];
+    for (int r = 0; r < 3; r++) c[r] /= (double)k;
+    double M[9] = {0};
+    for (int n = 0; n < k; n++) {
+      const double d0 = (double)xyz[3 * nb[n].idx] - c[0], d1 = (double)xyz[3 * nb[n].idx + 1] - c[1], d2 = (double)xyz[3 * nb[n].idx + 2] - c[2];
+      M[0] += d0 * d0; M[3] += d1 * d0; M[4] += d1 * d1; M[6] += d2 * d0; M[7] += d2 * d1; M[8] += d2 * d2;
+    }
+    M[1] = M[3]; M[2] = M[6]; M[5] = M[7];
+    double ev[3], V[9];
+    selfAdjointEigen3(M, ev, V);
+    int mn = 0;
+    for (int q = 1; q < 3; q++)
+      if (ev[q] < ev[mn]) mn = q;
+    double nrm[3] = {V[mn], V[3 + mn], V[6 + mn]};
+    // the last camera that sees the point wins (cloud.cpp:525-533 overwrites per camera)
+    for (int cam = 0; cam < n_cams; cam++) {
+      if (!cam_source[(size_t)cam * P + i]) continue;
+      double t[3] = {nrm[0], nrm[1], nrm[2]};
+      const double *vp = view_points + 3 * cam;
+      const double dot = (vp[0] - (double)xyz[3 * i]) * t[0] + (vp[1] - (double)xyz[3 * i + 1]) * t[1] + (vp[2] - (double)xyz[3 * i + 2]) * t[2];
+      if (dot < 0)
+        for (int r = 0; r < 3; r++) t[r] = -t[r];
+      for (int r = 0; r < 3; r++) normals_out[3 * i + r] = (float)t[r];
+    }
+    // reverseNormals: reverse unless some seeing camera has normal . (p - vp) < 0
+    bool needs_reverse = true;
+    for (int cam = 0; cam < n_cams && needs_reverse; cam++) {
+      if (cam_source[(size_t)cam * P + i] != 1) continue;
+      const double *vp = view_points + 3 * cam;
+      const double d = (double)normals_out[3 * i] * ((double)xyz[3 * i] - vp[0]) + (double)normals_out[3 * i + 1] * ((double)xyz[3 * i + 1] - vp[1]) +
+                       (double)normals_out[3 * i + 2] * ((double)xyz[3 * i + 2] - vp[2]);
+      if (d < 0) needs_reverse = false;
+    }
+    if (needs_reverse)
+      for (int r = 0; r < 3; r++) normals_out[3 * i + r] = (float)((double)normals_out[3 * i + r] * -1.0);
+  }
 }
 
 int gpd_oracle_num_threads() {

@@ -195,3 +195,23 @@ def detect(params, xyz, normals, cam_source, view_points, sample_idx, weights, m
 
 def num_threads():
     return lib().gpd_oracle_num_threads()
+
+
+def voxelize(xyz, cell_size=0.003):
+    """Cloud::voxelizeCloud -> (voxel points f32 [n,3], kept input index [n])."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    out = np.zeros((len(xyz), 3), np.float32)
+    src = np.zeros(len(xyz), np.int32)
+    n = lib().gpd_oracle_voxelize(_p(xyz), len(xyz), C.c_float(cell_size), _p(out), _p(src))
+    return out[:n].copy(), src[:n].copy()
+
+
+def estimate_normals(xyz, cam_source=None, view_points=None, radius=0.03):
+    """Cloud::calculateNormals (OMP radius PCA + reverseNormals) -> f32 [P,3]."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    P = len(xyz)
+    cam = np.ones((1, P), np.int32) if cam_source is None else np.ascontiguousarray(cam_source, np.int32).reshape(-1, P)
+    vp = np.zeros((1, 3)) if view_points is None else np.ascontiguousarray(view_points, np.float64).reshape(-1, 3)
+    out = np.zeros((P, 3), np.float32)
+    lib().gpd_oracle_normals(_p(xyz), P, _p(cam), cam.shape[0], _p(vp), C.c_double(radius), _p(out))
+    return out

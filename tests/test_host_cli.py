@@ -89,3 +89,30 @@ def test_detect_grasps_cli_matches_oracle(tmp_path, oracle_mod, lenet15_real):
     gp = np.array([[float(x) for x in g[2:5]] for g in got])
     assert np.allclose(gp, want["position"], rtol=1e-12, atol=1e-15)
     assert [int(g[6]) for g in got] == want["finger_placement_index"].tolist()
+
+
+@pytest.mark.gpu
+def test_cli_on_raw_krylon_pcd(tmp_path, oracle_mod, lenet15_real):
+    """configs[0] through the product CLI: an x y z PCD without normals -> voxelise, GPU normals,
+    subsample(500), detect.  Compared with the oracle run on the same preprocessing."""
+    xyz = np.load(os.path.join(ROOT, "tests", "golden", "krylon_xyz.npz"))["xyz"]
+    cl = dict(xyz=xyz, normals=np.zeros_like(xyz))
+    cfg, pcd = _write_case(tmp_path, cl, lenet15_real, 500, 5)
+    with open(str(pcd), "w") as f:  # rewrite as a plain x y z cloud like tutorials/krylon.pcd
+        f.write("# .PCD v.7 - Point Cloud Data file format\nVERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
+                "WIDTH %d\nHEIGHT 1\nPOINTS %d\nDATA ascii\n" % (len(xyz), len(xyz)))
+        for p in xyz:
+            f.write("%.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+    out = subprocess.run([CLI, str(cfg), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Voxelized cloud: 3366" in out.stdout
+    got = [l.split() for l in out.stdout.splitlines() if l.startswith("GRASP ")]
+    assert len(got) == 5
+    v, _ = oracle_mod.voxelize(xyz, 0.003)
+    n = oracle_mod.estimate_normals(v)
+    si = _subsample_indices(len(v), 500)
+    p = oracle_mod.default_params(15)
+    hands, _, _ = oracle_mod.detect(p, v, n, np.ones((1, len(v)), np.int32), np.zeros((1, 3)), si, lenet15_real)
+    vv = hands[hands["valid"].astype(bool)]
+    want = vv[np.argsort(-vv["score"], kind="stable")[:5]]
+    assert np.abs(np.array([float(g[1]) for g in got]) - want["score"]).max() <= 1e-4
