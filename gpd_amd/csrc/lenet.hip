@@ -218,105 +218,158 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
   }
 }
 
-// conv2 + pool2.  One image per workgroup (4 waves).  The 100 KB of weights do not fit next to
-// the 62.7 KB input planes, so K is walked in channel-pair chunks (50 taps x 50 filters = 10 KB,
-// double-buffered) and every wave keeps its 9 (pixel tile, filter tile) accumulators live across
-// the chunks — k still ascends within each accumulator.
-__global__ __launch_bounds__(256) void conv2_mfma_kernel(const float *__restrict__ pool1, const float *__restrict__ wt,
-                                                         const float *__restrict__ bias, float *__restrict__ flat, int n) {
+// conv2 + pool2.  Persistent workgroups (one per CU) loop over images: the k-major weights of
+// filters 0..47 (96 KB) stay in LDS next to one image's pool1 planes (62.7 KB).
+//   waves 0-11  filters 0..47 on v_mfma_f32_16x16x4_f32: a wave owns one band of two output rows
+//               (3 pixel tiles of 2x8) x 3 filter tiles = 9 independent accumulators; per k-step
+//               3 weight reads + 3 input reads feed 9 MFMAs.  48 = 3 x 16 filters fill the MFMA
+//               tiles exactly (50 would pad 64-row tiles to 78 %).
+//   wave 12     filters 48, 49 by direct convolution on the VALU (scalar weights).
+// k-ascending fmaf chains as before; output in the reference's flatten order pixel*50 + filter.
+constexpr int C2_MFMA_WAVES = 12, C2_THREADS = 64 * (C2_MFMA_WAVES + 1);
+
+__global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__restrict__ pool1, const float *__restrict__ wt,
+                                                                const float *__restrict__ w, const float *__restrict__ bias,
+                                                                float *__restrict__ flat, int n) {
   __shared__ __attribute__((aligned(16))) float s_in[20 * 784];
-  __shared__ __attribute__((aligned(16))) float s_w[2][50 * 50];
-  const int img = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_w[500 * 48];
+  __shared__ uint16_t s_off[500];
   const int tid = threadIdx.x;
-  {
-    const float4 *src = reinterpret_cast<const float4 *>(pool1 + (size_t)img * 20 * 784);
-    float4 *dst = reinterpret_cast<float4 *>(s_in);
-    for (int i = tid; i < 20 * 784 / 4; i += 256) dst[i] = src[i];
-    for (int i = tid; i < 2500; i += 256) s_w[0][i] = wt[i];
+  for (int i = tid; i < 500 * 48; i += C2_THREADS) {
+    const int k = i / 48, f = i - k * 48;
+    s_w[i] = wt[k * 50 + f];
   }
-  __syncthreads();
+  for (int k = tid; k < 500; k += C2_THREADS) {
+    const int c = k / 25, tap = k - c * 25;
+    s_off[k] = (uint16_t)(c * 784 + (tap / 5) * 28 + tap % 5);
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int half = lane >> 5, j = lane & 31;
-  int xoff[9], woff[9];
-  f32x16 acc[9];
-#pragma unroll
-  for (int q = 0; q < 9; q++) {
-    const int pi = wave * 9 + q;  // 36 (pixel tile, filter tile) pairs per image
-    const int pt = pi >> 1, ft = pi & 1;
-    const int ty = pt / 3, tx = pt - ty * 3;
-    xoff[q] = (4 * ty + (j >> 3)) * 28 + 8 * tx + (j & 7);
-    const int f = ft * 32 + j;
-    woff[q] = f < 50 ? f : 49;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
-  }
-  for (int cp = 0; cp < 10; cp++) {
-    const int cur = cp & 1;
-    float nxt[10];
-    if (cp + 1 < 10) {
-#pragma unroll
-      for (int u = 0; u < 10; u++) {
-        const int i = tid + u * 256;
-        nxt[u] = i < 2500 ? wt[(cp + 1) * 2500 + i] : 0.f;
-      }
-    }
-    const float *xc = s_in + cp * 2 * 784;
-    const float *wc = s_w[cur];
-    // operands of step p+1 are requested before the nine MFMAs of step p are issued
-    float a_cur[9], b_cur[9], a_nxt[9], b_nxt[9];
+  for (int img = blockIdx.x; img < n; img += gridDim.x) {
+    __syncthreads();  // previous image fully consumed (and the weights are in place)
     {
-      const int boff = half ? tap_offset(1, 784, 28) : tap_offset(0, 784, 28);
-#pragma unroll
-      for (int q = 0; q < 9; q++) {
-        a_cur[q] = wc[half * 50 + woff[q]];
-        b_cur[q] = xc[xoff[q] + boff];
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < 25; p++) {
-      if (p + 1 < 25) {
-        const int boff = half ? tap_offset(2 * p + 3, 784, 28) : tap_offset(2 * p + 2, 784, 28);
-        const float *wrow = wc + (2 * p + 2 + half) * 50;
-#pragma unroll
-        for (int q = 0; q < 9; q++) {
-          a_nxt[q] = wrow[woff[q]];
-          b_nxt[q] = xc[xoff[q] + boff];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);  // next step's LDS reads stay ahead of this step's MFMAs
-#pragma unroll
-      for (int q = 0; q < 9; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q], b_cur[q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 9; q++) {
-        a_cur[q] = a_nxt[q];
-        b_cur[q] = b_nxt[q];
-      }
-    }
-    if (cp + 1 < 10) {
-#pragma unroll
-      for (int u = 0; u < 10; u++) {
-        const int i = tid + u * 256;
-        if (i < 2500) s_w[cur ^ 1][i] = nxt[u];
-      }
+      const float4 *src = reinterpret_cast<const float4 *>(pool1 + (size_t)img * 20 * 784);
+      float4 *dst = reinterpret_cast<float4 *>(s_in);
+      for (int i = tid; i < 20 * 784 / 4; i += C2_THREADS) dst[i] = src[i];
     }
     __syncthreads();
-  }
+    if (wave < C2_MFMA_WAVES) {
+      const int kq = lane >> 4, j = lane & 15;
+      const int rp = wave;  // output rows 2rp, 2rp+1
+      const float *xin = s_in + (2 * rp + (j >> 3)) * 28 + (j & 7);
+      f32x4 acc[3][3];  // [pixel tile][filter tile]
 #pragma unroll
-  for (int q = 0; q < 9; q++) {
-    const int pi = wave * 9 + q;
-    const int pt = pi >> 1, ft = pi & 1;
-    const int ty = pt / 3, tx = pt - ty * 3;
-    f32x16 v = pool_lanes(acc[q]);
-    if (!(j & 1) && !(j & 8)) {
-      const int py = 2 * ty + (j >> 4), px = 4 * tx + ((j & 7) >> 1);
-      // flatten: index = pixel*50 + channel (eigen_classifier.cpp:103-107)
-      float *o = flat + (size_t)img * kFc1In + (py * 12 + px) * 50;
+      for (int t = 0; t < 3; t++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int f = ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (f < 50) o[f] = v[r] + bias[f];
+        for (int ft = 0; ft < 3; ft++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[t][ft][r] = 0.f;
+      // operands of step st+1 are requested before the nine MFMAs of step st
+      float a_cur[3], b_cur[3], a_nxt[3], b_nxt[3];
+      {
+        const float *x0 = xin + s_off[kq];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          a_cur[q] = s_w[kq * 48 + 16 * q + j];
+          b_cur[q] = x0[8 * q];
+        }
+      }
+      int off_nxt = s_off[4 + kq];
+#pragma unroll 5
+      for (int st = 0; st < 125; st++) {
+        const int k1 = 4 * (st + 1 < 125 ? st + 1 : st) + kq;
+        const int k2 = 4 * (st + 2 < 125 ? st + 2 : 124) + kq;
+        const float *x1 = xin + off_nxt;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          a_nxt[q] = s_w[k1 * 48 + 16 * q + j];
+          b_nxt[q] = x1[8 * q];
+        }
+        const int off_nn = s_off[k2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+          for (int ft = 0; ft < 3; ft++) acc[t][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ft], b_cur[t], acc[t][ft], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        off_nxt = off_nn;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          a_cur[q] = a_nxt[q];
+          b_cur[q] = b_nxt[q];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+#pragma unroll
+        for (int ft = 0; ft < 3; ft++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            float x = acc[t][ft][r];
+            x = fmaxf(x, __shfl_xor(x, 1));
+            x = fmaxf(x, __shfl_xor(x, 8));
+            acc[t][ft][r] = x;
+          }
+        }
+        if (!(j & 1) && !(j & 8)) {
+          // flatten: index = pixel*50 + channel (eigen_classifier.cpp:103-107)
+          float *o = flat + (size_t)img * kFc1In + (rp * 12 + 4 * t + ((j & 7) >> 1)) * 50;
+#pragma unroll
+          for (int ft = 0; ft < 3; ft++) {
+            const int f0 = 16 * ft + 4 * kq;
+            float4 v = make_float4(acc[t][ft][0] + bias[f0], acc[t][ft][1] + bias[f0 + 1], acc[t][ft][2] + bias[f0 + 2],
+                                   acc[t][ft][3] + bias[f0 + 3]);
+            *reinterpret_cast<float2 *>(o + f0) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2 *>(o + f0 + 2) = make_float2(v.z, v.w);
+          }
+        }
+      }
+    } else {
+      // filters 48, 49: lane <-> pooled pixel, weights as scalars in the file layout [f][k]
+      const float *__restrict__ wf = w + (size_t)48 * 500;
+      for (int chunk = 0; chunk < 3; chunk++) {
+        const int p = chunk * 64 + lane;
+        const bool act = p < 144;
+        const int pp = act ? p : 0;
+        const int py = pp / 12, px = pp - py * 12;
+        float acc[2][4];
+#pragma unroll
+        for (int f = 0; f < 2; f++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[f][e] = 0.f;
+        const float *base = s_in + (2 * py) * 28 + 2 * px;
+        for (int c = 0; c < 20; c++) {
+          float patch[6][6];
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+              const float2 v = *reinterpret_cast<const float2 *>(base + c * 784 + r * 28 + 2 * e);
+              patch[r][2 * e] = v.x;
+              patch[r][2 * e + 1] = v.y;
+            }
+          }
+#pragma unroll
+          for (int kh = 0; kh < 5; kh++) {
+#pragma unroll
+            for (int kw = 0; kw < 5; kw++) {
+#pragma unroll
+              for (int f = 0; f < 2; f++) {
+                const float wv = wf[f * 500 + c * 25 + kh * 5 + kw];
+                acc[f][0] = __builtin_fmaf(wv, patch[kh][kw], acc[f][0]);
+                acc[f][1] = __builtin_fmaf(wv, patch[kh][kw + 1], acc[f][1]);
+                acc[f][2] = __builtin_fmaf(wv, patch[kh + 1][kw], acc[f][2]);
+                acc[f][3] = __builtin_fmaf(wv, patch[kh + 1][kw + 1], acc[f][3]);
+              }
+            }
+          }
+        }
+        if (act) {
+#pragma unroll
+          for (int f = 0; f < 2; f++)
+            flat[(size_t)img * kFc1In + p * 50 + 48 + f] =
+                fmaxf(fmaxf(acc[f][0], acc[f][1]), fmaxf(acc[f][2], acc[f][3])) + bias[48 + f];
+        }
       }
     }
   }
@@ -412,6 +465,13 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
                          hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   const int kChunk = 16384;
+  static int num_cus = 0;  // persistent conv2 workgroups: one per CU (256 on MI355X)
+  if (!num_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cus = prop.multiProcessorCount;
+    if (num_cus <= 0) num_cus = 256;
+  }
   hipError_t e = lenet_scratch_reserve(s, n < kChunk ? n : kChunk);
   if (e != hipSuccess) return e;
   for (int off = 0; off < n; off += kChunk) {
@@ -423,7 +483,7 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
       case 3: conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
       default: return hipErrorInvalidValue;
     }
-    conv2_mfma_kernel<<<m, 256, 0, stream>>>(s.pool1, w.c2wt, w.c2b, s.flat, m);
+    conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m);
     dim3 g((kFc1Out + FC_BU - 1) / FC_BU, (m + FC_BM - 1) / FC_BM);
     fc1_mfma_kernel<<<g, 256, 0, stream>>>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity);
     fc2_score_kernel<<<(m + 255) / 256, 256, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
