@@ -135,7 +135,7 @@ def main():
         }
         traffic = _pmc_traffic()
         if net_s >= img_s:
-            roofline = {"kernel": "lenet_forward (conv1_pool+conv2_pool+fc1_mfma+fc2)", "bound": "mfma",
+            roofline = {"kernel": "lenet_forward (conv1_mfma + conv2_mfma + fc1_mfma + fc2_score)", "bound": "mfma",
                         "achieved": net_tflops, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": net_tflops / F32_PEAK_TFLOPS, "traffic": traffic.get("lenet")}
         else:

@@ -1,5 +1,7 @@
 #!/bin/bash
-# MFMA utilisation / stall counters per kernel (own rocprofv3 run, PMC only + kernel trace)
+# MFMA utilisation / stall counters per kernel (own rocprofv3 run, PMC only + kernel trace).
+# MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); SQ_* wave counters are
+# fractions of SQ_WAVE_CYCLES.
 TAG=${1:-x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -17,6 +19,7 @@ d={}
 for k,cn,v in rows: d.setdefault(k,{})[cn]=v
 for k,v in sorted(d.items(), key=lambda kv:-dur.get(kv[0],0)):
     if dur.get(k,0)<2e4: continue
-    g=v.get("GRBM_GUI_ACTIVE",0); 
+    g=v.get("GRBM_GUI_ACTIVE",0)/8.0  # the counter is summed over the 8 XCDs
+
     print("%-44s dur %8.1f us  clk %.2f GHz  MfmaUtil %5.1f%%  wave_cyc %.3g  wait_inst %.1f%%  wait_any %.1f%%  active %.1f%%  lds_conf/idx %.1f%%"%(k[:44],dur[k]/1e3,g/dur[k] if dur.get(k) else 0,100*v.get("SQ_VALU_MFMA_BUSY_CYCLES",0)/(g*1024) if g else 0,v.get("SQ_WAVE_CYCLES",0),100*v.get("SQ_WAIT_INST_ANY",0)/max(v.get("SQ_WAVE_CYCLES",1),1),100*v.get("SQ_WAIT_ANY",0)/max(v.get("SQ_WAVE_CYCLES",1),1),100*v.get("SQ_ACTIVE_INST_ANY",0)/max(v.get("SQ_WAVE_CYCLES",1),1),100*v.get("SQ_LDS_BANK_CONFLICT",0)/max(v.get("SQ_LDS_IDX_ACTIVE",1),1)))
 PY
