@@ -10,10 +10,10 @@
 // used for FC1 is bitwise such a chain (cdna_hip_programming.md §3).
 //
 // Kernels:
-//   conv1_mfma   planar u8 images + k-major weights in LDS -> implicit GEMM on f32 MFMA,
-//                2x2 max-pool fused                              -> pool1 [n][20][28][28]
-//   conv2_mfma   pool1 plane set in LDS (62.7 KB), weights streamed in channel-pair chunks,
-//                implicit GEMM + pool, output in the reference's flatten order
+//   conv1_mfma   planar u8 images + k-major weights in LDS -> implicit GEMM on f32 MFMA (+ 4
+//                filters on VALU waves), 2x2 max-pool fused      -> pool1 [n][20][28][28]
+//   conv2_mfma   persistent; pool1 planes + 96 KB of weights in LDS, implicit GEMM + pool
+//                (+ 2 filters on a VALU wave), output in the reference's flatten order
 //                j = pixel*50 + channel                          -> flat  [n][7200]
 //   fc1_mfma     [500 x 7200] x [7200 x n] on v_mfma_f32_32x32x2_f32, + bias, ReLU
 //                                                               -> fc1t  [500][n]
@@ -25,32 +25,17 @@ namespace gpd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------
-// Convolutions as implicit GEMMs on v_mfma_f32_32x32x2_f32:  D[f][pix] = sum_k W[f][k] X[k][pix],
-// k = c*25 + kh*5 + kw ascending — the MFMA accumulates k, k+1 in order, so each output is
+// Convolutions: implicit GEMMs D[f][pix] = sum_k W[f][k] X[k][pix] on v_mfma_f32_16x16x4_f32,
+// k = c*25 + kh*5 + kw ascending — the MFMA accumulates k..k+3 in order, so each output is
 // still the oracle's fmaf chain (cdna_hip_programming.md §3, "bit-for-bit a k-ordered chain").
-//   A operand (lane l): W[f = l&31][k0 + (l>>5)]   (weights, k-major copy in LDS, rows >= F read
-//                                                    a clamped row and their outputs are dropped)
-//   B operand (lane l): X[k0 + (l>>5)][pix = l&31] (image/pool1 planes in LDS)
-//   D (lane l, reg r):  pixel l&31, filter (r&3) + 8*(r>>2) + 4*(l>>5)
-// A pixel tile is 4 rows x 8 columns of conv outputs, so the 2x2 max-pool is two lane
+//   A operand (lane l): W[f = l&15][k0 + (l>>4)]   (k-major weight copy in LDS)
+//   B operand (lane l): X[k0 + (l>>4)][pix = l&15] (image / pool1 planes in LDS)
+//   D (lane l, reg r):  pixel l&15, filter 4*(l>>4) + r
+// A pixel tile is 2 rows x 8 columns of conv outputs, so the 2x2 max-pool is two lane
 // exchanges (xor 1, xor 8).  max(a_i + b) == max(a_i) + b (rounding is monotone).
+// Filters that do not fill a 16-row tile (4 of conv1's 20, 2 of conv2's 50) run as direct
+// convolutions on otherwise idle VALU waves of the same workgroup.
 // ---------------------------------------------------------------------------
-__device__ inline int tap_offset(int k_rel, int plane, int row_stride) {  // k_rel in [0, 50): (channel, kh, kw) of a channel pair
-  const int c = k_rel / 25, tap = k_rel - c * 25;
-  return c * plane + (tap / 5) * row_stride + tap % 5;
-}
-
-__device__ inline f32x16 pool_lanes(f32x16 v) {
-#pragma unroll
-  for (int r = 0; r < 16; r++) {
-    float x = v[r];
-    x = fmaxf(x, __shfl_xor(x, 1));
-    x = fmaxf(x, __shfl_xor(x, 8));
-    v[r] = x;
-  }
-  return v;
-}
-
 // conv1 + pool1.  Two images per workgroup, 12 waves with two roles that use different pipes:
 //   waves 0-7  filters 0..15 as an implicit GEMM on v_mfma_f32_16x16x4_f32.  A wave owns a band
 //              of two output rows (7 tiles of 2x8 pixels) and keeps the 7 accumulators
