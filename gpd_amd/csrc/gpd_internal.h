@@ -48,7 +48,41 @@ struct Cloud {
   int32_t *cam_source = nullptr;      // [num_cams][num_points]
   float *staging = nullptr;           // AoS upload buffer, 6 floats per point
   double view_points[3 * kMaxCams] = {0};
+  // uniform grid over the cloud (cells of 2 cm, z fastest): the radius searches visit the cells
+  // that overlap the query sphere instead of streaming all P points (replaces the k-d tree of
+  // hand_search.cpp:29-31 / image_generator.cpp:37-38; only a candidate filter — the distance
+  // test and the (d2, index) order are unchanged)
+  float g_lo[3] = {0, 0, 0};
+  float g_cell = 0.02f;
+  int g_dim[3] = {1, 1, 1};
+  int g_cells_cap = 0;
+  int32_t *g_start = nullptr;         // [cells + 1]
+  int32_t *g_cursor = nullptr;        // [cells] scatter cursors
+  int32_t *g_idx = nullptr;           // [P] original index of the sorted points
+  float *g_x = nullptr, *g_y = nullptr, *g_z = nullptr;  // [P] coordinates in cell order
 };
+struct GridView {
+  float lo[3];
+  float cell;
+  int dim[3];
+  const int32_t *start;
+  const int32_t *idx;
+  const float *x, *y, *z;
+};
+inline GridView grid_view(const Cloud &c) {
+  GridView g;
+  for (int i = 0; i < 3; i++) {
+    g.lo[i] = c.g_lo[i];
+    g.dim[i] = c.g_dim[i];
+  }
+  g.cell = c.g_cell;
+  g.start = c.g_start;
+  g.idx = c.g_idx;
+  g.x = c.g_x;
+  g.y = c.g_y;
+  g.z = c.g_z;
+  return g;
+}
 hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
                         const double *view_points, hipStream_t stream);
 void cloud_free(Cloud &c);

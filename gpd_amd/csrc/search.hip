@@ -56,8 +56,86 @@ __global__ void split_soa_kernel(const float *__restrict__ xyz, const float *__r
   nz[i] = nrm[3 * i + 2];
 }
 
+// ---- uniform grid ----------------------------------------------------------------------
+__device__ inline int grid_coord(const GridView &g, int axis, float v) {
+  int k = (int)floorf((v - g.lo[axis]) / g.cell);
+  return k < 0 ? 0 : (k > g.dim[axis] - 1 ? g.dim[axis] - 1 : k);
+}
+__global__ void grid_count_kernel(GridView g, const float *px, const float *py, const float *pz, int n, int32_t *counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (grid_coord(g, 0, px[i]) * g.dim[1] + grid_coord(g, 1, py[i])) * g.dim[2] + grid_coord(g, 2, pz[i]);
+  atomicAdd(&counts[c], 1);
+}
+// exclusive scan of counts[0..n) into start[0..n], single workgroup with a running carry
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const int32_t *counts, int32_t *start, int32_t *cursor, int n) {
+  __shared__ int s_part[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int x = __shfl_up(incl, o);
+      if (lane >= o) incl += x;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int off = s_carry;
+    for (int w = 0; w < wave; w++) off += s_part[w];
+    if (i < n) {
+      start[i] = off + incl - v;
+      cursor[i] = off + incl - v;
+    }
+    __syncthreads();
+    if (tid == 1023) s_carry = off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) start[n] = s_carry;
+}
+__global__ void grid_scatter_kernel(GridView g, const float *px, const float *py, const float *pz, int n, int32_t *cursor,
+                                    int32_t *idx, float *sx, float *sy, float *sz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (grid_coord(g, 0, px[i]) * g.dim[1] + grid_coord(g, 1, py[i])) * g.dim[2] + grid_coord(g, 2, pz[i]);
+  const int pos = atomicAdd(&cursor[c], 1);
+  idx[pos] = i;
+  sx[pos] = px[i];
+  sy[pos] = py[i];
+  sz[pos] = pz[i];
+}
+
+// Visits every point of the cells overlapping the cube of half-edge `reach` around q: calls
+// visit(original index, x, y, z).  Wave w takes (x, y) cell columns w, w + nwaves, ...; a column's
+// cells are contiguous in memory (z fastest), its lanes stride the point range.  All lanes of a
+// wave run the same number of iterations, so `visit` may use wave-wide operations.
+template <class Visit>
+__device__ inline void grid_visit(const GridView &g, float qx, float qy, float qz, float reach, int wave, int nwaves, int lane,
+                                  Visit visit) {
+  const int x0 = grid_coord(g, 0, qx - reach), x1 = grid_coord(g, 0, qx + reach);
+  const int y0 = grid_coord(g, 1, qy - reach), y1 = grid_coord(g, 1, qy + reach);
+  const int z0 = grid_coord(g, 2, qz - reach), z1 = grid_coord(g, 2, qz + reach);
+  const int ny = y1 - y0 + 1;
+  const int ncol = (x1 - x0 + 1) * ny;
+  for (int col = wave; col < ncol; col += nwaves) {
+    const int cx = x0 + col / ny, cy = y0 + col % ny;
+    const int cbase = (cx * g.dim[1] + cy) * g.dim[2];
+    const int b = g.start[cbase + z0], e = g.start[cbase + z1 + 1];
+    for (int t0 = b; t0 < e; t0 += 64) {
+      const int t = t0 + lane;
+      const bool in = t < e;
+      const int tt = in ? t : b;
+      visit(in, g.idx[tt], g.x[tt], g.y[tt], g.z[tt]);
+    }
+  }
+}
+
 void cloud_free(Cloud &c) {
-  void *ptrs[] = {c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.cam_source, c.staging};
+  void *ptrs[] = {c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.cam_source, c.staging, c.g_start, c.g_cursor, c.g_idx, c.g_x, c.g_y, c.g_z};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   c = Cloud();
@@ -76,6 +154,10 @@ hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n,
       if ((e = hipMalloc(p, (size_t)n * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMalloc(&c.cam_source, (size_t)n * num_cams * sizeof(int32_t))) != hipSuccess) return e;
     if ((e = hipMalloc(&c.staging, (size_t)n * 6 * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMalloc(&c.g_idx, (size_t)n * sizeof(int32_t))) != hipSuccess) return e;
+    float **gp[] = {&c.g_x, &c.g_y, &c.g_z};
+    for (float **p : gp)
+      if ((e = hipMalloc(p, (size_t)n * sizeof(float))) != hipSuccess) return e;
     c.capacity = n;
   }
   c.num_points = n;
@@ -91,6 +173,40 @@ hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n,
     return e;
   split_soa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c.staging, c.staging + (size_t)n * 3, n, c.px, c.py, c.pz, c.nx, c.ny,
                                                          c.nz);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  // uniform grid: bounds on the host, counting sort on the device
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; i++)
+    for (int a = 0; a < 3; a++) {
+      lo[a] = xyz[3 * i + a] < lo[a] ? xyz[3 * i + a] : lo[a];
+      hi[a] = xyz[3 * i + a] > hi[a] ? xyz[3 * i + a] : hi[a];
+    }
+  c.g_cell = 0.02f;
+  for (;;) {  // at most 256 cells per axis
+    bool ok = true;
+    for (int a = 0; a < 3; a++) {
+      c.g_lo[a] = lo[a];
+      c.g_dim[a] = (int)std::floor((hi[a] - lo[a]) / c.g_cell) + 1;
+      if (c.g_dim[a] > 256) ok = false;
+    }
+    if (ok) break;
+    c.g_cell *= 2.f;
+  }
+  const int cells = c.g_dim[0] * c.g_dim[1] * c.g_dim[2];
+  if (cells > c.g_cells_cap) {
+    if (c.g_start) (void)hipFree(c.g_start);
+    if (c.g_cursor) (void)hipFree(c.g_cursor);
+    c.g_start = nullptr;
+    c.g_cursor = nullptr;
+    if ((e = hipMalloc(&c.g_start, (size_t)(cells + 1) * sizeof(int32_t))) != hipSuccess) return e;
+    if ((e = hipMalloc(&c.g_cursor, (size_t)cells * sizeof(int32_t))) != hipSuccess) return e;
+    c.g_cells_cap = cells;
+  }
+  GridView g = grid_view(c);
+  if ((e = hipMemsetAsync(c.g_cursor, 0, (size_t)cells * sizeof(int32_t), stream)) != hipSuccess) return e;
+  grid_count_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor);
+  grid_scan_kernel<<<1, 1024, 0, stream>>>(c.g_cursor, c.g_start, c.g_cursor, cells);
+  grid_scatter_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor, c.g_idx, c.g_x, c.g_y, c.g_z);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return hipStreamSynchronize(stream);
 }
@@ -249,6 +365,8 @@ struct NbParams {
   double *centers;  // [S][3] mean of the image neighbourhood (hand_set.cpp:131-133)
   const int32_t *cam_source;
   int num_cams;
+  GridView grid;
+  float reach;  // half-edge of the cube of cells to visit (radius + margin)
 };
 
 __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
@@ -269,21 +387,17 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     s_seen = 0;
   }
   __syncthreads();
-  // 1. stream the cloud; FLANN L2_Simple<float>: d2 accumulated over x,y,z, strict <
-  const int n_iter = (P.num_points + 255) / 256;
-  for (int it = 0; it < n_iter; it++) {
-    const int i = it * 256 + tid;
-    bool hit = false;
+  // 1. visit the grid cells around the sample; FLANN L2_Simple<float>: d2 accumulated over
+  //    x,y,z, strict <
+  grid_visit(P.grid, qx, qy, qz, P.reach, tid >> 6, 4, lane, [&](bool in, int i, float x, float y, float z) {
+    float d = qx - x;
     float d2 = 0.f;
-    if (i < P.num_points) {
-      float d = qx - P.px[i];
-      d2 += d * d;
-      d = qy - P.py[i];
-      d2 += d * d;
-      d = qz - P.pz[i];
-      d2 += d * d;
-      hit = d2 < P.r2_hands;
-    }
+    d2 += d * d;
+    d = qy - y;
+    d2 += d * d;
+    d = qz - z;
+    d2 += d * d;
+    const bool hit = in && d2 < P.r2_hands;
     const unsigned long long ballot = __ballot(hit);
     if (ballot) {
       int base = 0;
@@ -294,7 +408,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
         if (pos < P.cap) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
       }
     }
-  }
+  });
   __syncthreads();
   const int found = s_count;
   const int n = found < P.cap ? found : P.cap;
@@ -445,6 +559,8 @@ struct NormalsParams {
   int num_cams;
   double view_points[3 * kMaxCams];
   float r2;
+  GridView grid;
+  float reach;
   float *out;  // AoS [P][3]
   int32_t *overflow;
 };
@@ -459,20 +575,15 @@ __global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
   const float qx = P.px[pi], qy = P.py[pi], qz = P.pz[pi];
   if (tid == 0) s_count = 0;
   __syncthreads();
-  const int n_iter = (P.num_points + 255) / 256;
-  for (int it = 0; it < n_iter; it++) {
-    const int i = it * 256 + tid;
-    bool hit = false;
+  grid_visit(P.grid, qx, qy, qz, P.reach, tid >> 6, 4, lane, [&](bool in, int i, float x, float y, float z) {
+    float d = qx - x;
     float d2 = 0.f;
-    if (i < P.num_points) {
-      float d = qx - P.px[i];
-      d2 += d * d;
-      d = qy - P.py[i];
-      d2 += d * d;
-      d = qz - P.pz[i];
-      d2 += d * d;
-      hit = d2 < P.r2;
-    }
+    d2 += d * d;
+    d = qy - y;
+    d2 += d * d;
+    d = qz - z;
+    d2 += d * d;
+    const bool hit = in && d2 < P.r2;
     const unsigned long long ballot = __ballot(hit);
     if (ballot) {
       int base = 0;
@@ -483,7 +594,7 @@ __global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
         if (pos < NRM_CAP) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
       }
     }
-  }
+  });
   __syncthreads();
   const int found = s_count;
   if (found > NRM_CAP) {
@@ -584,6 +695,8 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
   np.num_cams = c.num_cams;
   std::memcpy(np.view_points, c.view_points, sizeof(np.view_points));
   np.r2 = (float)(radius * radius);
+  np.grid = grid_view(c);
+  np.reach = (float)radius * 1.001f + 1e-5f;
   np.out = d_out;
   np.overflow = d_ovf;
   normals_kernel<<<c.num_points, 256, 0, stream>>>(np);
@@ -980,6 +1093,8 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.centers = s.d_centers;
   np.cam_source = c.cam_source;
   np.num_cams = c.num_cams;
+  np.grid = grid_view(c);
+  np.reach = (float)hc.nn_radius_hands * 1.001f + 1e-5f;
   const size_t lds = (size_t)cap * sizeof(unsigned long long);
   HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
