@@ -48,7 +48,8 @@ namespace gpd {
     }                                                                                       \
   } while (0)
 
-constexpr int IMG_THREADS = 1024;
+constexpr int IMG_THREADS = 512;   // 256 VGPRs per lane: no spills (1024 threads measured equally fast but spilled)
+constexpr int SET_THREADS = 1024;  // shadow_set_kernel
 constexpr int IMG_WAVES = IMG_THREADS / 64;
 constexpr int PT_CAP = 2048;  // in-box points per candidate
 constexpr int SH_CAP = 8192;  // in-box shadow voxels per candidate
@@ -65,7 +66,7 @@ struct ImgConsts {
   double view_point[3 * kMaxCams];
   double shadow_length, voxel, voxel_mult, rand_inv;
   int num_shadow;
-  uint32_t stride_a, stride_c;  // LCG jump by IMG_THREADS * num_shadow draws
+  uint32_t stride_a, stride_c;  // LCG jump by SET_THREADS * num_shadow draws
   double len[3];                // box extent per hand axis: vol_depth, vol_width, dbl_h
   double inv_cell[3];           // approximate cells per metre (first guess only)
   double thr[3][kImg + 1];      // thr[a][k] = smallest x with floor((x/len[a])/(1/60)) >= k
@@ -746,7 +747,7 @@ struct SetParams {
   uint32_t *set_bits;       // [sets][SETWORDS]
 };
 
-__global__ __launch_bounds__(IMG_THREADS) void shadow_set_kernel(SetParams P) {
+__global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
   __shared__ uint32_t bits[SETWORDS];
   const ImgConsts &K = c_img;
   const int set = blockIdx.x;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_set_kernel(SetParams P) {
       ((unsigned long long)(uint32_t)P.set_meta[8 * set + 3] << 32) | (uint32_t)P.set_meta[8 * set + 2];
   const int cam = P.set_meta[8 * set + 4];
   const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
-  for (int w = tid; w < SETWORDS; w += IMG_THREADS) bits[w] = 0u;
+  for (int w = tid; w < SETWORDS; w += SET_THREADS) bits[w] = 0u;
   __syncthreads();
   const double *smp = P.frames + 12 * (size_t)slot_s;
   const int ox = (int)floor(smp[0] * K.voxel_mult) - SR, oy = (int)floor(smp[1] * K.voxel_mult) - SR,
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_set_kernel(SetParams P) {
   const double nrm = sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
   for (int r = 0; r < 3; r++) vec[r] = K.shadow_length * vec[r] / nrm;
   uint32_t state = lcg_jump(0u, off + (unsigned long long)tid * (unsigned)K.num_shadow);
-  for (int i = tid; i < N; i += IMG_THREADS) {
+  for (int i = tid; i < N; i += SET_THREADS) {
     const double p0 = (double)nn[0 * P.cap + i], p1 = (double)nn[1 * P.cap + i], p2 = (double)nn[2 * P.cap + i];
     uint32_t st = state;
     for (int k = 0; k < K.num_shadow; k++) {
@@ -782,11 +783,11 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_set_kernel(SetParams P) {
         atomicOr(&bits[bit >> 5], 1u << (bit & 31));
       }
     }
-    state = K.stride_a * state + K.stride_c;  // advance by IMG_THREADS * num_shadow draws
+    state = K.stride_a * state + K.stride_c;  // advance by SET_THREADS * num_shadow draws
   }
   __syncthreads();
   uint32_t *out = P.set_bits + (size_t)set * SETWORDS;
-  for (int w = tid; w < SETWORDS; w += IMG_THREADS) out[w] = bits[w];
+  for (int w = tid; w < SETWORDS; w += SET_THREADS) out[w] = bits[w];
 }
 
 // planar [n][C][3600] <-> HWC [n][3600][C] (cv::Mat CV_8UC(C), the reference's image layout)
@@ -994,9 +995,9 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
       if (std::fma(r, k.inv_len[a], q) != x / k.len[a]) k.true_div = 1;
     }
   }
-  {  // affine map of IMG_THREADS * num_shadow LCG steps
+  {  // affine map of SET_THREADS * num_shadow LCG steps
     uint32_t a = 214013u, cc = 2531011u, A = 1u, Cc = 0u;
-    unsigned long long nsteps = (unsigned long long)IMG_THREADS * (unsigned)k.num_shadow;
+    unsigned long long nsteps = (unsigned long long)SET_THREADS * (unsigned)k.num_shadow;
     while (nsteps) {
       if (nsteps & 1ull) {
         A = a * A;
@@ -1042,7 +1043,7 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     sp.frames = s.d_frames;
     sp.set_meta = im.d_set_meta;
     sp.set_bits = im.d_set_bits;
-    shadow_set_kernel<<<im.num_shadow_sets, IMG_THREADS, 0, stream>>>(sp);
+    shadow_set_kernel<<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
     HIP_RET(hipGetLastError());
   }
   grasp_image_kernel<<<n, IMG_THREADS, 0, stream>>>(ip);
