@@ -122,6 +122,9 @@ struct ImageState {
   int32_t *d_set_meta = nullptr;      // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera
   uint32_t *d_set_bits = nullptr;     // [sets][88^3/32] shadow voxel bitsets
   int num_shadow_sets = 0, cap_shadow_sets = 0;
+  int channels = 0;
+  int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
+  int num_overflow = 0;               // as found by the last checked launch (replays reuse it)
   int32_t *d_status = nullptr;        // error flags from the kernel
   int cap_hands = 0;
   long long stat_sets = 0, stat_sum_set_ni = 0, stat_sum_cand_ni = 0;  // for the algorithmic byte count

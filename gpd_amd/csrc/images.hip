@@ -52,7 +52,8 @@ constexpr int IMG_THREADS = 512;   // 256 VGPRs per lane: no spills (1024 thread
 constexpr int SET_THREADS = 1024;  // shadow_set_kernel
 constexpr int IMG_WAVES = IMG_THREADS / 64;
 constexpr int PT_CAP = 2048;  // in-box points per candidate
-constexpr int SH_CAP = 8192;  // in-box shadow voxels per candidate
+constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
+constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
 constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
 constexpr int VBITS = VDIM * VDIM * VDIM;
 constexpr int VWORDS = (VBITS + 31) / 32;
@@ -84,6 +85,9 @@ struct ImgParams {
   const uint32_t *set_bits;  // [live sets][SETWORDS] shadow voxel bitsets (shadow_set_kernel)
   uint8_t *images;        // planar [n][C][3600]
   int32_t *status;
+  const int32_t *cand_list;  // shadow kernel: candidates to process (nullptr: blockIdx)
+  int32_t *overflow_list;    // shadow kernel: candidates whose box exceeds SHC voxels
+  int32_t *overflow_count;
   unsigned long long *dbg;  // profiling aid (GPD_IMG_TIMING=1): per-phase cycle sums
 };
 
@@ -94,30 +98,40 @@ struct Box {
   double lo[3], hi[3];
 };
 
-struct SmemPts {
-  double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
-  float a[3][PT_CAP];   // |normal| in the hand frame
-  uint32_t key[PT_CAP]; // cx | cy << 6 | cz << 12 | neighbour rank << 18
-};
-struct SmemSh {
-  uint32_t bits[VWORDS];
-  uint32_t lin[SH_CAP];     // set bits inside the box, ascending
-  uint32_t cells3[SH_CAP];  // cx | cy << 6 | cz << 12
-};
+// points kernel: in-box points cached once, one projection's normals (3 planes) + depth at a time
 struct __attribute__((aligned(16))) Smem {
-  union {
-    SmemPts p;
-    SmemSh s;
-  } u;
+  struct {
+    double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
+    float a[3][PT_CAP];   // |normal| in the hand frame
+    uint32_t key[PT_CAP]; // cx | cy << 6 | cz << 12 | neighbour rank << 18
+  } p;
   float raster[3][kPix];  // cell-index order (row flip applied at the store)
   uint32_t cells[kPix];   // (segment start << 16) | count; reused as the f32 depth plane
-  uint16_t place[SH_CAP];
+  uint16_t place[PT_CAP + kPix];  // segment table + list of non-empty cells
   double thr[3][kImg + 1];
   double recip[256];  // 1.0 / k
   float red_f[4 * IMG_WAVES];
   int red_i[IMG_WAVES];
-  int vorg[3];
   int counter;
+  int flag;
+};
+// shadow kernel: kept under 80 KB (SHC = 6144) so that two workgroups share a CU
+template <int SHC>
+struct __attribute__((aligned(16))) SmemShadow {
+  float raster0[kPix];
+  uint32_t cells[kPix];
+  uint32_t lin[SHC];  // set bits inside the box, ascending: voxel index | cell x << 17 | cell y << 23
+  union {
+    uint32_t bits[VWORDS];  // candidate voxel bitset, dead once `lin` is built
+    uint16_t place[SHC];    // segment table of the counting sort
+  } bp;
+  uint16_t nz[kPix];
+  uint8_t cz[SHC];  // cell z of the list entries
+  double thr[3][kImg + 1];
+  double recip[128];
+  float red_f[4 * IMG_WAVES];
+  int red_i[IMG_WAVES];
+  int vorg[3];
   int flag;
 };
 
@@ -142,14 +156,16 @@ __device__ inline bool in_box(const Box &B, const double t[3]) {
   return (t[0] > B.lo[0]) && (t[0] < B.hi[0]) && (t[1] > B.lo[1]) && (t[1] < B.hi[1]) && (t[2] > B.lo[2]) && (t[2] < B.hi[2]);
 }
 // min(floor(((t - off)/len)/(1/60)), 59) by exact thresholds (see file header)
-__device__ inline int cell_coord(const Smem &S, int axis, double x) {
+template <class SM>
+__device__ inline int cell_coord(const SM &S, int axis, double x) {
   int k = (int)(x * c_img.inv_cell[axis]);
   k = k < 0 ? 0 : (k > kImg - 1 ? kImg - 1 : k);
   while (k > 0 && x < S.thr[axis][k]) k--;
   while (k < kImg - 1 && x >= S.thr[axis][k + 1]) k++;
   return k;
 }
-__device__ inline uint32_t cells_of(const Smem &S, const Box &B, const double t[3]) {
+template <class SM>
+__device__ inline uint32_t cells_of(const SM &S, const Box &B, const double t[3]) {
   const int cx = cell_coord(S, 0, t[0] - B.off[0]);
   const int cy = cell_coord(S, 1, t[1] - B.off[1]);
   const int cz = cell_coord(S, 2, t[2] - B.off[2]);
@@ -177,9 +193,10 @@ __device__ inline double div_len(double x, int axis) {
   return __builtin_fma(r, y, q);
 }
 // 1.0 / (double)count for the running means (image_strategy.cpp:170, 206)
+template <int NTAB>
 __device__ inline double recip_count(const double *tab, float fc) {
   const int k = (int)fc;
-  return k < 256 ? tab[k] : 1.0 / (double)fc;
+  return k < NTAB ? tab[k] : 1.0 / (double)fc;
 }
 
 __device__ inline uint32_t lcg_step(uint32_t &s) {  // HandSet::fastrand (hand_set.cpp:263-266)
@@ -201,7 +218,8 @@ __device__ inline uint32_t lcg_jump(uint32_t s, unsigned long long n) {
 }
 
 // block-wide exclusive scan of one int per thread; returns the exclusive prefix, total in *total
-__device__ inline int block_excl_scan(Smem &S, int v, int *total) {
+template <class SM>
+__device__ inline int block_excl_scan(SM &S, int v, int *total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int incl = v;
 #pragma unroll
@@ -224,7 +242,8 @@ __device__ inline int block_excl_scan(Smem &S, int v, int *total) {
 }
 
 // exclusive scan of cells[].count into the start field; returns the total
-__device__ int scan_cells(Smem &S) {
+template <class SM>
+__device__ int scan_cells(SM &S) {
   const int tid = threadIdx.x;
   constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;  // 4
   int c[PER];
@@ -249,7 +268,8 @@ __device__ int scan_cells(Smem &S) {
 
 // list of the non-empty cells (ascending) so that the walks give one pixel to one lane in a
 // single pass; returns their number
-__device__ int list_nonempty_cells(Smem &S, uint16_t *nz) {
+template <class SM>
+__device__ int list_nonempty_cells(SM &S, uint16_t *nz) {
   const int tid = threadIdx.x;
   constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;
   int cnt = 0;
@@ -278,8 +298,8 @@ __device__ int list_nonempty_cells(Smem &S, uint16_t *nz) {
 // image: a clamped duplicate cannot change a max), one dword store.
 // planes 0..2 (or 0 alone) start at p012 and are kPix apart; plane 3, if present, is p3 and is
 // normalised on its own; output channels are consecutive planes starting at out.
-template <int NPL>
-__device__ void finalize_planes(Smem &S, const float *p012, const float *p3, uint8_t *out) {
+template <int NPL, class SM>
+__device__ void finalize_planes(SM &S, const float *p012, const float *p3, uint8_t *out) {
   const int tid = threadIdx.x;
   constexpr int GROUPS = NPL * 900;
   constexpr int PER = (GROUPS + IMG_THREADS - 1) / IMG_THREADS;
@@ -404,26 +424,14 @@ __device__ inline void sort_by_rank(uint16_t *p, int n, const uint32_t *key) {
     }                                                               \
   } while (0)
 
-__global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
-  __shared__ Smem S;
-  unsigned long long t_last = __builtin_readcyclecounter();
+// the candidate's box in scalar registers, bounds exactly as findPointsInUnitImage /
+// transformPointsToUnitImage evaluate them (image_strategy.cpp:53-90)
+__device__ inline void load_box(const gpd_hand &H, Box &B) {
   const ImgConsts &K = c_img;
-  const int cand = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const gpd_hand &H = P.hands[cand];
-  const int slot_s = P.meta[4 * cand + 0];
-  const int N = P.meta[4 * cand + 1];
-  const int set_ord = P.meta[4 * cand + 2];
-  const int set_nb = P.meta[4 * cand + 3];
-  const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
-  uint8_t *out = P.images + (size_t)cand * kPix * K.C;
-  Box B;
 #pragma unroll
   for (int i = 0; i < 9; i++) B.F[i] = uniform_f64(H.frame[i]);
 #pragma unroll
   for (int i = 0; i < 3; i++) B.sample[i] = uniform_f64(H.sample[i]);
-  // bounds exactly as findPointsInUnitImage / transformPointsToUnitImage evaluate them
   const double hb = uniform_f64(H.bottom), hc = uniform_f64(H.center);
   B.off[0] = hb;
   B.off[1] = uniform_f64(hc - K.half_od);
@@ -434,197 +442,242 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   B.hi[1] = uniform_f64(hc + K.half_od);
   B.lo[2] = uniform_f64(-1.0 * K.vol_height);
   B.hi[2] = uniform_f64(K.vol_height);
+}
+
+// ---------------------------------------------------------------------------
+// shadow_image_kernel: the shadow channel of the three projections of one candidate
+// (createShadowImage, image_strategy.cpp:192-233; 15 channels only).
+// ---------------------------------------------------------------------------
+template <int SHC>
+__global__ __launch_bounds__(IMG_THREADS) void shadow_image_kernel(ImgParams P) {
+  __shared__ SmemShadow<SHC> S;
+  unsigned long long t_last = __builtin_readcyclecounter();
+  const ImgConsts &K = c_img;
+  const int cand = P.cand_list ? P.cand_list[blockIdx.x] : (int)blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int set_ord = P.meta[4 * cand + 2];
+  const int set_nb = P.meta[4 * cand + 3];
+  uint8_t *out = P.images + (size_t)cand * kPix * K.C;
+  Box B;
+  load_box(P.hands[cand], B);
+  for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
+  for (int i = tid; i < 128; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
+  for (int w = tid; w < VWORDS; w += IMG_THREADS) S.bp.bits[w] = 0u;
+  if (tid == 0) {
+    S.flag = 0;
+    // voxel AABB of the image box: corners sample + F * (bx, by, bz)
+    double lo0 = DBL_MAX, lo1 = DBL_MAX, lo2 = DBL_MAX;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const double bx = (k & 1) ? B.hi[0] : B.lo[0];
+      const double by = (k & 2) ? B.hi[1] : B.lo[1];
+      const double bz = (k & 4) ? B.hi[2] : B.lo[2];
+      lo0 = fmin(lo0, B.sample[0] + B.F[0] * bx + B.F[1] * by + B.F[2] * bz);
+      lo1 = fmin(lo1, B.sample[1] + B.F[3] * bx + B.F[4] * by + B.F[5] * bz);
+      lo2 = fmin(lo2, B.sample[2] + B.F[6] * bx + B.F[7] * by + B.F[8] * bz);
+    }
+    S.vorg[0] = (int)floor(lo0 * K.voxel_mult) - 1;
+    S.vorg[1] = (int)floor(lo1 * K.voxel_mult) - 1;
+    S.vorg[2] = (int)floor(lo2 * K.voxel_mult) - 1;
+  }
+  __syncthreads();
+  const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
+  // ---- the set's shadow voxels (shadow_set_kernel) restricted to this candidate's box:
+  //      walk the AABB rows of the set bitset(s), exact f64 box test per set voxel
+  if (set_ord >= 0) {
+    const uint32_t *sb = P.set_bits + (size_t)set_ord * SETWORDS;
+    const int ox = (int)floor(B.sample[0] * K.voxel_mult) - SR, oy = (int)floor(B.sample[1] * K.voxel_mult) - SR,
+              oz = (int)floor(B.sample[2] * K.voxel_mult) - SR;
+    const int zlo = z0 - oz;
+    for (int row = tid; row < VDIM * VDIM; row += IMG_THREADS) {
+      const int ix = row / VDIM, iy = row - ix * VDIM;
+      const int sx = x0 + ix - ox, sy = y0 + iy - oy;
+      if ((unsigned)sx >= (unsigned)SD || (unsigned)sy >= (unsigned)SD) continue;
+      const int rowbit = (sx * SD + sy) * SD;
+      // 46 bits starting at rowbit + zlo, clipped to the row [0, SD)
+      const int za = zlo < 0 ? 0 : zlo, zb = (zlo + VDIM < SD) ? zlo + VDIM : SD;
+      if (za >= zb) continue;
+      const int b0 = rowbit + za;
+      const int w0 = b0 >> 5, sh = b0 & 31;
+      // several cameras: the shadow is the intersection of their voxel sets (hand_set.cpp:159-172)
+      unsigned long long field = ~0ull;
+      for (int cb = 0; cb < set_nb; cb++) {
+        const uint32_t *sc = sb + (size_t)cb * SETWORDS;
+        const unsigned long long lo64 = (unsigned long long)sc[w0] | ((unsigned long long)(w0 + 1 < SETWORDS ? sc[w0 + 1] : 0u) << 32);
+        const unsigned long long hi = (w0 + 2 < SETWORDS) ? sc[w0 + 2] : 0u;
+        field &= (lo64 >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+      }
+      const int nbits = zb - za;
+      field &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
+      while (field) {
+        const int t = __ffsll((long long)field) - 1;
+        field &= field - 1;
+        const int iz = za + t - zlo;
+        double th[3];
+        to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
+        if (in_box(B, th)) {
+          const int bit = (ix * VDIM + iy) * VDIM + iz;
+          atomicOr(&S.bp.bits[bit >> 5], 1u << (bit & 31));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  TICK(0);
+  // ---- ordered list of the set bits
+  constexpr int WPT = (VWORDS + IMG_THREADS - 1) / IMG_THREADS;  // words per thread, contiguous
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < WPT; k++) {
+    const int w = tid * WPT + k;
+    if (w < VWORDS) cnt += __popc(S.bp.bits[w]);
+  }
+  int n_sh;
+  int pos = block_excl_scan(S, cnt, &n_sh);
+  if (n_sh > SHC) {  // this instantiation cannot list the box: queue the candidate for the large one
+    if (tid == 0) {
+      if (P.overflow_list) {
+        const int slot = atomicAdd(P.overflow_count, 1);
+        P.overflow_list[slot] = cand;
+      } else {
+        atomicOr(P.status, 4);
+      }
+    }
+    return;
+  }
+  for (int k = 0; k < WPT; k++) {
+    const int w = tid * WPT + k;
+    if (w >= VWORDS) break;
+    uint32_t bits = S.bp.bits[w];
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      if (pos < SHC) S.lin[pos] = (uint32_t)(w * 32 + b);
+      pos++;
+    }
+  }
+  __syncthreads();  // from here on bp.place may overwrite bp.bits
+  const int ns = n_sh < SHC ? n_sh : SHC;
+  if (P.dbg && tid == 0) {
+    atomicMax(&P.dbg[12], (unsigned long long)n_sh);
+    atomicAdd(&P.dbg[13], (unsigned long long)n_sh);
+  }
+  // the three cell coordinates of every entry, once: voxel -> hand frame -> exact threshold lookup
+  for (int k = tid; k < ns; k += IMG_THREADS) {
+    const int lin = (int)S.lin[k];
+    const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
+    double th[3];
+    to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
+    const uint32_t c3 = cells_of(S, B, th);
+    S.lin[k] = (uint32_t)lin | ((c3 & 0xfffu) << 17);
+    S.cz[k] = (uint8_t)(c3 >> 12);
+  }
+  __syncthreads();
+  TICK(1);
+  auto cell_of_entry = [&](int k, int pr) {
+    const uint32_t v = S.lin[k];
+    return cell_of_key(((v >> 17) & 0xfffu) | ((uint32_t)S.cz[k] << 12), pr);
+  };
+  for (int pr = 0; pr < 3; pr++) {
+    for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
+    __syncthreads();
+    for (int k = tid; k < ns; k += IMG_THREADS) atomicAdd(&S.cells[cell_of_entry(k, pr)], 1u);
+    __syncthreads();
+    scan_cells(S);
+    for (int k = tid; k < ns; k += IMG_THREADS) {
+      const uint32_t old = atomicAdd(&S.cells[cell_of_entry(k, pr)], 1u);
+      S.bp.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)k;
+    }
+    __syncthreads();
+    TICK(2);
+    const int da = depth_axis(pr);
+    // column `da` of F and the matching offset, selected without indexing the register-resident box
+    const double Fd0 = da == 0 ? B.F[0] : (da == 1 ? B.F[1] : B.F[2]);
+    const double Fd1 = da == 0 ? B.F[3] : (da == 1 ? B.F[4] : B.F[5]);
+    const double Fd2 = da == 0 ? B.F[6] : (da == 1 ? B.F[7] : B.F[8]);
+    const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
+    float lmax = -FLT_MAX;
+    int lany = 0;
+    const int n_nz = list_nonempty_cells(S, S.nz);
+    for (int c = tid; c < kPix; c += IMG_THREADS) S.raster0[c] = 0.f;
+    __syncthreads();
+    for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
+      const int c = S.nz[qn];
+      const uint32_t w = S.cells[c];
+      const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
+      sort_u16(&S.bp.place[start], cn);
+      float v = 0.f, fc = 0.f;
+      for (int e = 0; e < cn; e++) {
+        const int lin = (int)(S.lin[S.bp.place[start + e]] & 0x1ffffu);
+        const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
+        const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
+                     c2 = (double)(iz + z0) * K.voxel - B.sample[2];
+        const double td = Fd0 * c0 + Fd1 * c1 + Fd2 * c2;
+        const double d = div_len(td - offd, da);
+        fc = (float)((double)fc + 1.0);
+        v = (float)((double)v + (d - (double)v) * recip_count<128>(S.recip, fc));
+      }
+      lmax = fmaxf(lmax, v);
+      lany = 1;
+      S.raster0[c] = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+      lany |= __shfl_xor(lany, o);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      S.red_f[tid >> 6] = lmax;
+      S.red_i[tid >> 6] = lany;
+    }
+    __syncthreads();
+    float gmax = -FLT_MAX;
+    int gany = 0;
+#pragma unroll
+    for (int w = 0; w < IMG_WAVES; w++) {
+      gmax = fmaxf(gmax, S.red_f[w]);
+      gany |= S.red_i[w];
+    }
+    // minMaxLoc with mask -> max (0 if the mask is empty); image = max_img - image
+    const double mxd = gany ? (double)gmax : 0.0;
+    __syncthreads();
+    for (int c = tid; c < kPix; c += IMG_THREADS) {
+      const float m = (S.cells[c] & 0xffffu) ? (float)mxd : 0.0f;
+      S.raster0[c] = m - S.raster0[c];
+    }
+    __syncthreads();
+    TICK(3);
+    finalize_planes<1>(S, &S.raster0[0], nullptr, out + (size_t)(pr * K.per + 4) * kPix);
+    TICK(4);
+  }
+  if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
+}
+
+// ---------------------------------------------------------------------------
+// grasp_image_kernel: normals (3) and depth (1) channels per projection of one candidate
+// (createNormalsImage / createDepthImage, image_strategy.cpp:124-190).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
+  __shared__ Smem S;
+  unsigned long long t_last = __builtin_readcyclecounter();
+  const ImgConsts &K = c_img;
+  const int cand = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int slot_s = P.meta[4 * cand + 0];
+  const int N = P.meta[4 * cand + 1];
+  const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
+  uint8_t *out = P.images + (size_t)cand * kPix * K.C;
+  Box B;
+  load_box(P.hands[cand], B);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
   for (int i = tid; i < 256; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
   if (tid == 0) {
     S.flag = 0;
     S.counter = 0;
   }
-  const bool with_shadow = (K.C == 15);
-
-  // =====================================================================
-  // Shadow channels first (their LDS is reused by the point phase).
-  // =====================================================================
-  if (with_shadow) {
-    for (int w = tid; w < VWORDS; w += IMG_THREADS) S.u.s.bits[w] = 0u;
-    if (tid == 0) {
-      // voxel AABB of the image box: corners sample + F * (bx, by, bz)
-      double lo0 = DBL_MAX, lo1 = DBL_MAX, lo2 = DBL_MAX;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const double bx = (k & 1) ? B.hi[0] : B.lo[0];
-        const double by = (k & 2) ? B.hi[1] : B.lo[1];
-        const double bz = (k & 4) ? B.hi[2] : B.lo[2];
-        lo0 = fmin(lo0, B.sample[0] + B.F[0] * bx + B.F[1] * by + B.F[2] * bz);
-        lo1 = fmin(lo1, B.sample[1] + B.F[3] * bx + B.F[4] * by + B.F[5] * bz);
-        lo2 = fmin(lo2, B.sample[2] + B.F[6] * bx + B.F[7] * by + B.F[8] * bz);
-      }
-      S.vorg[0] = (int)floor(lo0 * K.voxel_mult) - 1;
-      S.vorg[1] = (int)floor(lo1 * K.voxel_mult) - 1;
-      S.vorg[2] = (int)floor(lo2 * K.voxel_mult) - 1;
-    }
-    __syncthreads();
-    const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
-    // ---- the set's shadow voxels (shadow_set_kernel) restricted to this candidate's box:
-    //      walk the AABB rows of the set bitset, exact f64 box test per set voxel
-    if (set_ord >= 0) {
-      const uint32_t *sb = P.set_bits + (size_t)set_ord * SETWORDS;
-      const int ox = (int)floor(B.sample[0] * K.voxel_mult) - SR, oy = (int)floor(B.sample[1] * K.voxel_mult) - SR,
-                oz = (int)floor(B.sample[2] * K.voxel_mult) - SR;
-      const int zlo = z0 - oz;
-      for (int row = tid; row < VDIM * VDIM; row += IMG_THREADS) {
-        const int ix = row / VDIM, iy = row - ix * VDIM;
-        const int sx = x0 + ix - ox, sy = y0 + iy - oy;
-        if ((unsigned)sx >= (unsigned)SD || (unsigned)sy >= (unsigned)SD) continue;
-        const int rowbit = (sx * SD + sy) * SD;
-        // 46 bits starting at rowbit + zlo, clipped to the row [0, SD)
-        const int za = zlo < 0 ? 0 : zlo, zb = (zlo + VDIM < SD) ? zlo + VDIM : SD;
-        if (za >= zb) continue;
-        const int b0 = rowbit + za;
-        const int w0 = b0 >> 5, sh = b0 & 31;
-        // several cameras: the shadow is the intersection of their voxel sets (hand_set.cpp:159-172)
-        unsigned long long field = ~0ull;
-        for (int cb = 0; cb < set_nb; cb++) {
-          const uint32_t *sc = sb + (size_t)cb * SETWORDS;
-          const unsigned long long lo64 = (unsigned long long)sc[w0] | ((unsigned long long)(w0 + 1 < SETWORDS ? sc[w0 + 1] : 0u) << 32);
-          const unsigned long long hi = (w0 + 2 < SETWORDS) ? sc[w0 + 2] : 0u;
-          field &= (lo64 >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
-        }
-        const int nbits = zb - za;
-        field &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
-        while (field) {
-          const int t = __ffsll((long long)field) - 1;
-          field &= field - 1;
-          const int iz = za + t - zlo;
-          double th[3];
-          to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
-          if (in_box(B, th)) {
-            const int bit = (ix * VDIM + iy) * VDIM + iz;
-            atomicOr(&S.u.s.bits[bit >> 5], 1u << (bit & 31));
-          }
-        }
-      }
-    }
-    __syncthreads();
-    TICK(0);
-    // ---- ordered list of the set bits + their three cell coordinates
-    constexpr int WPT = (VWORDS + IMG_THREADS - 1) / IMG_THREADS;  // words per thread, contiguous
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < WPT; k++) {
-      const int w = tid * WPT + k;
-      if (w < VWORDS) cnt += __popc(S.u.s.bits[w]);
-    }
-    int n_sh;
-    int pos = block_excl_scan(S, cnt, &n_sh);
-    if (n_sh > SH_CAP) {
-      if (tid == 0) atomicOr(&S.flag, 4);
-    }
-    for (int k = 0; k < WPT; k++) {
-      const int w = tid * WPT + k;
-      if (w >= VWORDS) break;
-      uint32_t bits = S.u.s.bits[w];
-      while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        if (pos < SH_CAP) S.u.s.lin[pos] = (uint32_t)(w * 32 + b);
-        pos++;
-      }
-    }
-    __syncthreads();
-    const int ns = n_sh < SH_CAP ? n_sh : SH_CAP;
-    for (int k = tid; k < ns; k += IMG_THREADS) {
-      const int lin = (int)S.u.s.lin[k];
-      const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
-      double th[3];
-      to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
-      S.u.s.cells3[k] = cells_of(S, B, th);
-    }
-    __syncthreads();
-    TICK(1);
-    for (int pr = 0; pr < 3; pr++) {
-      // ---- createShadowImage (image_strategy.cpp:192-233)
-      for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
-      __syncthreads();
-      for (int k = tid; k < ns; k += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(S.u.s.cells3[k], pr)], 1u);
-      __syncthreads();
-      scan_cells(S);
-      for (int k = tid; k < ns; k += IMG_THREADS) {
-        const uint32_t old = atomicAdd(&S.cells[cell_of_key(S.u.s.cells3[k], pr)], 1u);
-        S.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)k;
-      }
-      __syncthreads();
-      TICK(2);
-      const int da = depth_axis(pr);
-      // column `da` of F and the matching offset, selected without indexing the register-resident box
-      const double Fd0 = da == 0 ? B.F[0] : (da == 1 ? B.F[1] : B.F[2]);
-      const double Fd1 = da == 0 ? B.F[3] : (da == 1 ? B.F[4] : B.F[5]);
-      const double Fd2 = da == 0 ? B.F[6] : (da == 1 ? B.F[7] : B.F[8]);
-      const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
-      float lmax = -FLT_MAX;
-      int lany = 0;
-      uint16_t *nz = reinterpret_cast<uint16_t *>(&S.raster[1][0]);
-      const int n_nz = list_nonempty_cells(S, nz);
-      for (int c = tid; c < kPix; c += IMG_THREADS) S.raster[0][c] = 0.f;
-      __syncthreads();
-      for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
-        const int c = nz[qn];
-        const uint32_t w = S.cells[c];
-        const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
-        float v = 0.f;
-        {
-          sort_u16(&S.place[start], cn);
-          float fc = 0.f;
-          for (int e = 0; e < cn; e++) {
-            const int lin = (int)S.u.s.lin[S.place[start + e]];
-            const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
-            const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
-                         c2 = (double)(iz + z0) * K.voxel - B.sample[2];
-            const double td = Fd0 * c0 + Fd1 * c1 + Fd2 * c2;
-            const double d = div_len(td - offd, da);
-            fc = (float)((double)fc + 1.0);
-            v = (float)((double)v + (d - (double)v) * recip_count(S.recip, fc));
-          }
-          lmax = fmaxf(lmax, v);
-          lany = 1;
-        }
-        S.raster[0][c] = v;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        lany |= __shfl_xor(lany, o);
-      }
-      __syncthreads();
-      if (lane == 0) {
-        S.red_f[tid >> 6] = lmax;
-        S.red_i[tid >> 6] = lany;
-      }
-      __syncthreads();
-      float gmax = -FLT_MAX;
-      int gany = 0;
-#pragma unroll
-      for (int w = 0; w < IMG_WAVES; w++) {
-        gmax = fmaxf(gmax, S.red_f[w]);
-        gany |= S.red_i[w];
-      }
-      // minMaxLoc with mask -> max (0 if the mask is empty); image = max_img - image
-      const double mxd = gany ? (double)gmax : 0.0;
-      __syncthreads();
-      for (int c = tid; c < kPix; c += IMG_THREADS) {
-        const float m = (S.cells[c] & 0xffffu) ? (float)mxd : 0.0f;
-        S.raster[0][c] = m - S.raster[0][c];
-      }
-      __syncthreads();
-      TICK(3);
-      finalize_planes<1>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per + 4) * kPix);
-      TICK(4);
-    }
-  }
-
-  // =====================================================================
-  // Point channels: normals (3) and depth (1) per projection.
-  // =====================================================================
   __syncthreads();
   for (int i0 = 0; i0 < N; i0 += IMG_THREADS) {
     const int i = i0 + tid;
@@ -643,13 +696,13 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
         const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
         if (e < PT_CAP) {
           const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
-          S.u.p.t[0][e] = t[0];
-          S.u.p.t[1][e] = t[1];
-          S.u.p.t[2][e] = t[2];
-          S.u.p.a[0][e] = (float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2);
-          S.u.p.a[1][e] = (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2);
-          S.u.p.a[2][e] = (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2);
-          S.u.p.key[e] = cells_of(S, B, t) | ((uint32_t)i << 18);
+          S.p.t[0][e] = t[0];
+          S.p.t[1][e] = t[1];
+          S.p.t[2][e] = t[2];
+          S.p.a[0][e] = (float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2);
+          S.p.a[1][e] = (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2);
+          S.p.a[2][e] = (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2);
+          S.p.key[e] = cells_of(S, B, t) | ((uint32_t)i << 18);
         }
       }
     }
@@ -658,21 +711,24 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   const int n_box_all = S.counter;
   if (n_box_all > PT_CAP && tid == 0) atomicOr(&S.flag, 2);
   const int nb = n_box_all < PT_CAP ? n_box_all : PT_CAP;
+  if (P.dbg && tid == 0) {
+    atomicMax(&P.dbg[14], (unsigned long long)n_box_all);
+    atomicAdd(&P.dbg[15], (unsigned long long)n_box_all);
+  }
   TICK(5);
   for (int pr = 0; pr < K.nproj; pr++) {
     for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
     __syncthreads();
-    for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(S.u.p.key[e], pr)], 1u);
+    for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(S.p.key[e], pr)], 1u);
     __syncthreads();
     scan_cells(S);
     for (int e = tid; e < nb; e += IMG_THREADS) {
-      const uint32_t old = atomicAdd(&S.cells[cell_of_key(S.u.p.key[e], pr)], 1u);
+      const uint32_t old = atomicAdd(&S.cells[cell_of_key(S.p.key[e], pr)], 1u);
       S.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)e;
     }
     __syncthreads();
     TICK(6);
-    // ---- createNormalsImage + createDepthImage (image_strategy.cpp:124-190): the pixel owner
-    //      walks its segment in neighbour order
+    // the pixel owner walks its segment in neighbour order
     const int da = depth_axis(pr);
     const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
     uint16_t *nz = &S.place[PT_CAP];
@@ -690,35 +746,32 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       const int c = nz[qn];
       const uint32_t w = S.cells[c];
       const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f, pix = 0.f;
-      {
-        sort_by_rank(&S.place[start], cn, S.u.p.key);
-        float avg = 0.f, fc = 0.f;
-        for (int q = 0; q < cn; q++) {
-          const int e = S.place[start + q];
-          const float a0 = S.u.p.a[0][e], a1 = S.u.p.a[1][e], a2 = S.u.p.a[2][e];
-          if (v0 == 0.f && v1 == 0.f && v2 == 0.f) {
-            v0 = a0;
-            v1 = a1;
-            v2 = a2;
-          } else {
-            const float s = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
-            const double inv = 1.0 / (double)s;
-            const float d0 = a0 - v0, d1 = a1 - v1, d2 = a2 - v2;
-            v0 = v0 + (float)((double)d0 * inv);
-            v1 = v1 + (float)((double)d1 * inv);
-            v2 = v2 + (float)((double)d2 * inv);
-          }
-          const double d = div_len(S.u.p.t[da][e] - offd, da);
-          fc = (float)((double)fc + 1.0);
-          avg = (float)((double)avg + (d - (double)avg) * recip_count(S.recip, fc));
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      sort_by_rank(&S.place[start], cn, S.p.key);
+      float avg = 0.f, fc = 0.f;
+      for (int q = 0; q < cn; q++) {
+        const int e = S.place[start + q];
+        const float a0 = S.p.a[0][e], a1 = S.p.a[1][e], a2 = S.p.a[2][e];
+        if (v0 == 0.f && v1 == 0.f && v2 == 0.f) {
+          v0 = a0;
+          v1 = a1;
+          v2 = a2;
+        } else {
+          const float sq = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+          const double inv = 1.0 / (double)sq;
+          const float d0 = a0 - v0, d1 = a1 - v1, d2 = a2 - v2;
+          v0 = v0 + (float)((double)d0 * inv);
+          v1 = v1 + (float)((double)d1 * inv);
+          v2 = v2 + (float)((double)d2 * inv);
         }
-        pix = (float)(1.0 - (double)avg);
+        const double d = div_len(S.p.t[da][e] - offd, da);
+        fc = (float)((double)fc + 1.0);
+        avg = (float)((double)avg + (d - (double)avg) * recip_count<256>(S.recip, fc));
       }
       S.raster[0][c] = v0;
       S.raster[1][c] = v1;
       S.raster[2][c] = v2;
-      S.cells[c] = __float_as_uint(pix);  // the depth plane, in place of the segment table
+      S.cells[c] = __float_as_uint((float)(1.0 - (double)avg));  // the depth plane, in place of the segment table
     }
     __syncthreads();
     TICK(7);
@@ -853,7 +906,7 @@ void image_cell_thresholds(double len, double *out) {
 }
 
 void images_free(ImageState &im) {
-  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status, im.d_set_meta, im.d_set_bits};
+  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status, im.d_set_meta, im.d_set_bits, im.d_overflow};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   im = ImageState();
@@ -924,11 +977,14 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   }
   const int n = (int)cand.size();
   im.num_candidates = n;
+  im.channels = C;
+  im.num_overflow = 0;
   if (n == 0) return GPD_OK;
   if (n > im.capacity) {
-    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta};
+    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_overflow};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
+    im.d_overflow = nullptr;
     im.d_images = nullptr;
     im.d_images_hwc = nullptr;
     im.d_hands = nullptr;
@@ -937,6 +993,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
     HIP_RET(hipMalloc(&im.d_images, (size_t)n * kPix * C));
     HIP_RET(hipMalloc(&im.d_hands, (size_t)n * sizeof(gpd_hand)));
     HIP_RET(hipMalloc(&im.d_cand_meta, (size_t)n * 4 * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&im.d_overflow, (size_t)(n + 1) * sizeof(int32_t)));  // list + its counter
     im.capacity = n;
   }
   if (!im.d_status) HIP_RET(hipMalloc(&im.d_status, sizeof(int32_t)));
@@ -1046,19 +1103,45 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     shadow_set_kernel<<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
     HIP_RET(hipGetLastError());
   }
+  ip.cand_list = nullptr;
+  ip.overflow_list = im.d_overflow;
+  ip.overflow_count = im.d_overflow + im.capacity;
+  if (im.channels == 15) {
+    // most boxes fit the two-per-CU instantiation; the few that do not are queued by it and
+    // redone by the large one
+    HIP_RET(hipMemsetAsync(im.d_overflow + im.capacity, 0, sizeof(int32_t), stream));
+    shadow_image_kernel<SH_CAP><<<n, IMG_THREADS, 0, stream>>>(ip);
+    HIP_RET(hipGetLastError());
+    if (check) {
+      int32_t n_over = 0;
+      HIP_RET(hipMemcpyAsync(&n_over, im.d_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+      HIP_RET(hipStreamSynchronize(stream));
+      im.num_overflow = n_over;
+    }
+    if (im.num_overflow > 0) {
+      ImgParams ib = ip;
+      ib.cand_list = im.d_overflow;
+      ib.overflow_list = nullptr;
+      ib.overflow_count = nullptr;
+      shadow_image_kernel<SH_CAP_BIG><<<im.num_overflow, IMG_THREADS, 0, stream>>>(ib);
+      HIP_RET(hipGetLastError());
+    }
+  }
   grasp_image_kernel<<<n, IMG_THREADS, 0, stream>>>(ip);
   HIP_RET(hipGetLastError());
   if (ip.dbg) {
     unsigned long long h[16];
     HIP_RET(hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_RET(hipStreamSynchronize(stream));
-    static const char *names[9] = {"shadow_gen",  "sh_list_cells",   "sh_count_place", "sh_walk",  "sh_final",
+    static const char *names[9] = {"sh_extract",  "sh_list",         "sh_count_place", "sh_walk",  "sh_final",
                                    "pts_collect", "pts_count_place", "pts_walk",       "pts_final"};
     unsigned long long tot = 0;
     for (int i = 0; i < 9; i++) tot += h[i];
     for (int i = 0; i < 9; i++)
       fprintf(stderr, "[img-timing] %-16s %10.1f kcycles/cand  %5.1f%%\n", names[i], (double)h[i] / n / 1e3,
               100.0 * h[i] / (double)tot);
+    fprintf(stderr, "[img-timing] shadow voxels in box: max %llu mean %.0f; in-box points: max %llu mean %.0f\n", h[12],
+            (double)h[13] / n, h[14], (double)h[15] / n);
   }
   if (!check) return GPD_OK;
   int32_t status = 0;
@@ -1066,7 +1149,7 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
   HIP_RET(hipStreamSynchronize(stream));
   if (status) {
     set_error("images: kernel capacity exceeded (flags %d: 1 voxel AABB, 2 in-box points > %d, 4 shadow voxels > %d)", status,
-              PT_CAP, SH_CAP);
+              PT_CAP, SH_CAP_BIG);
     return GPD_ERR_CAPACITY;
   }
   return GPD_OK;
