@@ -139,7 +139,7 @@ def main():
                         "achieved": net_tflops, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": net_tflops / F32_PEAK_TFLOPS, "traffic": traffic.get("lenet")}
         else:
-            roofline = {"kernel": "grasp_image_kernel", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
+            roofline = {"kernel": "image stage (shadow_set + shadow_image + grasp_image kernels)", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}
         out = {
             "metric": "15-ch grasp candidates scored/sec (imagegen+LeNet)" if C == 15 else "%d-ch grasp candidates scored/sec (imagegen+LeNet)" % C,
@@ -191,9 +191,10 @@ def _pmc_traffic():
         return {}
     d = json.load(open(path))["kernels"]
     out = {"source": "profiles/r01_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes; reads x2 per gfx950 note)"}
-    img = [v for k, v in d.items() if "grasp_image_kernel" in k]
+    img = [v["hbm_bytes_per_launch"] for k, v in d.items()
+           if any(s in k for s in ("grasp_image_kernel", "shadow_image_kernel<6144>", "shadow_set_kernel"))]
     if img:
-        out["image"] = img[0]["hbm_bytes_per_launch"]
+        out["image"] = float(sum(img))
     net = [v["hbm_bytes_per_launch"] for k, v in d.items() if any(s in k for s in ("conv1", "conv2", "fc1_mfma", "fc2_score"))]
     if net:
         out["lenet"] = float(sum(net))
