@@ -142,7 +142,7 @@ def main():
             roofline = {"kernel": "image stage (shadow_set + shadow_image + grasp_image kernels)", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}
         out = {
-            "metric": "15-ch grasp candidates scored/sec (imagegen+LeNet)" if C == 15 else "%d-ch grasp candidates scored/sec (imagegen+LeNet)" % C,
+            "metric": "15-ch grasp candidates scored/sec (imagegen+LeNet) at 1/2/4/8 MI355X" if C == 15 else "%d-ch grasp candidates scored/sec (imagegen+LeNet)" % C,
             "value": value, "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 geometry / f32 LeNet / u8 images", "data": "synthetic",

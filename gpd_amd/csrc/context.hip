@@ -101,8 +101,8 @@ int gpd_hip_create(int device, const gpd_params *params, gpd_hip_ctx **out) {
     return GPD_ERR_INVALID;
   }
   const int C = params->image_num_channels;
-  if (params->image_size != kImg || (C != 3 && C != 12 && C != 15)) {
-    set_error("gpd_hip_create: image_size must be 60 and image_num_channels one of 3/12/15");
+  if (params->image_size != kImg || (C != 1 && C != 3 && C != 12 && C != 15)) {
+    set_error("gpd_hip_create: image_size must be 60 and image_num_channels one of 1/3/12/15");
     return GPD_ERR_INVALID;
   }
   const int slots = params->num_hand_axes * params->num_orientations;

@@ -5,7 +5,8 @@
 // findCellIndices, createNormalsImage, createDepthImage, createShadowImage}
 // (descriptor/image_strategy.cpp:32-243), Image{15,12,3}ChannelsStrategy::{createImage,
 // calculateImage, calculateChannels} (image_15_channels_strategy.cpp:27-105,
-// image_12_channels_strategy.cpp:27-86, image_3_channels_strategy.cpp:27-42) and
+// image_12_channels_strategy.cpp:27-86, image_3_channels_strategy.cpp:27-42,
+// image_1_channels_strategy.cpp:25-49) and
 // HandSet::{calculateShadow, calculateShadowForCamera, shadowVoxelsToPoints, fastrand}
 // (candidate/hand_set.cpp:118-283).
 //
@@ -775,7 +776,9 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     }
     __syncthreads();
     TICK(7);
-    if (K.C >= 12)
+    if (K.C == 1)  // Image1ChannelsStrategy: the depth image alone (image_1_channels_strategy.cpp:25-40)
+      finalize_planes<1>(S, reinterpret_cast<const float *>(S.cells), nullptr, out);
+    else if (K.C >= 12)
       finalize_planes<4>(S, &S.raster[0][0], reinterpret_cast<const float *>(S.cells), out + (size_t)(pr * K.per) * kPix);
     else
       finalize_planes<3>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per) * kPix);
@@ -1021,8 +1024,8 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   k.half_od = p.volume_width / 2.0;
   k.dbl_h = 2.0 * p.volume_height;
   k.C = C;
-  k.nproj = (C == 3) ? 1 : 3;
-  k.per = (C == 15) ? 5 : (C == 12 ? 4 : 3);
+  k.nproj = (C <= 3) ? 1 : 3;
+  k.per = (C == 15) ? 5 : (C == 12 ? 4 : C);
   for (int r = 0; r < 3 * c.num_cams; r++) k.view_point[r] = c.view_points[r];
   // shadow_length_ = max(volume_depth, volume_height/2, volume_width) (image_15_channels_strategy.h:70-75)
   k.shadow_length = std::fmax(std::fmax(p.volume_depth, p.volume_height / 2.0), p.volume_width);

@@ -466,6 +466,7 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
       case 15: conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
       case 12: conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
       case 3: conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
+      case 1: conv1_mfma_kernel<1><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
       default: return hipErrorInvalidValue;
     }
     conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m);

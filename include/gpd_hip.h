@@ -52,7 +52,7 @@ typedef struct gpd_params {
   double max_aperture;        /* 0.085 */
   double workspace_grasps[6]; /* -1 1 -1 1 -1 1 */
   int32_t image_size;         /* 60 (only 60 is supported, as eigen_classifier.cpp:12) */
-  int32_t image_num_channels; /* 3, 12 or 15 */
+  int32_t image_num_channels; /* 1, 3, 12 or 15 (image_strategy.cpp:15-29) */
   int32_t num_orientations;   /* 8 */
   int32_t num_finger_placements; /* 10 */
   int32_t num_hand_axes;      /* 1 */

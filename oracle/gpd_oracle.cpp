@@ -867,8 +867,9 @@ static void toUnitImage(const gpd_params &P, const gpd_hand &H, int N, Src src, 
   }
 }
 
-// Image{15,12,3}ChannelsStrategy::createImage/calculateImage/calculateChannels —
-// image_15_channels_strategy.cpp:27-105, image_12…:27-86, image_3…:27-42.
+// Image{15,12,3,1}ChannelsStrategy::createImage/calculateImage/calculateChannels —
+// image_15_channels_strategy.cpp:27-105, image_12…:27-86, image_3…:27-42,
+// image_1_channels_strategy.cpp:25-49 (one channel = the depth image of projection 0).
 static void createImage(const gpd_params &P, const gpd_hand &H, const float *xyz, const float *normals, const std::vector<Neighbour> &nbr,
                         const std::vector<Voxel> &shadow, uint8_t *img) {
   const int C = P.image_num_channels;
@@ -892,14 +893,18 @@ static void createImage(const gpd_params &P, const gpd_hand &H, const float *xyz
   const int np = (int)pts.u.size() / 3, ns = (int)sh.u.size() / 3;
   // projections by cumulative row swaps (0<->2 then 1<->2): (x,y,z),(z,y,x),(z,x,y)
   static const int perm[3][3] = {{0, 1, 2}, {2, 1, 0}, {2, 0, 1}};
-  const int nproj = (C == 3) ? 1 : 3;
-  const int per = (C == 15) ? 5 : (C == 12 ? 4 : 3);
+  const int nproj = (C <= 3) ? 1 : 3;
+  const int per = (C == 15) ? 5 : (C == 12 ? 4 : C);
   std::vector<int> cells(np), scells(ns);
   std::vector<double> depth(np), sdepth(ns);
   for (int pr = 0; pr < nproj; pr++) {
     for (int i = 0; i < np; i++) {
       cells[i] = cellIndex(pts.u[3 * i + perm[pr][0]], pts.u[3 * i + perm[pr][1]]);
       depth[i] = pts.u[3 * i + perm[pr][2]];
+    }
+    if (C == 1) {
+      depthImage(depth, cells, img, C, 0);
+      break;
     }
     normalsImage(pts.n, cells, img, C, pr * per);
     if (C >= 12) depthImage(depth, cells, img, C, pr * per + 3);

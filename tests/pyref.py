@@ -141,12 +141,15 @@ def grasp_image(P, hand, xyz, normals, nbr_idx, shadow_vox=None):
         sp = np.array(shadow_vox, np.float64).reshape(-1, 3) * 0.003
         _, su = _to_unit(F, sample, float(hand["bottom"]), float(hand["center"]), sp, P)
     perm = [(0, 1, 2), (2, 1, 0), (2, 0, 1)]
-    nproj = 1 if C == 3 else 3
-    per = {15: 5, 12: 4, 3: 3}[C]
+    nproj = 1 if C <= 3 else 3
+    per = {15: 5, 12: 4, 3: 3, 1: 1}[C]
     img = np.zeros((60, 60, C), np.uint8)
     for pr in range(nproj):
         a, b, d = perm[pr]
         cells = _cells(u[:, a], u[:, b]) if len(u) else []
+        if C == 1:  # image_1_channels_strategy.cpp:25-40: the depth image alone
+            img[..., 0] = _depth_image(u[:, d] if len(u) else [], cells)
+            break
         img[..., pr * per:pr * per + 3] = _normals_image(nrm, cells)
         if C >= 12:
             img[..., pr * per + 3] = _depth_image(u[:, d] if len(u) else [], cells)

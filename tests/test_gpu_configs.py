@@ -44,7 +44,7 @@ def test_config2_30k_cloud_5000_candidates(oracle_mod, cloud30k):
     assert n > 4500
 
 
-@pytest.mark.parametrize("C", [3, 12])
+@pytest.mark.parametrize("C", [1, 3, 12])
 def test_config3_other_image_geometries(oracle_mod, cloud30k, C):
     """configs[2]: 3- and 12-channel geometries on the same cloud."""
     si = synth.sample_indices(cloud30k, 500)

@@ -56,7 +56,7 @@ def test_search_matches_oracle(ctx15, oracle_mod, cloud30k):
     assert all(exact.values()), exact
 
 
-@pytest.mark.parametrize("channels", [15, 12, 3])
+@pytest.mark.parametrize("channels", [15, 12, 3, 1])
 def test_images_match_oracle(oracle_mod, cloud30k, channels):
     si = synth.sample_indices(cloud30k, 60)
     ctx = api.Context(api.default_params(channels))

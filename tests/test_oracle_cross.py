@@ -115,7 +115,7 @@ def test_workspace_filter_matches_numpy(oracle_mod, cloud30k):
     assert a["valid"].sum() < hands["valid"].sum()  # the 0.085 aperture removes some
 
 
-@pytest.mark.parametrize("C", [15, 12, 3])
+@pytest.mark.parametrize("C", [15, 12, 3, 1])
 def test_images_against_python_reference(oracle_mod, small_cloud, C):
     cl = small_cloud
     p = oracle_mod.default_params(C)
