@@ -13,7 +13,7 @@ namespace candidate {
 class Hand {
  public:
   Hand() { rec_ = gpd_hand(); }
-  explicit Hand(const gpd_hand &r) : rec_(r) {}
+  explicit Hand(const gpd_hand &r) : rec_(r), score_(r.score) {}
   std::array<double, 3> getSample() const { return {rec_.sample[0], rec_.sample[1], rec_.sample[2]}; }
   std::array<double, 3> getPosition() const { return {rec_.position[0], rec_.position[1], rec_.position[2]}; }
   std::array<double, 9> getFrame() const {  // row-major, columns approach | binormal | axis
@@ -26,8 +26,18 @@ class Hand {
   std::array<double, 3> getBinormal() const { return {rec_.frame[1], rec_.frame[4], rec_.frame[7]}; }
   std::array<double, 3> getAxis() const { return {rec_.frame[2], rec_.frame[5], rec_.frame[8]}; }
   double getGraspWidth() const { return rec_.grasp_width; }
-  double getScore() const { return rec_.score; }
-  void setScore(double s) { rec_.score = (float)s; }
+  // the reference keeps the score as a double (hand.h:150-156); the POD record holds the LeNet
+  // float, the double survives Clustering's confidence bound (clustering.cpp:95)
+  double getScore() const { return score_; }
+  void setScore(double s) {
+    score_ = s;
+    rec_.score = (float)s;
+  }
+  void setPosition(const std::array<double, 3> &p) {
+    for (int i = 0; i < 3; i++) rec_.position[i] = p[i];
+  }
+  void setFullAntipodal(bool b) { rec_.full_antipodal = b ? 1 : 0; }
+  void setHalfAntipodal(bool b) { rec_.half_antipodal = b ? 1 : 0; }
   bool isFullAntipodal() const { return rec_.full_antipodal; }
   bool isHalfAntipodal() const { return rec_.half_antipodal; }
   double getTop() const { return rec_.top; }
@@ -39,6 +49,7 @@ class Hand {
 
  private:
   gpd_hand rec_;
+  double score_ = 0.0;
 };
 
 // HandSet (candidate/hand_set.h): the hands of one sample + their validity flags.

@@ -1,13 +1,14 @@
 // gpd::GraspDetector — the reference's public API (include/gpd/grasp_detector.h:66-186) over the
 // HIP path.  Same constructor (a cfg file), same call sequence in detectGrasps
-// (grasp_detector.cpp:192-328): candidates -> workspace/aperture filter -> images -> classify ->
-// select top num_selected -> sort; clustering (out of scope) is skipped like `min_inliers = 0`.
+// (grasp_detector.cpp:192-328): candidates -> workspace/aperture filter [-> approach-direction
+// filter] -> images -> classify -> select top num_selected -> cluster (min_inliers > 0) -> sort.
 #pragma once
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "gpd/candidate/hand.h"
+#include "gpd/clustering.h"
 #include "gpd/net/classifier.h"
 #include "gpd/util/cloud.h"
 #include "gpd_hip.h"
@@ -25,6 +26,15 @@ class GraspDetector {
   std::vector<std::unique_ptr<candidate::HandSet>> generateGraspCandidates(const util::Cloud &cloud);
   std::vector<std::unique_ptr<candidate::HandSet>> filterGraspsWorkspace(
       std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, const std::vector<double> &workspace) const;
+  // grasp_detector.cpp:422-453: clears hands whose approach axis is more than thresh_rad away from
+  // `direction`; sets left without a valid hand are dropped.
+  std::vector<std::unique_ptr<candidate::HandSet>> filterGraspsDirection(
+      std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, const std::array<double, 3> &direction, double thresh_rad);
+  // grasp_detector.cpp:528-551: images + scores for the given sets (they must stem from the last
+  // generateGraspCandidates on this detector: the device keeps their neighbourhoods), keeps the
+  // hands with score > min_score.
+  std::vector<std::unique_ptr<candidate::Hand>> pruneGraspCandidates(
+      const util::Cloud &cloud, const std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, double min_score);
   bool createGraspImages(util::Cloud &cloud, std::vector<std::unique_ptr<candidate::Hand>> &hands_out,
                          std::vector<std::unique_ptr<net::Image>> &images_out);
   std::vector<std::unique_ptr<candidate::Hand>> selectGrasps(std::vector<std::unique_ptr<candidate::Hand>> &hands) const;
@@ -38,6 +48,7 @@ class GraspDetector {
 
  private:
   bool upload(const util::Cloud &cloud);
+  std::vector<gpd_hand> flatten(const std::vector<std::unique_ptr<candidate::HandSet>> &sets) const;
   gpd_params params_;
   gpd_hip_ctx *ctx_ = nullptr;
   bool has_classifier_ = false;
@@ -46,6 +57,12 @@ class GraspDetector {
   double voxel_size_ = 0.003, normals_radius_ = 0.03;
   int num_selected_ = 100;
   std::vector<double> workspace_grasps_;
+  bool filter_approach_direction_ = false;
+  std::array<double, 3> direction_ = {1, 0, 0};
+  double thresh_rad_ = 2.3;
+  std::unique_ptr<Clustering> clustering_;
+  bool cluster_grasps_ = false;
+  int last_num_sets_ = 0;  // hand sets of the last device search
   double runtimes_[4] = {0, 0, 0, 0};
 };
 

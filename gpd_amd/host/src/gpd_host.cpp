@@ -13,6 +13,7 @@
 #include <numeric>
 #include <set>
 
+#include "gpd/clustering.h"
 #include "gpd/grasp_detector.h"
 #include "gpd/util/config_file.h"
 
@@ -354,6 +355,15 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   for (int i = 0; i < 6; i++) params_.workspace_grasps[i] = workspace_grasps_[i];
   params_.min_aperture = config_file.getValueOfKey<double>("min_aperture", 0.0);
   params_.max_aperture = config_file.getValueOfKey<double>("max_aperture", 0.085);
+  // approach-direction filter, clustering, selection (grasp_detector.cpp:168-185)
+  filter_approach_direction_ = config_file.getValueOfKey<bool>("filter_approach_direction", false);
+  std::vector<double> approach = config_file.getValueOfKeyAsStdVectorDouble("direction", "1 0 0");
+  approach.resize(3, 0.0);
+  direction_ = {approach[0], approach[1], approach[2]};
+  thresh_rad_ = config_file.getValueOfKey<double>("thresh_rad", 2.3);
+  const int min_inliers = config_file.getValueOfKey<int>("min_inliers", 1);
+  clustering_ = std::make_unique<Clustering>(min_inliers);
+  cluster_grasps_ = min_inliers > 0;
   num_selected_ = config_file.getValueOfKey<int>("num_selected", 100);
   printf("============ CANDIDATE GENERATION ============\n");
   printf("num_samples: %d\nnn_radius: %3.2f\nnum_orientations: %d\nnum_finger_placements: %d\ndeepen_hand: %s\n", num_samples_,
@@ -459,6 +469,7 @@ std::vector<std::unique_ptr<candidate::HandSet>> GraspDetector::generateGraspCan
     printf("ERROR: %s\n", gpd_hip_last_error());
     return none;
   }
+  last_num_sets_ = n_sets;
   return to_sets(recs, n_sets, slots);
 }
 
@@ -497,6 +508,79 @@ std::vector<std::unique_ptr<candidate::HandSet>> GraspDetector::filterGraspsWork
   }
   printf("Number of grasp candidates within workspace and gripper width: %d\n", remaining);
   return out;
+}
+
+// grasp_detector.cpp:422-453
+std::vector<std::unique_ptr<candidate::HandSet>> GraspDetector::filterGraspsDirection(
+    std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, const std::array<double, 3> &direction, double thresh_rad) {
+  std::vector<std::unique_ptr<candidate::HandSet>> out;
+  int remaining = 0;
+  for (size_t i = 0; i < hand_set_list.size(); i++) {
+    const auto &hands = hand_set_list[i]->getHands();
+    std::vector<bool> is_valid = hand_set_list[i]->getIsValid();
+    bool any = false;
+    for (size_t j = 0; j < hands.size(); j++) {
+      if (!is_valid[j]) continue;
+      const auto app = hands[j]->getApproach();
+      const double angle = acos(direction[0] * app[0] + direction[1] * app[1] + direction[2] * app[2]);
+      if (angle > thresh_rad) {
+        is_valid[j] = false;
+      } else {
+        remaining++;
+        any = true;
+      }
+    }
+    if (any) {
+      hand_set_list[i]->setIsValid(is_valid);
+      out.push_back(std::move(hand_set_list[i]));
+    }
+  }
+  printf("Number of grasp candidates with correct approach direction: %d\n", remaining);
+  return out;
+}
+
+// the flat record array gpd_hip_images reads: one row of slots per set of the last search, rows of
+// sets that are not in `sets` stay invalid
+std::vector<gpd_hand> GraspDetector::flatten(const std::vector<std::unique_ptr<candidate::HandSet>> &sets) const {
+  const int slots = params_.num_hand_axes * params_.num_orientations;
+  std::vector<gpd_hand> recs((size_t)last_num_sets_ * slots, gpd_hand());
+  for (const auto &hs : sets) {
+    if (!hs || hs->getHands().empty()) continue;
+    const int si = hs->getHands()[0]->record().set_index;
+    if (si < 0 || si >= last_num_sets_) continue;
+    for (int j = 0; j < slots && j < (int)hs->getHands().size(); j++) {
+      recs[(size_t)si * slots + j] = hs->getHands()[j]->record();
+      recs[(size_t)si * slots + j].valid = hs->getIsValid()[j] ? 1 : 0;
+    }
+  }
+  return recs;
+}
+
+// grasp_detector.cpp:528-551
+std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::pruneGraspCandidates(
+    const util::Cloud &cloud, const std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, double min_score) {
+  std::vector<std::unique_ptr<candidate::Hand>> hands_out;
+  if (!ctx_ || !has_classifier_ || last_num_sets_ == 0) return hands_out;
+  (void)cloud;  // resident on the device since generateGraspCandidates
+  std::vector<gpd_hand> recs = flatten(hand_set_list);
+  size_t nv = 0;
+  for (const gpd_hand &r : recs) nv += r.valid;
+  std::vector<int32_t> cand(nv);
+  std::vector<float> scores(nv);
+  int n_cand = 0;
+  if (gpd_hip_images(ctx_, recs.data(), last_num_sets_, nullptr, cand.data(), &n_cand) != GPD_OK ||
+      (n_cand > 0 && gpd_hip_score(ctx_, nullptr, n_cand, scores.data()) != GPD_OK)) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return hands_out;
+  }
+  for (int k = 0; k < n_cand; k++) {
+    if (scores[k] > min_score) {
+      auto h = std::make_unique<candidate::Hand>(recs[cand[k]]);
+      h->setScore(scores[k]);
+      hands_out.push_back(std::move(h));
+    }
+  }
+  return hands_out;
 }
 
 bool GraspDetector::createGraspImages(util::Cloud &cloud, std::vector<std::unique_ptr<candidate::Hand>> &hands_out,
@@ -569,19 +653,56 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
   const int slots = params_.num_hand_axes * params_.num_orientations;
   std::vector<gpd_hand> recs(idx.size() * slots);
   int n_sets = 0, n_cand = 0;
-  // steps 1-4 fused on the device (grasp_detector.cpp:222-273)
-  if (gpd_hip_detect(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets, &n_cand) != GPD_OK) {
-    printf("ERROR: %s\n", gpd_hip_last_error());
-    return hands_out;
-  }
-  printf("Generated %d hand sets.\n", n_sets);
-  float ms[3] = {0, 0, 0};
-  gpd_hip_last_stage_ms(ctx_, ms);
   std::vector<std::unique_ptr<candidate::Hand>> hands;
-  for (size_t i = 0; i < (size_t)n_sets * slots; i++)
-    if (recs[i].valid) hands.push_back(std::make_unique<candidate::Hand>(recs[i]));
-  // 5. select the highest scoring grasps; 6. clustering is out of scope (min_inliers = 0); 7. sort
-  std::vector<std::unique_ptr<candidate::Hand>> clusters = selectGrasps(hands);
+  float ms[3] = {0, 0, 0};
+  if (!filter_approach_direction_) {
+    // steps 1-4 fused on the device (grasp_detector.cpp:222-273)
+    if (gpd_hip_detect(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets, &n_cand) != GPD_OK) {
+      printf("ERROR: %s\n", gpd_hip_last_error());
+      return hands_out;
+    }
+    last_num_sets_ = n_sets;
+    printf("Generated %d hand sets.\n", n_sets);
+    gpd_hip_last_stage_ms(ctx_, ms);
+    for (size_t i = 0; i < (size_t)n_sets * slots; i++)
+      if (recs[i].valid) hands.push_back(std::make_unique<candidate::Hand>(recs[i]));
+  } else {
+    // the approach-direction filter sits between the stages (grasp_detector.cpp:247-255): search,
+    // both host filters, then images and scores for what is left
+    if (gpd_hip_search(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets) != GPD_OK) {
+      printf("ERROR: %s\n", gpd_hip_last_error());
+      return hands_out;
+    }
+    last_num_sets_ = n_sets;
+    printf("Generated %d hand sets.\n", n_sets);
+    float t[3];
+    gpd_hip_last_stage_ms(ctx_, t);
+    ms[0] = t[0];
+    auto sets = to_sets(recs, n_sets, slots);
+    auto filtered = filterGraspsWorkspace(sets, workspace_grasps_);
+    if (filtered.empty()) return hands_out;
+    filtered = filterGraspsDirection(filtered, direction_, thresh_rad_);
+    if (filtered.empty()) return hands_out;
+    hands = pruneGraspCandidates(cloud, filtered, -FLT_MAX);
+    gpd_hip_last_stage_ms(ctx_, t);
+    ms[1] = t[1];
+    ms[2] = t[2];
+  }
+  // 5. select the highest scoring grasps
+  hands = selectGrasps(hands);
+  // 6. cluster the grasps (grasp_detector.cpp:283-303)
+  std::vector<std::unique_ptr<candidate::Hand>> clusters;
+  if (cluster_grasps_) {
+    clusters = clustering_->findClusters(hands);
+    printf("Found %d clusters.\n", (int)clusters.size());
+    if (clusters.size() <= 3) {
+      printf("Not enough clusters found! Adding all grasps from previous step.");
+      for (size_t i = 0; i < hands.size(); i++) clusters.push_back(std::move(hands[i]));
+    }
+  } else {
+    clusters = std::move(hands);
+  }
+  // 7. sort by score
   std::sort(clusters.begin(), clusters.end(), isScoreGreater);
   printf("======== Selected grasps ========\n");
   for (size_t i = 0; i < clusters.size(); i++) std::cout << "Grasp " << i << ": " << clusters[i]->getScore() << "\n";
@@ -596,4 +717,89 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
   return clusters;
 }
 
+
+// ---------------------------------------------------------------------------
+// Clustering::findClusters — clustering.cpp:5-105.  fp64 throughout; the thresholds are the
+// reference's constants (:9-13).  `inliers.push_back(i)` (:62) feeds nothing and is dropped.
+// ---------------------------------------------------------------------------
+std::vector<std::unique_ptr<candidate::Hand>> Clustering::findClusters(const std::vector<std::unique_ptr<candidate::Hand>> &hand_list,
+                                                                        bool remove_inliers) {
+  const double AXIS_ALIGN_ANGLE_THRESH = 12.0 * M_PI / 180.0;
+  const double AXIS_ALIGN_DIST_THRESH = 0.005;
+  const double MAX_DIST_THRESH = 0.05;
+  const double cos_thresh = cos(AXIS_ALIGN_ANGLE_THRESH);
+  const int n = (int)hand_list.size();
+  std::vector<std::unique_ptr<candidate::Hand>> hands_out;
+  std::vector<bool> has_used(remove_inliers ? n : 0, false);
+  for (int i = 0; i < n; i++) {
+    int num_inliers = 0;
+    const std::array<double, 3> ai = hand_list[i]->getAxis(), pi = hand_list[i]->getPosition();
+    double proj[3][3];  // I - a a^T
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) proj[r][c] = (r == c ? 1.0 : 0.0) - ai[r] * ai[c];
+    double position_delta[3] = {0, 0, 0};
+    double mean = 0.0, standard_deviation = 0.0;
+    for (int j = 0; j < n; j++) {
+      if (i == j || (remove_inliers && has_used[j])) continue;
+      const std::array<double, 3> aj = hand_list[j]->getAxis(), pj = hand_list[j]->getPosition();
+      const double axis_aligned = ai[0] * aj[0] + ai[1] * aj[1] + ai[2] * aj[2];
+      const bool axis_aligned_binary = fabs(axis_aligned) > cos_thresh;
+      const double d[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
+      const bool delta_pos_mag_binary = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) <= MAX_DIST_THRESH;
+      double q[3];
+      for (int r = 0; r < 3; r++) q[r] = proj[r][0] * d[0] + proj[r][1] * d[1] + proj[r][2] * d[2];
+      const bool delta_pos_proj_mag_binary = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) <= AXIS_ALIGN_DIST_THRESH;
+      if (axis_aligned_binary && delta_pos_mag_binary && delta_pos_proj_mag_binary) {
+        num_inliers++;
+        for (int r = 0; r < 3; r++) position_delta[r] += pj[r];
+        const double sj = hand_list[j]->getScore();
+        const double old_mean = mean;
+        mean += (sj - mean) / static_cast<double>(num_inliers);
+        standard_deviation += (sj - mean) * (sj - old_mean);
+        if (remove_inliers) has_used[j] = true;
+      }
+    }
+    if (num_inliers >= min_inliers_) {
+      const double dn = static_cast<double>(num_inliers);
+      for (int r = 0; r < 3; r++) position_delta[r] = position_delta[r] / dn - pi[r];
+      standard_deviation /= dn;
+      if (standard_deviation != 0) standard_deviation = sqrt(standard_deviation);
+      const double sqrt_n = sqrt((double)num_inliers);
+      const double conf_lb = mean - 2.576 * standard_deviation / sqrt_n;
+      const double conf_ub = mean + 2.576 * standard_deviation / sqrt_n;
+      printf("grasp %d, inliers: %d, ||position_delta||: %3.4f, ", i, num_inliers,
+             sqrt(position_delta[0] * position_delta[0] + position_delta[1] * position_delta[1] + position_delta[2] * position_delta[2]));
+      printf("mean: %3.4f, STD: %3.4f, conf_int: (%3.4f, %3.4f)\n", mean, standard_deviation, conf_lb, conf_ub);
+      auto hand = std::make_unique<candidate::Hand>(*hand_list[i]);
+      hand->setPosition({pi[0] + position_delta[0], pi[1] + position_delta[1], pi[2] + position_delta[2]});
+      hand->setScore(conf_lb);
+      hand->setFullAntipodal(hand_list[i]->isFullAntipodal());
+      hands_out.push_back(std::move(hand));
+    }
+  }
+  return hands_out;
+}
+
 }  // namespace gpd
+
+// Flat entry for callers without the C++ classes (tests, ctypes): cluster n records with double
+// scores; out / out_scores / out_src (the index of the seeding hand) hold up to n results.
+extern "C" int gpd_host_find_clusters(const gpd_hand *hands, const double *scores, int n, int min_inliers, int remove_inliers,
+                                      gpd_hand *out, double *out_scores, int *out_src) {
+  std::vector<std::unique_ptr<gpd::candidate::Hand>> list;
+  for (int i = 0; i < n; i++) {
+    gpd_hand r = hands[i];
+    r.slot = i;  // carries the source index through the copy
+    list.push_back(std::make_unique<gpd::candidate::Hand>(r));
+    list.back()->setScore(scores[i]);
+  }
+  gpd::Clustering c(min_inliers);
+  auto res = c.findClusters(list, remove_inliers != 0);
+  for (size_t k = 0; k < res.size(); k++) {
+    out[k] = res[k]->record();
+    out_src[k] = out[k].slot;
+    out[k].slot = hands[out_src[k]].slot;
+    out_scores[k] = res[k]->getScore();
+  }
+  return (int)res.size();
+}

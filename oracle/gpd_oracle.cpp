@@ -1372,4 +1372,70 @@ void gpd_oracle_set_num_threads(int n) {
 #endif
 }
 
+
+// Clustering::findClusters — clustering.cpp:5-105 (step 6 of detectGrasps, grasp_detector.cpp:283-303).
+// hands: n records whose frame column 2 is the hand axis and `position` the hand position; scores
+// as doubles (Hand::score_ is a double in the reference).  Output record k is a copy of seed
+// src[k] with position moved to the inliers' mean position and out_scores[k] = lower 99 %
+// confidence bound; returns the number of clusters.
+int gpd_oracle_find_clusters(const gpd_hand *hands, const double *scores, int n, int min_inliers, int remove_inliers, gpd_hand *out,
+                             double *out_scores, int32_t *out_src) {
+  const double AXIS_ALIGN_ANGLE_THRESH = 12.0 * M_PI / 180.0;  // clustering.cpp:9
+  const double AXIS_ALIGN_DIST_THRESH = 0.005;                 // :10
+  const double MAX_DIST_THRESH = 0.05;                         // :12
+  std::vector<char> used(n, 0);
+  int n_out = 0;
+  auto axis = [&](int i, int r) { return hands[i].frame[3 * r + 2]; };
+  for (int i = 0; i < n; i++) {
+    int num_inliers = 0;
+    double pos_sum[3] = {0, 0, 0};
+    double outer[9];  // axis * axis^T (:29-30)
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) outer[3 * r + c] = axis(i, r) * axis(i, c);
+    double mean = 0.0, sd = 0.0;
+    for (int j = 0; j < n; j++) {
+      if (i == j || (remove_inliers && used[j])) continue;
+      double dot = 0.0;  // :39-42
+      for (int r = 0; r < 3; r++) dot += axis(i, r) * axis(j, r);
+      const bool aligned = std::fabs(dot) > std::cos(AXIS_ALIGN_ANGLE_THRESH);
+      double delta[3], mag2 = 0.0;  // :45-48
+      for (int r = 0; r < 3; r++) {
+        delta[r] = hands[i].position[r] - hands[j].position[r];
+        mag2 += delta[r] * delta[r];
+      }
+      const bool near = std::sqrt(mag2) <= MAX_DIST_THRESH;
+      double pm2 = 0.0;  // :53-58: (I - a a^T) * delta
+      for (int r = 0; r < 3; r++) {
+        double v = 0.0;
+        for (int c = 0; c < 3; c++) v += ((r == c ? 1.0 : 0.0) - outer[3 * r + c]) * delta[c];
+        pm2 += v * v;
+      }
+      const bool on_axis = std::sqrt(pm2) <= AXIS_ALIGN_DIST_THRESH;
+      if (aligned && near && on_axis) {  // :60-76
+        num_inliers++;
+        for (int r = 0; r < 3; r++) pos_sum[r] += hands[j].position[r];
+        const double old_mean = mean;
+        mean += (scores[j] - mean) / (double)num_inliers;
+        sd += (scores[j] - mean) * (scores[j] - old_mean);
+        if (remove_inliers) used[j] = 1;
+      }
+    }
+    if (num_inliers >= min_inliers) {  // :79-101
+      const double dn = (double)num_inliers;
+      double pd[3];
+      for (int r = 0; r < 3; r++) pd[r] = pos_sum[r] / dn - hands[i].position[r];
+      sd /= dn;
+      if (sd != 0) sd = std::sqrt(sd);
+      const double conf_lb = mean - 2.576 * sd / std::sqrt((double)num_inliers);
+      out[n_out] = hands[i];
+      for (int r = 0; r < 3; r++) out[n_out].position[r] = hands[i].position[r] + pd[r];
+      out[n_out].score = (float)conf_lb;
+      out_scores[n_out] = conf_lb;
+      out_src[n_out] = i;
+      n_out++;
+    }
+  }
+  return n_out;
+}
+
 }  // extern "C"

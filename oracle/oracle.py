@@ -215,3 +215,15 @@ def estimate_normals(xyz, cam_source=None, view_points=None, radius=0.03):
     out = np.zeros((P, 3), np.float32)
     lib().gpd_oracle_normals(_p(xyz), P, _p(cam), cam.shape[0], _p(vp), C.c_double(radius), _p(out))
     return out
+
+
+def find_clusters(hands, scores, min_inliers=1, remove_inliers=False):
+    """Clustering::findClusters -> (cluster records, double scores, seed index)."""
+    hands = np.ascontiguousarray(hands).reshape(-1)
+    scores = np.ascontiguousarray(scores, np.float64)
+    n = len(hands)
+    out = np.zeros(max(n, 1), hands.dtype)
+    osc = np.zeros(max(n, 1), np.float64)
+    src = np.zeros(max(n, 1), np.int32)
+    k = lib().gpd_oracle_find_clusters(_p(hands), _p(scores), n, int(min_inliers), int(bool(remove_inliers)), _p(out), _p(osc), _p(src))
+    return out[:k].copy(), osc[:k].copy(), src[:k].copy()

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "gpd_amd", "host", "detect_grasps")
 
 
-def _write_case(tmp, cl, w, num_samples, num_selected, channels=15):
+def _write_case(tmp, cl, w, num_samples, num_selected, channels=15, min_inliers=0, extra=""):
     params = tmp / "params"
     params.mkdir()
     names = dict(c1w="conv1_weights", c1b="conv1_biases", c2w="conv2_weights", c2b="conv2_biases", f1w="ip1_weights",
@@ -28,7 +28,8 @@ def _write_case(tmp, cl, w, num_samples, num_selected, channels=15):
                    "weights_file = params/\ndevice = 1\ncamera_position = 0 0 0\n"
                    "num_samples = %d\nnum_threads = 4\nnn_radius = 0.01\nnum_orientations = 8\nnum_finger_placements = 10\n"
                    "hand_axes = 2\ndeepen_hand = 1\nfriction_coeff = 20\nmin_viable = 6\nmin_aperture = 0.0\nmax_aperture = 0.085\n"
-                   "workspace_grasps = -1 1 -1 1 -1 1\nmin_inliers = 0\nnum_selected = %d\nplot_normals = 0\n" % (num_samples, num_selected))
+                   "workspace_grasps = -1 1 -1 1 -1 1\nmin_inliers = %d\nnum_selected = %d\nplot_normals = 0\n%s"
+                   % (num_samples, min_inliers, num_selected, extra))
     pcd = tmp / "cloud.pcd"
     P = len(cl["xyz"])
     with open(str(pcd), "w") as f:
@@ -89,6 +90,44 @@ def test_detect_grasps_cli_matches_oracle(tmp_path, oracle_mod, lenet15_real):
     gp = np.array([[float(x) for x in g[2:5]] for g in got])
     assert np.allclose(gp, want["position"], rtol=1e-12, atol=1e-15)
     assert [int(g[6]) for g in got] == want["finger_placement_index"].tolist()
+
+
+@pytest.mark.gpu
+def test_cli_direction_filter_and_clustering(tmp_path, oracle_mod, lenet15_real):
+    """detectGrasps with filter_approach_direction = 1 and min_inliers = 1 (grasp_detector.cpp:247-255,
+    283-303): search -> workspace filter -> direction filter -> images -> scores -> top-k -> clusters."""
+    cl = synth.make_cloud(99, 12000)
+    direction, thresh, k = np.array([0.0, 0.0, -1.0]), 1.2, 120
+    cfg, pcd = _write_case(tmp_path, cl, lenet15_real, 300, k, min_inliers=1,
+                           extra="filter_approach_direction = 1\ndirection = 0 0 -1\nthresh_rad = %g\n" % thresh)
+    out = subprocess.run([CLI, str(cfg), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    got = [l.split() for l in out.stdout.splitlines() if l.startswith("GRASP ")]
+    si = _subsample_indices(len(cl["xyz"]), 300)
+    p = oracle_mod.default_params(15)
+    hands = oracle_mod.filter_workspace(p, oracle_mod.search(p, cl["xyz"], cl["normals"], si))
+    app = hands["frame"].reshape(hands.shape + (3, 3))[..., :, 0]
+    with np.errstate(invalid="ignore"):
+        ang = np.arccos(app @ direction)  # |dot| a hair above 1 -> NaN -> `angle > thresh` is false: kept, as in the reference
+    n_before = int(hands["valid"].sum())
+    hands["valid"] &= (~(ang > thresh)).astype(np.uint8)
+    assert 0 < hands["valid"].sum() < n_before           # the filter removed some, not all
+    lines = [l for l in out.stdout.splitlines() if l.startswith("Number of grasp candidates")]
+    assert ("Number of grasp candidates with correct approach direction: %d" % hands["valid"].sum()) in lines, lines
+    img, cand = oracle_mod.images(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], hands)
+    sc = oracle_mod.lenet(img, lenet15_real)
+    flat = hands.reshape(-1)[cand]
+    order = np.argsort(-sc, kind="stable")[:k]
+    sel, ssc = flat[order], sc[order].astype(np.float64)
+    clusters, csc, _ = oracle_mod.find_clusters(sel, ssc, 1, False)
+    assert len(clusters) > 3
+    o2 = np.argsort(-csc, kind="stable")
+    clusters, csc = clusters[o2], csc[o2]
+    assert len(got) == len(clusters)
+    gs = np.array([float(g[1]) for g in got])
+    assert np.abs(gs - csc).max() <= 2e-4                 # bound of up to 120 float scores within 1e-4 each
+    gp = np.array([[float(x) for x in g[2:5]] for g in got])
+    assert np.allclose(gp, clusters["position"], rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.gpu
