@@ -41,7 +41,8 @@ class GpdHipError(RuntimeError):
 
 EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
-           "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals"]
+           "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
+           "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate"]
 
 
 def build():
@@ -64,6 +65,9 @@ def lib():
         L.gpd_hip_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.gpd_hip_upload_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.gpd_hip_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.gpd_hip_search_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.gpd_hip_detect_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.gpd_hip_reevaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.gpd_hip_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.gpd_hip_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
@@ -141,6 +145,28 @@ class Context:
         ns = C.c_int(0)
         self._check(lib().gpd_hip_search(self._h, _ptr(si), len(si), _ptr(hands), C.byref(ns)))
         return hands[: ns.value].copy()
+
+    def search_samples(self, samples_xyz):
+        """generateGraspCandidateSets for samples given by coordinates (f64 [S,3])."""
+        sm = np.ascontiguousarray(samples_xyz, np.float64).reshape(-1, 3)
+        hands = np.zeros((len(sm), self.n_slots), HAND_DTYPE)
+        ns = C.c_int(0)
+        self._check(lib().gpd_hip_search_samples(self._h, _ptr(sm), len(sm), _ptr(hands), C.byref(ns)))
+        return hands[: ns.value].copy()
+
+    def detect_samples(self, samples_xyz):
+        sm = np.ascontiguousarray(samples_xyz, np.float64).reshape(-1, 3)
+        hands = np.zeros((len(sm), self.n_slots), HAND_DTYPE)
+        ns, nc = C.c_int(0), C.c_int(0)
+        self._check(lib().gpd_hip_detect_samples(self._h, _ptr(sm), len(sm), _ptr(hands), C.byref(ns), C.byref(nc)))
+        return hands[: ns.value].copy(), nc.value
+
+    def reevaluate(self, hands):
+        """HandSearch::reevaluateHypotheses on the uploaded cloud -> (labels int32 [n], rewritten hands [n])."""
+        h = np.ascontiguousarray(hands, HAND_DTYPE).reshape(-1).copy()
+        labels = np.zeros(len(h), np.int32)
+        self._check(lib().gpd_hip_reevaluate(self._h, _ptr(h), len(h), _ptr(labels)))
+        return labels, h
 
     def images(self, hands, download=True):
         """ImageGenerator::createImages -> (images[n,60,60,C] or None, cand_index[n])."""

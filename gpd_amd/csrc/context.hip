@@ -4,6 +4,8 @@
 #include <cstring>
 #include <vector>
 
+#include <cmath>
+
 #include "gpd_internal.h"
 
 namespace gpd {
@@ -267,31 +269,77 @@ int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals) {
   return normals_run(ctx->cloud, radius, normals, ctx->stream);
 }
 
-int gpd_hip_search(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, gpd_hand *hands, int *num_sets) {
-  if (!ctx || !sample_indices || num_samples < 0 || !hands || !num_sets) {
-    set_error("gpd_hip_search: bad argument");
+// samples by index (sample_xyz == nullptr) or by coordinates (sample_indices == nullptr)
+static int search_any(gpd_hip_ctx *ctx, const char *who, const int32_t *sample_indices, const double *sample_xyz, int num_samples,
+                      gpd_hand *hands, int *num_sets) {
+  if (!ctx || (!sample_indices && !sample_xyz) || num_samples < 0 || !hands || !num_sets) {
+    set_error("%s: bad argument", who);
     return GPD_ERR_INVALID;
   }
   if (!ctx->cloud.num_points) {
-    set_error("gpd_hip_search: no cloud uploaded");
+    set_error("%s: no cloud uploaded", who);
     return GPD_ERR_STATE;
   }
   *num_sets = 0;
   if (num_samples == 0) return GPD_OK;
-  for (int i = 0; i < num_samples; i++)
-    if (sample_indices[i] < 0 || sample_indices[i] >= ctx->cloud.num_points) {
-      set_error("gpd_hip_search: sample index %d out of range", sample_indices[i]);
-      return GPD_ERR_INVALID;
-    }
+  if (sample_indices) {
+    for (int i = 0; i < num_samples; i++)
+      if (sample_indices[i] < 0 || sample_indices[i] >= ctx->cloud.num_points) {
+        set_error("%s: sample index %d out of range", who, sample_indices[i]);
+        return GPD_ERR_INVALID;
+      }
+  } else {
+    for (int i = 0; i < 3 * num_samples; i++)
+      if (!std::isfinite(sample_xyz[i])) {
+        set_error("%s: sample %d is not finite", who, i / 3);
+        return GPD_ERR_INVALID;
+      }
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-  int rc = search_run(ctx->params, ctx->cloud, ctx->search, sample_indices, num_samples, ctx->stream);
+  int rc = search_run(ctx->params, ctx->cloud, ctx->search, sample_indices, sample_xyz, num_samples, ctx->stream);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
   rc = search_download(ctx->params, ctx->search, hands, num_sets, ctx->stream);
   if (rc) return rc;
   HIP_TRY(hipEventElapsedTime(&ctx->stage_ms[0], ctx->ev[0], ctx->ev[1]));
   return GPD_OK;
+}
+
+int gpd_hip_search(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, gpd_hand *hands, int *num_sets) {
+  if (!sample_indices) {
+    set_error("gpd_hip_search: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  return search_any(ctx, "gpd_hip_search", sample_indices, nullptr, num_samples, hands, num_sets);
+}
+
+int gpd_hip_search_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples, gpd_hand *hands, int *num_sets) {
+  if (!samples_xyz) {
+    set_error("gpd_hip_search_samples: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  return search_any(ctx, "gpd_hip_search_samples", nullptr, samples_xyz, num_samples, hands, num_sets);
+}
+
+int gpd_hip_reevaluate(gpd_hip_ctx *ctx, gpd_hand *hands, int num_hands, int32_t *labels) {
+  if (!ctx || num_hands < 0 || (num_hands > 0 && (!hands || !labels))) {
+    set_error("gpd_hip_reevaluate: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  if (!ctx->cloud.num_points) {
+    set_error("gpd_hip_reevaluate: no cloud uploaded");
+    return GPD_ERR_STATE;
+  }
+  if (num_hands == 0) return GPD_OK;
+  for (int i = 0; i < num_hands; i++)
+    for (int r = 0; r < 3; r++)
+      if (!std::isfinite(hands[i].sample[r])) {
+        set_error("gpd_hip_reevaluate: hand %d has a non-finite sample", i);
+        return GPD_ERR_INVALID;
+      }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return reevaluate_run(ctx->params, ctx->cloud, ctx->search, hands, num_hands, labels, ctx->stream);
 }
 
 int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets, uint8_t *images, int32_t *cand_index,
@@ -325,9 +373,9 @@ int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets, uint8_
   return GPD_OK;
 }
 
-int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, gpd_hand *hands, int *num_sets,
-                   int *num_candidates) {
-  if (!ctx || !hands || !num_sets || !num_candidates) {
+static int detect_any(gpd_hip_ctx *ctx, const int32_t *sample_indices, const double *sample_xyz, int num_samples, gpd_hand *hands,
+                      int *num_sets, int *num_candidates) {
+  if (!ctx || !hands || !num_sets || !num_candidates || (!sample_indices && !sample_xyz)) {
     set_error("gpd_hip_detect: bad argument");
     return GPD_ERR_INVALID;
   }
@@ -336,7 +384,7 @@ int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samp
     return GPD_ERR_STATE;
   }
   *num_candidates = 0;
-  int rc = gpd_hip_search(ctx, sample_indices, num_samples, hands, num_sets);
+  int rc = search_any(ctx, "gpd_hip_detect", sample_indices, sample_xyz, num_samples, hands, num_sets);
   if (rc) return rc;
   if (*num_sets == 0) return GPD_OK;
   filter_workspace_host(ctx->params, hands, *num_sets);
@@ -349,6 +397,24 @@ int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samp
   if (rc) return rc;
   for (int i = 0; i < *num_candidates; i++) hands[cand[i]].score = scores[i];
   return GPD_OK;
+}
+
+int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, gpd_hand *hands, int *num_sets,
+                   int *num_candidates) {
+  if (!sample_indices) {
+    set_error("gpd_hip_detect: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  return detect_any(ctx, sample_indices, nullptr, num_samples, hands, num_sets, num_candidates);
+}
+
+int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples, gpd_hand *hands, int *num_sets,
+                           int *num_candidates) {
+  if (!samples_xyz) {
+    set_error("gpd_hip_detect_samples: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  return detect_any(ctx, nullptr, samples_xyz, num_samples, hands, num_sets, num_candidates);
 }
 
 int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {

@@ -94,6 +94,7 @@ struct SearchState {
   int nn_cap = 0;                     // entries per neighbourhood list (8192 or 16384)
   uint64_t cloud_generation = 0;
   int32_t *d_sample_idx = nullptr;    // [S]
+  double *d_sample_xyz = nullptr;     // [S][3] samples given by coordinates (used instead of the indices)
   int32_t *d_counts = nullptr;        // [S][8]: N_hands, N_images, k_frames, total found, seen by camera 0
   int32_t *d_nn_idx = nullptr;        // [S][nn_cap] sorted by (d2, index)
   float *d_nn = nullptr;              // [S][6][nn_cap] gathered px,py,pz,nx,ny,nz in that order
@@ -104,7 +105,11 @@ struct SearchState {
   std::vector<int32_t> h_set_sample;  // set -> sample slot
   std::vector<double> h_samples;      // [S][3] sample coordinates (to validate hands passed to images)
 };
-int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, int S, hipStream_t stream);
+// samples by index (sample_xyz == nullptr) or by coordinates (sample_idx == nullptr)
+int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, const double *sample_xyz, int S,
+               hipStream_t stream);
+// HandSearch::reevaluateHypotheses on the uploaded cloud; invalidates the search state
+int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand *hands, int n, int32_t *labels, hipStream_t stream);
 int search_download(const gpd_params &p, SearchState &s, gpd_hand *hands, int *num_sets, hipStream_t stream);
 void search_free(SearchState &s);
 

@@ -356,6 +356,7 @@ struct NbParams {
   const float *px, *py, *pz, *nx, *ny, *nz;
   int num_points;
   const int32_t *sample_idx;
+  const double *sample_xyz;  // non-null: samples by coordinates; the query is their float cast (eigenVectorToPcl)
   float r2_hands, r2_images, r2_frames;
   int cap;  // power of two
   int32_t *counts;  // [S][8]: N_hands, N_images, k_frames, found, mask of cameras that see the image neighbourhood, -, -, -
@@ -378,8 +379,24 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int sidx = P.sample_idx[s];
-  const float qx = P.px[sidx], qy = P.py[sidx], qz = P.pz[sidx];
+  float qx, qy, qz;
+  double sx, sy, sz;  // the sample the hand frame keeps (frame_estimator.cpp:20-22, 53-54)
+  if (P.sample_xyz) {
+    sx = P.sample_xyz[3 * (size_t)s + 0];
+    sy = P.sample_xyz[3 * (size_t)s + 1];
+    sz = P.sample_xyz[3 * (size_t)s + 2];
+    qx = (float)sx;
+    qy = (float)sy;
+    qz = (float)sz;
+  } else {
+    const int sidx = P.sample_idx[s];
+    qx = P.px[sidx];
+    qy = P.py[sidx];
+    qz = P.pz[sidx];
+    sx = (double)qx;
+    sy = (double)qy;
+    sz = (double)qz;
+  }
   if (tid == 0) {
     s_count = 0;
     s_bounds[0] = 0;
@@ -488,9 +505,9 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     P.counts[8 * s + 2] = kf;
     P.counts[8 * s + 3] = found;
     double *f = P.frames + 12 * (size_t)s;
-    f[0] = (double)qx;
-    f[1] = (double)qy;
-    f[2] = (double)qz;
+    f[0] = sx;
+    f[1] = sy;
+    f[2] = sz;
     if (kf > 0) {
       double m00 = 0, m10 = 0, m11 = 0, m20 = 0, m21 = 0, m22 = 0, a0 = 0, a1 = 0, a2 = 0;
       for (int t = 0; t < kf; t++) {
@@ -745,6 +762,7 @@ struct HandParams {
   const double *frames;
   int cap;
   gpd_hand *hands;
+  int32_t *labels;  // reeval_kernel only: [n][8] rows of the counts table, column 5
 };
 
 __device__ inline void mat3mul(const double *a, const double *b, double *c) {
@@ -819,6 +837,148 @@ __device__ inline bool list_entry(const ListCtx &L, int e, double t[3], double t
 }
 
 __constant__ HandConsts c_hand;
+
+// computePointsInClosingRegion (finger_hand.cpp:141-171) + grasp width (hand_set.cpp:235-245) +
+// Antipodal::evaluateGrasp (antipodal.cpp:10-96; lateral 1, forward 0, vertical 2) over the list of
+// L.  Returns false when the closing region is empty; label 0 none, 1 half, 2 full.
+__device__ bool closing_region_label(const ListCtx &L, int N, double top, double bottom, double left, double right, const HandConsts &K,
+                                     double &width, int &label, unsigned *s_u, double *s_d, long long *s_l) {
+  const int tid = threadIdx.x;
+  double ymin = DBL_MAX, ymax = -DBL_MAX;
+  unsigned any_c = 0;
+  for (int e = tid; e <= N; e += 256) {
+    double t[3], tn[3];
+    int mult;
+    if (!list_entry(L, e, t, tn, mult)) continue;
+    if (t[0] > bottom && t[0] < top && t[1] > left && t[1] < right) {
+      any_c = 1;
+      ymin = fmin(ymin, t[1]);
+      ymax = fmax(ymax, t[1]);
+    }
+  }
+  any_c = block_or(any_c, s_u);
+  label = 0;
+  width = 0.0;
+  if (!any_c) return false;
+  ymin = block_min(ymin, s_d);
+  ymax = block_max(ymax, s_d);
+  width = ymax - ymin;
+  const double min_x = ymin + 0.003, max_x = ymax - 0.003;
+  double lx0 = DBL_MAX, lx1 = -DBL_MAX, lz0 = DBL_MAX, lz1 = -DBL_MAX;
+  double rx0 = DBL_MAX, rx1 = -DBL_MAX, rz0 = DBL_MAX, rz1 = -DBL_MAX;
+  unsigned lr = 0;
+  for (int e = tid; e <= N; e += 256) {
+    double t[3], tn[3];
+    int mult;
+    if (!list_entry(L, e, t, tn, mult)) continue;
+    if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
+    const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
+    const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
+    if (ln > K.cos_friction && t[1] < min_x) {
+      lr |= 1u;
+      lx0 = fmin(lx0, t[0]);
+      lx1 = fmax(lx1, t[0]);
+      lz0 = fmin(lz0, t[2]);
+      lz1 = fmax(lz1, t[2]);
+    }
+    if (rn > K.cos_friction && t[1] > max_x) {
+      lr |= 2u;
+      rx0 = fmin(rx0, t[0]);
+      rx1 = fmax(rx1, t[0]);
+      rz0 = fmin(rz0, t[2]);
+      rz1 = fmax(rz1, t[2]);
+    }
+  }
+  lr = block_or(lr, s_u);
+  if (lr) label = 1;
+  if (lr == 3u) {
+    lx0 = block_min(lx0, s_d);
+    lx1 = block_max(lx1, s_d);
+    lz0 = block_min(lz0, s_d);
+    lz1 = block_max(lz1, s_d);
+    rx0 = block_min(rx0, s_d);
+    rx1 = block_max(rx1, s_d);
+    rz0 = block_min(rz0, s_d);
+    rz1 = block_max(rz1, s_d);
+    const double top_y = fmin(lx1, rx1), bot_y = fmax(lx0, rx0);
+    const double top_z = fmin(lz1, rz1), bot_z = fmax(lz0, rz0);
+    long long nl = 0, nr = 0;
+    for (int e = tid; e <= N; e += 256) {
+      double t[3], tn[3];
+      int mult;
+      if (!list_entry(L, e, t, tn, mult)) continue;
+      if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
+      const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
+      const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
+      const bool inb = t[0] >= bot_y && t[0] <= top_y && t[2] >= bot_z && t[2] <= top_z;
+      if (ln > K.cos_friction && t[1] < min_x && inb) nl += mult;
+      if (rn > K.cos_friction && t[1] > max_x && inb) nr += mult;
+    }
+    nl = block_sum(nl, s_l);
+    nr = block_sum(nr, s_l);
+    if (nl >= K.min_viable && nr >= K.min_viable) label = 2;
+  }
+  return true;
+}
+
+// HandSearch::reevaluateHypotheses (hand_search.cpp:66-134, 190-228): one
+// workgroup per hand checks it again against the uploaded (ground-truth) cloud with the hand's own
+// frame, depth and finger placement: evaluateFingers(points, top, idx), evaluateHand(idx), closing
+// region, antipodal label.  counts[8*i+5] receives the label (1 = full antipodal grasp).
+__global__ __launch_bounds__(256) void reeval_kernel(HandParams P) {
+  __shared__ unsigned s_u[4];
+  __shared__ double s_d[4];
+  __shared__ long long s_l[4];
+  const HandConsts &K = c_hand;
+  const int s = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int N = P.counts[8 * s + 0];
+  gpd_hand *H = P.hands + s;
+  const int idx = H->finger_placement_index;
+  int label = 0;
+  if (N > 0 && idx >= 0 && idx < K.nfp) {
+    ListCtx L;
+    L.nn = P.nn + (size_t)s * 6 * P.cap;
+    L.cap = P.cap;
+    L.N = N;
+    L.hand_height = K.hand_height;
+#pragma unroll
+    for (int r = 0; r < 3; r++) L.sample[r] = H->sample[r];
+#pragma unroll
+    for (int i = 0; i < 9; i++) L.FR[i] = H->frame[i];
+    L.ghost_mult = 0;
+    long long kin = 0;
+    for (int e = tid; e < N; e += 256) {
+      double t[3], tn[3];
+      int mult;
+      if (list_entry(L, e, t, tn, mult)) kin++;
+    }
+    L.ghost_mult = N - (int)block_sum(kin, s_l);
+    const double top = H->top, bottom = top - K.hand_depth;
+    const double sl = K.spacing[idx], sr = K.spacing[K.nfp + idx];
+    unsigned flags = 0;  // bit0 some x<top, bit1 some x<bottom, bit2 a finger of the pair is blocked
+    for (int e = tid; e <= N; e += 256) {
+      double t[3], tn[3];
+      int mult;
+      if (!list_entry(L, e, t, tn, mult)) continue;
+      if (t[0] < top) {
+        flags |= 1u;
+        if (t[0] < bottom) flags |= 2u;
+        if ((t[1] > sl && t[1] < sl + K.fw) || (t[1] > sr && t[1] < sr + K.fw)) flags |= 4u;
+      }
+    }
+    flags = block_or(flags, s_u);
+    if (flags == 1u) {
+      double width;
+      closing_region_label(L, N, top, bottom, sl + K.fw, sr, K, width, label, s_u, s_d, s_l);
+    }
+  }
+  if (tid == 0) {
+    H->half_antipodal = label == 1;
+    H->full_antipodal = label == 2;
+    P.labels[8 * s + 5] = label == 2 ? 1 : 0;
+  }
+}
 
 __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   __shared__ unsigned s_u[4];
@@ -937,86 +1097,14 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
       }
       hand = 1u << mid;
     }
-    // ---- pass 3: computePointsInClosingRegion (finger_hand.cpp:141-171)
+    // ---- pass 3-5: closing region, width, antipodal label
     const double left = K.spacing[mid] + K.fw;
     const double right = K.spacing[nfp + mid];
     const double center_c = 0.5 * (left + right);
-    double ymin = DBL_MAX, ymax = -DBL_MAX;
-    unsigned any_c = 0;
-    for (int e = tid; e <= N; e += 256) {
-      double t[3], tn[3];
-      int mult;
-      if (!list_entry(L, e, t, tn, mult)) continue;
-      if (t[0] > bottom && t[0] < top && t[1] > left && t[1] < right) {
-        any_c = 1;
-        ymin = fmin(ymin, t[1]);
-        ymax = fmax(ymax, t[1]);
-      }
-    }
-    any_c = block_or(any_c, s_u);
-    if (any_c) {
+    if (closing_region_label(L, N, top, bottom, left, right, K, width, label, s_u, s_d, s_l)) {
       valid = true;
       center = center_c;
       fidx = __ffs(hand) - 1;
-      ymin = block_min(ymin, s_d);
-      ymax = block_max(ymax, s_d);
-      width = ymax - ymin;
-      // ---- pass 4+5: Antipodal::evaluateGrasp (antipodal.cpp:10-96), lateral 1, forward 0, vertical 2
-      const double min_x = ymin + 0.003, max_x = ymax - 0.003;
-      double lx0 = DBL_MAX, lx1 = -DBL_MAX, lz0 = DBL_MAX, lz1 = -DBL_MAX;
-      double rx0 = DBL_MAX, rx1 = -DBL_MAX, rz0 = DBL_MAX, rz1 = -DBL_MAX;
-      unsigned lr = 0;
-      for (int e = tid; e <= N; e += 256) {
-        double t[3], tn[3];
-        int mult;
-        if (!list_entry(L, e, t, tn, mult)) continue;
-        if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
-        const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
-        const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
-        if (ln > K.cos_friction && t[1] < min_x) {
-          lr |= 1u;
-          lx0 = fmin(lx0, t[0]);
-          lx1 = fmax(lx1, t[0]);
-          lz0 = fmin(lz0, t[2]);
-          lz1 = fmax(lz1, t[2]);
-        }
-        if (rn > K.cos_friction && t[1] > max_x) {
-          lr |= 2u;
-          rx0 = fmin(rx0, t[0]);
-          rx1 = fmax(rx1, t[0]);
-          rz0 = fmin(rz0, t[2]);
-          rz1 = fmax(rz1, t[2]);
-        }
-      }
-      lr = block_or(lr, s_u);
-      if (lr) label = 1;
-      if (lr == 3u) {
-        lx0 = block_min(lx0, s_d);
-        lx1 = block_max(lx1, s_d);
-        lz0 = block_min(lz0, s_d);
-        lz1 = block_max(lz1, s_d);
-        rx0 = block_min(rx0, s_d);
-        rx1 = block_max(rx1, s_d);
-        rz0 = block_min(rz0, s_d);
-        rz1 = block_max(rz1, s_d);
-        const double top_y = fmin(lx1, rx1), bot_y = fmax(lx0, rx0);
-        const double top_z = fmin(lz1, rz1), bot_z = fmax(lz0, rz0);
-        long long nl = 0, nr = 0;
-        for (int e = tid; e <= N; e += 256) {
-          double t[3], tn[3];
-          int mult;
-          if (!list_entry(L, e, t, tn, mult)) continue;
-          if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
-          const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
-          const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
-          const bool inb = t[0] >= bot_y && t[0] <= top_y && t[2] >= bot_z && t[2] <= top_z;
-          if (ln > K.cos_friction && t[1] < min_x && inb) nl += mult;
-          if (rn > K.cos_friction && t[1] > max_x && inb) nr += mult;
-        }
-        nl = block_sum(nl, s_l);
-        nr = block_sum(nr, s_l);
-        if (nl >= K.min_viable && nr >= K.min_viable) label = 2;
-      }
     } else {
       // closing region empty: the hand keeps what Hand() saw before deepening (hand_set.cpp:89-109)
       top = bite;
@@ -1053,7 +1141,7 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
 // Host side
 // ---------------------------------------------------------------------------
 void search_free(SearchState &s) {
-  void *ptrs[] = {s.d_sample_idx, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands};
+  void *ptrs[] = {s.d_sample_idx, s.d_sample_xyz, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   s = SearchState();
@@ -1064,6 +1152,7 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
   const int newS = S > s.capacity_samples ? S : s.capacity_samples;
   search_free(s);
   HIP_RET(hipMalloc(&s.d_sample_idx, (size_t)newS * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&s.d_sample_xyz, (size_t)newS * 3 * sizeof(double)));
   HIP_RET(hipMalloc(&s.d_counts, (size_t)newS * 8 * sizeof(int32_t)));
   HIP_RET(hipMalloc(&s.d_nn_idx, (size_t)newS * cap * sizeof(int32_t)));
   HIP_RET(hipMalloc(&s.d_nn, (size_t)newS * 6 * cap * sizeof(float)));
@@ -1075,12 +1164,13 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
   return GPD_OK;
 }
 
-static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, int S, int cap,
+static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, int S, int cap, bool by_xyz,
                               hipStream_t stream) {
   NbParams np;
   np.px = c.px; np.py = c.py; np.pz = c.pz; np.nx = c.nx; np.ny = c.ny; np.nz = c.nz;
   np.num_points = c.num_points;
   np.sample_idx = s.d_sample_idx;
+  np.sample_xyz = by_xyz ? s.d_sample_xyz : nullptr;
   // pcl::KdTreeFLANN::radiusSearch passes (float)(radius*radius) to FLANN
   np.r2_hands = (float)(hc.nn_radius_hands * hc.nn_radius_hands);
   np.r2_images = (float)(hc.nn_radius_images * hc.nn_radius_images);
@@ -1106,20 +1196,18 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   return GPD_OK;
 }
 
-int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, int S, hipStream_t stream) {
-  const int slots = p.num_hand_axes * p.num_orientations;
-  HostConsts hc;
-  host_consts(p, hc);
-  if (hc.nn_radius_images > hc.nn_radius_hands || p.nn_radius_frames > hc.nn_radius_hands) {
-    set_error("search: image/frame radius larger than the hand-search radius is not supported");
-    return GPD_ERR_INVALID;
-  }
+// neighbourhoods of S samples (by index or by coordinates), list capacity grown once if needed
+static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, const int32_t *sample_idx,
+                          const double *sample_xyz, int S, int slots, int *cap_out, hipStream_t stream) {
   int cap = s.nn_cap ? s.nn_cap : 8192;
   int rc = search_reserve(s, S, cap, slots);
   if (rc) return rc;
-  HIP_RET(hipMemcpyAsync(s.d_sample_idx, sample_idx, (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   for (;;) {
-    rc = run_neighbourhoods(p, c, s, hc, S, cap, stream);
+    if (sample_xyz)
+      HIP_RET(hipMemcpyAsync(s.d_sample_xyz, sample_xyz, (size_t)S * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+    else
+      HIP_RET(hipMemcpyAsync(s.d_sample_idx, sample_idx, (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    rc = run_neighbourhoods(p, c, s, hc, S, cap, sample_xyz != nullptr, stream);
     if (rc) return rc;
     int worst = 0;
     for (int i = 0; i < S; i++) worst = s.h_counts[8 * i + 3] > worst ? s.h_counts[8 * i + 3] : worst;
@@ -1131,8 +1219,12 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
     cap = 16384;  // 128 KB of LDS per workgroup
     rc = search_reserve(s, S, cap, slots);
     if (rc) return rc;
-    HIP_RET(hipMemcpyAsync(s.d_sample_idx, sample_idx, (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   }
+  *cap_out = cap;
+  return GPD_OK;
+}
+
+static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slots, hipStream_t stream) {
   HandConsts hk;
   std::memset(&hk, 0, sizeof(hk));
   std::memcpy(hk.rot, hc.rot, sizeof(hk.rot));
@@ -1150,16 +1242,66 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   hk.hand_height = p.hand_height;
   hk.init_bite = p.init_bite;
   HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_hand), &hk, sizeof(hk), 0, hipMemcpyHostToDevice, stream));
+  return GPD_OK;
+}
+
+int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, const double *sample_xyz, int S,
+               hipStream_t stream) {
+  const int slots = p.num_hand_axes * p.num_orientations;
+  HostConsts hc;
+  host_consts(p, hc);
+  if (hc.nn_radius_images > hc.nn_radius_hands || p.nn_radius_frames > hc.nn_radius_hands) {
+    set_error("search: image/frame radius larger than the hand-search radius is not supported");
+    return GPD_ERR_INVALID;
+  }
+  int cap = 0;
+  int rc = neighbourhoods(p, c, s, hc, sample_idx, sample_xyz, S, slots, &cap, stream);
+  if (rc) return rc;
+  rc = upload_hand_consts(p, hc, slots, stream);
+  if (rc) return rc;
   HandParams hp;
   hp.counts = s.d_counts;
   hp.nn = s.d_nn;
   hp.frames = s.d_frames;
   hp.cap = cap;
   hp.hands = s.d_hands;
+  hp.labels = nullptr;
   hand_eval_kernel<<<S * slots, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
   s.num_samples = S;
   s.cloud_generation = c.generation;
+  return GPD_OK;
+}
+
+int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand *hands, int n, int32_t *labels, hipStream_t stream) {
+  const int slots = p.num_hand_axes * p.num_orientations;
+  HostConsts hc;
+  host_consts(p, hc);
+  s.num_samples = 0;  // the buffers are reused: hands of an earlier search can no longer be imaged
+  s.h_set_sample.clear();
+  s.h_samples.clear();
+  std::vector<double> xyz((size_t)n * 3);
+  for (int i = 0; i < n; i++)
+    for (int r = 0; r < 3; r++) xyz[3 * (size_t)i + r] = hands[i].sample[r];
+  int cap = 0;
+  int rc = neighbourhoods(p, c, s, hc, nullptr, xyz.data(), n, slots, &cap, stream);
+  if (rc) return rc;
+  rc = upload_hand_consts(p, hc, slots, stream);
+  if (rc) return rc;
+  HIP_RET(hipMemcpyAsync(s.d_hands, hands, (size_t)n * sizeof(gpd_hand), hipMemcpyHostToDevice, stream));
+  HandParams hp;
+  hp.counts = s.d_counts;
+  hp.nn = s.d_nn;
+  hp.frames = s.d_frames;
+  hp.cap = cap;
+  hp.hands = s.d_hands;
+  hp.labels = s.d_counts;
+  reeval_kernel<<<n, 256, 0, stream>>>(hp);
+  HIP_RET(hipGetLastError());
+  HIP_RET(hipMemcpyAsync(hands, s.d_hands, (size_t)n * sizeof(gpd_hand), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipMemcpyAsync(s.h_counts.data(), s.d_counts, (size_t)n * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipStreamSynchronize(stream));
+  for (int i = 0; i < n; i++) labels[i] = s.h_counts[8 * (size_t)i + 5];
   return GPD_OK;
 }
 

@@ -35,6 +35,9 @@ class GraspDetector {
   // hands with score > min_score.
   std::vector<std::unique_ptr<candidate::Hand>> pruneGraspCandidates(
       const util::Cloud &cloud, const std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, double min_score);
+  // grasp_detector.cpp:522-526 -> HandSearch::reevaluateHypotheses (hand_search.cpp:66-134): labels
+  // (1 = full antipodal on cloud_gt) and rewritten half/full flags of `hands`.  Uploads cloud_gt.
+  std::vector<int> evalGroundTruth(const util::Cloud &cloud_gt, std::vector<std::unique_ptr<candidate::Hand>> &hands);
   bool createGraspImages(util::Cloud &cloud, std::vector<std::unique_ptr<candidate::Hand>> &hands_out,
                          std::vector<std::unique_ptr<net::Image>> &images_out);
   std::vector<std::unique_ptr<candidate::Hand>> selectGrasps(std::vector<std::unique_ptr<candidate::Hand>> &hands) const;
@@ -48,6 +51,8 @@ class GraspDetector {
 
  private:
   bool upload(const util::Cloud &cloud);
+  // device search for the cloud's samples (coordinates if set, else indices); recs sized here
+  bool searchDevice(const util::Cloud &cloud, bool fused, std::vector<gpd_hand> &recs, int &n_sets, int &n_cand);
   std::vector<gpd_hand> flatten(const std::vector<std::unique_ptr<candidate::HandSet>> &sets) const;
   gpd_params params_;
   gpd_hip_ctx *ctx_ = nullptr;

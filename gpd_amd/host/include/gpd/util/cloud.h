@@ -1,7 +1,7 @@
 // util::Cloud — the part of the reference's PCL wrapper that the hot path reads
 // (util/cloud.h: getCloudProcessed, getNormals, getCameraSource, getViewPoints,
-// getSampleIndices/setSampleIndices, subsample).  Preprocessing (voxelise, normal
-// estimation) is out of scope: clouds arrive with normals.
+// getSampleIndices/setSampleIndices, getSamples/setSamples, subsample, voxelizeCloud).  Normal
+// estimation runs on the device (gpd_hip_estimate_normals) from GraspDetector::preprocessPointCloud.
 #pragma once
 #include <string>
 #include <vector>
@@ -27,6 +27,10 @@ class Cloud {
   int numCameras() const { return (int)(view_points_.size() / 3); }
   const std::vector<int> &getSampleIndices() const { return sample_indices_; }
   void setSampleIndices(const std::vector<int> &idx) { sample_indices_ = idx; }
+  // Cloud::getSamples / setSamples (cloud.h:248-262): samples by coordinates, 3 doubles each; when
+  // present they take precedence over the indices (hand_search.cpp:37-44)
+  const std::vector<double> &getSamples() const { return samples_; }
+  void setSamples(const std::vector<double> &samples) { samples_ = samples; }
   void setNormals(const std::vector<float> &normals) { normals_ = normals; }
   // Cloud::voxelizeCloud (cloud.cpp:286-348), including what its std::set comparator (cloud.h:105-122,
   // not an ordering) keeps under libstdc++; drops normals like the reference's preprocessing order does.
@@ -40,6 +44,7 @@ class Cloud {
   std::vector<int> camera_source_;
   std::vector<double> view_points_;
   std::vector<int> sample_indices_;
+  std::vector<double> samples_;
 };
 
 }  // namespace util

@@ -428,7 +428,7 @@ bool GraspDetector::upload(const util::Cloud &cloud) {
     return false;
   }
   if (!cloud.hasNormals()) {
-    printf("ERROR: the cloud has no normals (normal estimation is outside this build's scope)\n");
+    printf("ERROR: the cloud has no normals (call preprocessPointCloud first)\n");
     return false;
   }
   if (gpd_hip_upload_cloud(ctx_, cloud.getCloudProcessed().data(), cloud.getNormals().data(), (int)cloud.size(),
@@ -454,22 +454,60 @@ static std::vector<std::unique_ptr<candidate::HandSet>> to_sets(const std::vecto
   return sets;
 }
 
+bool GraspDetector::searchDevice(const util::Cloud &cloud, bool fused, std::vector<gpd_hand> &recs, int &n_sets, int &n_cand) {
+  const std::vector<double> &samples = cloud.getSamples();
+  const std::vector<int> &idx = cloud.getSampleIndices();
+  const int slots = params_.num_hand_axes * params_.num_orientations;
+  n_sets = n_cand = 0;
+  int rc;
+  if (samples.size() >= 3) {  // use samples (hand_search.cpp:37-39)
+    const int S = (int)(samples.size() / 3);
+    recs.assign((size_t)S * slots, gpd_hand());
+    rc = fused ? gpd_hip_detect_samples(ctx_, samples.data(), S, recs.data(), &n_sets, &n_cand)
+               : gpd_hip_search_samples(ctx_, samples.data(), S, recs.data(), &n_sets);
+  } else if (!idx.empty()) {  // use indices (:40-43)
+    recs.assign(idx.size() * slots, gpd_hand());
+    rc = fused ? gpd_hip_detect(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets, &n_cand)
+               : gpd_hip_search(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets);
+  } else {
+    std::cout << "Error: No samples or no indices!\n";  // hand_search.cpp:44-48
+    return false;
+  }
+  if (rc != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return false;
+  }
+  last_num_sets_ = n_sets;
+  return true;
+}
+
+// grasp_detector.cpp:522-526
+std::vector<int> GraspDetector::evalGroundTruth(const util::Cloud &cloud_gt, std::vector<std::unique_ptr<candidate::Hand>> &hands) {
+  std::vector<int> labels(hands.size(), 0);
+  if (hands.empty() || !upload(cloud_gt)) return labels;
+  last_num_sets_ = 0;  // the device search buffers now belong to cloud_gt
+  std::vector<gpd_hand> recs(hands.size());
+  for (size_t i = 0; i < hands.size(); i++) recs[i] = hands[i]->record();
+  std::vector<int32_t> l(hands.size(), 0);
+  if (gpd_hip_reevaluate(ctx_, recs.data(), (int)recs.size(), l.data()) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return labels;
+  }
+  for (size_t i = 0; i < hands.size(); i++) {
+    labels[i] = l[i];
+    hands[i]->setHalfAntipodal(recs[i].half_antipodal != 0);
+    hands[i]->setFullAntipodal(recs[i].full_antipodal != 0);
+  }
+  return labels;
+}
+
 std::vector<std::unique_ptr<candidate::HandSet>> GraspDetector::generateGraspCandidates(const util::Cloud &cloud) {
   std::vector<std::unique_ptr<candidate::HandSet>> none;
   if (!upload(cloud)) return none;
-  const std::vector<int> &idx = cloud.getSampleIndices();
-  if (idx.empty()) {
-    std::cout << "Error: No samples or no indices!\n";  // hand_search.cpp:44-48
-    return none;
-  }
   const int slots = params_.num_hand_axes * params_.num_orientations;
-  std::vector<gpd_hand> recs(idx.size() * slots);
-  int n_sets = 0;
-  if (gpd_hip_search(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets) != GPD_OK) {
-    printf("ERROR: %s\n", gpd_hip_last_error());
-    return none;
-  }
-  last_num_sets_ = n_sets;
+  std::vector<gpd_hand> recs;
+  int n_sets = 0, n_cand = 0;
+  if (!searchDevice(cloud, false, recs, n_sets, n_cand)) return none;
   return to_sets(recs, n_sets, slots);
 }
 
@@ -588,14 +626,10 @@ bool GraspDetector::createGraspImages(util::Cloud &cloud, std::vector<std::uniqu
   hands_out.clear();
   images_out.clear();
   if (!upload(cloud)) return false;
-  const std::vector<int> &idx = cloud.getSampleIndices();
   const int slots = params_.num_hand_axes * params_.num_orientations;
-  std::vector<gpd_hand> recs(idx.size() * slots);
+  std::vector<gpd_hand> recs;
   int n_sets = 0, n_cand = 0;
-  if (idx.empty() || gpd_hip_search(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets) != GPD_OK) {
-    printf("ERROR: %s\n", idx.empty() ? "no sample indices" : gpd_hip_last_error());
-    return false;
-  }
+  if (!searchDevice(cloud, false, recs, n_sets, n_cand)) return false;
   printf("Generated %d hand sets.\n", n_sets);
   // workspace / aperture filter on the flat records (same predicate as filterGraspsWorkspace)
   {
@@ -645,23 +679,14 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
     printf("ERROR: no classifier weights loaded (cfg key weights_file)\n");
     return hands_out;
   }
-  const std::vector<int> &idx = cloud.getSampleIndices();
-  if (idx.empty()) {
-    std::cout << "Error: No samples or no indices!\n";
-    return hands_out;
-  }
   const int slots = params_.num_hand_axes * params_.num_orientations;
-  std::vector<gpd_hand> recs(idx.size() * slots);
+  std::vector<gpd_hand> recs;
   int n_sets = 0, n_cand = 0;
   std::vector<std::unique_ptr<candidate::Hand>> hands;
   float ms[3] = {0, 0, 0};
   if (!filter_approach_direction_) {
     // steps 1-4 fused on the device (grasp_detector.cpp:222-273)
-    if (gpd_hip_detect(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets, &n_cand) != GPD_OK) {
-      printf("ERROR: %s\n", gpd_hip_last_error());
-      return hands_out;
-    }
-    last_num_sets_ = n_sets;
+    if (!searchDevice(cloud, true, recs, n_sets, n_cand)) return hands_out;
     printf("Generated %d hand sets.\n", n_sets);
     gpd_hip_last_stage_ms(ctx_, ms);
     for (size_t i = 0; i < (size_t)n_sets * slots; i++)
@@ -669,11 +694,7 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
   } else {
     // the approach-direction filter sits between the stages (grasp_detector.cpp:247-255): search,
     // both host filters, then images and scores for what is left
-    if (gpd_hip_search(ctx_, idx.data(), (int)idx.size(), recs.data(), &n_sets) != GPD_OK) {
-      printf("ERROR: %s\n", gpd_hip_last_error());
-      return hands_out;
-    }
-    last_num_sets_ = n_sets;
+    if (!searchDevice(cloud, false, recs, n_sets, n_cand)) return hands_out;
     printf("Generated %d hand sets.\n", n_sets);
     float t[3];
     gpd_hip_last_stage_ms(ctx_, t);

@@ -135,6 +135,21 @@ int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals);
 int gpd_hip_search(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples,
                    gpd_hand *hands, int *num_sets);
 
+/* The same for samples given by coordinates (Cloud::getSamples; hand_search.cpp:37-39,
+ * FrameEstimator::calculateLocalFrames(cloud, samples, ...) frame_estimator.cpp:38-65):
+ * samples_xyz holds 3 doubles per sample.  As in the reference the kd-tree queries use the float
+ * cast of the sample (eigenVectorToPcl) while the hand frame keeps the double. */
+int gpd_hip_search_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples,
+                           gpd_hand *hands, int *num_sets);
+
+/* replaces HandSearch::reevaluateHypotheses (hand_search.cpp:66-134, 190-228;
+ * GraspDetector::evalGroundTruth, grasp_detector.cpp:522-526) on the cloud uploaded last (the
+ * ground-truth cloud): each hand is checked again with its own frame, `top` and
+ * finger_placement_index; labels[i] = 1 for a full antipodal grasp, half_antipodal /
+ * full_antipodal of the records are rewritten.  Reuses the search buffers: hands of an earlier
+ * gpd_hip_search can no longer be passed to gpd_hip_images afterwards. */
+int gpd_hip_reevaluate(gpd_hip_ctx *ctx, gpd_hand *hands, int num_hands, int32_t *labels);
+
 /* Replaces ImageGenerator::createImages (image_generator.cpp:17-99) for hand
  * sets produced by gpd_hip_search (optionally after the host workspace filter,
  * grasp_detector.cpp:334-398, which clears `valid`).  One image per valid hand
@@ -151,6 +166,10 @@ int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets,
  * num_samples*num_slots records with `score` set on the valid ones. */
 int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples,
                    gpd_hand *hands, int *num_sets, int *num_candidates);
+
+/* gpd_hip_detect for samples given by coordinates (see gpd_hip_search_samples). */
+int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples,
+                           gpd_hand *hands, int *num_sets, int *num_candidates);
 
 /* Stage times of the last call in milliseconds (HIP events on the context's
  * stream): [0] search, [1] images (incl. shadow), [2] score.  The counterpart

@@ -424,6 +424,10 @@ struct FingerHand {
   void evaluateHand() {  // finger_hand.cpp:75-81
     for (int i = 0; i < n; i++) hand[i] = fingers[i] && fingers[n + i];
   }
+  void evaluateHand(int idx) {  // finger_hand.cpp:83-87
+    std::fill(hand.begin(), hand.end(), 0);
+    hand[idx] = fingers[idx] && fingers[n + idx];
+  }
   bool any() const {
     for (char h : hand)
       if (h) return true;
@@ -531,6 +535,41 @@ static std::vector<double> orientationAngles(int n) {
   return a;
 }
 
+// transformToHandFrame (point_list.cpp:22-33) with rotation = FR^T, then cropByHandHeight
+// (point_list.cpp:44-55, quirk Q1: the N-k rejected columns come back as copies of column 0).
+static void handFramePoints(const gpd_params &P, const float *xyz, const float *normals, const std::vector<Neighbour> &nbr,
+                            const double *sample, const double *FR, FramePts &pts) {
+  const int N = (int)nbr.size();
+  pts.clear();
+  double g[6] = {0, 0, 0, 0, 0, 0};
+  int k = 0;
+  for (int i = 0; i < N; i++) {
+    const float *pp = xyz + 3 * nbr[i].idx;
+    const float *nn = normals + 3 * nbr[i].idx;
+    double c[3] = {(double)pp[0] - sample[0], (double)pp[1] - sample[1], (double)pp[2] - sample[2]};
+    double nd[3] = {(double)nn[0], (double)nn[1], (double)nn[2]};
+    double t[3], tn[3];
+    for (int r = 0; r < 3; r++) {
+      t[r] = FR[0 + r] * c[0] + FR[3 + r] * c[1] + FR[6 + r] * c[2];
+      tn[r] = FR[0 + r] * nd[0] + FR[3 + r] * nd[1] + FR[6 + r] * nd[2];
+    }
+    if (i == 0) {
+      g[0] = t[0]; g[1] = t[1]; g[2] = t[2]; g[3] = tn[0]; g[4] = tn[1]; g[5] = tn[2];
+    }
+    if (t[2] > -1.0 * P.hand_height && t[2] < P.hand_height) {
+      pts.x.push_back(t[0]); pts.y.push_back(t[1]); pts.z.push_back(t[2]);
+      pts.nx.push_back(tn[0]); pts.ny.push_back(tn[1]); pts.nz.push_back(tn[2]);
+      pts.mult.push_back(1);
+      k++;
+    }
+  }
+  if (N - k > 0) {  // ghosts: N-k copies of column 0
+    pts.x.push_back(g[0]); pts.y.push_back(g[1]); pts.z.push_back(g[2]);
+    pts.nx.push_back(g[3]); pts.ny.push_back(g[4]); pts.nz.push_back(g[5]);
+    pts.mult.push_back(N - k);
+  }
+}
+
 // HandSet::evalHandSet / evalHands — hand_set.cpp:31-116, 235-261.
 // nbr: the nn_radius (0.11) neighbourhood of the sample in (d2,idx) order.
 static void evalHandSet(const gpd_params &P, const float *xyz, const float *normals, const std::vector<Neighbour> &nbr,
@@ -550,7 +589,6 @@ static void evalHandSet(const gpd_params &P, const float *xyz, const float *norm
   mat3mul(F, RB, FRB);
   std::vector<double> angles = orientationAngles(P.num_orientations);
   const double AX[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  const int N = (int)nbr.size();
   FramePts pts;
   for (int ai = 0; ai < P.num_hand_axes; ai++) {
     FingerHand fh(P.finger_width, P.hand_outer_diameter, P.hand_depth, P.num_finger_placements);
@@ -561,36 +599,7 @@ static void evalHandSet(const gpd_params &P, const float *xyz, const float *norm
       double R[9], FR[9];
       angleAxis(angles[oi], AX[P.hand_axes[ai]], R);
       mat3mul(FRB, R, FR);
-      // transformToHandFrame (point_list.cpp:22-33) with rotation = FR^T, then
-      // cropByHandHeight (point_list.cpp:44-55, quirk Q1)
-      pts.clear();
-      double g[6] = {0, 0, 0, 0, 0, 0};
-      int k = 0;
-      for (int i = 0; i < N; i++) {
-        const float *pp = xyz + 3 * nbr[i].idx;
-        const float *nn = normals + 3 * nbr[i].idx;
-        double c[3] = {(double)pp[0] - sample[0], (double)pp[1] - sample[1], (double)pp[2] - sample[2]};
-        double nd[3] = {(double)nn[0], (double)nn[1], (double)nn[2]};
-        double t[3], tn[3];
-        for (int r = 0; r < 3; r++) {
-          t[r] = FR[0 + r] * c[0] + FR[3 + r] * c[1] + FR[6 + r] * c[2];
-          tn[r] = FR[0 + r] * nd[0] + FR[3 + r] * nd[1] + FR[6 + r] * nd[2];
-        }
-        if (i == 0) {
-          g[0] = t[0]; g[1] = t[1]; g[2] = t[2]; g[3] = tn[0]; g[4] = tn[1]; g[5] = tn[2];
-        }
-        if (t[2] > -1.0 * P.hand_height && t[2] < P.hand_height) {
-          pts.x.push_back(t[0]); pts.y.push_back(t[1]); pts.z.push_back(t[2]);
-          pts.nx.push_back(tn[0]); pts.ny.push_back(tn[1]); pts.nz.push_back(tn[2]);
-          pts.mult.push_back(1);
-          k++;
-        }
-      }
-      if (N - k > 0) {  // ghosts: N-k copies of column 0
-        pts.x.push_back(g[0]); pts.y.push_back(g[1]); pts.z.push_back(g[2]);
-        pts.nx.push_back(g[3]); pts.ny.push_back(g[4]); pts.nz.push_back(g[5]);
-        pts.mult.push_back(N - k);
-      }
+      handFramePoints(P, xyz, normals, nbr, sample, FR, pts);
       fh.evaluateFingers(pts, P.init_bite);
       fh.evaluateHand();
       // Hand(sample, frame_rot, finger_hand, 0.0) — hand_set.cpp:89-90, hand.cpp:24-45
@@ -1079,14 +1088,23 @@ int gpd_oracle_fastrand_at(uint64_t offset) {  // draw number `offset` (0-based)
 void gpd_oracle_angle_axis(double angle, const double *axis, double *R) { angleAxis(angle, axis, R); }
 
 // frames: out 12 doubles per sample (sample, normal, binormal, curvature), has[i]=0 if no neighbour
-void gpd_oracle_frames(const gpd_params *P, const float *xyz, const float *normals, int np, const int32_t *sample_idx, int S,
-                       double *frames, uint8_t *has) {
+// FrameEstimator::calculateLocalFrames for samples by index (frame_estimator.cpp:6-36) or by
+// coordinates (:38-65; sample_xyz != NULL): the kd-tree query is the float cast of the sample
+// (eigenVectorToPcl, frame_estimator.cpp:88-95), the frame keeps the double.
+static void localFrames(const gpd_params *P, const float *xyz, const float *normals, int np, const int32_t *sample_idx,
+                        const double *sample_xyz, int S, double *frames, uint8_t *has) {
   Grid g;
   g.build(xyz, np, 0.02f);
 #pragma omp parallel for schedule(dynamic, 8)
   for (int i = 0; i < S; i++) {
     std::vector<Neighbour> nb;
-    const float *q = xyz + 3 * sample_idx[i];
+    float qf[3];
+    double qd[3];
+    for (int r = 0; r < 3; r++) {
+      qd[r] = sample_xyz ? sample_xyz[3 * i + r] : (double)xyz[3 * sample_idx[i] + r];
+      qf[r] = (float)qd[r];
+    }
+    const float *q = qf;
     radiusSearch(g, q, P->nn_radius_frames, nb);
     has[i] = !nb.empty();
     if (nb.empty()) continue;
@@ -1094,19 +1112,23 @@ void gpd_oracle_frames(const gpd_params *P, const float *xyz, const float *norma
     for (size_t k = 0; k < nb.size(); k++)
       for (int r = 0; r < 3; r++) nn[3 * k + r] = (double)normals[3 * nb[k].idx + r];
     double *f = frames + 12 * i;
-    for (int r = 0; r < 3; r++) f[r] = (double)q[r];
+    for (int r = 0; r < 3; r++) f[r] = qd[r];
     averageNormalAxis(nn, f + 3, f + 6, f + 9);
   }
+}
+void gpd_oracle_frames(const gpd_params *P, const float *xyz, const float *normals, int np, const int32_t *sample_idx, int S,
+                       double *frames, uint8_t *has) {
+  localFrames(P, xyz, normals, np, sample_idx, nullptr, S, frames, has);
 }
 
 // HandSearch::searchHands (hand_search.cpp:24-64, 144-188), samples by index.
 // hands: S*n_slots records; returns n_sets via pointer.
-int gpd_oracle_search(const gpd_params *P, const float *xyz, const float *normals, int np, const int32_t *sample_idx, int S, gpd_hand *hands,
-                      int *num_sets) {
+static int searchHands(const gpd_params *P, const float *xyz, const float *normals, int np, const int32_t *sample_idx,
+                       const double *sample_xyz, int S, gpd_hand *hands, int *num_sets) {
   const int n_slots = P->num_hand_axes * P->num_orientations;
   std::vector<double> frames((size_t)12 * S);
   std::vector<uint8_t> has(S);
-  gpd_oracle_frames(P, xyz, normals, np, sample_idx, S, frames.data(), has.data());
+  localFrames(P, xyz, normals, np, sample_idx, sample_xyz, S, frames.data(), has.data());
   std::vector<int> kept;
   for (int i = 0; i < S; i++)
     if (has[i]) kept.push_back(i);
@@ -1128,6 +1150,54 @@ int gpd_oracle_search(const gpd_params *P, const float *xyz, const float *normal
   }
   *num_sets = (int)kept.size();
   return 0;
+}
+int gpd_oracle_search(const gpd_params *P, const float *xyz, const float *normals, int np, const int32_t *sample_idx, int S, gpd_hand *hands,
+                      int *num_sets) {
+  return searchHands(P, xyz, normals, np, sample_idx, nullptr, S, hands, num_sets);
+}
+// the same for samples given by coordinates (Cloud::getSamples, hand_search.cpp:37-39)
+int gpd_oracle_search_xyz(const gpd_params *P, const float *xyz, const float *normals, int np, const double *sample_xyz, int S,
+                          gpd_hand *hands, int *num_sets) {
+  return searchHands(P, xyz, normals, np, nullptr, sample_xyz, S, hands, num_sets);
+}
+
+// HandSearch::reevaluateHypotheses / reevaluateHypothesis / labelHypothesis (hand_search.cpp:66-134,
+// 190-228): every hand is checked again against this (ground-truth) cloud with its own frame, depth
+// (top) and finger placement; labels[i] = 1 for a full antipodal grasp, the hands' half/full flags are
+// rewritten.  A hand without a finger placement (index < 0) would index out of bounds in the
+// reference; here it is labelled 0.
+void gpd_oracle_reevaluate(const gpd_params *P, const float *xyz, const float *normals, int np, gpd_hand *hands, int n, int32_t *labels) {
+  Grid g;
+  g.build(xyz, np, 0.02f);
+  const double radius = nnRadiusHands(*P);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int i = 0; i < n; i++) {
+    gpd_hand &H = hands[i];
+    labels[i] = 0;
+    H.half_antipodal = 0;
+    H.full_antipodal = 0;
+    const int idx = H.finger_placement_index;
+    if (idx < 0 || idx >= P->num_finger_placements) continue;
+    float q[3] = {(float)H.sample[0], (float)H.sample[1], (float)H.sample[2]};
+    std::vector<Neighbour> nb;
+    radiusSearch(g, q, radius, nb);
+    if (nb.empty()) continue;
+    FramePts pts;
+    handFramePoints(*P, xyz, normals, nb, H.sample, H.frame, pts);
+    FingerHand fh(P->finger_width, P->hand_outer_diameter, P->hand_depth, P->num_finger_placements);
+    fh.evaluateFingers(pts, H.top, idx);
+    fh.evaluateHand(idx);
+    if (!fh.any()) continue;
+    std::vector<int> closing = fh.closingRegion(pts, -1);
+    if (closing.empty()) continue;
+    const int label = antipodalLabel(pts, closing, P->friction_coeff, P->min_viable);
+    if (label == 2) {
+      labels[i] = 1;
+      H.full_antipodal = 1;
+    } else if (label == 1) {
+      H.half_antipodal = 1;
+    }
+  }
 }
 
 void gpd_oracle_filter(const gpd_params *P, gpd_hand *hands, int n_sets) {

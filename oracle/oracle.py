@@ -227,3 +227,25 @@ def find_clusters(hands, scores, min_inliers=1, remove_inliers=False):
     src = np.zeros(max(n, 1), np.int32)
     k = lib().gpd_oracle_find_clusters(_p(hands), _p(scores), n, int(min_inliers), int(bool(remove_inliers)), _p(out), _p(osc), _p(src))
     return out[:k].copy(), osc[:k].copy(), src[:k].copy()
+
+
+def search_xyz(params, xyz, normals, samples):
+    """HandSearch::searchHands for samples given by coordinates (f64 [S,3]) -> hands [n_sets, n_slots]."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    normals = np.ascontiguousarray(normals, np.float32)
+    sm = np.ascontiguousarray(samples, np.float64).reshape(-1, 3)
+    n_slots = params.num_hand_axes * params.num_orientations
+    hands = np.zeros((len(sm), n_slots), HAND_DTYPE)
+    ns = C.c_int(0)
+    lib().gpd_oracle_search_xyz(C.byref(params), _p(xyz), _p(normals), len(xyz), _p(sm), len(sm), _p(hands), C.byref(ns))
+    return hands[:ns.value].copy()
+
+
+def reevaluate(params, xyz, normals, hands):
+    """HandSearch::reevaluateHypotheses on this cloud -> (labels int32 [n], hands with rewritten antipodal flags)."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    normals = np.ascontiguousarray(normals, np.float32)
+    h = np.ascontiguousarray(hands, HAND_DTYPE).reshape(-1).copy()
+    labels = np.zeros(len(h), np.int32)
+    lib().gpd_oracle_reevaluate(C.byref(params), _p(xyz), _p(normals), len(xyz), _p(h), len(h), _p(labels))
+    return labels, h

@@ -131,6 +131,19 @@ def test_cli_direction_filter_and_clustering(tmp_path, oracle_mod, lenet15_real)
 
 
 @pytest.mark.gpu
+def test_host_selftest_samples_prune_groundtruth(tmp_path, lenet15_real):
+    """GraspDetector members the CLI does not reach: Cloud::setSamples, pruneGraspCandidates, evalGroundTruth."""
+    exe = os.path.join(ROOT, "gpd_amd", "host", "host_selftest")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    cl = synth.make_cloud(99, 12000)
+    cfg, pcd = _write_case(tmp_path, cl, lenet15_real, 120, 4000)
+    out = subprocess.run([exe, str(cfg), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    last = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
+    assert out.returncode == 0 and last.startswith("SELFTEST OK"), last + out.stderr[-1000:]
+    assert int(last.split()[4]) > 50  # candidates re-evaluated against the "ground truth" cloud
+
+
+@pytest.mark.gpu
 def test_cli_on_raw_krylon_pcd(tmp_path, oracle_mod, lenet15_real):
     """configs[0] through the product CLI: an x y z PCD without normals -> voxelise, GPU normals,
     subsample(500), detect.  Compared with the oracle run on the same preprocessing."""
