@@ -36,6 +36,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <mutex>
+
 #include "gpd_internal.h"
 
 namespace gpd {
@@ -1037,22 +1039,41 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   k.len[1] = k.vol_width;
   k.len[2] = k.dbl_h;
   k.true_div = 0;
-  for (int a = 0; a < 3; a++) {
-    k.inv_cell[a] = (double)kImg / k.len[a];
-    image_cell_thresholds(k.len[a], k.thr[a]);
-    k.inv_len[a] = 1.0 / k.len[a];
-    // self-check of div_len(): the FMA sequence must reproduce the IEEE quotient
-    uint64_t rs = 88172645463325252ull;
-    for (int i = 0; i < 200000 && !k.true_div; i++) {
-      rs ^= rs << 13;
-      rs ^= rs >> 7;
-      rs ^= rs << 17;
-      double x = (double)(rs >> 11) * (1.0 / 9007199254740992.0) * k.len[a];
-      if (i & 1) x = (double)(float)x;
-      if (i < kImg) x = k.thr[a][i];
-      const double q = x * k.inv_len[a];
-      const double r = std::fma(-k.len[a], q, x);
-      if (std::fma(r, k.inv_len[a], q) != x / k.len[a]) k.true_div = 1;
+  {
+    // thresholds and the div_len() self-check depend on the box extents only: computed once per
+    // geometry (the self-check alone is ~2 ms of host time)
+    struct AxisCache {
+      double len = -1.0, thr[kImg + 1], inv_len = 0.0;
+      int true_div = 0;
+    };
+    static AxisCache cache[3];
+    static std::mutex cache_mutex;
+    std::lock_guard<std::mutex> lock(cache_mutex);
+    for (int a = 0; a < 3; a++) {
+      AxisCache &ac = cache[a];
+      if (ac.len != k.len[a]) {
+        ac.len = k.len[a];
+        image_cell_thresholds(k.len[a], ac.thr);
+        ac.inv_len = 1.0 / k.len[a];
+        ac.true_div = 0;
+        // self-check of div_len(): the FMA sequence must reproduce the IEEE quotient
+        uint64_t rs = 88172645463325252ull;
+        for (int i = 0; i < 200000 && !ac.true_div; i++) {
+          rs ^= rs << 13;
+          rs ^= rs >> 7;
+          rs ^= rs << 17;
+          double x = (double)(rs >> 11) * (1.0 / 9007199254740992.0) * k.len[a];
+          if (i & 1) x = (double)(float)x;
+          if (i < kImg) x = ac.thr[i];
+          const double q = x * ac.inv_len;
+          const double r = std::fma(-k.len[a], q, x);
+          if (std::fma(r, ac.inv_len, q) != x / k.len[a]) ac.true_div = 1;
+        }
+      }
+      k.inv_cell[a] = (double)kImg / k.len[a];
+      std::memcpy(k.thr[a], ac.thr, sizeof(ac.thr));
+      k.inv_len[a] = ac.inv_len;
+      if (ac.true_div) k.true_div = 1;
     }
   }
   {  // affine map of SET_THREADS * num_shadow LCG steps
@@ -1070,8 +1091,8 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
     k.stride_a = A;
     k.stride_c = Cc;
   }
-  HIP_RET(hipStreamSynchronize(stream));
-  HIP_RET(hipMemcpyToSymbol(HIP_SYMBOL(c_img), &k, sizeof(k), 0, hipMemcpyHostToDevice));
+  // stream-ordered after the kernels of an earlier call that still read the old constants
+  HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_img), &k, sizeof(k), 0, hipMemcpyHostToDevice, stream));
   return images_launch(s, im, stream, true);
 }
 
