@@ -42,7 +42,7 @@ class GpdHipError(RuntimeError):
 EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
-           "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate"]
+           "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms"]
 
 
 def build():
@@ -74,6 +74,7 @@ def lib():
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
         L.gpd_hip_estimate_normals.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.gpd_hip_last_images_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpd_hip_replay_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         _LIB = L
     return _LIB
@@ -204,6 +205,12 @@ class Context:
         sc = np.zeros(n_scores, np.float32) if n_scores else None
         self._check(lib().gpd_hip_replay_times(self._h, _ptr(ms), C.byref(n), _ptr(sc)))
         return float(ms[0]), float(ms[1]), n.value, sc
+
+    def replay_kernel_ms(self):
+        """Summed HIP-event time of conv1, conv2, ip1, ip2 over the replays of the last replay_times()."""
+        ms = np.zeros(4, np.float32)
+        self._check(lib().gpd_hip_replay_kernel_ms(self._h, _ptr(ms)))
+        return [float(x) for x in ms]
 
     def images_stats(self):
         out = np.zeros(4, np.int64)

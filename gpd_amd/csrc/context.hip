@@ -49,7 +49,8 @@ struct gpd_hip_ctx {
   size_t d_img_in_bytes = 0;
   float *d_scores = nullptr;
   int d_scores_cap = 0;
-  std::vector<hipEvent_t> replay_events;  // 3 per gpd_hip_replay call
+  std::vector<hipEvent_t> replay_events;  // 6 per gpd_hip_replay call: start, images done, conv1, conv2, fc1, end
+  float replay_kernel_ms[4] = {0, 0, 0, 0};  // conv1, conv2, fc1, fc2 sums of the replays of the last gpd_hip_replay_times
   size_t replay_used = 0;
 };
 
@@ -434,21 +435,25 @@ int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
   const int n = ctx->images.num_candidates;
   int rc = reserve_scores(ctx, n);
   if (rc) return rc;
-  while (ctx->replay_events.size() < ctx->replay_used + 3) {
+  while (ctx->replay_events.size() < ctx->replay_used + 6) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     ctx->replay_events.push_back(e);
   }
   hipEvent_t *ev = &ctx->replay_events[ctx->replay_used];
-  ctx->replay_used += 3;
+  ctx->replay_used += 6;
   HIP_TRY(hipEventRecord(ev[0], ctx->stream));
   if (stages & 1) {
     rc = images_launch(ctx->search, ctx->images, ctx->stream, false);
     if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-  if (stages & 2) HIP_TRY(lenet_forward(ctx->lenet, ctx->lenet_scratch, ctx->images.d_images, n, ctx->d_scores, ctx->stream));
-  HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+  if (stages & 2) {
+    HIP_TRY(lenet_forward(ctx->lenet, ctx->lenet_scratch, ctx->images.d_images, n, ctx->d_scores, ctx->stream, ev + 2));
+  } else {
+    for (int i = 2; i < 5; i++) HIP_TRY(hipEventRecord(ev[i], ctx->stream));
+  }
+  HIP_TRY(hipEventRecord(ev[5], ctx->stream));
   return GPD_OK;
 }
 
@@ -457,14 +462,20 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ms[0] = ms[1] = 0.f;
-  for (size_t i = 0; i + 2 < ctx->replay_used + 0 && i < ctx->replay_used; i += 3) {
+  for (int k = 0; k < 4; k++) ctx->replay_kernel_ms[k] = 0.f;
+  for (size_t i = 0; i + 5 < ctx->replay_used; i += 6) {
     float a = 0.f, b = 0.f;
     HIP_TRY(hipEventElapsedTime(&a, ctx->replay_events[i], ctx->replay_events[i + 1]));
-    HIP_TRY(hipEventElapsedTime(&b, ctx->replay_events[i + 1], ctx->replay_events[i + 2]));
+    HIP_TRY(hipEventElapsedTime(&b, ctx->replay_events[i + 1], ctx->replay_events[i + 5]));
     ms[0] += a;
     ms[1] += b;
+    for (int k = 0; k < 4; k++) {
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, ctx->replay_events[i + 1 + k], ctx->replay_events[i + 2 + k]));
+      ctx->replay_kernel_ms[k] += t;
+    }
   }
-  if (launches) *launches = (int)(ctx->replay_used / 3);
+  if (launches) *launches = (int)(ctx->replay_used / 6);
   ctx->replay_used = 0;
   if (scores && ctx->images.num_candidates > 0 && ctx->d_scores)
     HIP_TRY(hipMemcpy(scores, ctx->d_scores, (size_t)ctx->images.num_candidates * sizeof(float), hipMemcpyDeviceToHost));
@@ -474,6 +485,12 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
     set_error("gpd_hip_replay_times: image kernel reported capacity flags %d", status);
     return GPD_ERR_CAPACITY;
   }
+  return GPD_OK;
+}
+
+int gpd_hip_replay_kernel_ms(gpd_hip_ctx *ctx, float ms[4]) {
+  if (!ctx || !ms) return GPD_ERR_INVALID;
+  for (int k = 0; k < 4; k++) ms[k] = ctx->replay_kernel_ms[k];
   return GPD_OK;
 }
 

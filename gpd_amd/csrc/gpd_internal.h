@@ -31,7 +31,7 @@ struct LeNetScratch {
 
 // Scores n images (device pointer, planar u8 [n][C][3600]) into d_scores (device). Async on stream.
 hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *d_images, int n, float *d_scores,
-                         hipStream_t stream);
+                         hipStream_t stream, hipEvent_t *kernel_events = nullptr);
 hipError_t lenet_scratch_reserve(LeNetScratch &s, int n);
 void lenet_scratch_free(LeNetScratch &s);
 

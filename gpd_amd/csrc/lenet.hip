@@ -370,12 +370,20 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
 constexpr int FC_BU = 64, FC_BM = 64, FC_BK = 16;
 
 __global__ __launch_bounds__(256) void fc1_mfma_kernel(const float *__restrict__ W, const float *__restrict__ bias,
-                                                       const float *__restrict__ X, float *__restrict__ out_t, int n, int ld_out) {
+                                                       const float *__restrict__ X, float *__restrict__ out_t, int n, int ld_out, int n_u_tiles) {
   __shared__ __attribute__((aligned(16))) float s_w[FC_BK][FC_BU];
   __shared__ __attribute__((aligned(16))) float s_x[FC_BK][FC_BM + 1];
   const int tid = threadIdx.x;
-  const int u0 = blockIdx.x * FC_BU;
-  const int m0 = blockIdx.y * FC_BM;
+  // XCD-aware tile order (workgroup L runs on XCD L % 8, each XCD has its own L2): the eight output
+  // tiles of one image tile get consecutive slots on ONE XCD, so the image rows (64 x 7200 floats)
+  // are fetched from HBM once instead of once per XCD; measured 1.26 GB -> see profiles/ traffic.
+  const int L = blockIdx.x;
+  const int xcd = L & 7, slot = L >> 3;
+  const int u_tile = slot % n_u_tiles;
+  const int m_tile = (slot / n_u_tiles) * 8 + xcd;
+  const int u0 = u_tile * FC_BU;
+  const int m0 = m_tile * FC_BM;
+  if (m0 >= n) return;
   const int wave = tid >> 6, lane = tid & 63;
   const int wu = (wave & 1) * 32, wm = (wave >> 1) * 32;
   f32x16 acc;
@@ -446,8 +454,10 @@ void lenet_scratch_free(LeNetScratch &s) {
   s = LeNetScratch();
 }
 
+// kernel_events (may be null): three events recorded after conv1, conv2 and fc1 of the first chunk,
+// so that a caller bracketing the call with its own events gets the four kernel durations.
 hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *d_images, int n, float *d_scores,
-                         hipStream_t stream) {
+                         hipStream_t stream, hipEvent_t *kernel_events) {
   if (n <= 0) return hipSuccess;
   const int kChunk = 16384;
   static int num_cus = 0;  // persistent conv2 workgroups: one per CU (256 on MI355X)
@@ -469,9 +479,12 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
       case 1: conv1_mfma_kernel<1><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
       default: return hipErrorInvalidValue;
     }
+    if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
     conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m);
-    dim3 g((kFc1Out + FC_BU - 1) / FC_BU, (m + FC_BM - 1) / FC_BM);
-    fc1_mfma_kernel<<<g, 256, 0, stream>>>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity);
+    if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[1], stream);
+    const int n_u_tiles = (kFc1Out + FC_BU - 1) / FC_BU, n_m_groups = ((m + FC_BM - 1) / FC_BM + 7) / 8;
+    fc1_mfma_kernel<<<n_u_tiles * n_m_groups * 8, 256, 0, stream>>>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, n_u_tiles);
+    if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[2], stream);
     fc2_score_kernel<<<(m + 255) / 256, 256, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
   }
   return hipGetLastError();
