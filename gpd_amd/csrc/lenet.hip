@@ -362,21 +362,23 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
 
 // ---------------------------------------------------------------------------
 // FC1 on f32 MFMA:  D[u][m] = sum_k W[k][u] * X[m][k]   (W = ip1 weights, column-
-// major 500x7200 == row-major [7200][500]; X = flat).  Block tile 64(u) x 64(m),
-// 4 waves each one 32x32 tile, K stepped by 16 through LDS.
+// major 500x7200 == row-major [7200][500]; X = flat).  Block tile FC_BU(u) x FC_BM(m),
+// one 32x32 tile per wave, K stepped by 16 through LDS.
 // A operand (lane l): W[k0 + (l>>5)][u0 + (l&31)],  B operand: X[m0 + (l&31)][k0 + (l>>5)].
 // D layout: col(m) = lane&31, row(u) = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // ---------------------------------------------------------------------------
-constexpr int FC_BU = 64, FC_BM = 64, FC_BK = 16;
+constexpr int FC_BU = 64, FC_BM = 64, FC_BK = 32;  // 16 x 79 = 1264 two-wave tiles at n = 5000: ~5 per CU, balanced
+constexpr int FC_THREADS = 64 * (FC_BU / 32) * (FC_BM / 32);
 
-__global__ __launch_bounds__(256) void fc1_mfma_kernel(const float *__restrict__ W, const float *__restrict__ bias,
-                                                       const float *__restrict__ X, float *__restrict__ out_t, int n, int ld_out, int n_u_tiles) {
-  __shared__ __attribute__((aligned(16))) float s_w[FC_BK][FC_BU];
-  __shared__ __attribute__((aligned(16))) float s_x[FC_BK][FC_BM + 1];
+__global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__restrict__ W, const float *__restrict__ bias,
+                                                              const float *__restrict__ X, float *__restrict__ out_t, int n, int ld_out,
+                                                              int n_u_tiles) {
+  __shared__ __attribute__((aligned(16))) float s_w[2][FC_BK][FC_BU];  // double-buffered: one barrier per K step
+  __shared__ __attribute__((aligned(16))) float s_x[2][FC_BK][FC_BM + 1];
   const int tid = threadIdx.x;
-  // XCD-aware tile order (workgroup L runs on XCD L % 8, each XCD has its own L2): the eight output
+  // XCD-aware tile order (workgroup L runs on XCD L % 8, each XCD has its own L2): the output
   // tiles of one image tile get consecutive slots on ONE XCD, so the image rows (64 x 7200 floats)
-  // are fetched from HBM once instead of once per XCD; measured 1.26 GB -> see profiles/ traffic.
+  // are fetched from HBM once instead of once per XCD (1.26 GB -> ~0.2 GB per launch).
   const int L = blockIdx.x;
   const int xcd = L & 7, slot = L >> 3;
   const int u_tile = slot % n_u_tiles;
@@ -385,31 +387,65 @@ __global__ __launch_bounds__(256) void fc1_mfma_kernel(const float *__restrict__
   const int m0 = m_tile * FC_BM;
   if (m0 >= n) return;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wu = (wave & 1) * 32, wm = (wave >> 1) * 32;
+  constexpr int WU = FC_BU / 32;
+  const int wu = (wave % WU) * 32, wm = (wave / WU) * 32;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  // loader roles
-  const int lw_k = tid >> 4, lw_u = (tid & 15) * 4;  // 16 rows x 16 float4
-  const int lx_m = tid >> 2, lx_k = (tid & 3) * 4;   // 64 rows x 4 float4
-  const int xm = min(m0 + lx_m, n - 1);
+  // loader roles: W tile FC_BK x FC_BU and X tile FC_BM x FC_BK as float4, round-robin over the threads
+  constexpr int W_V = FC_BK * FC_BU / 4, X_V = FC_BM * FC_BK / 4;
+  constexpr int W_PT = (W_V + FC_THREADS - 1) / FC_THREADS, X_PT = (X_V + FC_THREADS - 1) / FC_THREADS;
+  // register prefetch: the loads of step k0 + FC_BK are in flight during the MFMAs of step k0
+  float4 wv[W_PT], xv[X_PT];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < W_PT; i++) {
+      const int v = tid + i * FC_THREADS;
+      const int k = v / (FC_BU / 4), u = (v % (FC_BU / 4)) * 4;
+      wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < W_V && u0 + u < kFc1Out) wv[i] = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + k) * kFc1Out + u0 + u);
+    }
+#pragma unroll
+    for (int i = 0; i < X_PT; i++) {
+      const int v = tid + i * FC_THREADS;
+      const int m = v / (FC_BK / 4), k = (v % (FC_BK / 4)) * 4;
+      xv[i] = *reinterpret_cast<const float4 *>(X + (size_t)min(m0 + m, n - 1) * kFc1In + k0 + k);
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < W_PT; i++) {
+      const int v = tid + i * FC_THREADS;
+      if (v < W_V) *reinterpret_cast<float4 *>(&s_w[buf][v / (FC_BU / 4)][(v % (FC_BU / 4)) * 4]) = wv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < X_PT; i++) {
+      const int v = tid + i * FC_THREADS;
+      const int m = v / (FC_BK / 4), k = (v % (FC_BK / 4)) * 4;
+      if (v < X_V) {
+        s_x[buf][k + 0][m] = xv[i].x;
+        s_x[buf][k + 1][m] = xv[i].y;
+        s_x[buf][k + 2][m] = xv[i].z;
+        s_x[buf][k + 3][m] = xv[i].w;
+      }
+    }
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int cur = 0;
   for (int k0 = 0; k0 < kFc1In; k0 += FC_BK) {
-    float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (u0 + lw_u < kFc1Out) wv = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + lw_k) * kFc1Out + u0 + lw_u);
-    float4 xv = *reinterpret_cast<const float4 *>(X + (size_t)xm * kFc1In + k0 + lx_k);
-    __syncthreads();
-    *reinterpret_cast<float4 *>(&s_w[lw_k][lw_u]) = wv;
-    s_x[lx_k + 0][lx_m] = xv.x;
-    s_x[lx_k + 1][lx_m] = xv.y;
-    s_x[lx_k + 2][lx_m] = xv.z;
-    s_x[lx_k + 3][lx_m] = xv.w;
-    __syncthreads();
+    const bool more = k0 + FC_BK < kFc1In;
+    if (more) fetch(k0 + FC_BK);
 #pragma unroll
     for (int kk = 0; kk < FC_BK; kk += 2) {
-      const float a = s_w[kk + (lane >> 5)][wu + (lane & 31)];
-      const float bb = s_x[kk + (lane >> 5)][wm + (lane & 31)];
+      const float a = s_w[cur][kk + (lane >> 5)][wu + (lane & 31)];
+      const float bb = s_x[cur][kk + (lane >> 5)][wm + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
     }
+    if (more) stage(cur ^ 1);  // the other buffer was last read before the previous barrier
+    __syncthreads();
+    cur ^= 1;
   }
   const int m = m0 + wm + (lane & 31);
 #pragma unroll
@@ -483,7 +519,7 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m);
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[1], stream);
     const int n_u_tiles = (kFc1Out + FC_BU - 1) / FC_BU, n_m_groups = ((m + FC_BM - 1) / FC_BM + 7) / 8;
-    fc1_mfma_kernel<<<n_u_tiles * n_m_groups * 8, 256, 0, stream>>>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, n_u_tiles);
+    fc1_mfma_kernel<<<n_u_tiles * n_m_groups * 8, FC_THREADS, 0, stream>>>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, n_u_tiles);
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[2], stream);
     fc2_score_kernel<<<(m + 255) / 256, 256, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
   }
