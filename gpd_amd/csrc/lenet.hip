@@ -209,27 +209,41 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
 //               (3 pixel tiles of 2x8) x 3 filter tiles = 9 independent accumulators; per k-step
 //               3 weight reads + 3 input reads feed 9 MFMAs.  48 = 3 x 16 filters fill the MFMA
 //               tiles exactly (50 would pad 64-row tiles to 78 %).
-//   wave 12     filters 48, 49 by direct convolution on the VALU (scalar weights).
+//               filters 48, 49 ride along in the same waves as a direct convolution on the VALU
+//               (lane <-> conv pixel of the band, scalar weights): 8 fmas per k-step in the
+//               shadow of the other waves' MFMAs.  A separate VALU wave for them was the
+//               critical path of the workgroup (1.53 ms vs 1.16 ms without it).
 // k-ascending fmaf chains as before; output in the reference's flatten order pixel*50 + filter.
-constexpr int C2_MFMA_WAVES = 12, C2_THREADS = 64 * (C2_MFMA_WAVES + 1);
+constexpr int C2_MFMA_WAVES = 12, C2_THREADS = 64 * C2_MFMA_WAVES;
+
+// tap offset inside a 4-channel period: k in [0, 100) -> c * 784 + kh * 28 + kw
+__host__ __device__ constexpr int c2_tap_off(int k) { return (k / 25) * 784 + ((k % 25) / 5) * 28 + (k % 5); }
 
 __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__restrict__ pool1, const float *__restrict__ wt,
                                                                 const float *__restrict__ w, const float *__restrict__ bias,
                                                                 float *__restrict__ flat, int n) {
-  __shared__ __attribute__((aligned(16))) float s_in[20 * 784];
-  __shared__ __attribute__((aligned(16))) float s_w[500 * 48];
-  __shared__ uint16_t s_off[500];
+  // one array: reads one step past the image / the weights (operand prefetch of the last step)
+  // land in the next region, never outside the allocation
+  __shared__ __attribute__((aligned(16))) float s_all[20 * 784 + 500 * 48 + 4 * 48];
+  float *s_in = s_all, *s_w = s_all + 20 * 784;
   const int tid = threadIdx.x;
-  for (int i = tid; i < 500 * 48; i += C2_THREADS) {
+  for (int i = tid; i < 504 * 48; i += C2_THREADS) {
     const int k = i / 48, f = i - k * 48;
-    s_w[i] = wt[k * 50 + f];
-  }
-  for (int k = tid; k < 500; k += C2_THREADS) {
-    const int c = k / 25, tap = k - c * 25;
-    s_off[k] = (uint16_t)(c * 784 + (tap / 5) * 28 + tap % 5);
+    s_w[i] = k < 500 ? wt[k * 50 + f] : 0.f;
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
+  const int kq = lane >> 4, j = lane & 15;
+  // The k axis is walked in periods of 100 taps = 4 channels = 25 MFMA steps: inside a period
+  // every tap offset is a compile-time constant, except the B operand's, whose tap 4s + kq
+  // depends on the lane group: those 25 offsets live in registers.
+  int offp[25];
+#pragma unroll
+  for (int sI = 0; sI < 25; sI++) {
+    const int k = 4 * sI + kq;
+    const int c = k / 25, tap = k - 25 * c;
+    offp[sI] = c * 784 + (tap / 5) * 28 + tap % 5;
+  }
   for (int img = blockIdx.x; img < n; img += gridDim.x) {
     __syncthreads();  // previous image fully consumed (and the weights are in place)
     {
@@ -238,50 +252,85 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
       for (int i = tid; i < 20 * 784 / 4; i += C2_THREADS) dst[i] = src[i];
     }
     __syncthreads();
-    if (wave < C2_MFMA_WAVES) {
-      const int kq = lane >> 4, j = lane & 15;
+    {
       const int rp = wave;  // output rows 2rp, 2rp+1
-      const float *xin = s_in + (2 * rp + (j >> 3)) * 28 + (j & 7);
-      f32x4 acc[3][3];  // [pixel tile][filter tile]
+      f32x4 acc[3][3];      // [pixel tile][filter tile]
 #pragma unroll
       for (int t = 0; t < 3; t++)
 #pragma unroll
         for (int ft = 0; ft < 3; ft++)
 #pragma unroll
           for (int r = 0; r < 4; r++) acc[t][ft][r] = 0.f;
-      // operands of step st+1 are requested before the nine MFMAs of step st
-      float a_cur[3], b_cur[3], a_nxt[3], b_nxt[3];
-      {
-        const float *x0 = xin + s_off[kq];
+      // per-lane bases, advanced by one period per outer iteration
+      const float *xin = s_in + (2 * rp + (j >> 3)) * 28 + (j & 7);  // MFMA B operand: pixel j of tile 0
+      const float *aw = s_w + kq * 48 + j;                            // MFMA A operand: W[k0 + kq][f = j]
+      // filters 48, 49 on the VALU: lane = r * 32 + col is conv pixel (2rp + r, col), col < 24
+      const float *xv = s_in + (2 * rp + (lane >> 5)) * 28 + min(lane & 31, 23);
+      const float *__restrict__ wf = w + (size_t)48 * 500;
+      float t48 = 0.f, t49 = 0.f;
+      // operands of step s+1 are requested before the nine MFMAs of step s
+      float a_cur[3], b_cur[3], a_nxt[3], b_nxt[3], xc[4], xn[4];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          a_cur[q] = s_w[kq * 48 + 16 * q + j];
-          b_cur[q] = x0[8 * q];
-        }
+      for (int q = 0; q < 3; q++) {
+        a_cur[q] = aw[16 * q];
+        b_cur[q] = xin[offp[0] + 8 * q];
       }
-      int off_nxt = s_off[4 + kq];
-#pragma unroll 5
-      for (int st = 0; st < 125; st++) {
-        const int k1 = 4 * (st + 1 < 125 ? st + 1 : st) + kq;
-        const int k2 = 4 * (st + 2 < 125 ? st + 2 : 124) + kq;
-        const float *x1 = xin + off_nxt;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          a_nxt[q] = s_w[k1 * 48 + 16 * q + j];
-          b_nxt[q] = x1[8 * q];
+      for (int i = 0; i < 4; i++) xc[i] = xv[c2_tap_off(i)];
+      for (int it = 0; it < 5; it++) {
+#pragma unroll
+        for (int sI = 0; sI < 25; sI++) {
+          // ---- requests for step s+1 (step 0 of the next period when s = 24)
+          const int s1 = sI + 1 < 25 ? sI + 1 : 0;
+          const int bump = sI + 1 < 25 ? 0 : 4 * 784;
+          const float *x1 = xin + offp[s1] + bump;
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            a_nxt[q] = aw[(sI + 1) * 4 * 48 + 16 * q];
+            b_nxt[q] = x1[8 * q];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) xn[i] = xv[c2_tap_off(4 * s1 + i) + bump];
+          // ---- filters 48, 49: four taps of this step, k ascending
+          const float4 wa = *reinterpret_cast<const float4 *>(wf + 4 * sI);
+          const float4 wb = *reinterpret_cast<const float4 *>(wf + 500 + 4 * sI);
+          t48 = __builtin_fmaf(wa.x, xc[0], t48);
+          t49 = __builtin_fmaf(wb.x, xc[0], t49);
+          t48 = __builtin_fmaf(wa.y, xc[1], t48);
+          t49 = __builtin_fmaf(wb.y, xc[1], t49);
+          t48 = __builtin_fmaf(wa.z, xc[2], t48);
+          t49 = __builtin_fmaf(wb.z, xc[2], t49);
+          t48 = __builtin_fmaf(wa.w, xc[3], t48);
+          t49 = __builtin_fmaf(wb.w, xc[3], t49);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int ft = 0; ft < 3; ft++)
+              acc[t][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ft], b_cur[t], acc[t][ft], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            a_cur[q] = a_nxt[q];
+            b_cur[q] = b_nxt[q];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) xc[i] = xn[i];
         }
-        const int off_nn = s_off[k2];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 3; t++)
-#pragma unroll
-          for (int ft = 0; ft < 3; ft++) acc[t][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ft], b_cur[t], acc[t][ft], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        off_nxt = off_nn;
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          a_cur[q] = a_nxt[q];
-          b_cur[q] = b_nxt[q];
+        xin += 4 * 784;
+        xv += 4 * 784;
+        aw += 100 * 48;
+        wf += 100;
+      }
+      {
+        // pool 2x2: column partner lane ^ 1, row partner lane ^ 32; bias after the max
+        float m48 = fmaxf(t48, __shfl_xor(t48, 1)), m49 = fmaxf(t49, __shfl_xor(t49, 1));
+        m48 = fmaxf(m48, __shfl_xor(m48, 32));
+        m49 = fmaxf(m49, __shfl_xor(m49, 32));
+        const int col = lane & 31;
+        if (lane < 32 && col < 24 && !(col & 1)) {
+          float *o = flat + (size_t)img * kFc1In + (rp * 12 + (col >> 1)) * 50 + 48;
+          *reinterpret_cast<float2 *>(o) = make_float2(m48 + bias[48], m49 + bias[49]);
         }
       }
 #pragma unroll
@@ -307,53 +356,6 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
             *reinterpret_cast<float2 *>(o + f0) = make_float2(v.x, v.y);
             *reinterpret_cast<float2 *>(o + f0 + 2) = make_float2(v.z, v.w);
           }
-        }
-      }
-    } else {
-      // filters 48, 49: lane <-> pooled pixel, weights as scalars in the file layout [f][k]
-      const float *__restrict__ wf = w + (size_t)48 * 500;
-      for (int chunk = 0; chunk < 3; chunk++) {
-        const int p = chunk * 64 + lane;
-        const bool act = p < 144;
-        const int pp = act ? p : 0;
-        const int py = pp / 12, px = pp - py * 12;
-        float acc[2][4];
-#pragma unroll
-        for (int f = 0; f < 2; f++)
-#pragma unroll
-          for (int e = 0; e < 4; e++) acc[f][e] = 0.f;
-        const float *base = s_in + (2 * py) * 28 + 2 * px;
-        for (int c = 0; c < 20; c++) {
-          float patch[6][6];
-#pragma unroll
-          for (int r = 0; r < 6; r++) {
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-              const float2 v = *reinterpret_cast<const float2 *>(base + c * 784 + r * 28 + 2 * e);
-              patch[r][2 * e] = v.x;
-              patch[r][2 * e + 1] = v.y;
-            }
-          }
-#pragma unroll
-          for (int kh = 0; kh < 5; kh++) {
-#pragma unroll
-            for (int kw = 0; kw < 5; kw++) {
-#pragma unroll
-              for (int f = 0; f < 2; f++) {
-                const float wv = wf[f * 500 + c * 25 + kh * 5 + kw];
-                acc[f][0] = __builtin_fmaf(wv, patch[kh][kw], acc[f][0]);
-                acc[f][1] = __builtin_fmaf(wv, patch[kh][kw + 1], acc[f][1]);
-                acc[f][2] = __builtin_fmaf(wv, patch[kh + 1][kw], acc[f][2]);
-                acc[f][3] = __builtin_fmaf(wv, patch[kh + 1][kw + 1], acc[f][3]);
-              }
-            }
-          }
-        }
-        if (act) {
-#pragma unroll
-          for (int f = 0; f < 2; f++)
-            flat[(size_t)img * kFc1In + p * 50 + 48 + f] =
-                fmaxf(fmaxf(acc[f][0], acc[f][1]), fmaxf(acc[f][2], acc[f][3])) + bias[48 + f];
         }
       }
     }
