@@ -54,7 +54,7 @@ namespace gpd {
 constexpr int IMG_THREADS = 512;   // 256 VGPRs per lane: no spills (1024 threads measured equally fast but spilled)
 constexpr int SET_THREADS = 1024;  // shadow_set_kernel
 constexpr int IMG_WAVES = IMG_THREADS / 64;
-constexpr int PT_CAP = 2048;  // in-box points per candidate
+constexpr int PT_CAP = 2048;  // in-box points per candidate (entry indices are packed into 11 bits by sort_by_rank)
 constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
 constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
 constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
@@ -269,27 +269,44 @@ __device__ int scan_cells(SM &S) {
   return total;
 }
 
-// list of the non-empty cells (ascending) so that the walks give one pixel to one lane in a
-// single pass; returns their number
+// list of the non-empty cells, ordered by their point count, descending (counting sort into 32
+// buckets; counts >= 31 share the first).  The walks give one pixel to one lane, so a wave runs as
+// long as its longest pixel: with equal lengths side by side the waves execute ~40 % fewer
+// (mostly idle) iterations than in cell order.  Pixels are independent, their order is free.
+// Returns the number of non-empty cells.
 template <class SM>
 __device__ int list_nonempty_cells(SM &S, uint16_t *nz) {
   const int tid = threadIdx.x;
   constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;
-  int cnt = 0;
+  int *hist = reinterpret_cast<int *>(S.red_f);  // 32 counters; red_f is idle until finalize_planes
+  if (tid < 32) hist[tid] = 0;
+  __syncthreads();
+  int bucket[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const int i = tid * PER + k;
-    if (i < kPix && (S.cells[i] & 0xffffu)) cnt++;
-  }
-  int total;
-  int pos = block_excl_scan(S, cnt, &total);
-#pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const int i = tid * PER + k;
-    if (i < kPix && (S.cells[i] & 0xffffu)) nz[pos++] = (uint16_t)i;
+    const int cn = i < kPix ? (int)(S.cells[i] & 0xffffu) : 0;
+    bucket[k] = cn ? 31 - (cn < 31 ? cn : 31) : -1;
+    if (cn) atomicAdd(&hist[bucket[k]], 1);
   }
   __syncthreads();
-  return total;
+  if (tid < 64) {
+    const int v = tid < 32 ? hist[tid] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int x = __shfl_up(incl, o);
+      if (tid >= o) incl += x;
+    }
+    if (tid < 32) hist[tid] = incl - v;
+    if (tid == 31) S.red_i[0] = incl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; k++)
+    if (bucket[k] >= 0) nz[atomicAdd(&hist[bucket[k]], 1)] = (uint16_t)(tid * PER + k);
+  __syncthreads();
+  return S.red_i[0];
 }
 
 // 3x3 rect max-dilate (border ignored), NORM_MINMAX to [0,1], u8 = round-half-even(v*255)
@@ -393,7 +410,12 @@ __device__ void finalize_planes(SM &S, const float *p012, const float *p3, uint8
   __syncthreads();
 }
 
+template <int N>
+__device__ inline void sort_u16_regs(uint16_t *p, int n);
 __device__ inline void sort_u16(uint16_t *p, int n) {
+  if (n <= 8) return sort_u16_regs<8>(p, n);
+  if (n <= 16) return sort_u16_regs<16>(p, n);
+  if (n <= 32) return sort_u16_regs<32>(p, n);
   for (int i = 1; i < n; i++) {
     const uint16_t v = p[i];
     int j = i - 1;
@@ -404,8 +426,58 @@ __device__ inline void sort_u16(uint16_t *p, int n) {
     p[j + 1] = v;
   }
 }
+// N keys in registers, ascending (bitonic network, fully unrolled: 24 / 80 / 240 compare-exchanges
+// for N = 8 / 16 / 32).  The walks order their short per-pixel segments through registers: N
+// independent LDS reads, the network, N writes — one LDS round trip instead of the dependent
+// read-compare-write chain of an insertion sort (~300 cycles per step, O(n^2) steps).
+template <int N>
+__device__ inline void sort_regs(uint32_t (&k)[N]) {
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const uint32_t lo = min(k[i], k[j]), hi = max(k[i], k[j]);
+          const bool up = (i & size) == 0;
+          k[i] = up ? lo : hi;
+          k[j] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+template <int N>
+__device__ inline void sort_u16_regs(uint16_t *p, int n) {
+  uint32_t k[N];
+#pragma unroll
+  for (int q = 0; q < N; q++) k[q] = q < n ? (uint32_t)p[q] : 0xffffffffu;
+  sort_regs<N>(k);
+#pragma unroll
+  for (int q = 0; q < N; q++)
+    if (q < n) p[q] = (uint16_t)k[q];
+}
+// (rank << 11 | entry) packed keys; entries are < 2048, rank = key[entry] >> 18
+template <int N>
+__device__ inline void sort_by_rank_regs(uint16_t *p, int n, const uint32_t *key) {
+  uint32_t k[N];
+#pragma unroll
+  for (int q = 0; q < N; q++) {
+    const uint32_t e = p[q];
+    k[q] = q < n ? ((key[e & 2047u] >> 18) << 11) | e : 0xffffffffu;
+  }
+  sort_regs<N>(k);
+#pragma unroll
+  for (int q = 0; q < N; q++)
+    if (q < n) p[q] = (uint16_t)(k[q] & 2047u);
+}
 // sort entry indices by the neighbour rank stored in key[] (rank = key >> 18)
 __device__ inline void sort_by_rank(uint16_t *p, int n, const uint32_t *key) {
+  if (n <= 8) return sort_by_rank_regs<8>(p, n, key);
+  if (n <= 16) return sort_by_rank_regs<16>(p, n, key);
+  if (n <= 32) return sort_by_rank_regs<32>(p, n, key);
   for (int i = 1; i < n; i++) {
     const uint16_t v = p[i];
     const uint32_t kv = key[v] >> 18;
@@ -452,7 +524,7 @@ __device__ inline void load_box(const gpd_hand &H, Box &B) {
 // (createShadowImage, image_strategy.cpp:192-233; 15 channels only).
 // ---------------------------------------------------------------------------
 template <int SHC>
-__global__ __launch_bounds__(IMG_THREADS) void shadow_image_kernel(ImgParams P) {
+__global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_image_kernel(ImgParams P) {
   __shared__ SmemShadow<SHC> S;
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
@@ -563,8 +635,8 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_image_kernel(ImgParams P) 
   __syncthreads();  // from here on bp.place may overwrite bp.bits
   const int ns = n_sh < SHC ? n_sh : SHC;
   if (P.dbg && tid == 0) {
-    atomicMax(&P.dbg[12], (unsigned long long)n_sh);
-    atomicAdd(&P.dbg[13], (unsigned long long)n_sh);
+    atomicMax(&P.dbg[28], (unsigned long long)n_sh);
+    atomicAdd(&P.dbg[29], (unsigned long long)n_sh);
   }
   // the three cell coordinates of every entry, once: voxel -> hand frame -> exact threshold lookup
   for (int k = tid; k < ns; k += IMG_THREADS) {
@@ -605,14 +677,14 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_image_kernel(ImgParams P) 
     const int n_nz = list_nonempty_cells(S, S.nz);
     for (int c = tid; c < kPix; c += IMG_THREADS) S.raster0[c] = 0.f;
     __syncthreads();
+    TICK(9);
     for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
       const int c = S.nz[qn];
       const uint32_t w = S.cells[c];
       const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
-      sort_u16(&S.bp.place[start], cn);
       float v = 0.f, fc = 0.f;
-      for (int e = 0; e < cn; e++) {
-        const int lin = (int)(S.lin[S.bp.place[start + e]] & 0x1ffffu);
+      auto visit = [&](int k) {  // one set voxel, in ascending voxel order (the std::set order of the oracle)
+        const int lin = (int)(S.lin[k] & 0x1ffffu);
         const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
         const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
                      c2 = (double)(iz + z0) * K.voxel - B.sample[2];
@@ -620,11 +692,15 @@ __global__ __launch_bounds__(IMG_THREADS) void shadow_image_kernel(ImgParams P) 
         const double d = div_len(td - offd, da);
         fc = (float)((double)fc + 1.0);
         v = (float)((double)v + (d - (double)v) * recip_count<128>(S.recip, fc));
-      }
+      };
+      sort_u16(&S.bp.place[start], cn);
+      for (int e = 0; e < cn; e++) visit((int)S.bp.place[start + e]);
       lmax = fmaxf(lmax, v);
       lany = 1;
       S.raster0[c] = v;
     }
+    __syncthreads();
+    TICK(10);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       lmax = fmaxf(lmax, __shfl_xor(lmax, o));
@@ -715,8 +791,8 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   if (n_box_all > PT_CAP && tid == 0) atomicOr(&S.flag, 2);
   const int nb = n_box_all < PT_CAP ? n_box_all : PT_CAP;
   if (P.dbg && tid == 0) {
-    atomicMax(&P.dbg[14], (unsigned long long)n_box_all);
-    atomicAdd(&P.dbg[15], (unsigned long long)n_box_all);
+    atomicMax(&P.dbg[30], (unsigned long long)n_box_all);
+    atomicAdd(&P.dbg[31], (unsigned long long)n_box_all);
   }
   TICK(5);
   for (int pr = 0; pr < K.nproj; pr++) {
@@ -736,6 +812,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
     uint16_t *nz = &S.place[PT_CAP];
     const int n_nz = list_nonempty_cells(S, nz);
+    TICK(11);
     for (int c = tid; c < kPix; c += IMG_THREADS) {
       if (!(S.cells[c] & 0xffffu)) {
         S.raster[0][c] = 0.f;
@@ -745,15 +822,14 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       }
     }
     __syncthreads();
+    TICK(12);
     for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
       const int c = nz[qn];
       const uint32_t w = S.cells[c];
       const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      sort_by_rank(&S.place[start], cn, S.p.key);
       float avg = 0.f, fc = 0.f;
-      for (int q = 0; q < cn; q++) {
-        const int e = S.place[start + q];
+      auto visit = [&](int e) {  // one in-box point, in neighbour order
         const float a0 = S.p.a[0][e], a1 = S.p.a[1][e], a2 = S.p.a[2][e];
         if (v0 == 0.f && v1 == 0.f && v2 == 0.f) {
           v0 = a0;
@@ -770,12 +846,15 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
         const double d = div_len(S.p.t[da][e] - offd, da);
         fc = (float)((double)fc + 1.0);
         avg = (float)((double)avg + (d - (double)avg) * recip_count<256>(S.recip, fc));
-      }
+      };
+      sort_by_rank(&S.place[start], cn, S.p.key);
+      for (int q = 0; q < cn; q++) visit((int)S.place[start + q]);
       S.raster[0][c] = v0;
       S.raster[1][c] = v1;
       S.raster[2][c] = v2;
       S.cells[c] = __float_as_uint((float)(1.0 - (double)avg));  // the depth plane, in place of the segment table
     }
+    TICK(13);
     __syncthreads();
     TICK(7);
     if (K.C == 1)  // Image1ChannelsStrategy: the depth image alone (image_1_channels_strategy.cpp:25-40)
@@ -1111,8 +1190,8 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
   static unsigned long long *d_dbg = nullptr;
   ip.dbg = nullptr;
   if (getenv("GPD_IMG_TIMING")) {
-    if (!d_dbg) HIP_RET(hipMalloc(&d_dbg, 16 * sizeof(unsigned long long)));
-    HIP_RET(hipMemsetAsync(d_dbg, 0, 16 * sizeof(unsigned long long), stream));
+    if (!d_dbg) HIP_RET(hipMalloc(&d_dbg, 32 * sizeof(unsigned long long)));
+    HIP_RET(hipMemsetAsync(d_dbg, 0, 32 * sizeof(unsigned long long), stream));
     ip.dbg = d_dbg;
   }
   ip.set_bits = im.d_set_bits;
@@ -1154,18 +1233,19 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
   grasp_image_kernel<<<n, IMG_THREADS, 0, stream>>>(ip);
   HIP_RET(hipGetLastError());
   if (ip.dbg) {
-    unsigned long long h[16];
+    unsigned long long h[32];
     HIP_RET(hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_RET(hipStreamSynchronize(stream));
-    static const char *names[9] = {"sh_extract",  "sh_list",         "sh_count_place", "sh_walk",  "sh_final",
-                                   "pts_collect", "pts_count_place", "pts_walk",       "pts_final"};
+    static const char *names[14] = {"sh_extract",  "sh_list",         "sh_count_place", "sh_walk_tail", "sh_final",
+                                    "pts_collect", "pts_count_place", "pts_walk_tail",  "pts_final",    "sh_nzlist",
+                                    "sh_walk_loop", "pts_nzlist",     "pts_zero",       "pts_walk_loop"};
     unsigned long long tot = 0;
-    for (int i = 0; i < 9; i++) tot += h[i];
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < 14; i++) tot += h[i];
+    for (int i = 0; i < 14; i++)
       fprintf(stderr, "[img-timing] %-16s %10.1f kcycles/cand  %5.1f%%\n", names[i], (double)h[i] / n / 1e3,
               100.0 * h[i] / (double)tot);
-    fprintf(stderr, "[img-timing] shadow voxels in box: max %llu mean %.0f; in-box points: max %llu mean %.0f\n", h[12],
-            (double)h[13] / n, h[14], (double)h[15] / n);
+    fprintf(stderr, "[img-timing] shadow voxels in box: max %llu mean %.0f; in-box points: max %llu mean %.0f\n", h[28],
+            (double)h[29] / n, h[30], (double)h[31] / n);
   }
   if (!check) return GPD_OK;
   int32_t status = 0;
