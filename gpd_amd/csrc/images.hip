@@ -859,8 +859,11 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     TICK(7);
     if (K.C == 1)  // Image1ChannelsStrategy: the depth image alone (image_1_channels_strategy.cpp:25-40)
       finalize_planes<1>(S, reinterpret_cast<const float *>(S.cells), nullptr, out);
-    else if (K.C >= 12)
-      finalize_planes<4>(S, &S.raster[0][0], reinterpret_cast<const float *>(S.cells), out + (size_t)(pr * K.per) * kPix);
+    else if (K.C >= 12) {
+      // two passes (normals, then depth): one 4-plane pass keeps 32 dilated values per lane and spills
+      finalize_planes<3>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per) * kPix);
+      finalize_planes<1>(S, reinterpret_cast<const float *>(S.cells), nullptr, out + (size_t)(pr * K.per + 3) * kPix);
+    }
     else
       finalize_planes<3>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per) * kPix);
     TICK(8);
