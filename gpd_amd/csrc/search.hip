@@ -28,6 +28,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <type_traits>
+
 #include "gpd_internal.h"
 
 namespace gpd {
@@ -358,7 +360,8 @@ struct NbParams {
   const int32_t *sample_idx;
   const double *sample_xyz;  // non-null: samples by coordinates; the query is their float cast (eigenVectorToPcl)
   float r2_hands, r2_images, r2_frames;
-  int cap;  // power of two
+  int cap;  // list capacity; a power of two in bitonic mode
+  int bucket;  // 1: bucket sort (keys + u16 slot table + 2 x 1024 counters in LDS), 0: in-place bitonic sort
   int32_t *counts;  // [S][8]: N_hands, N_images, k_frames, found, mask of cameras that see the image neighbourhood, -, -, -
   int32_t *nn_idx;
   float *nn;
@@ -370,12 +373,40 @@ struct NbParams {
   float reach;  // half-edge of the cube of cells to visit (radius + margin)
 };
 
+// ---- bucket sort of the (d2, index) keys -------------------------------------------------
+// d2 < r2 maps monotonically to one of NB_BUCKETS buckets (about 3-5 keys each at the reference's
+// radii); a counting sort groups the point indices bucket by bucket and every bucket is ordered
+// through registers.  LDS holds two u32 arrays (visit order / bucket order of the indices; after
+// the sort: d2 bits / indices, both sorted) — the same 64 KB as the u64 keys of the bitonic path,
+// d2 is recomputed from the coordinates (bit-identical, L2 hits) instead of being stored twice.
+// Five barriers instead of the 78 barrier-separated bitonic stages (648 of the kernel's 1320 us).
+constexpr int NB_BUCKETS = 1024;
+template <int N>
+__device__ inline void sort_regs64(unsigned long long (&k)[N]) {
+#pragma unroll
+  for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const bool up = (i & size) == 0;
+          const unsigned long long a = k[i], b = k[j];
+          const bool sw = (a > b) == up;
+          k[i] = sw ? b : a;
+          k[j] = sw ? a : b;
+        }
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
   __shared__ int s_count;
   __shared__ int s_bounds[2];
   __shared__ int s_seen;
-  __shared__ double s_center[3];
+  __shared__ int s_ncrowd;
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -402,7 +433,30 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     s_bounds[0] = 0;
     s_bounds[1] = 0;
     s_seen = 0;
+    s_ncrowd = 0;
   }
+  // bucket mode: two u32 arrays in the key storage, counters behind them
+  uint32_t *s_a = reinterpret_cast<uint32_t *>(s_keys);  // indices in visit order, then sorted d2 bits
+  uint32_t *s_b = s_a + P.cap;                           // indices in bucket order, then sorted
+  int *s_hist = reinterpret_cast<int *>(s_keys + P.cap);
+  int *s_start = s_hist + NB_BUCKETS;  // NB_BUCKETS + 1 entries
+  auto d2_of = [&](int i) {  // FLANN L2_Simple<float>, the same operation order as in the visit
+    float d = qx - P.px[i];
+    float d2 = 0.f;
+    d2 += d * d;
+    d = qy - P.py[i];
+    d2 += d * d;
+    d = qz - P.pz[i];
+    d2 += d * d;
+    return d2;
+  };
+  const float bscale = (float)NB_BUCKETS / P.r2_hands;
+  auto bucket_of = [&](float d2) {
+    const int b = (int)(d2 * bscale);
+    return b < NB_BUCKETS - 1 ? b : NB_BUCKETS - 1;
+  };
+  if (P.bucket)
+    for (int i = tid; i < NB_BUCKETS; i += 256) s_hist[i] = 0;
   __syncthreads();
   // 1. visit the grid cells around the sample; FLANN L2_Simple<float>: d2 accumulated over
   //    x,y,z, strict <
@@ -422,38 +476,161 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
       base = __shfl(base, 0);
       if (hit) {
         const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (pos < P.cap) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+        if (pos < P.cap) {
+          if (P.bucket) {
+            s_a[pos] = (uint32_t)i;
+            atomicAdd(&s_hist[bucket_of(d2)], 1);
+          } else {
+            s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+          }
+        }
       }
     }
   });
   __syncthreads();
   const int found = s_count;
   const int n = found < P.cap ? found : P.cap;
-  int m = 1;
-  while (m < n) m <<= 1;
-  for (int i = n + tid; i < m; i += 256) s_keys[i] = ~0ull;
-  __syncthreads();
-  // 2. bitonic sort ascending by (d2 bits, index); non-negative floats order as unsigned
-  for (int k = 2; k <= m; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (m >> 1); t += 256) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const unsigned long long a = s_keys[lo], b = s_keys[hi];
-        if ((a > b) == up) {
-          s_keys[lo] = b;
-          s_keys[hi] = a;
+  if (P.bucket) {
+    // 2. bucket sort: exclusive scan of the counters (four buckets per lane) ...
+    __shared__ int s_wsum[4];
+    int c4[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      c4[q] = s_hist[4 * tid + q];
+      sum += c4[q];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int x = __shfl_up(incl, o);
+      if (lane >= o) incl += x;
+    }
+    if (lane == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (tid >> 6); w++) run += s_wsum[w];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      s_start[4 * tid + q] = run;
+      s_hist[4 * tid + q] = run;  // the scatter cursor
+      run += c4[q];
+    }
+    if (tid == 255) s_start[NB_BUCKETS] = run;
+    __syncthreads();
+    // ... indices grouped bucket by bucket ...
+    for (int t = tid; t < n; t += 256) {
+      const uint32_t i = s_a[t];
+      s_b[atomicAdd(&s_hist[bucket_of(d2_of((int)i))], 1)] = i;
+    }
+    __syncthreads();
+    // ... and every bucket ordered by (d2 bits, index); non-negative floats order as unsigned.
+    // s_a (dead) receives the sorted d2 bits.
+    for (int b = tid; b < NB_BUCKETS; b += 256) {
+      const int st = s_start[b], nb = s_start[b + 1] - st;
+      if (nb <= 0) continue;
+      auto run = [&](auto tag) {
+        constexpr int N = decltype(tag)::value;
+        unsigned long long k[N];
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+          const uint32_t i = s_b[st + (q < nb ? q : 0)];
+          k[q] = q < nb ? ((unsigned long long)__float_as_uint(d2_of((int)i)) << 32) | i : ~0ull;
+        }
+        sort_regs64<N>(k);
+#pragma unroll
+        for (int q = 0; q < N; q++)
+          if (q < nb) {
+            s_a[st + q] = (uint32_t)(k[q] >> 32);
+            s_b[st + q] = (uint32_t)k[q];
+          }
+      };
+      if (nb <= 4)
+        run(std::integral_constant<int, 4>());
+      else if (nb <= 8)
+        run(std::integral_constant<int, 8>());
+      else if (nb <= 16)
+        run(std::integral_constant<int, 16>());
+      else {
+        // crowded bucket (lattice clouds put dozens of points at exactly the same distance): left
+        // to a whole wave below
+        const int c = atomicAdd(&s_ncrowd, 1);
+        if (c < NB_BUCKETS) s_hist[c] = b;  // the scatter cursors are dead: their storage lists the crowded buckets
+      }
+    }
+    __syncthreads();
+    const int ncrowd = s_ncrowd < NB_BUCKETS ? s_ncrowd : NB_BUCKETS;
+    for (int c = tid >> 6; c < ncrowd; c += 4) {
+      const int b = s_hist[c];
+      const int st = s_start[b], nb = s_start[b + 1] - st;
+      if (nb <= 64) {
+        // one key per lane, bitonic network across the wave
+        const uint32_t i = lane < nb ? s_b[st + lane] : 0u;
+        unsigned long long k = lane < nb ? ((unsigned long long)__float_as_uint(d2_of((int)i)) << 32) | i : ~0ull;
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+          for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)k, stride), hi = __shfl_xor((unsigned)(k >> 32), stride);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            const bool keep_min = ((lane & stride) == 0) == ((lane & size) == 0);
+            k = keep_min ? (k < other ? k : other) : (k > other ? k : other);
+          }
+        }
+        if (lane < nb) {
+          s_a[st + lane] = (uint32_t)(k >> 32);
+          s_b[st + lane] = (uint32_t)k;
+        }
+      } else {
+        // more than 64 equal-ish distances: d2 column first (all lanes), then one lane sorts in LDS
+        for (int x = lane; x < nb; x += 64) s_a[st + x] = __float_as_uint(d2_of((int)s_b[st + x]));
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          for (int x = 1; x < nb; x++) {
+            const uint32_t vd = s_a[st + x], vi = s_b[st + x];
+            const unsigned long long v = ((unsigned long long)vd << 32) | vi;
+            int j = x - 1;
+            while (j >= 0 && (((unsigned long long)s_a[st + j] << 32) | s_b[st + j]) > v) {
+              s_a[st + j + 1] = s_a[st + j];
+              s_b[st + j + 1] = s_b[st + j];
+              j--;
+            }
+            s_a[st + j + 1] = vd;
+            s_b[st + j + 1] = vi;
+          }
         }
       }
-      __syncthreads();
+    }
+    __syncthreads();
+  } else {
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int i = n + tid; i < m; i += 256) s_keys[i] = ~0ull;
+    __syncthreads();
+    // 2. bitonic sort ascending by (d2 bits, index); non-negative floats order as unsigned
+    for (int k = 2; k <= m; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (m >> 1); t += 256) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool up = (lo & k) == 0;
+          const unsigned long long a = s_keys[lo], b = s_keys[hi];
+          if ((a > b) == up) {
+            s_keys[lo] = b;
+            s_keys[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
     }
   }
+  // sorted position t -> d2 bits / point index
+  auto d2bits_at = [&](int t) { return P.bucket ? s_a[t] : (unsigned)(s_keys[t] >> 32); };
+  auto index_at = [&](int t) { return P.bucket ? (int)s_b[t] : (int)(unsigned)(s_keys[t] & 0xffffffffull); };
   // 3. prefix lengths of the image and frame neighbourhoods
   const unsigned ri = __float_as_uint(P.r2_images), rf = __float_as_uint(P.r2_frames);
   for (int t = tid; t < n; t += 256) {
-    const unsigned d = (unsigned)(s_keys[t] >> 32);
-    const unsigned dn = (t + 1 < n) ? (unsigned)(s_keys[t + 1] >> 32) : 0xffffffffu;
+    const unsigned d = d2bits_at(t);
+    const unsigned dn = (t + 1 < n) ? d2bits_at(t + 1) : 0xffffffffu;
     if (d < ri && dn >= ri) s_bounds[0] = t + 1;
     if (d < rf && dn >= rf) s_bounds[1] = t + 1;
   }
@@ -465,7 +642,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   const int n_img = s_bounds[0];
   int seen = 0;
   for (int t = tid; t < n; t += 256) {
-    const int i = (int)(unsigned)(s_keys[t] & 0xffffffffull);
+    const int i = index_at(t);
     oi[t] = i;
     const float x = P.px[i], y = P.py[i];
     on[0 * P.cap + t] = x;
@@ -476,27 +653,10 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     on[5 * P.cap + t] = P.nz[i];
     if (t < n_img)
       for (int cam = 0; cam < P.num_cams; cam++) seen |= (P.cam_source[(size_t)cam * P.num_points + i] != 0) << cam;
-    s_keys[t] = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x);
   }
   if (seen) atomicOr(&s_seen, seen);
-  __threadfence_block();
+  __threadfence_block();  // lane 0 reads the gathered normals back below
   __syncthreads();
-  // 4b. centre of the image neighbourhood: sequential fp64 sums in neighbour order
-  //     (HandSet::calculateShadow, hand_set.cpp:131-133), one lane per coordinate.
-  if (tid == 64 || tid == 128) {
-    const int sh = (tid == 128) ? 32 : 0;
-    double acc = 0.0;
-    for (int t = 0; t < n_img; t++) acc += (double)__uint_as_float((unsigned)(s_keys[t] >> sh));
-    s_center[tid == 128 ? 1 : 0] = acc;
-  }
-  __syncthreads();
-  for (int t = tid; t < n_img; t += 256) s_keys[t] = __float_as_uint(on[2 * P.cap + t]);
-  __syncthreads();
-  if (tid == 64) {
-    double acc = 0.0;
-    for (int t = 0; t < n_img; t++) acc += (double)__uint_as_float((unsigned)s_keys[t]);
-    s_center[2] = acc;
-  }
   // 5. local frame (local_frame.cpp:14-41), sequential sums in neighbour order
   if (tid == 0) {
     const int kf = s_bounds[1];
@@ -553,11 +713,36 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    P.counts[8 * s + 4] = s_seen;
-    const int ni = s_bounds[0];
-    for (int r = 0; r < 3; r++) P.centers[3 * (size_t)s + r] = ni > 0 ? s_center[r] / (double)ni : 0.0;
+  if (tid == 0) P.counts[8 * s + 4] = s_seen;
+}
+
+// centre of the image neighbourhood (HandSet::calculateShadow, hand_set.cpp:131-133): sequential
+// fp64 sums in neighbour order.  The chain is serial, so one LANE per (sample, coordinate) walks it
+// and the whole batch runs side by side (inside neighbourhood_kernel the three chains of a sample
+// kept a 256-thread workgroup waiting: 390 of its 1320 us).
+__global__ __launch_bounds__(64) void centre_kernel(const float *__restrict__ nn, const int32_t *__restrict__ counts, int cap,
+                                                    int num_samples, double *__restrict__ centers) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= 3 * num_samples) return;
+  const int s = g / 3, c = g - 3 * s;
+  const int n_img = counts[8 * s + 1];
+  const float *row = nn + ((size_t)s * 6 + c) * cap;
+  double acc = 0.0;
+  int t = 0;
+  for (; t + 16 <= n_img; t += 16) {  // four 16-byte loads in flight, adds in order
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const float4 *>(row + t + 4 * i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      acc += (double)v[i].x;
+      acc += (double)v[i].y;
+      acc += (double)v[i].z;
+      acc += (double)v[i].w;
+    }
   }
+  for (; t < n_img; t++) acc += (double)row[t];
+  centers[g] = n_img > 0 ? acc / (double)n_img : 0.0;
 }
 
 // ---------------------------------------------------------------------------
@@ -762,6 +947,7 @@ struct HandParams {
   const double *frames;
   int cap;
   gpd_hand *hands;
+  int num_samples;
   int32_t *labels;  // reeval_kernel only: [n][8] rows of the counts table, column 5
 };
 
@@ -985,8 +1171,13 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   __shared__ double s_d[4];
   __shared__ long long s_l[4];
   const HandConsts &K = c_hand;
-  const int s = blockIdx.x / K.slots;
-  const int slot = blockIdx.x - s * K.slots;
+  // XCD-aware order (workgroup L runs on XCD L % 8, one L2 per XCD): all orientations of a sample
+  // run on the same XCD, so its neighbourhood is fetched from HBM once, not once per XCD
+  // (1.87 GB per launch before, 9x the algorithmic bytes).  L = 8 * (slots * g + slot) + xcd.
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int s = (idx / K.slots) * 8 + xcd;
+  const int slot = idx % K.slots;
+  if (s >= P.num_samples) return;
   const int tid = threadIdx.x;
   const int N = P.counts[8 * s + 0];
   const int kf = P.counts[8 * s + 2];
@@ -1185,10 +1376,15 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.num_cams = c.num_cams;
   np.grid = grid_view(c);
   np.reach = (float)hc.nn_radius_hands * 1.001f + 1e-5f;
-  const size_t lds = (size_t)cap * sizeof(unsigned long long);
+  // 8192-entry lists are bucket-sorted (64 + 8 KB of LDS: two workgroups per CU); the 16384-entry
+  // retry of an overfull neighbourhood sorts in place (bitonic, 128 KB)
+  np.bucket = cap < 16384 ? 1 : 0;
+  const size_t lds = (size_t)cap * sizeof(unsigned long long) + (np.bucket ? (2 * NB_BUCKETS + 1) * sizeof(int) : 0);
   HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
   neighbourhood_kernel<<<S, 256, lds, stream>>>(np);
+  HIP_RET(hipGetLastError());
+  centre_kernel<<<(3 * S + 63) / 64, 64, 0, stream>>>(s.d_nn, s.d_counts, cap, S, s.d_centers);
   HIP_RET(hipGetLastError());
   s.h_counts.resize((size_t)S * 8);
   HIP_RET(hipMemcpyAsync(s.h_counts.data(), s.d_counts, (size_t)S * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -1266,7 +1462,8 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   hp.cap = cap;
   hp.hands = s.d_hands;
   hp.labels = nullptr;
-  hand_eval_kernel<<<S * slots, 256, 0, stream>>>(hp);
+  hp.num_samples = S;
+  hand_eval_kernel<<<((S + 7) / 8) * 8 * slots, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
   s.num_samples = S;
   s.cloud_generation = c.generation;
@@ -1296,6 +1493,7 @@ int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand
   hp.cap = cap;
   hp.hands = s.d_hands;
   hp.labels = s.d_counts;
+  hp.num_samples = n;
   reeval_kernel<<<n, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
   HIP_RET(hipMemcpyAsync(hands, s.d_hands, (size_t)n * sizeof(gpd_hand), hipMemcpyDeviceToHost, stream));
