@@ -1002,6 +1002,12 @@ struct ListCtx {
   double sample[3];
   double hand_height;
   int ghost_mult;  // N - k (valid after pass 0)
+  // hand_eval_kernel: the in-height entries compacted into LDS by pass 0 — forward / lateral
+  // coordinate and neighbour rank of each (ct0 == nullptr: not compacted, every pass transforms
+  // all N points again)
+  const double *ct0, *ct1;
+  const unsigned short *ce;
+  int kc;
 };
 __device__ inline bool list_entry(const ListCtx &L, int e, double t[3], double tn[3], int &mult) {
   const int i = (e == L.N) ? 0 : e;
@@ -1022,26 +1028,44 @@ __device__ inline bool list_entry(const ListCtx &L, int e, double t[3], double t
   return t[2] > -1.0 * L.hand_height && t[2] < L.hand_height;
 }
 
+// f(t0, t1, mult, rank) for every entry of the list FingerHand sees (in-height points, then the
+// ghost with rank N); the passes are order-free reductions, so the compacted order is as good
+template <class F>
+__device__ inline void for_each_entry(const ListCtx &L, F f) {
+  if (L.ct0) {
+    for (int c = threadIdx.x; c < L.kc; c += 256) f(L.ct0[c], L.ct1[c], 1, (int)L.ce[c]);
+    if (threadIdx.x == 255 && L.ghost_mult > 0) {
+      double t[3], tn[3];
+      int mult;
+      list_entry(L, L.N, t, tn, mult);
+      f(t[0], t[1], mult, L.N);
+    }
+  } else {
+    for (int e = threadIdx.x; e <= L.N; e += 256) {
+      double t[3], tn[3];
+      int mult;
+      if (list_entry(L, e, t, tn, mult)) f(t[0], t[1], mult, e);
+    }
+  }
+}
+
 __constant__ HandConsts c_hand;
+constexpr int HE_COMPACT = 2048;  // in-height entries kept in LDS by hand_eval_kernel (36 KB: four workgroups per CU)
 
 // computePointsInClosingRegion (finger_hand.cpp:141-171) + grasp width (hand_set.cpp:235-245) +
 // Antipodal::evaluateGrasp (antipodal.cpp:10-96; lateral 1, forward 0, vertical 2) over the list of
 // L.  Returns false when the closing region is empty; label 0 none, 1 half, 2 full.
 __device__ bool closing_region_label(const ListCtx &L, int N, double top, double bottom, double left, double right, const HandConsts &K,
                                      double &width, int &label, unsigned *s_u, double *s_d, long long *s_l) {
-  const int tid = threadIdx.x;
   double ymin = DBL_MAX, ymax = -DBL_MAX;
   unsigned any_c = 0;
-  for (int e = tid; e <= N; e += 256) {
-    double t[3], tn[3];
-    int mult;
-    if (!list_entry(L, e, t, tn, mult)) continue;
-    if (t[0] > bottom && t[0] < top && t[1] > left && t[1] < right) {
+  for_each_entry(L, [&](double t0, double t1, int, int) {
+    if (t0 > bottom && t0 < top && t1 > left && t1 < right) {
       any_c = 1;
-      ymin = fmin(ymin, t[1]);
-      ymax = fmax(ymax, t[1]);
+      ymin = fmin(ymin, t1);
+      ymax = fmax(ymax, t1);
     }
-  }
+  });
   any_c = block_or(any_c, s_u);
   label = 0;
   width = 0.0;
@@ -1053,11 +1077,11 @@ __device__ bool closing_region_label(const ListCtx &L, int N, double top, double
   double lx0 = DBL_MAX, lx1 = -DBL_MAX, lz0 = DBL_MAX, lz1 = -DBL_MAX;
   double rx0 = DBL_MAX, rx1 = -DBL_MAX, rz0 = DBL_MAX, rz1 = -DBL_MAX;
   unsigned lr = 0;
-  for (int e = tid; e <= N; e += 256) {
-    double t[3], tn[3];
+  for_each_entry(L, [&](double t0, double t1, int, int e) {
+    if (!(t0 > bottom && t0 < top && t1 > left && t1 < right)) return;
+    double t[3], tn[3];  // the vertical coordinate and the normal only of the few points between the fingers
     int mult;
-    if (!list_entry(L, e, t, tn, mult)) continue;
-    if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
+    list_entry(L, e, t, tn, mult);
     const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
     const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
     if (ln > K.cos_friction && t[1] < min_x) {
@@ -1074,7 +1098,7 @@ __device__ bool closing_region_label(const ListCtx &L, int N, double top, double
       rz0 = fmin(rz0, t[2]);
       rz1 = fmax(rz1, t[2]);
     }
-  }
+  });
   lr = block_or(lr, s_u);
   if (lr) label = 1;
   if (lr == 3u) {
@@ -1089,17 +1113,17 @@ __device__ bool closing_region_label(const ListCtx &L, int N, double top, double
     const double top_y = fmin(lx1, rx1), bot_y = fmax(lx0, rx0);
     const double top_z = fmin(lz1, rz1), bot_z = fmax(lz0, rz0);
     long long nl = 0, nr = 0;
-    for (int e = tid; e <= N; e += 256) {
+    for_each_entry(L, [&](double t0, double t1, int mult, int e) {
+      if (!(t0 > bottom && t0 < top && t1 > left && t1 < right)) return;
       double t[3], tn[3];
-      int mult;
-      if (!list_entry(L, e, t, tn, mult)) continue;
-      if (!(t[0] > bottom && t[0] < top && t[1] > left && t[1] < right)) continue;
+      int m1;
+      list_entry(L, e, t, tn, m1);
       const double ln = 0.0 * tn[0] + -1.0 * tn[1] + 0.0 * tn[2];
       const double rn = 0.0 * tn[0] + 1.0 * tn[1] + 0.0 * tn[2];
       const bool inb = t[0] >= bot_y && t[0] <= top_y && t[2] >= bot_z && t[2] <= top_z;
       if (ln > K.cos_friction && t[1] < min_x && inb) nl += mult;
       if (rn > K.cos_friction && t[1] > max_x && inb) nr += mult;
-    }
+    });
     nl = block_sum(nl, s_l);
     nr = block_sum(nr, s_l);
     if (nl >= K.min_viable && nr >= K.min_viable) label = 2;
@@ -1133,6 +1157,10 @@ __global__ __launch_bounds__(256) void reeval_kernel(HandParams P) {
 #pragma unroll
     for (int i = 0; i < 9; i++) L.FR[i] = H->frame[i];
     L.ghost_mult = 0;
+    L.ct0 = nullptr;
+    L.ct1 = nullptr;
+    L.ce = nullptr;
+    L.kc = 0;
     long long kin = 0;
     for (int e = tid; e < N; e += 256) {
       double t[3], tn[3];
@@ -1214,27 +1242,58 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   const int nfp = K.nfp;
   const double bite = K.init_bite;
   const double bottom0 = bite - K.hand_depth;
-  // ---- pass 0+1: height count, finger collision masks at init_bite (finger_hand.cpp:26-73)
-  long long kin = 0;
-  for (int e = tid; e < N; e += 256) {
-    double t[3], tn[3];
+  // ---- pass 0: the one transform of all N points (PointList::transformToHandFrame +
+  //      cropByHandHeight, point_list.cpp:22-55): in-height entries are compacted into LDS
+  //      (forward / lateral coordinate, rank), every later pass reads those k entries instead of
+  //      transforming the N points again (the kernel is fp64-VALU bound: k is ~0.3 N).
+  __shared__ double s_t0[HE_COMPACT], s_t1[HE_COMPACT];
+  __shared__ unsigned short s_e[HE_COMPACT];
+  __shared__ int s_kc;
+  if (tid == 0) s_kc = 0;
+  __syncthreads();
+  L.ct0 = nullptr;
+  L.ct1 = nullptr;
+  L.ce = nullptr;
+  L.kc = 0;
+  for (int e0 = 0; e0 < N; e0 += 256) {
+    const int e = e0 + tid;
+    double t[3] = {0, 0, 0}, tn[3];
     int mult;
-    if (list_entry(L, e, t, tn, mult)) kin++;
-  }
-  const long long k = block_sum(kin, s_l);
-  L.ghost_mult = N - (int)k;
-  unsigned blocked = 0, flags = 0;  // flags bit0: some x<bite, bit1: some x<bottom
-  for (int e = tid; e <= N; e += 256) {
-    double t[3], tn[3];
-    int mult;
-    if (!list_entry(L, e, t, tn, mult)) continue;
-    if (t[0] < bite) {
-      flags |= 1u;
-      if (t[0] < bottom0) flags |= 2u;
-      for (int i = 0; i < 2 * nfp; i++)
-        if (t[1] > K.spacing[i] && t[1] < K.spacing[i] + K.fw) blocked |= 1u << i;
+    const bool in = e < N && list_entry(L, e, t, tn, mult);
+    const unsigned long long ballot = __ballot(in);
+    if (ballot) {
+      int base = 0;
+      if ((tid & 63) == 0) base = atomicAdd(&s_kc, __popcll(ballot));
+      base = __shfl(base, 0);
+      if (in) {
+        const int c = base + __popcll(ballot & ((1ull << (tid & 63)) - 1ull));
+        if (c < HE_COMPACT) {
+          s_t0[c] = t[0];
+          s_t1[c] = t[1];
+          s_e[c] = (unsigned short)e;
+        }
+      }
     }
   }
+  __syncthreads();
+  const int k = s_kc;
+  L.ghost_mult = N - k;
+  if (k <= HE_COMPACT) {
+    L.ct0 = s_t0;
+    L.ct1 = s_t1;
+    L.ce = s_e;
+    L.kc = k;
+  }
+  // ---- pass 1: finger collision masks at init_bite (finger_hand.cpp:26-73)
+  unsigned blocked = 0, flags = 0;  // flags bit0: some x<bite, bit1: some x<bottom
+  for_each_entry(L, [&](double t0, double t1, int, int) {
+    if (t0 < bite) {
+      flags |= 1u;
+      if (t0 < bottom0) flags |= 2u;
+      for (int i = 0; i < 2 * nfp; i++)
+        if (t1 > K.spacing[i] && t1 < K.spacing[i] + K.fw) blocked |= 1u << i;
+    }
+  });
   blocked = block_or(blocked, s_u);
   flags = block_or(flags, s_u);
   unsigned fingers = 0;
@@ -1263,20 +1322,17 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
       // ---- pass 2: deepenHand (finger_hand.cpp:107-139) for all depths at once
       unsigned m_any = 0, m_back = 0, m_blk = 0;
       const double sl = K.spacing[mid], sr = K.spacing[nfp + mid];
-      for (int e = tid; e <= N; e += 256) {
-        double t[3], tn[3];
-        int mult;
-        if (!list_entry(L, e, t, tn, mult)) continue;
-        const bool blk = (t[1] > sl && t[1] < sl + K.fw) || (t[1] > sr && t[1] < sr + K.fw);
+      for_each_entry(L, [&](double t0, double t1, int, int) {
+        const bool blk = (t1 > sl && t1 < sl + K.fw) || (t1 > sr && t1 < sr + K.fw);
         for (int j = 0; j < K.num_deepen; j++) {
           const double d = K.depths[j];
-          if (t[0] < d) {
+          if (t0 < d) {
             m_any |= 1u << j;
-            if (t[0] < d - K.hand_depth) m_back |= 1u << j;
+            if (t0 < d - K.hand_depth) m_back |= 1u << j;
             if (blk) m_blk |= 1u << j;
           }
         }
-      }
+      });
       m_any = block_or(m_any, s_u);
       m_back = block_or(m_back, s_u);
       m_blk = block_or(m_blk, s_u);
