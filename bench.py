@@ -40,12 +40,17 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON of rank 0): everything else that libraries print to
+    # fd 1 (RCCL's start-up banner, HIP warnings) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GPD_BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -168,7 +173,8 @@ def main():
         }
         if args.cpu_samples > 0:
             out["cpu_baseline"] = _cpu_baseline(cloud, w, C, args.cpu_samples)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.barrier()
