@@ -359,7 +359,7 @@ struct NbParams {
   int num_points;
   const int32_t *sample_idx;
   const double *sample_xyz;  // non-null: samples by coordinates; the query is their float cast (eigenVectorToPcl)
-  float r2_hands, r2_images, r2_frames;
+  float r2_all, r2_hands, r2_images, r2_frames;  // r2_all = the largest: one search, the three neighbourhoods are prefixes
   int cap;  // list capacity; a power of two in bitonic mode
   int bucket;  // 1: bucket sort (keys + u16 slot table + 2 x 1024 counters in LDS), 0: in-place bitonic sort
   int32_t *counts;  // [S][8]: N_hands, N_images, k_frames, found, mask of cameras that see the image neighbourhood, -, -, -
@@ -404,7 +404,7 @@ __device__ inline void sort_regs64(unsigned long long (&k)[N]) {
 __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
   __shared__ int s_count;
-  __shared__ int s_bounds[2];
+  __shared__ int s_bounds[3];
   __shared__ int s_seen;
   __shared__ int s_ncrowd;
   const int s = blockIdx.x;
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     s_count = 0;
     s_bounds[0] = 0;
     s_bounds[1] = 0;
+    s_bounds[2] = 0;
     s_seen = 0;
     s_ncrowd = 0;
   }
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     d2 += d * d;
     return d2;
   };
-  const float bscale = (float)NB_BUCKETS / P.r2_hands;
+  const float bscale = (float)NB_BUCKETS / P.r2_all;
   auto bucket_of = [&](float d2) {
     const int b = (int)(d2 * bscale);
     return b < NB_BUCKETS - 1 ? b : NB_BUCKETS - 1;
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     d2 += d * d;
     d = qz - z;
     d2 += d * d;
-    const bool hit = in && d2 < P.r2_hands;
+    const bool hit = in && d2 < P.r2_all;
     const unsigned long long ballot = __ballot(hit);
     if (ballot) {
       int base = 0;
@@ -626,13 +627,14 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   // sorted position t -> d2 bits / point index
   auto d2bits_at = [&](int t) { return P.bucket ? s_a[t] : (unsigned)(s_keys[t] >> 32); };
   auto index_at = [&](int t) { return P.bucket ? (int)s_b[t] : (int)(unsigned)(s_keys[t] & 0xffffffffull); };
-  // 3. prefix lengths of the image and frame neighbourhoods
-  const unsigned ri = __float_as_uint(P.r2_images), rf = __float_as_uint(P.r2_frames);
+  // 3. prefix lengths of the image, frame and hand-search neighbourhoods
+  const unsigned ri = __float_as_uint(P.r2_images), rf = __float_as_uint(P.r2_frames), rh = __float_as_uint(P.r2_hands);
   for (int t = tid; t < n; t += 256) {
     const unsigned d = d2bits_at(t);
     const unsigned dn = (t + 1 < n) ? d2bits_at(t + 1) : 0xffffffffu;
     if (d < ri && dn >= ri) s_bounds[0] = t + 1;
     if (d < rf && dn >= rf) s_bounds[1] = t + 1;
+    if (d < rh && dn >= rh) s_bounds[2] = t + 1;
   }
   __syncthreads();
   // 4. sorted index list + gathered SoA neighbourhood.  Each key slot is then reused
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   // 5. local frame (local_frame.cpp:14-41), sequential sums in neighbour order
   if (tid == 0) {
     const int kf = s_bounds[1];
-    P.counts[8 * s + 0] = n;
+    P.counts[8 * s + 0] = s_bounds[2];
     P.counts[8 * s + 1] = s_bounds[0];
     P.counts[8 * s + 2] = kf;
     P.counts[8 * s + 3] = found;
@@ -1419,6 +1421,8 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.sample_idx = s.d_sample_idx;
   np.sample_xyz = by_xyz ? s.d_sample_xyz : nullptr;
   // pcl::KdTreeFLANN::radiusSearch passes (float)(radius*radius) to FLANN
+  const double r_all = std::fmax(hc.nn_radius_hands, std::fmax(hc.nn_radius_images, p.nn_radius_frames));
+  np.r2_all = (float)(r_all * r_all);
   np.r2_hands = (float)(hc.nn_radius_hands * hc.nn_radius_hands);
   np.r2_images = (float)(hc.nn_radius_images * hc.nn_radius_images);
   np.r2_frames = (float)(p.nn_radius_frames * p.nn_radius_frames);
@@ -1431,7 +1435,7 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.cam_source = c.cam_source;
   np.num_cams = c.num_cams;
   np.grid = grid_view(c);
-  np.reach = (float)hc.nn_radius_hands * 1.001f + 1e-5f;
+  np.reach = (float)r_all * 1.001f + 1e-5f;
   // 8192-entry lists are bucket-sorted (64 + 8 KB of LDS: two workgroups per CU); the 16384-entry
   // retry of an overfull neighbourhood sorts in place (bitonic, 128 KB)
   np.bucket = cap < 16384 ? 1 : 0;
@@ -1502,10 +1506,6 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   const int slots = p.num_hand_axes * p.num_orientations;
   HostConsts hc;
   host_consts(p, hc);
-  if (hc.nn_radius_images > hc.nn_radius_hands || p.nn_radius_frames > hc.nn_radius_hands) {
-    set_error("search: image/frame radius larger than the hand-search radius is not supported");
-    return GPD_ERR_INVALID;
-  }
   int cap = 0;
   int rc = neighbourhoods(p, c, s, hc, sample_idx, sample_xyz, S, slots, &cap, stream);
   if (rc) return rc;
