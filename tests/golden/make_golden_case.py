@@ -1,8 +1,8 @@
-"""Generates tests/golden/case_small_c{15,12,3}.npz from the CPU oracle (the reference ships
+"""Generates tests/golden/case_small_c{15,12,3,1}.npz from the CPU oracle (the reference ships
 no golden vectors and cannot be built here, SURVEY.md §4/§8c — "parity unpinned").
 The fixture pins the oracle against regressions and gives the GPU tests a committed target.
 
-Run:  python tests/golden/make_golden_case.py
+Run:  python tests/golden/make_golden_case.py [channels ...]   (default: 15 12 3 1)
 Inputs: synth.make_cloud(seed=4242, num_points=8000), first 10 sample indices, real LeNet
 parameters (tests/golden/lenet{15,3}_params.npz) + synthetic ip1 (seed 42).
 """
@@ -25,7 +25,7 @@ try:
     rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"]).decode().strip()
 except Exception:
     rev = "unknown"
-for C in (15, 12, 3):
+for C in ([int(a) for a in sys.argv[1:]] or (15, 12, 3, 1)):
     p = oracle.default_params(C)
     gold = os.path.join(HERE, "lenet%d_params.npz" % C)
     w = synth.lenet_weights(C, real=dict(np.load(gold)) if os.path.exists(gold) else None)

@@ -17,7 +17,7 @@ def _case(C):
     return d, cl, w
 
 
-@pytest.mark.parametrize("C", [15, 12, 3])
+@pytest.mark.parametrize("C", [15, 12, 3, 1])
 def test_oracle_reproduces_golden(oracle_mod, C):
     d, cl, w = _case(C)
     p = oracle_mod.default_params(C)
@@ -31,7 +31,7 @@ def test_oracle_reproduces_golden(oracle_mod, C):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C", [15, 12, 3])
+@pytest.mark.parametrize("C", [15, 12, 3, 1])
 def test_hip_reproduces_golden(C):
     from gpd_amd import api
     d, cl, w = _case(C)
