@@ -4,6 +4,7 @@
 #include <cstring>
 #include <vector>
 
+#include <chrono>
 #include <cmath>
 
 #include "gpd_internal.h"
@@ -385,18 +386,29 @@ static int detect_any(gpd_hip_ctx *ctx, const int32_t *sample_indices, const dou
     return GPD_ERR_STATE;
   }
   *num_candidates = 0;
+  // GPD_DETECT_TIMING=1: wall time of the stages incl. their host hops, to stderr
+  const bool timing = getenv("GPD_DETECT_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   int rc = search_any(ctx, "gpd_hip_detect", sample_indices, sample_xyz, num_samples, hands, num_sets);
   if (rc) return rc;
   if (*num_sets == 0) return GPD_OK;
+  const double t1 = now();
   filter_workspace_host(ctx->params, hands, *num_sets);
+  const double t2 = now();
   std::vector<int32_t> cand((size_t)(*num_sets) * ctx->params.num_hand_axes * ctx->params.num_orientations);
   rc = gpd_hip_images(ctx, hands, *num_sets, nullptr, cand.data(), num_candidates);
   if (rc) return rc;
   if (*num_candidates == 0) return GPD_OK;
+  const double t3 = now();
   std::vector<float> scores(*num_candidates);
   rc = gpd_hip_score(ctx, nullptr, *num_candidates, scores.data());
   if (rc) return rc;
+  const double t4 = now();
   for (int i = 0; i < *num_candidates; i++) hands[cand[i]].score = scores[i];
+  if (timing)
+    fprintf(stderr, "[detect-timing] search %.2f ms (kernels %.2f)  filter %.2f  images %.2f (kernels %.2f)  score %.2f (kernels %.2f)  scatter %.2f\n",
+            t1 - t0, ctx->stage_ms[0], t2 - t1, t3 - t2, ctx->stage_ms[1], t4 - t3, ctx->stage_ms[2], now() - t4);
   return GPD_OK;
 }
 

@@ -27,6 +27,7 @@ struct LeNetScratch {
   float *pool1 = nullptr;  // [cap][20][28][28]
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
+  int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)
 };
 
 // Scores n images (device pointer, planar u8 [n][C][3600]) into d_scores (device). Async on stream.

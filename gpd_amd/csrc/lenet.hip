@@ -498,13 +498,13 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
                          hipStream_t stream, hipEvent_t *kernel_events) {
   if (n <= 0) return hipSuccess;
   const int kChunk = 16384;
-  static int num_cus = 0;  // persistent conv2 workgroups: one per CU (256 on MI355X)
-  if (!num_cus) {
+  if (!s.num_cus) {  // persistent conv2 workgroups: one per CU (256 on MI355X)
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cus = prop.multiProcessorCount;
-    if (num_cus <= 0) num_cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) s.num_cus = prop.multiProcessorCount;
+    if (s.num_cus <= 0) s.num_cus = 256;
   }
+  const int num_cus = s.num_cus;
   hipError_t e = lenet_scratch_reserve(s, n < kChunk ? n : kChunk);
   if (e != hipSuccess) return e;
   for (int off = 0; off < n; off += kChunk) {

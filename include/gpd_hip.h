@@ -4,8 +4,11 @@
  *
  * Everything here is `extern "C"`, plain pointers and sizes.  Host buffers are
  * owned by the caller, device memory is owned by the context.  One context per
- * device; a context is not thread-safe (the reference's GraspDetector is not
- * either: grasp_detector.cpp:192-328 is called from one thread).
+ * device (the hand / image geometry lives in the device's constant memory: two
+ * contexts with DIFFERENT parameters on one device must not run concurrently);
+ * a context is not thread-safe (the reference's GraspDetector is not either:
+ * grasp_detector.cpp:192-328 is called from one thread).  Contexts on different
+ * devices may be driven from different threads.
  *
  * Each entry point names the reference interface it replaces (paths relative to
  * the reference tree).  Return value: 0 on success, <0 on error
