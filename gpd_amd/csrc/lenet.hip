@@ -42,20 +42,100 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //              independent, so LDS reads and converts slot between MFMAs without stalling them;
 //              20 filters would pad a 32-row MFMA tile to 62 % efficiency, 16 fill it exactly.
 //   waves 8-11 filters 16..19 by direct convolution on the VALU (weights as wave-uniform
-//              scalars, 2x2 pool window per lane), which is idle otherwise.
+//              scalars, 2x2 pool window per lane).
 // Both are k-ascending fmaf chains (16x16x4 accumulates k..k+3 in order), bias after the pool.
+// Zero skipping: grasp images are ~70 % zeros with large empty regions; a per-(band, half, channel)
+// zero map built from the LDS copy lets both roles drop the k-steps / channels whose inputs are
+// all zero — the dropped terms are exact zeros, results are bit-identical (see conv1_unit).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int C1_MFMA_WAVES = 8, C1_VALU_WAVES = 4;
 constexpr int C1_THREADS = 64 * (C1_MFMA_WAVES + C1_VALU_WAVES);
+
+// One MFMA work unit: NT pixel tiles (tiles t0 .. t0+NT-1 of the band's seven) x 16 filters over all
+// taps.  nzc has bit c set when channel c has a non-zero byte anywhere in the unit's input window:
+// a k-step whose taps all lie in all-zero channels is skipped — its products are exact zeros
+// (fmaf(w, 0, acc) == acc for finite w; acc is never -0), so the chain and every bit of the result
+// stay the same.  Grasp images are ~70 % zeros; at this granularity ~28 % of the steps drop out.
+// Software pipeline per step st (fully unrolled, the channels of a step are compile-time constants):
+// the LDS bytes and the weight column of step st+1 are requested, then the bytes of step st are
+// converted and multiplied; each stage is guarded by the liveness of ITS step (scalar branches).
+template <int C, int NT>
+__device__ __forceinline__ void conv1_unit(const uint8_t *s_imgq, const float *s_w, const uint16_t *s_off, int rp, int t0, uint32_t nzc,
+                                           int kq, int j, int img, int n, const float *__restrict__ bias, float *__restrict__ out) {
+  constexpr int K = 25 * C, KP = (K + 3) & ~3, NS = KP / 4;
+  const uint8_t *xin = s_imgq + (2 * rp + (j >> 3)) * kImg + (j & 7) + 8 * t0;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
+  auto live = [&](int st) -> bool {  // st is a compile-time constant after unrolling: two shifts, or, and
+    if (st >= NS) return false;
+    const int c0 = (4 * st) / 25, c1 = (4 * st + 3 < K ? 4 * st + 3 : K - 1) / 25;
+    return (((nzc >> c0) | (nzc >> c1)) & 1u) != 0u;
+  };
+  // two register sets, step st computes from set st & 1 while the loads of step st+1 land in the
+  // other one (no moves, no wait on the loads just issued).  Values of dead steps are never used:
+  // "some value" instead of a zero fill keeps selects out of the loop.
+  uint32_t raw[2][NT];
+  float a[2];
+#pragma unroll
+  for (int z = 0; z < 2; z++) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) raw[z][t] = __builtin_nondeterministic_value(raw[z][t]);
+    a[z] = __builtin_nondeterministic_value(a[z]);
+  }
+  if (live(0)) {
+    a[0] = s_w[kq * 16 + j];
+    const uint8_t *x0 = xin + s_off[kq];
+#pragma unroll
+    for (int t = 0; t < NT; t++) raw[0][t] = x0[8 * t];
+  }
+#pragma unroll
+  for (int st = 0; st < NS; st++) {
+    if (live(st + 1)) {
+      a[(st + 1) & 1] = s_w[(4 * (st + 1) + kq) * 16 + j];
+      const uint8_t *x1 = xin + s_off[4 * (st + 1) + kq];
+#pragma unroll
+      for (int t = 0; t < NT; t++) raw[(st + 1) & 1][t] = x1[8 * t];
+    }
+    if (live(st)) {
+      float f[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) f[t] = (float)raw[st & 1][t];
+#pragma unroll
+      for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1], f[t], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float x = acc[t][r];
+      x = fmaxf(x, __shfl_xor(x, 1));
+      x = fmaxf(x, __shfl_xor(x, 8));
+      acc[t][r] = x;
+    }
+    if (img < n && !(j & 1) && !(j & 8)) {
+      float *o = out + (size_t)img * 20 * 784 + rp * 28 + 4 * (t0 + t) + ((j & 7) >> 1);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int f = kq * 4 + r;
+        o[f * 784] = acc[t][r] + bias[f];
+      }
+    }
+  }
+}
 
 template <int C>
 __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wt,
                                                                 const float *__restrict__ w, const float *__restrict__ bias,
                                                                 float *__restrict__ out, int n) {
-  constexpr int K = 25 * C, KP = (K + 3) & ~3, NS = KP / 4;
+  constexpr int K = 25 * C, KP = (K + 3) & ~3;
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
   __shared__ __attribute__((aligned(16))) float s_w[KP * 16];  // [k][16 filters], rows >= K are zero
   __shared__ uint16_t s_off[KP];                                // byte offset of tap k in an image
+  __shared__ uint32_t s_nz[2 * 28 * 2];  // per (image, band, half): channels with a non-zero byte in the input window
   const int tid = threadIdx.x;
   const int img0 = blockIdx.x * 2;
   for (int q = 0; q < 2; q++) {
@@ -73,6 +153,20 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     const int c = kk / 25, tap = kk - c * 25;
     s_off[k] = (uint16_t)(c * kPix + (tap / 5) * kImg + tap % 5);
   }
+  for (int i = tid; i < 2 * 28 * 2; i += C1_THREADS) s_nz[i] = 0u;
+  __syncthreads();
+  // zero map: unit u = (image q, band rp, half h) reads input rows 2rp..2rp+5, columns 0..35 (tiles
+  // 0..3) or 32..59 (tiles 4..6); one (unit, channel) window per thread and turn, dword reads
+  for (int pr = tid; pr < 2 * 28 * 2 * C; pr += C1_THREADS) {
+    const int u = pr / C, c = pr - u * C;
+    const int q = u / 56, r2 = u - q * 56, rp = r2 >> 1, h = r2 & 1;
+    const uint8_t *base = s_img[q] + c * kPix + (2 * rp) * kImg + (h ? 32 : 0);
+    const int nd = h ? 7 : 9;
+    uint32_t any = 0;
+    for (int r = 0; r < 6; r++)
+      for (int d = 0; d < nd; d++) any |= *reinterpret_cast<const uint32_t *>(base + r * kImg + 4 * d);
+    if (any) atomicOr(&s_nz[u], 1u << c);
+  }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -80,74 +174,16 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     // the matrix waves win issue arbitration; the VALU waves of the same SIMD fill the gaps
     __builtin_amdgcn_s_setprio(3);
     const int kq = lane >> 4, j = lane & 15;
-    for (int g = wave; g < 2 * 28; g += C1_MFMA_WAVES) {
-      const int q = g / 28, rp = g - q * 28;
-      const uint8_t *xin = s_img[q] + (2 * rp + (j >> 3)) * kImg + (j & 7);
-      f32x4 acc[7];
-#pragma unroll
-      for (int t = 0; t < 7; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
-      // three-stage software pipeline per step st: LDS bytes of step st+2 are requested, the
-      // bytes of step st+1 (requested one step ago) are converted, and the seven MFMAs of step
-      // st run on floats converted one step ago — no MFMA waits on a load or a convert.
-      auto off_of = [&](int st) { return (int)s_off[4 * (st < NS ? st : NS - 1) + kq]; };
-      auto w_of = [&](int st) { return s_w[(4 * (st < NS ? st : NS - 1) + kq) * 16 + j]; };
-      float a0 = w_of(0), a1 = w_of(1);
-      float f0[7];
-      uint8_t raw1[7];
-      {
-        const uint8_t *x0 = xin + off_of(0), *x1 = xin + off_of(1);
-#pragma unroll
-        for (int t = 0; t < 7; t++) {
-          f0[t] = (float)x0[8 * t];
-          raw1[t] = x1[8 * t];
-        }
-      }
-      int off2 = off_of(2);
-#pragma unroll 6
-      for (int st = 0; st < NS; st++) {
-        uint8_t raw2[7];
-        float f1[7];
-        const uint8_t *x2 = xin + off2;
-#pragma unroll
-        for (int t = 0; t < 7; t++) raw2[t] = x2[8 * t];
-        const float a2 = w_of(st + 2);
-        const int off3 = off_of(st + 3);
-#pragma unroll
-        for (int t = 0; t < 7; t++) f1[t] = (float)raw1[t];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 7; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, f0[t], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = a1;
-        a1 = a2;
-        off2 = off3;
-#pragma unroll
-        for (int t = 0; t < 7; t++) {
-          f0[t] = f1[t];
-          raw1[t] = raw2[t];
-        }
-      }
-      const int img = img0 + q;
-#pragma unroll
-      for (int t = 0; t < 7; t++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          float x = acc[t][r];
-          x = fmaxf(x, __shfl_xor(x, 1));
-          x = fmaxf(x, __shfl_xor(x, 8));
-          acc[t][r] = x;
-        }
-        if (img < n && !(j & 1) && !(j & 8)) {
-          float *o = out + (size_t)img * 20 * 784 + rp * 28 + 4 * t + ((j & 7) >> 1);
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int f = kq * 4 + r;
-            o[f * 784] = acc[t][r] + bias[f];
-          }
-        }
-      }
+    // a wave owns seven of the pair's 56 bands and runs both halves of each (4 + 3 tiles)
+    for (int i = 0; i < 14; i++) {
+      const int band = wave + C1_MFMA_WAVES * (i >> 1);
+      const int h = i & 1;
+      const int q = band / 28, rp = band - q * 28;
+      const uint32_t nzc = __builtin_amdgcn_readfirstlane(s_nz[band * 2 + h]);
+      if (h == 0)
+        conv1_unit<C, 4>(s_img[q], s_w, s_off, rp, 0, nzc, kq, j, img0 + q, n, bias, out);
+      else
+        conv1_unit<C, 3>(s_img[q], s_w, s_off, rp, 4, nzc, kq, j, img0 + q, n, bias, out);
     }
   } else {
     // filters 16..19: lane <-> pooled pixel, weights read as scalars in the file layout [f][k]
@@ -165,7 +201,16 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[f][e] = 0.f;
       const uint8_t *base = s_img[q] + (2 * py) * kImg + 2 * px;
+      // channels that are zero under every window of this chunk (pooled rows chunk*64/28 ..) add
+      // exact zeros to all sixteen chains: skipped
+      uint32_t nzc = 0;
+      {
+        const int r0 = (chunk * 64) / 28, r1 = (chunk * 64 + 63 < 783 ? chunk * 64 + 63 : 783) / 28;
+        for (int r = r0; r <= r1; r++) nzc |= s_nz[(q * 28 + r) * 2] | s_nz[(q * 28 + r) * 2 + 1];
+        nzc = __builtin_amdgcn_readfirstlane(nzc);
+      }
       for (int c = 0; c < C; c++) {
+        if (!((nzc >> c) & 1u)) continue;
         float patch[6][6];
 #pragma unroll
         for (int r = 0; r < 6; r++) {
