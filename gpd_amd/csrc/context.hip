@@ -173,6 +173,13 @@ int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1
                {&ctx->lenet.c2w, conv2_w, (size_t)50 * 500},          {&ctx->lenet.c2b, conv2_b, 50},
                {&ctx->lenet.f1w, ip1_w, (size_t)kFc1In * kFc1Out},    {&ctx->lenet.f1b, ip1_b, kFc1Out},
                {&ctx->lenet.f2w, ip2_w, (size_t)2 * kFc1Out},         {&ctx->lenet.f2b, ip2_b, 2}};
+  // conv1 drops input windows that are entirely zero; that is exact only for finite weights
+  // (inf * 0 would be NaN in the reference's dense GEMM)
+  for (size_t i = 0; i < (size_t)20 * channels * 25; i++)
+    if (!std::isfinite(conv1_w[i])) {
+      set_error("gpd_hip_set_lenet_weights: conv1 weight %zu is not finite", i);
+      return GPD_ERR_INVALID;
+    }
   for (auto &it : items) {
     if (*it.dst) (void)hipFree(*it.dst);
     *it.dst = nullptr;

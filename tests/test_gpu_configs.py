@@ -117,6 +117,31 @@ def test_edge_cases_and_errors(oracle_mod, cloud30k):
         img = np.zeros((2, 60, 60, 15), np.uint8)
         img[1] = 255
         assert np.array_equal(ctx.score(img), oracle_mod.lenet(img, w))
+        # conv1's zero skipping on structured sparsity: single channels, single rows / columns / pixels set,
+        # an odd image count (the second image of the last pair is a phantom)
+        rng = np.random.RandomState(11)
+        img = np.zeros((37, 60, 60, 15), np.uint8)
+        for i in range(37):
+            kind = i % 6
+            if kind == 0:
+                img[i, :, :, rng.randint(15)] = rng.randint(1, 256, (60, 60))
+            elif kind == 1:
+                img[i, rng.randint(60), :, :] = rng.randint(0, 256, (60, 15))
+            elif kind == 2:
+                img[i, :, rng.randint(60), rng.randint(15)] = rng.randint(1, 256, 60)
+            elif kind == 3:
+                img[i, rng.randint(60), rng.randint(60), rng.randint(15)] = 255
+            elif kind == 4:
+                img[i, 30:, 28:40, ::2] = rng.randint(0, 256, (30, 12, 8))
+            else:
+                img[i] = rng.randint(0, 256, (60, 60, 15)) * (rng.rand(60, 60, 15) < 0.05)
+        assert np.array_equal(ctx.score(img), oracle_mod.lenet(img, w))
+        # the skipping is exact for finite weights only: anything else is refused
+        bad = {k: v.copy() for k, v in w.items()}
+        bad["c1w"][7] = np.inf
+        with pytest.raises(api.GpdHipError):
+            ctx.set_lenet_weights(bad)
+        ctx.set_lenet_weights(w)
         ctx.upload_cloud(cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"], cloud30k["view_points"])
         assert ctx.search(np.zeros(0, np.int32)).shape == (0, 8)
         with pytest.raises(api.GpdHipError):  # index out of range
