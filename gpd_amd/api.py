@@ -142,7 +142,7 @@ class Context:
     def search(self, sample_indices):
         """generateGraspCandidateSets -> hands[n_sets, n_slots]."""
         si = np.ascontiguousarray(sample_indices, np.int32)
-        hands = np.zeros((len(si), self.n_slots), HAND_DTYPE)
+        hands = np.empty((len(si), self.n_slots), HAND_DTYPE)  # rows [0, num_sets) are written by the call
         ns = C.c_int(0)
         self._check(lib().gpd_hip_search(self._h, _ptr(si), len(si), _ptr(hands), C.byref(ns)))
         return hands[: ns.value].copy()
@@ -150,14 +150,14 @@ class Context:
     def search_samples(self, samples_xyz):
         """generateGraspCandidateSets for samples given by coordinates (f64 [S,3])."""
         sm = np.ascontiguousarray(samples_xyz, np.float64).reshape(-1, 3)
-        hands = np.zeros((len(sm), self.n_slots), HAND_DTYPE)
+        hands = np.empty((len(sm), self.n_slots), HAND_DTYPE)
         ns = C.c_int(0)
         self._check(lib().gpd_hip_search_samples(self._h, _ptr(sm), len(sm), _ptr(hands), C.byref(ns)))
         return hands[: ns.value].copy()
 
     def detect_samples(self, samples_xyz):
         sm = np.ascontiguousarray(samples_xyz, np.float64).reshape(-1, 3)
-        hands = np.zeros((len(sm), self.n_slots), HAND_DTYPE)
+        hands = np.empty((len(sm), self.n_slots), HAND_DTYPE)
         ns, nc = C.c_int(0), C.c_int(0)
         self._check(lib().gpd_hip_detect_samples(self._h, _ptr(sm), len(sm), _ptr(hands), C.byref(ns), C.byref(nc)))
         return hands[: ns.value].copy(), nc.value
@@ -184,7 +184,7 @@ class Context:
     def detect(self, sample_indices):
         """detectGrasps steps 1-4 -> (hands[n_sets, n_slots] with scores, n_candidates)."""
         si = np.ascontiguousarray(sample_indices, np.int32)
-        hands = np.zeros((len(si), self.n_slots), HAND_DTYPE)
+        hands = np.empty((len(si), self.n_slots), HAND_DTYPE)  # rows [0, num_sets) are written by the call
         ns, nc = C.c_int(0), C.c_int(0)
         self._check(lib().gpd_hip_detect(self._h, _ptr(si), len(si), _ptr(hands), C.byref(ns), C.byref(nc)))
         return hands[: ns.value].copy(), nc.value
