@@ -103,6 +103,7 @@ __device__ __forceinline__ void conv1_unit(const uint8_t *s_imgq, const float *s
       float f[NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) f[t] = (float)raw[st & 1][t];
+      __builtin_amdgcn_sched_barrier(0);  // converts first, then the MFMAs back to back (no hazard nops in between)
 #pragma unroll
       for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1], f[t], acc[t], 0, 0, 0);
     }
