@@ -13,9 +13,9 @@
 // The reference rasterises with per-pixel recurrences whose result depends on the order
 // in which points hit a pixel (neighbour order; image_strategy.cpp:130-142, 166-174,
 // 202-210).  Here every projection is a counting sort of the in-box points by pixel
-// (LDS atomics, any order), after which the thread that owns a pixel sorts its short
-// segment by neighbour rank and runs the recurrence sequentially — same arithmetic, same
-// order, all lanes busy.  Shadow voxels (hand_set.cpp:202-233 hash set) become a bitset
+// (LDS atomics, any order), after which the thread that owns a pixel orders its short
+// segment by neighbour rank — through registers (bitonic network on 8/16/32 keys), the pixels
+// handed out longest first — and runs the recurrence sequentially: same arithmetic, same order.  Shadow voxels (hand_set.cpp:202-233 hash set) become a bitset
 // over the candidate's voxel AABB: set semantics for free, and walking the bits in index
 // order is the lexicographic voxel order the oracle defines.
 //

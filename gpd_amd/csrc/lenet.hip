@@ -11,10 +11,11 @@
 //
 // Kernels:
 //   conv1_mfma   planar u8 images + k-major weights in LDS -> implicit GEMM on f32 MFMA (+ 4
-//                filters on VALU waves), 2x2 max-pool fused      -> pool1 [n][20][28][28]
+//                filters on VALU waves), all-zero input windows skipped (exact), 2x2 max-pool
+//                fused                                           -> pool1 [n][20][28][28]
 //   conv2_mfma   persistent; pool1 planes + 96 KB of weights in LDS, implicit GEMM + pool
-//                (+ 2 filters on a VALU wave), output in the reference's flatten order
-//                j = pixel*50 + channel                          -> flat  [n][7200]
+//                (+ 2 filters riding in the same waves on the VALU), output in the reference's
+//                flatten order j = pixel*50 + channel            -> flat  [n][7200]
 //   fc1_mfma     [500 x 7200] x [7200 x n] on v_mfma_f32_32x32x2_f32, + bias, ReLU
 //                                                               -> fc1t  [500][n]
 //   fc2_score    2 x 500 chains per image, score = y1 - y0       -> scores[n]

@@ -8,19 +8,23 @@
 // HandSet::modifyCandidate/labelHypothesis (hand_set.cpp:235-261) and
 // Antipodal::evaluateGrasp (candidate/antipodal.cpp:10-96).
 //
-// neighbourhood_kernel   one workgroup per sample: streams the whole cloud (SoA,
-//     coalesced) instead of walking PCL's k-d tree, collects (d2, index) keys with
-//     d2 < r_hands^2 in LDS, bitonic-sorts them — FLANN's (distance, index) order —
-//     and writes the sorted neighbourhood gathered as SoA.  The 0.10 m image
-//     neighbourhood and the 0.01 m frame neighbourhood are prefixes of this list
-//     (same query point, same float d2, same sort).  Lane 0 then forms
+// neighbourhood_kernel   one workgroup per sample: visits the cells of a uniform 2 cm grid
+//     around the sample (instead of walking PCL's k-d tree), collects the points with
+//     d2 < r^2 (r = the largest of the hand / image / frame radii) in LDS and sorts them
+//     by (d2, index) — FLANN's order — with a 1024-bucket counting sort whose buckets are
+//     ordered through registers (bitonic sort in place for the 16384-entry retry); writes
+//     the sorted neighbourhood gathered as SoA.  The three neighbourhoods are prefixes of
+//     this list (same query point, same float d2, same sort).  Lane 0 then forms
 //     M = sum n n^T in neighbour order and runs the 3x3 symmetric QR eigensolver
 //     (Eigen's SelfAdjointEigenSolver algorithm, fp64, unfused).
-// hand_eval_kernel       one workgroup per (sample, orientation): five order-free
-//     reductions over the neighbourhood (finger collision masks, deepen masks,
-//     closing region, antipodal extremes, antipodal counts).  The reference's
-//     cropByHandHeight quirk (point_list.cpp:44-55 pads with copies of column 0)
-//     is reproduced by a ghost point with multiplicity N-k.
+// centre_kernel          centre of the image neighbourhood, one lane per serial fp64 chain.
+// hand_eval_kernel       one workgroup per (sample, orientation): one transform pass compacts
+//     the in-height points into LDS, then order-free reductions over them (finger
+//     collision masks, deepen masks, closing region, antipodal extremes, antipodal
+//     counts).  The reference's cropByHandHeight quirk (point_list.cpp:44-55 pads with
+//     copies of column 0) is reproduced by a ghost point with multiplicity N-k.
+// reeval_kernel          HandSearch::reevaluateHypotheses (hand_search.cpp:66-134, 190-228).
+// normals_kernel         Cloud::calculateNormals (util/cloud.cpp:451-604).
 //
 // All fp64 expressions are evaluated unfused, left to right (-ffp-contract=off),
 // exactly as oracle/gpd_oracle.cpp defines them.
