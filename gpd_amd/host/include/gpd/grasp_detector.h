@@ -30,9 +30,10 @@ class GraspDetector {
   // `direction`; sets left without a valid hand are dropped.
   std::vector<std::unique_ptr<candidate::HandSet>> filterGraspsDirection(
       std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, const std::array<double, 3> &direction, double thresh_rad);
-  // grasp_detector.cpp:528-551: images + scores for the given sets (they must stem from the last
-  // generateGraspCandidates on this detector: the device keeps their neighbourhoods), keeps the
-  // hands with score > min_score.
+  // grasp_detector.cpp:528-551: images + scores for the given sets, keeps the hands with
+  // score > min_score.  Sets of the last generateGraspCandidates use the neighbourhoods still on
+  // the device; any other list (sets collected over several searches, as the importance sampler
+  // does) has its neighbourhoods searched again from the sets' samples.
   std::vector<std::unique_ptr<candidate::Hand>> pruneGraspCandidates(
       const util::Cloud &cloud, const std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, double min_score);
   // grasp_detector.cpp:522-526 -> HandSearch::reevaluateHypotheses (hand_search.cpp:66-134): labels
@@ -68,6 +69,7 @@ class GraspDetector {
   std::unique_ptr<Clustering> clustering_;
   bool cluster_grasps_ = false;
   int last_num_sets_ = 0;  // hand sets of the last device search
+  std::vector<double> last_samples_;  // their samples, [set][3]
   double runtimes_[4] = {0, 0, 0, 0};
 };
 

@@ -15,6 +15,7 @@
 
 #include "gpd/clustering.h"
 #include "gpd/grasp_detector.h"
+#include "gpd/sequential_importance_sampling.h"
 #include "gpd/util/config_file.h"
 
 namespace gpd {
@@ -478,6 +479,9 @@ bool GraspDetector::searchDevice(const util::Cloud &cloud, bool fused, std::vect
     return false;
   }
   last_num_sets_ = n_sets;
+  last_samples_.resize((size_t)n_sets * 3);
+  for (int s = 0; s < n_sets; s++)
+    for (int r = 0; r < 3; r++) last_samples_[3 * (size_t)s + r] = recs[(size_t)s * slots].sample[r];
   return true;
 }
 
@@ -598,15 +602,60 @@ std::vector<gpd_hand> GraspDetector::flatten(const std::vector<std::unique_ptr<c
 std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::pruneGraspCandidates(
     const util::Cloud &cloud, const std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, double min_score) {
   std::vector<std::unique_ptr<candidate::Hand>> hands_out;
-  if (!ctx_ || !has_classifier_ || last_num_sets_ == 0) return hands_out;
-  (void)cloud;  // resident on the device since generateGraspCandidates
-  std::vector<gpd_hand> recs = flatten(hand_set_list);
+  if (!ctx_ || !has_classifier_ || hand_set_list.empty()) return hands_out;
+  const int slots = params_.num_hand_axes * params_.num_orientations;
+  // do the sets still match the neighbourhoods on the device (same search, same numbering)?
+  bool resident = last_num_sets_ > 0;
+  for (const auto &hs : hand_set_list) {
+    if (!resident) break;
+    if (!hs || hs->getHands().empty()) continue;
+    const gpd_hand &r0 = hs->getHands()[0]->record();
+    resident = r0.set_index >= 0 && r0.set_index < last_num_sets_;
+    for (int r = 0; r < 3 && resident; r++) resident = last_samples_[3 * (size_t)r0.set_index + r] == r0.sample[r];
+  }
+  std::vector<gpd_hand> recs;
+  int n_sets = last_num_sets_;
+  if (resident) {
+    recs = flatten(hand_set_list);
+  } else {
+    // a list gathered over several searches: search the neighbourhoods of its samples again (the
+    // samples are the same doubles, so the neighbourhoods are the same) and number the sets as listed
+    if (!upload(cloud)) return hands_out;
+    std::vector<double> samples;
+    std::vector<const candidate::HandSet *> sets;
+    for (const auto &hs : hand_set_list) {
+      if (!hs || hs->getHands().empty()) continue;
+      const gpd_hand &r0 = hs->getHands()[0]->record();
+      for (int r = 0; r < 3; r++) samples.push_back(r0.sample[r]);
+      sets.push_back(hs.get());
+    }
+    if (sets.empty()) return hands_out;
+    std::vector<gpd_hand> fresh(sets.size() * slots);
+    if (gpd_hip_search_samples(ctx_, samples.data(), (int)sets.size(), fresh.data(), &n_sets) != GPD_OK) {
+      printf("ERROR: %s\n", gpd_hip_last_error());
+      return hands_out;
+    }
+    if (n_sets != (int)sets.size()) {
+      printf("ERROR: pruneGraspCandidates: %zu hand sets do not belong to this cloud\n", sets.size() - (size_t)n_sets);
+      return hands_out;
+    }
+    last_num_sets_ = n_sets;
+    last_samples_ = samples;
+    recs.assign((size_t)n_sets * slots, gpd_hand());
+    for (int s = 0; s < n_sets; s++)
+      for (int j = 0; j < slots && j < (int)sets[s]->getHands().size(); j++) {
+        gpd_hand r = sets[s]->getHands()[j]->record();
+        r.set_index = s;
+        r.valid = sets[s]->getIsValid()[j] ? 1 : 0;
+        recs[(size_t)s * slots + j] = r;
+      }
+  }
   size_t nv = 0;
   for (const gpd_hand &r : recs) nv += r.valid;
   std::vector<int32_t> cand(nv);
   std::vector<float> scores(nv);
   int n_cand = 0;
-  if (gpd_hip_images(ctx_, recs.data(), last_num_sets_, nullptr, cand.data(), &n_cand) != GPD_OK ||
+  if (gpd_hip_images(ctx_, recs.data(), n_sets, nullptr, cand.data(), &n_cand) != GPD_OK ||
       (n_cand > 0 && gpd_hip_score(ctx_, nullptr, n_cand, scores.data()) != GPD_OK)) {
     printf("ERROR: %s\n", gpd_hip_last_error());
     return hands_out;
@@ -738,6 +787,171 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
   return clusters;
 }
 
+
+// ---------------------------------------------------------------------------
+// SequentialImportanceSampling — sequential_importance_sampling.cpp:11-272
+// ---------------------------------------------------------------------------
+static const int SUM_OF_GAUSSIANS = 0, MAX_OF_GAUSSIANS = 1;
+
+SequentialImportanceSampling::SequentialImportanceSampling(const std::string &config_filename) {
+  util::ConfigFile config_file(config_filename);
+  config_file.ExtractKeys();
+  num_init_samples_ = config_file.getValueOfKey<int>("num_init_samples", 50);
+  num_iterations_ = config_file.getValueOfKey<int>("num_iterations", 5);
+  num_samples_ = config_file.getValueOfKey<int>("num_samples_per_iteration", 50);
+  prob_rand_samples_ = config_file.getValueOfKey<double>("prob_rand_samples", 0.3);
+  radius_ = config_file.getValueOfKey<double>("standard_deviation", 0.02);
+  sampling_method_ = config_file.getValueOfKey<int>("sampling_method", SUM_OF_GAUSSIANS);
+  min_score_ = config_file.getValueOfKey<double>("min_score", 0);
+  workspace_ = config_file.getValueOfKeyAsStdVectorDouble("workspace", "-1 1 -1 1 -1 1");
+  workspace_.resize(6, 0.0);
+  workspace_grasps_ = config_file.getValueOfKeyAsStdVectorDouble("workspace_grasps", "-1 1 -1 1 -1 1");
+  workspace_grasps_.resize(6, 0.0);
+  filter_approach_direction_ = config_file.getValueOfKey<bool>("filter_approach_direction", false);
+  std::vector<double> approach = config_file.getValueOfKeyAsStdVectorDouble("direction", "1 0 0");
+  approach.resize(3, 0.0);
+  direction_ = {approach[0], approach[1], approach[2]};
+  thresh_rad_ = config_file.getValueOfKey<double>("thresh_rad", 2.3);
+  rng_state_ = 0x9E3779B97F4A7C15ull ^ (unsigned long long)config_file.getValueOfKey<int>("random_seed", 0);
+  grasp_detector_ = std::make_unique<GraspDetector>(config_filename);
+  clustering_ = std::make_unique<Clustering>(config_file.getValueOfKey<int>("min_inliers", 1));
+}
+
+unsigned long long SequentialImportanceSampling::nextRandom() {
+  rng_state_ ^= rng_state_ << 13;
+  rng_state_ ^= rng_state_ >> 7;
+  rng_state_ ^= rng_state_ << 17;
+  return rng_state_;
+}
+
+double SequentialImportanceSampling::randNormal(double sigma) {  // Box-Muller on two 53-bit uniforms
+  const double u1 = ((double)(nextRandom() >> 11) + 1.0) * (1.0 / 9007199254740993.0);
+  const double u2 = (double)(nextRandom() >> 11) * (1.0 / 9007199254740992.0);
+  return sigma * sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+
+// :189-201
+void SequentialImportanceSampling::drawSamplesFromSumOfGaussians(const std::vector<std::unique_ptr<candidate::HandSet>> &hand_sets,
+                                                                 double sigma, int num_gauss_samples, std::vector<double> &samples_out) {
+  for (int j = 0; j < num_gauss_samples; j++) {
+    const int idx = randInt((int)hand_sets.size());
+    const auto s = hand_sets[idx]->getSample();
+    for (int r = 0; r < 3; r++) samples_out[3 * (size_t)j + r] = s[r] + randNormal(sigma);
+  }
+}
+
+// :203-237, rejection sampling
+void SequentialImportanceSampling::drawSamplesFromMaxOfGaussians(const std::vector<std::unique_ptr<candidate::HandSet>> &hand_sets,
+                                                                 double sigma, int num_gauss_samples, std::vector<double> &samples_out,
+                                                                 double term) {
+  int j = 0;
+  while (j < num_gauss_samples) {
+    const int idx = randInt((int)hand_sets.size());
+    const auto s = hand_sets[idx]->getSample();
+    double x[3];
+    for (int r = 0; r < 3; r++) x[r] = s[r] + randNormal(sigma);
+    auto density = [&](const std::array<double, 3> &c) {
+      double p = 0.0;
+      for (int r = 0; r < 3; r++) p += (x[r] - c[r]) * (x[r] - c[r]);
+      return term * exp((-1.0 / (2.0 * sigma)) * p);
+    };
+    double maxp = 0;
+    for (size_t k = 0; k < hand_sets.size(); k++) {
+      const double p = density(hand_sets[k]->getSample());
+      if (p > maxp) maxp = p;
+    }
+    if (density(s) >= maxp) {
+      for (int r = 0; r < 3; r++) samples_out[3 * (size_t)j + r] = x[r];
+      j++;
+    }
+  }
+}
+
+// :239-270: uniform over the cloud's sample indices (or samples, or all points), inside the workspace
+void SequentialImportanceSampling::drawUniformSamples(const util::Cloud &cloud, int num_samples, int start_idx, std::vector<double> &samples) {
+  const std::vector<float> &xyz = cloud.getCloudProcessed();
+  int i = 0, guard = 0;
+  while (i < num_samples && guard++ < 1000000) {
+    double sample[3];
+    if (!cloud.getSampleIndices().empty()) {
+      const int idx = cloud.getSampleIndices()[randInt((int)cloud.getSampleIndices().size())];
+      for (int r = 0; r < 3; r++) sample[r] = (double)xyz[3 * (size_t)idx + r];
+    } else if (cloud.getSamples().size() >= 3) {
+      const int idx = randInt((int)(cloud.getSamples().size() / 3));
+      for (int r = 0; r < 3; r++) sample[r] = cloud.getSamples()[3 * (size_t)idx + r];
+    } else {
+      const int idx = randInt((int)cloud.size());
+      for (int r = 0; r < 3; r++) sample[r] = (double)xyz[3 * (size_t)idx + r];
+    }
+    if (sample[0] >= workspace_[0] && sample[0] <= workspace_[1] && sample[1] >= workspace_[2] && sample[1] <= workspace_[3] &&
+        sample[2] >= workspace_[4] && sample[2] <= workspace_[5]) {
+      for (int r = 0; r < 3; r++) samples[3 * (size_t)(start_idx + i) + r] = sample[r];
+      i++;
+    }
+  }
+}
+
+// :54-187
+std::vector<std::unique_ptr<candidate::Hand>> SequentialImportanceSampling::detectGrasps(util::Cloud &cloud) {
+  std::vector<std::unique_ptr<candidate::Hand>> none;
+  if (cloud.size() == 0) {
+    printf("Error: Point cloud is empty!");
+    return none;
+  }
+  const double t0 = now_s();
+  FILE *dump = getenv("GPD_SIS_DUMP") ? fopen(getenv("GPD_SIS_DUMP"), "w") : nullptr;
+  // 1. initial grasp hypotheses
+  cloud.setSamples({});
+  cloud.subsample(num_init_samples_);
+  if (dump) {
+    fprintf(dump, "INIT %zu\n", cloud.getSampleIndices().size());
+    for (int i : cloud.getSampleIndices()) fprintf(dump, "%d\n", i);
+  }
+  std::vector<std::unique_ptr<candidate::HandSet>> hand_set_list = grasp_detector_->generateGraspCandidates(cloud);
+  printf("Initially detected grasp candidates: %zu\n", hand_set_list.size());
+  if (hand_set_list.empty()) {
+    if (dump) fclose(dump);
+    return none;
+  }
+  hand_set_list = grasp_detector_->filterGraspsWorkspace(hand_set_list, workspace_grasps_);
+  printf("Grasps within workspace: %zu", hand_set_list.size());
+  if (filter_approach_direction_) hand_set_list = grasp_detector_->filterGraspsDirection(hand_set_list, direction_, thresh_rad_);
+  const int num_rand_samples = (int)(prob_rand_samples_ * num_samples_);
+  const int num_gauss_samples = num_samples_ - num_rand_samples;
+  const double sigma = radius_;
+  const double term = 1.0 / sqrt(pow(2.0 * M_PI, 3.0) * pow(sigma, 3.0));
+  std::vector<double> samples((size_t)3 * num_samples_, 0.0);
+  // 2. importance sampling rounds
+  for (int i = 0; i < num_iterations_ && !hand_set_list.empty(); i++) {
+    std::cout << i << " " << num_gauss_samples << std::endl;
+    if (sampling_method_ == SUM_OF_GAUSSIANS)
+      drawSamplesFromSumOfGaussians(hand_set_list, sigma, num_gauss_samples, samples);
+    else if (sampling_method_ == MAX_OF_GAUSSIANS)
+      drawSamplesFromMaxOfGaussians(hand_set_list, sigma, num_gauss_samples, samples, term);
+    drawUniformSamples(cloud, num_rand_samples, num_samples_ - num_rand_samples, samples);
+    if (dump) {
+      fprintf(dump, "ROUND %d %d\n", i, num_samples_);
+      for (int k = 0; k < num_samples_; k++) fprintf(dump, "%.17g %.17g %.17g\n", samples[3 * k], samples[3 * k + 1], samples[3 * k + 2]);
+    }
+    cloud.setSamples(samples);
+    std::vector<std::unique_ptr<candidate::HandSet>> hand_set_list_new = grasp_detector_->generateGraspCandidates(cloud);
+    hand_set_list_new = grasp_detector_->filterGraspsWorkspace(hand_set_list_new, workspace_grasps_);
+    if (filter_approach_direction_) hand_set_list_new = grasp_detector_->filterGraspsDirection(hand_set_list_new, direction_, thresh_rad_);
+    const size_t added = hand_set_list_new.size();
+    hand_set_list.insert(hand_set_list.end(), std::make_move_iterator(hand_set_list_new.begin()),
+                         std::make_move_iterator(hand_set_list_new.end()));
+    printf("Added %zu grasp candidates in round %d. Total: %zu.\n", added, i, hand_set_list.size());
+  }
+  if (dump) fclose(dump);
+  // 3. classify everything at once
+  std::vector<std::unique_ptr<candidate::Hand>> valid_grasps = grasp_detector_->pruneGraspCandidates(cloud, hand_set_list, min_score_);
+  printf("Valid grasps: %zu\n", valid_grasps.size());
+  // 4. cluster
+  if (clustering_->getMinInliers() > 0) valid_grasps = clustering_->findClusters(valid_grasps);
+  printf("Final result: found %zu grasps.\n", valid_grasps.size());
+  printf("Total runtime: %3.4fs\n.\n", now_s() - t0);
+  return valid_grasps;
+}
 
 // ---------------------------------------------------------------------------
 // Clustering::findClusters — clustering.cpp:5-105.  fp64 throughout; the thresholds are the

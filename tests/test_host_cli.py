@@ -168,3 +168,60 @@ def test_cli_on_raw_krylon_pcd(tmp_path, oracle_mod, lenet15_real):
     vv = hands[hands["valid"].astype(bool)]
     want = vv[np.argsort(-vv["score"], kind="stable")[:5]]
     assert np.abs(np.array([float(g[1]) for g in got]) - want["score"]).max() <= 1e-4
+
+
+CEM = os.path.join(ROOT, "gpd_amd", "host", "cem_detect_grasps")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,min_inliers", [(0, 0), (1, 0), (0, 1)])
+def test_cem_detect_grasps_matches_oracle_replay(tmp_path, oracle_mod, lenet15_real, method, min_inliers):
+    """SequentialImportanceSampling::detectGrasps (sequential_importance_sampling.cpp:54-187) through the
+    product CLI; the samples it drew are dumped and replayed through the oracle: initial candidates,
+    three sampling rounds by coordinates, ONE classification of all collected hand sets, clustering."""
+    assert os.path.exists(CEM), "run __graft_entry__.build()"
+    cl = synth.make_cloud(99, 12000)
+    cfg, pcd = _write_case(tmp_path, cl, lenet15_real, 100, 50, min_inliers=min_inliers,
+                           extra="num_init_samples = 40\nnum_iterations = 3\nnum_samples_per_iteration = 40\nprob_rand_samples = 0.3\n"
+                                 "standard_deviation = 0.02\nsampling_method = %d\nmin_score = -300\nrandom_seed = 7\n" % method)
+    dump = tmp_path / "sis_samples.txt"
+    env = dict(os.environ, GPD_SIS_DUMP=str(dump))
+    out = subprocess.run([CEM, str(cfg), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path), timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    got = [l.split() for l in out.stdout.splitlines() if l.startswith("GRASP ")]
+    # ---- replay
+    lines = dump.read_text().splitlines()
+    n_init = int(lines[0].split()[1])
+    idx = np.array([int(x) for x in lines[1:1 + n_init]], np.int32)
+    rounds, k = [], 1 + n_init
+    while k < len(lines):
+        n = int(lines[k].split()[2])
+        rounds.append(np.array([[float(v) for v in l.split()] for l in lines[k + 1:k + 1 + n]], np.float64))
+        k += 1 + n
+    assert len(rounds) == 3 and all(len(r) == 40 for r in rounds)
+    if method == 0:  # 28 Gaussian samples around known hand sets + 12 cloud points per round
+        assert all(np.isin(r[28:].astype(np.float32), cl["xyz"][idx]).all() for r in rounds)
+    p = oracle_mod.default_params(15)
+
+    def live_sets(h):
+        h = oracle_mod.filter_workspace(p, h)
+        return h[h["valid"].any(axis=1)]
+
+    sets = [live_sets(oracle_mod.search(p, cl["xyz"], cl["normals"], idx))]
+    for r in rounds:
+        sets.append(live_sets(oracle_mod.search_xyz(p, cl["xyz"], cl["normals"], r)))
+    allh = np.concatenate(sets)
+    assert len(allh) > 40
+    img, cand = oracle_mod.images(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], allh)
+    sc = oracle_mod.lenet(img, lenet15_real)
+    keep = sc > -300
+    want, wsc = allh.reshape(-1)[cand][keep], sc[keep].astype(np.float64)
+    assert len(want) > 5, (len(want), np.sort(sc)[::-1][:10])
+    if min_inliers > 0:
+        want, wsc, _ = oracle_mod.find_clusters(want, wsc, min_inliers, False)
+    assert len(got) == len(want)
+    gs = np.array([float(g[1]) for g in got])
+    assert np.abs(gs - wsc).max() <= 2e-4
+    gp = np.array([[float(x) for x in g[2:5]] for g in got])
+    assert np.allclose(gp, want["position"], rtol=1e-9, atol=1e-12)
+    assert [int(g[6]) for g in got] == want["finger_placement_index"].tolist()
