@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # f32 vector == f32-input MFMA peak
-LENET_MFLOP = {15: 83.04, 12: 73.63, 3: 45.41}
+LENET_MFLOP = {15: 83.04, 12: 73.63, 3: 45.41, 1: 39.14}  # SURVEY.md §8d (+ the 1-channel strategy)
 
 
 def main():
