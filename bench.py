@@ -173,7 +173,7 @@ def main():
             "detect_end_to_end": {"candidates": int(n_detect), "wall_ms": detect_wall * 1e3,
                                   "note": "gpd_hip_detect: all candidates of the sample set, host buffers in, scored hands out"},
         }
-        if args.cpu_samples > 0:
+        if args.cpu_samples > 0 and args.gpus == 1:  # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = _cpu_baseline(cloud, w, C, args.cpu_samples)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
