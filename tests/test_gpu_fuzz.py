@@ -1,0 +1,73 @@
+"""Differential fuzz of the HIP path against the oracle: random clouds (sizes, clutter, off-lattice
+jitter, random normals, one to three cameras with random per-point visibility), random samples by
+index and by coordinate, random parameter draws.  Records and images byte for byte, scores to 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+from gpd_amd import api, synth
+
+
+def _weights(C):
+    g = os.path.join(os.path.dirname(__file__), "golden", "lenet%d_params.npz" % C)
+    return synth.lenet_weights(C, real=dict(np.load(g)) if os.path.exists(g) else None)
+
+
+def _case(seed):
+    rng = np.random.RandomState(1000 + seed)
+    cl = synth.make_cloud(5000 + seed, int(rng.choice([3000, 9000, 20000])), clutter=bool(rng.randint(2)))
+    xyz, nrm = cl["xyz"].copy(), cl["normals"].copy()
+    if seed % 3 == 1:  # off the 3 mm lattice: no exact distance ties, arbitrary floats
+        xyz += rng.uniform(-0.0012, 0.0012, xyz.shape).astype(np.float32)
+    if seed % 4 == 2:  # noisy normals (not unit length, like a sloppy estimator's)
+        nrm = (nrm + rng.normal(0, 0.2, nrm.shape)).astype(np.float32)
+    n_cams = 1 + seed % 3
+    cam = (rng.rand(n_cams, len(xyz)) < 0.8).astype(np.int32)
+    cam[0] |= (cam.sum(0) == 0).astype(np.int32)  # every point seen by somebody
+    vp = np.array([[0.0, 0.0, 0.0], [0.3, -0.2, 0.1], [-0.25, 0.3, 0.05]])[:n_cams]
+    kw = {}
+    if seed % 2:
+        kw["num_orientations"] = int(rng.choice([3, 5, 8]))
+        kw["friction_coeff"] = float(rng.choice([10.0, 20.0, 30.0]))
+        kw["min_viable"] = int(rng.choice([1, 6, 12]))
+        kw["nn_radius_frames"] = float(rng.choice([0.008, 0.01, 0.015]))
+    C = int(rng.choice([15, 15, 12, 3, 1]))
+    return dict(xyz=xyz, normals=nrm, cam=cam, vp=vp, kw=kw, C=C, obj=cl["is_object"], rng=rng)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_detect_matches_oracle(oracle_mod, seed):
+    c = _case(seed)
+    C = c["C"]
+    w = _weights(C)
+    gp, op = api.default_params(C), oracle_mod.default_params(C)
+    for k, v in c["kw"].items():
+        setattr(gp, k, v)
+        setattr(op, k, v)
+    obj = np.flatnonzero(c["obj"])
+    si = c["rng"].choice(obj, size=min(120, len(obj)), replace=False).astype(np.int32)
+    ctx = api.Context(gp)
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(c["xyz"], c["normals"], c["cam"], c["vp"])
+        hands, n_cand = ctx.detect(si)
+        ohands, on_cand, _ = oracle_mod.detect(op, c["xyz"], c["normals"], c["cam"], c["vp"], si, w)
+        assert hands.shape == ohands.shape and n_cand == on_cand
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes()
+        fw = oracle_mod.filter_workspace(op, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(op, c["xyz"], c["normals"], c["cam"], c["vp"], fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
+        # the same samples by coordinate, nudged off the cloud
+        sm = c["xyz"][si[:40]].astype(np.float64) + c["rng"].uniform(-0.003, 0.003, (40, 3))
+        got = ctx.search_samples(sm)
+        want = oracle_mod.search_xyz(op, c["xyz"], c["normals"], sm)
+        assert got.shape == want.shape and got.tobytes() == want.tobytes()
+    finally:
+        ctx.close()
