@@ -71,3 +71,22 @@ def test_fuzz_detect_matches_oracle(oracle_mod, seed):
         assert got.shape == want.shape and got.tobytes() == want.tobytes()
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 4, 7])
+def test_fuzz_normals_match_oracle(oracle_mod, seed):
+    """Cloud::calculateNormals on random clouds (off-lattice, several cameras): float32 normals bit for bit."""
+    c = _case(seed)
+    xyz = c["xyz"][:6000]
+    cam = c["cam"][:, :6000]
+    radius = [0.02, 0.03, 0.015][seed % 3]
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.upload_cloud(xyz, np.zeros_like(xyz), cam, c["vp"])
+        got = ctx.estimate_normals(radius)
+        want = oracle_mod.estimate_normals(xyz, cam, c["vp"], radius)
+        assert got.shape == want.shape and got.tobytes() == want.tobytes()
+        assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+    finally:
+        ctx.close()
