@@ -525,7 +525,8 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     // ... indices grouped bucket by bucket ...
     for (int t = tid; t < n; t += 256) {
       const uint32_t i = s_a[t];
-      s_b[atomicAdd(&s_hist[bucket_of(d2_of((int)i))], 1)] = i;
+      const int pos = atomicAdd(&s_hist[bucket_of(d2_of((int)i))], 1);
+      if (pos < n) s_b[pos] = i;  // always true (the counters come from the same d2 values); keeps a corrupted table out of LDS
     }
     __syncthreads();
     // ... and every bucket ordered by (d2 bits, index); non-negative floats order as unsigned.
