@@ -86,30 +86,43 @@ Cloud::Cloud(const std::vector<float> &xyz, const std::vector<float> &normals, c
 }
 
 Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points) : view_points_(view_points) {
-  std::ifstream f(filename.c_str());
+  // pcl::io::loadPCDFile (cloud.cpp:643-660) for the ASCII and the uncompressed binary layout
+  std::ifstream f(filename.c_str(), std::ios::binary);
   if (!f) {
     printf("Couldn't read .pcd file: %s\n", filename.c_str());
     return;
   }
   std::string line;
-  std::vector<std::string> fields;
-  bool ascii = false;
+  std::vector<std::string> fields, types;
+  std::vector<int> sizes, counts;
+  std::string kind;
+  size_t points = 0;
   while (std::getline(f, line)) {
+    if (!line.empty() && line.back() == '\r') line.pop_back();
     std::stringstream ss(line);
     std::string tag;
     ss >> tag;
     if (tag == "FIELDS") {
       std::string x;
       while (ss >> x) fields.push_back(x);
+    } else if (tag == "SIZE") {
+      int x;
+      while (ss >> x) sizes.push_back(x);
+    } else if (tag == "TYPE") {
+      std::string x;
+      while (ss >> x) types.push_back(x);
+    } else if (tag == "COUNT") {
+      int x;
+      while (ss >> x) counts.push_back(x);
+    } else if (tag == "POINTS") {
+      ss >> points;
     } else if (tag == "DATA") {
-      std::string kind;
       ss >> kind;
-      ascii = (kind == "ascii");
       break;
     }
   }
-  if (!ascii) {
-    printf("Only ASCII .pcd files are supported: %s\n", filename.c_str());
+  if (kind != "ascii" && kind != "binary") {
+    printf("Only ASCII and uncompressed binary .pcd files are supported (DATA %s): %s\n", kind.c_str(), filename.c_str());
     return;
   }
   int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
@@ -125,20 +138,65 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
     printf("PCD file has no x y z fields: %s\n", filename.c_str());
     return;
   }
-  std::vector<double> row(fields.size());
-  while (std::getline(f, line)) {
-    std::stringstream ss(line);
-    bool good = true;
-    for (size_t i = 0; i < fields.size(); i++)
-      if (!(ss >> row[i])) good = false;
-    if (!good || row[ix] != row[ix] || row[iy] != row[iy] || row[iz] != row[iz]) continue;  // removeNans
+  const bool with_normals = inx >= 0 && iny >= 0 && inz >= 0;
+  auto keep = [&](const double *row) {
+    if (row[ix] != row[ix] || row[iy] != row[iy] || row[iz] != row[iz]) return;  // removeNans
     xyz_.push_back((float)row[ix]);
     xyz_.push_back((float)row[iy]);
     xyz_.push_back((float)row[iz]);
-    if (inx >= 0 && iny >= 0 && inz >= 0) {
+    if (with_normals) {
       normals_.push_back((float)row[inx]);
       normals_.push_back((float)row[iny]);
       normals_.push_back((float)row[inz]);
+    }
+  };
+  std::vector<double> row(fields.size());
+  if (kind == "ascii") {
+    while (std::getline(f, line)) {
+      std::stringstream ss(line);
+      bool good = true;
+      for (size_t i = 0; i < fields.size(); i++)
+        if (!(ss >> row[i])) good = false;
+      if (good) keep(row.data());
+    }
+  } else {
+    // one record per point: the fields back to back, SIZE bytes each (x COUNT), little endian
+    if (sizes.size() != fields.size() || types.size() != fields.size()) {
+      printf("PCD header is incomplete (SIZE / TYPE): %s\n", filename.c_str());
+      return;
+    }
+    counts.resize(fields.size(), 1);
+    std::vector<size_t> offset(fields.size());
+    size_t stride = 0;
+    for (size_t i = 0; i < fields.size(); i++) {
+      offset[i] = stride;
+      stride += (size_t)sizes[i] * (size_t)counts[i];
+    }
+    std::vector<char> rec(stride);
+    for (size_t n = 0; n < points && f.read(rec.data(), (std::streamsize)stride); n++) {
+      for (size_t i = 0; i < fields.size(); i++) {
+        const char *p = rec.data() + offset[i];
+        double v = 0.0;
+        if (types[i] == "F" && sizes[i] == 4) {
+          float x;
+          std::memcpy(&x, p, 4);
+          v = x;
+        } else if (types[i] == "F" && sizes[i] == 8) {
+          std::memcpy(&v, p, 8);
+        } else if (sizes[i] == 4) {
+          int32_t x;
+          std::memcpy(&x, p, 4);
+          v = types[i] == "U" ? (double)(uint32_t)x : (double)x;
+        } else if (sizes[i] == 2) {
+          int16_t x;
+          std::memcpy(&x, p, 2);
+          v = types[i] == "U" ? (double)(uint16_t)x : (double)x;
+        } else if (sizes[i] == 1) {
+          v = types[i] == "U" ? (double)(uint8_t)p[0] : (double)(int8_t)p[0];
+        }
+        row[i] = v;
+      }
+      keep(row.data());
     }
   }
   if (view_points_.empty()) view_points_.assign(3, 0.0);
@@ -1037,4 +1095,16 @@ extern "C" int gpd_host_find_clusters(const gpd_hand *hands, const double *score
     out_scores[k] = res[k]->getScore();
   }
   return (int)res.size();
+}
+
+// Flat entry for tests / ctypes: loads a PCD like util::Cloud does; returns the number of points
+// (at most cap are copied), *has_normals tells whether normal_x/y/z fields were present.
+extern "C" int gpd_host_load_pcd(const char *path, float *xyz, float *normals, int cap, int *has_normals) {
+  gpd::util::Cloud cloud(path, {0.0, 0.0, 0.0});
+  const int n = (int)cloud.size();
+  if (has_normals) *has_normals = cloud.hasNormals() ? 1 : 0;
+  const int m = n < cap ? n : cap;
+  if (xyz && m > 0) std::memcpy(xyz, cloud.getCloudProcessed().data(), (size_t)m * 3 * sizeof(float));
+  if (normals && cloud.hasNormals() && m > 0) std::memcpy(normals, cloud.getNormals().data(), (size_t)m * 3 * sizeof(float));
+  return n;
 }

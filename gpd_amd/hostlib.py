@@ -37,3 +37,15 @@ def find_clusters(hands, scores, min_inliers=1, remove_inliers=False):
                                      int(bool(remove_inliers)), out.ctypes.data_as(C.c_void_p), osc.ctypes.data_as(C.c_void_p),
                                      src.ctypes.data_as(C.c_void_p))
     return out[:k].copy(), osc[:k].copy(), src[:k].copy()
+
+
+def load_pcd(path, cap=1 << 22):
+    """util::Cloud(filename): ASCII or uncompressed binary PCD -> (xyz f32 [n,3], normals f32 [n,3] or None)."""
+    xyz = np.zeros((cap, 3), np.float32)
+    nrm = np.zeros((cap, 3), np.float32)
+    has = C.c_int(0)
+    L = lib()
+    L.gpd_host_load_pcd.restype = C.c_int
+    n = L.gpd_host_load_pcd(str(path).encode(), xyz.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p), cap, C.byref(has))
+    n = min(n, cap)
+    return xyz[:n].copy(), (nrm[:n].copy() if has.value else None)

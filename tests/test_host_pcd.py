@@ -1,0 +1,59 @@
+"""util::Cloud PCD reader of the host mirror (pcl::io::loadPCDFile, cloud.cpp:643-660): ASCII and
+uncompressed binary layouts, extra fields, NaN rows removed."""
+import numpy as np
+
+from gpd_amd import hostlib
+
+
+def _write(path, xyz, normals, binary, extra_rgb=False):
+    n = len(xyz)
+    fields = ["x", "y", "z"] + (["rgb"] if extra_rgb else []) + (["normal_x", "normal_y", "normal_z"] if normals is not None else [])
+    sizes = ["4"] * len(fields)
+    types = ["F", "F", "F"] + (["U"] if extra_rgb else []) + (["F"] * 3 if normals is not None else [])
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT 1\n"
+           "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n" % (" ".join(fields), " ".join(sizes), " ".join(types),
+                                                              " ".join(["1"] * len(fields)), n, n, "binary" if binary else "ascii"))
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        for i in range(n):
+            if binary:
+                rec = xyz[i].astype("<f4").tobytes()
+                if extra_rgb:
+                    rec += np.uint32(0x00ff8040 + i).tobytes()
+                if normals is not None:
+                    rec += normals[i].astype("<f4").tobytes()
+                f.write(rec)
+            else:
+                vals = ["%.9g" % v for v in xyz[i]] + (["%d" % (4286578688 + i)] if extra_rgb else [])
+                if normals is not None:
+                    vals += ["%.9g" % v for v in normals[i]]
+                f.write((" ".join(vals) + "\n").encode())
+
+
+def test_pcd_ascii_and_binary_roundtrip(tmp_path):
+    rng = np.random.RandomState(0)
+    xyz = rng.normal(0, 0.3, (500, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (500, 3)).astype(np.float32)
+    xyz[17] = np.nan  # removed on load (Cloud::removeNans)
+    keep = np.ones(500, bool)
+    keep[17] = False
+    for binary in (False, True):
+        for normals in (None, nrm):
+            for rgb in (False, True):
+                p = tmp_path / ("c_%d_%d_%d.pcd" % (binary, normals is not None, rgb))
+                _write(str(p), xyz, normals, binary, rgb)
+                gx, gn = hostlib.load_pcd(p)
+                assert np.array_equal(gx, xyz[keep]), (binary, rgb)
+                if normals is None:
+                    assert gn is None
+                else:
+                    assert np.array_equal(gn, nrm[keep])
+
+
+def test_pcd_unsupported_or_missing_is_empty(tmp_path):
+    p = tmp_path / "z.pcd"
+    p.write_bytes(b"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary_compressed\n\x00\x00")
+    gx, _ = hostlib.load_pcd(p)
+    assert len(gx) == 0
+    gx, _ = hostlib.load_pcd(tmp_path / "does_not_exist.pcd")
+    assert len(gx) == 0
