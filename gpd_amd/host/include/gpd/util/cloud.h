@@ -32,6 +32,9 @@ class Cloud {
   const std::vector<double> &getSamples() const { return samples_; }
   void setSamples(const std::vector<double> &samples) { samples_ = samples; }
   void setNormals(const std::vector<float> &normals) { normals_ = normals; }
+  // Cloud::setNormalsFromFile (cloud.cpp:622-641): a CSV of three rows (x, y, z components) with one
+  // column per point.  The device boundary carries float32 normals (the reference keeps these doubles).
+  void setNormalsFromFile(const std::string &filename);
   // Cloud::voxelizeCloud (cloud.cpp:286-348), including what its std::set comparator (cloud.h:105-122,
   // not an ordering) keeps under libstdc++; drops normals like the reference's preprocessing order does.
   void voxelizeCloud(float cell_size);

@@ -9,7 +9,7 @@
 int main(int argc, char *argv[]) {
   if (argc < 3) {
     std::cout << "Error: Not enough input arguments!\n\n";
-    std::cout << "Usage: cem_detect_grasps CONFIG_FILE PCD_FILE\n\n";
+    std::cout << "Usage: cem_detect_grasps CONFIG_FILE PCD_FILE [NORMALS_FILE]\n\n";
     std::cout << "Detect grasp poses for a point cloud, PCD_FILE (*.pcd), using parameters from CONFIG_FILE (*.cfg).\n";
     return -1;
   }
@@ -17,6 +17,10 @@ int main(int argc, char *argv[]) {
   if (cloud.size() == 0) {
     std::cout << "Error: Input point cloud is empty or does not exist!\n";
     return -1;
+  }
+  if (argc > 3) {
+    cloud.setNormalsFromFile(argv[3]);
+    std::cout << "Loaded surface normals from file: " << argv[3] << "\n";
   }
   gpd::SequentialImportanceSampling sis(argv[1]);
   if (!sis.ok()) return -1;

@@ -10,7 +10,7 @@
 int main(int argc, char *argv[]) {
   if (argc < 3) {
     std::cout << "Error: Not enough input arguments!\n\n";
-    std::cout << "Usage: detect_grasps CONFIG_FILE PCD_FILE\n\n";
+    std::cout << "Usage: detect_grasps CONFIG_FILE PCD_FILE [NORMALS_FILE]\n\n";
     std::cout << "Detect grasp poses for a point cloud, PCD_FILE (*.pcd with normals), using parameters from CONFIG_FILE (*.cfg).\n";
     return -1;
   }
@@ -22,6 +22,10 @@ int main(int argc, char *argv[]) {
   if (cloud.size() == 0) {
     std::cout << "Error: Input point cloud is empty or does not exist!\n";
     return -1;
+  }
+  if (argc > 3) {  // [NORMALS_FILE]: a surface normal for each point of the cloud (*.csv)
+    cloud.setNormalsFromFile(argv[3]);
+    std::cout << "Loaded surface normals from file: " << argv[3] << "\n";
   }
   gpd::GraspDetector detector(argv[1]);
   if (!detector.ok()) return -1;

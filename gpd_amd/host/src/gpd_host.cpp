@@ -211,6 +211,24 @@ struct VoxelDiffers {  // UniqueVector4First3Comparator (cloud.h:105-122)
 };
 }  // namespace
 
+void Cloud::setNormalsFromFile(const std::string &filename) {
+  std::ifstream in(filename.c_str());
+  std::string line;
+  std::vector<float> normals(xyz_.size(), 0.f);
+  size_t i = 0;
+  while (i < 3 && std::getline(in, line)) {
+    std::stringstream ls(line);
+    std::string cell;
+    size_t j = 0;
+    while (std::getline(ls, cell, ',')) {
+      if (j < size()) normals[3 * j + i] = (float)std::stod(cell);
+      j++;
+    }
+    i++;
+  }
+  if (i == 3) normals_ = normals;
+}
+
 void Cloud::voxelizeCloud(float cell_size) {
   const int n = (int)size();
   if (n == 0) return;
@@ -1106,5 +1124,14 @@ extern "C" int gpd_host_load_pcd(const char *path, float *xyz, float *normals, i
   const int m = n < cap ? n : cap;
   if (xyz && m > 0) std::memcpy(xyz, cloud.getCloudProcessed().data(), (size_t)m * 3 * sizeof(float));
   if (normals && cloud.hasNormals() && m > 0) std::memcpy(normals, cloud.getNormals().data(), (size_t)m * 3 * sizeof(float));
+  return n;
+}
+
+extern "C" int gpd_host_load_normals_csv(const char *pcd_path, const char *csv_path, float *normals, int cap) {
+  gpd::util::Cloud cloud(pcd_path, {0.0, 0.0, 0.0});
+  cloud.setNormalsFromFile(csv_path);
+  if (!cloud.hasNormals()) return -1;
+  const int n = (int)cloud.size(), m = n < cap ? n : cap;
+  std::memcpy(normals, cloud.getNormals().data(), (size_t)m * 3 * sizeof(float));
   return n;
 }

@@ -57,3 +57,18 @@ def test_pcd_unsupported_or_missing_is_empty(tmp_path):
     assert len(gx) == 0
     gx, _ = hostlib.load_pcd(tmp_path / "does_not_exist.pcd")
     assert len(gx) == 0
+
+
+def test_normals_csv(tmp_path):
+    import ctypes as C
+    rng = np.random.RandomState(1)
+    xyz = rng.normal(0, 0.3, (40, 3)).astype(np.float32)
+    nrm = rng.normal(0, 1, (40, 3)).astype(np.float32)
+    pcd, csv = tmp_path / "c.pcd", tmp_path / "n.csv"
+    _write(str(pcd), xyz, None, False)
+    csv.write_text("\n".join(",".join("%.9g" % v for v in nrm[:, r]) for r in range(3)) + "\n")
+    out = np.zeros((40, 3), np.float32)
+    L = hostlib.lib()
+    L.gpd_host_load_normals_csv.restype = C.c_int
+    n = L.gpd_host_load_normals_csv(str(pcd).encode(), str(csv).encode(), out.ctypes.data_as(C.c_void_p), 40)
+    assert n == 40 and np.array_equal(out, nrm)
