@@ -15,6 +15,31 @@
 
 namespace gpd {
 
+namespace candidate {
+// HandGeometry (candidate/hand_geometry.h:50-72) and HandSearch::Parameters (candidate/hand_search.h:76-94)
+struct HandGeometry {
+  double finger_width_, outer_diameter_, depth_, height_, init_bite_;
+};
+struct HandSearch {
+  struct Parameters {
+    double nn_radius_frames_;
+    int num_threads_, num_samples_, num_orientations_, num_finger_placements_;
+    std::vector<int> hand_axes_;
+    bool deepen_hand_;
+    double friction_coeff_;
+    int min_viable_;
+    HandGeometry hand_geometry_;
+  };
+};
+}  // namespace candidate
+namespace descriptor {
+// ImageGeometry (descriptor/image_geometry.h:50-78)
+struct ImageGeometry {
+  double outer_diameter_, depth_, height_;
+  int size_, num_channels_;
+};
+}  // namespace descriptor
+
 class GraspDetector {
  public:
   explicit GraspDetector(const std::string &config_filename);
@@ -46,6 +71,12 @@ class GraspDetector {
     return a->getScore() > b->getScore();
   }
   const gpd_params &getParams() const { return params_; }
+  // grasp_detector.h:176-186
+  candidate::HandSearch::Parameters getHandSearchParameters() const;
+  descriptor::ImageGeometry getImageGeometry() const {
+    return {params_.volume_width, params_.volume_depth, params_.volume_height, params_.image_size, params_.image_num_channels};
+  }
+  const std::vector<double> &getWorkspaceGrasps() const { return workspace_grasps_; }
   bool ok() const { return ctx_ != nullptr; }
   // stage runtimes of the last detectGrasps, seconds: candidates, images, classification, total
   const double *lastRuntimes() const { return runtimes_; }

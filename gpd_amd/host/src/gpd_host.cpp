@@ -474,6 +474,21 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   }
 }
 
+candidate::HandSearch::Parameters GraspDetector::getHandSearchParameters() const {
+  candidate::HandSearch::Parameters p;
+  p.nn_radius_frames_ = params_.nn_radius_frames;
+  p.num_threads_ = 1;
+  p.num_samples_ = num_samples_;
+  p.num_orientations_ = params_.num_orientations;
+  p.num_finger_placements_ = params_.num_finger_placements;
+  p.hand_axes_.assign(params_.hand_axes, params_.hand_axes + params_.num_hand_axes);
+  p.deepen_hand_ = params_.deepen_hand != 0;
+  p.friction_coeff_ = params_.friction_coeff;
+  p.min_viable_ = params_.min_viable;
+  p.hand_geometry_ = {params_.finger_width, params_.hand_outer_diameter, params_.hand_depth, params_.hand_height, params_.init_bite};
+  return p;
+}
+
 GraspDetector::~GraspDetector() {
   if (ctx_) gpd_hip_destroy(ctx_);
 }
