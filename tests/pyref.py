@@ -125,6 +125,25 @@ def shadow_voxels(pts, view_point, rng, shadow_length=0.10):
     return sorted(out)
 
 
+def shadow_voxels_cameras(pts, cam_rows, view_points, rng, shadow_length=0.10):
+    """HandSet::calculateShadow for several cameras (hand_set.cpp:118-185): every camera that sees at
+    least one neighbourhood point casts the shadow of ALL the points from its view point (in camera
+    order, consuming LCG draws); one camera: its set; several: camera 0's set (empty when camera 0
+    sees nothing) intersected with the sets of the other seeing cameras."""
+    cam_rows = np.asarray(cam_rows)
+    n_cams = cam_rows.shape[0]
+    sets = []
+    for c in range(n_cams):
+        sets.append(set(shadow_voxels(pts, view_points[c], rng, shadow_length)) if cam_rows[c].sum() >= 1 else set())
+    if n_cams == 1:
+        return sorted(sets[0])
+    allv = sets[0]
+    for c in range(1, n_cams):
+        if cam_rows[c].sum() >= 1:
+            allv = allv & sets[c]
+    return sorted(allv)
+
+
 def grasp_image(P, hand, xyz, normals, nbr_idx, shadow_vox=None):
     """One candidate's image [60,60,C] from its 0.10 m neighbourhood (in neighbour order)."""
     C = P.image_num_channels

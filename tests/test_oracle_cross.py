@@ -192,3 +192,42 @@ def test_openmp_matches_single_thread(oracle_mod, small_cloud, lenet15_real):
     a, na, _ = oracle_mod.detect(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, lenet15_real, threads=1)
     b, nb, _ = oracle_mod.detect(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, lenet15_real, threads=4)
     assert na == nb and a.tobytes() == b.tobytes()
+
+
+def test_multi_camera_shadow_against_python_reference(oracle_mod):
+    """Two and three cameras with partial visibility (one set where camera 0 sees nothing): the oracle's
+    15-channel images against the independent python rasteriser + camera-set intersection."""
+    cl = synth.make_cloud(77, 5000)
+    P = len(cl["xyz"])
+    rng0 = np.random.RandomState(5)
+    for n_cams in (2, 3):
+        cam = (rng0.rand(n_cams, P) < 0.7).astype(np.int32)
+        vp = np.array([[0.0, 0.0, 0.0], [0.3, -0.2, 0.1], [-0.25, 0.3, 0.05]])[:n_cams]
+        p = oracle_mod.default_params(15)
+        si = synth.sample_indices(cl, 5)
+        hands = oracle_mod.filter_workspace(p, oracle_mod.search(p, cl["xyz"], cl["normals"], si))
+        # blind camera 0 around the second live sample
+        live = [s for s in range(len(si)) if hands[s]["valid"].any()]
+        assert len(live) >= 2
+        blind = pyref.radius_neighbours(cl["xyz"], hands[live[1], 0]["sample"].astype(np.float32), 0.10)
+        cam[0, blind] = 0
+        cam[1, blind[0]] = 1
+        img, cand = oracle_mod.images(p, cl["xyz"], cl["normals"], cam, vp, hands)
+        flat = hands.reshape(-1)
+        rng = pyref.Lcg(0)
+        k = 0
+        for s in live:
+            nbr = pyref.radius_neighbours(cl["xyz"], hands[s, 0]["sample"].astype(np.float32), 0.10)
+            vox = pyref.shadow_voxels_cameras(cl["xyz"][nbr], cam[:, nbr], vp, rng)
+            first = True
+            for j in range(hands.shape[1]):
+                if not hands[s, j]["valid"]:
+                    continue
+                if first:  # one image per set is enough (the python rasteriser is slow)
+                    want = pyref.grasp_image(p, flat[cand[k]], cl["xyz"], cl["normals"], nbr, vox)
+                    assert np.array_equal(img[k], want), (n_cams, s, j, (img[k] != want).sum())
+                    if s == live[1]:
+                        assert not want[..., 4].any()  # camera 0 sees nothing here: empty intersection, no shadow
+                    first = False
+                k += 1
+        assert k == len(cand)
