@@ -291,14 +291,28 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
     const int c = k / 25, tap = k - 25 * c;
     offp[sI] = c * 784 + (tap / 5) * 28 + tap % 5;
   }
+  // the next image's planes travel HBM -> registers while the current image is convolved (six named
+  // 16-byte registers per lane: an array would live in scratch memory)
+  constexpr int IN_V = 20 * 784 / 4;
+  static_assert(IN_V <= 6 * C2_THREADS, "prefetch registers");
+  float4 p0, p1, p2, p3, p4, p5;
+  p0 = p1 = p2 = p3 = p4 = p5 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define C2_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define C2_FETCH1(v) \
+  if (tid + v * C2_THREADS < IN_V) p##v = fsrc[tid + v * C2_THREADS];
+#define C2_STAGE1(v) \
+  if (tid + v * C2_THREADS < IN_V) reinterpret_cast<float4 *>(s_in)[tid + v * C2_THREADS] = p##v;
+#define C2_FETCH(IMG)                                                                              \
+  {                                                                                                \
+    const float4 *fsrc = reinterpret_cast<const float4 *>(pool1 + (size_t)(IMG) * 20 * 784);       \
+    C2_EACH(C2_FETCH1)                                                                             \
+  }
+  if ((int)blockIdx.x < n) C2_FETCH(blockIdx.x)
   for (int img = blockIdx.x; img < n; img += gridDim.x) {
     __syncthreads();  // previous image fully consumed (and the weights are in place)
-    {
-      const float4 *src = reinterpret_cast<const float4 *>(pool1 + (size_t)img * 20 * 784);
-      float4 *dst = reinterpret_cast<float4 *>(s_in);
-      for (int i = tid; i < 20 * 784 / 4; i += C2_THREADS) dst[i] = src[i];
-    }
+    C2_EACH(C2_STAGE1)
     __syncthreads();
+    if (img + (int)gridDim.x < n) C2_FETCH(img + gridDim.x)
     {
       const int rp = wave;  // output rows 2rp, 2rp+1
       f32x4 acc[3][3];      // [pixel tile][filter tile]
@@ -408,6 +422,11 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
     }
   }
 }
+
+#undef C2_FETCH
+#undef C2_FETCH1
+#undef C2_STAGE1
+#undef C2_EACH
 
 // ---------------------------------------------------------------------------
 // FC1 on f32 MFMA:  D[u][m] = sum_k W[k][u] * X[m][k]   (W = ip1 weights, column-
