@@ -131,6 +131,10 @@ struct ImageState {
   int channels = 0;
   int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
   int num_overflow = 0;               // as found by the last checked launch (replays reuse it)
+  int32_t *d_pts_overflow = nullptr;  // [capacity + 1]: candidates for the large points instantiation, then their count
+  int num_pts_overflow = 0;
+  char *d_pts_scratch = nullptr;      // point arrays of the large instantiation, one row per listed candidate
+  int cap_pts_scratch = 0;            // rows
   int32_t *d_status = nullptr;        // error flags from the kernel
   int cap_hands = 0;
   long long stat_sets = 0, stat_sum_set_ni = 0, stat_sum_cand_ni = 0;  // for the algorithmic byte count

@@ -37,6 +37,7 @@
 #include <cstring>
 
 #include <mutex>
+#include <type_traits>
 
 #include "gpd_internal.h"
 
@@ -55,6 +56,7 @@ constexpr int IMG_THREADS = 512;   // 256 VGPRs per lane: no spills (1024 thread
 constexpr int SET_THREADS = 1024;  // shadow_set_kernel
 constexpr int IMG_WAVES = IMG_THREADS / 64;
 constexpr int PT_CAP = 2048;  // in-box points per candidate (entry indices are packed into 11 bits by sort_by_rank)
+constexpr int PT_CAP_BIG = 16384;  // fallback instantiation of the points kernel: storage in a global scratch row
 constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
 constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
 constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
@@ -92,6 +94,9 @@ struct ImgParams {
   int32_t *overflow_list;    // shadow kernel: candidates whose box exceeds SHC voxels
   int32_t *overflow_count;
   unsigned long long *dbg;  // profiling aid (GPD_IMG_TIMING=1): per-phase cycle sums
+  int32_t *pts_overflow_list;   // points kernel: candidates with more than PT_CAP in-box points
+  int32_t *pts_overflow_count;
+  char *pts_scratch;            // fallback instantiation: PTS_SCRATCH_BYTES per listed candidate
 };
 
 struct Box {
@@ -101,16 +106,22 @@ struct Box {
   double lo[3], hi[3];
 };
 
-// points kernel: in-box points cached once, one projection's normals (3 planes) + depth at a time
-struct __attribute__((aligned(16))) Smem {
-  struct {
-    double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
-    float a[3][PT_CAP];   // |normal| in the hand frame
-    uint32_t key[PT_CAP]; // cx | cy << 6 | cz << 12 | neighbour rank << 18
-  } p;
+// points kernel: in-box points cached once, one projection's normals (3 planes) + depth at a time.
+// BIG (the overflow fallback, up to PT_CAP_BIG in-box points): the point arrays live in a global
+// scratch row instead of LDS.
+constexpr size_t PTS_SCRATCH_BYTES = (size_t)PT_CAP_BIG * (3 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t));
+struct PointArrays {
+  double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
+  float a[3][PT_CAP];   // |normal| in the hand frame
+  uint32_t key[PT_CAP]; // cx | cy << 6 | cz << 12 | neighbour rank << 18
+};
+struct NoPointArrays {};
+template <bool BIG>
+struct __attribute__((aligned(16))) SmemPts {
+  typename std::conditional<BIG, NoPointArrays, PointArrays>::type p;
   float raster[3][kPix];  // cell-index order (row flip applied at the store)
   uint32_t cells[kPix];   // (segment start << 16) | count; reused as the f32 depth plane
-  uint16_t place[PT_CAP + kPix];  // segment table + list of non-empty cells
+  uint16_t place[(BIG ? PT_CAP_BIG : PT_CAP) + kPix];  // segment table + list of non-empty cells
   double thr[3][kImg + 1];
   double recip[256];  // 1.0 / k
   float red_f[4 * IMG_WAVES];
@@ -118,6 +129,7 @@ struct __attribute__((aligned(16))) Smem {
   int counter;
   int flag;
 };
+typedef SmemPts<false> Smem;
 // shadow kernel: kept under 80 KB (SHC = 6144) so that two workgroups share a CU
 template <int SHC>
 struct __attribute__((aligned(16))) SmemShadow {
@@ -459,25 +471,26 @@ __device__ inline void sort_u16_regs(uint16_t *p, int n) {
   for (int q = 0; q < N; q++)
     if (q < n) p[q] = (uint16_t)k[q];
 }
-// (rank << 11 | entry) packed keys; entries are < 2048, rank = key[entry] >> 18
-template <int N>
+// (rank << EB | entry) packed keys; entries are < 2^EB, rank = key[entry] >> 18 (14 bits)
+template <int N, int EB>
 __device__ inline void sort_by_rank_regs(uint16_t *p, int n, const uint32_t *key) {
   uint32_t k[N];
 #pragma unroll
   for (int q = 0; q < N; q++) {
     const uint32_t e = p[q];
-    k[q] = q < n ? ((key[e & 2047u] >> 18) << 11) | e : 0xffffffffu;
+    k[q] = q < n ? ((key[e & ((1u << EB) - 1u)] >> 18) << EB) | e : 0xffffffffu;
   }
   sort_regs<N>(k);
 #pragma unroll
   for (int q = 0; q < N; q++)
-    if (q < n) p[q] = (uint16_t)(k[q] & 2047u);
+    if (q < n) p[q] = (uint16_t)(k[q] & ((1u << EB) - 1u));
 }
 // sort entry indices by the neighbour rank stored in key[] (rank = key >> 18)
+template <int EB>
 __device__ inline void sort_by_rank(uint16_t *p, int n, const uint32_t *key) {
-  if (n <= 8) return sort_by_rank_regs<8>(p, n, key);
-  if (n <= 16) return sort_by_rank_regs<16>(p, n, key);
-  if (n <= 32) return sort_by_rank_regs<32>(p, n, key);
+  if (n <= 8) return sort_by_rank_regs<8, EB>(p, n, key);
+  if (n <= 16) return sort_by_rank_regs<16, EB>(p, n, key);
+  if (n <= 32) return sort_by_rank_regs<32, EB>(p, n, key);
   for (int i = 1; i < n; i++) {
     const uint16_t v = p[i];
     const uint32_t kv = key[v] >> 18;
@@ -738,17 +751,41 @@ __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_ima
 // grasp_image_kernel: normals (3) and depth (1) channels per projection of one candidate
 // (createNormalsImage / createDepthImage, image_strategy.cpp:124-190).
 // ---------------------------------------------------------------------------
+template <bool BIG>
 __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
-  __shared__ Smem S;
+  __shared__ SmemPts<BIG> S;
+  constexpr int CAP = BIG ? PT_CAP_BIG : PT_CAP;
+  constexpr int EB = BIG ? 14 : 11;  // bits of an entry index
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
-  const int cand = blockIdx.x;
+  const int cand = BIG ? P.cand_list[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int slot_s = P.meta[4 * cand + 0];
   const int N = P.meta[4 * cand + 1];
   const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
   uint8_t *out = P.images + (size_t)cand * kPix * K.C;
+  // the point arrays: LDS, or this workgroup's row of the global scratch
+  double *gt = nullptr;
+  float *ga = nullptr;
+  uint32_t *gkey = nullptr;
+  if constexpr (BIG) {
+    char *row = P.pts_scratch + (size_t)blockIdx.x * PTS_SCRATCH_BYTES;
+    gt = reinterpret_cast<double *>(row);
+    ga = reinterpret_cast<float *>(row + (size_t)CAP * 3 * sizeof(double));
+    gkey = reinterpret_cast<uint32_t *>(row + (size_t)CAP * (3 * sizeof(double) + 3 * sizeof(float)));
+  }
+  auto T = [&](int a, int e) -> double & {
+    if constexpr (BIG) return gt[(size_t)a * CAP + e];
+    else return S.p.t[a][e];
+  };
+  auto A = [&](int a, int e) -> float & {
+    if constexpr (BIG) return ga[(size_t)a * CAP + e];
+    else return S.p.a[a][e];
+  };
+  uint32_t *keys;
+  if constexpr (BIG) keys = gkey;
+  else keys = S.p.key;
   Box B;
   load_box(P.hands[cand], B);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
@@ -773,23 +810,37 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       base = __shfl(base, 0);
       if (in) {
         const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (e < PT_CAP) {
+        if (e < CAP) {
           const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
-          S.p.t[0][e] = t[0];
-          S.p.t[1][e] = t[1];
-          S.p.t[2][e] = t[2];
-          S.p.a[0][e] = (float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2);
-          S.p.a[1][e] = (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2);
-          S.p.a[2][e] = (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2);
-          S.p.key[e] = cells_of(S, B, t) | ((uint32_t)i << 18);
+          T(0, e) = t[0];
+          T(1, e) = t[1];
+          T(2, e) = t[2];
+          A(0, e) = (float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2);
+          A(1, e) = (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2);
+          A(2, e) = (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2);
+          keys[e] = cells_of(S, B, t) | ((uint32_t)i << 18);
         }
       }
     }
   }
   __syncthreads();
   const int n_box_all = S.counter;
-  if (n_box_all > PT_CAP && tid == 0) atomicOr(&S.flag, 2);
-  const int nb = n_box_all < PT_CAP ? n_box_all : PT_CAP;
+  if (n_box_all > CAP) {
+    // more in-box points than this instantiation holds: queue the candidate for the large one
+    // (nothing has been written yet), or report it when this already is the large one
+    if (tid == 0) {
+      if (!BIG && P.pts_overflow_list)
+        P.pts_overflow_list[atomicAdd(P.pts_overflow_count, 1)] = cand;
+      else
+        atomicOr(P.status, 2);
+    }
+    return;
+  }
+  if constexpr (BIG) {
+    __threadfence_block();  // the point arrays are global memory here: written above, read by other lanes below
+    __syncthreads();
+  }
+  const int nb = n_box_all;
   if (P.dbg && tid == 0) {
     atomicMax(&P.dbg[30], (unsigned long long)n_box_all);
     atomicAdd(&P.dbg[31], (unsigned long long)n_box_all);
@@ -798,11 +849,11 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   for (int pr = 0; pr < K.nproj; pr++) {
     for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
     __syncthreads();
-    for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(S.p.key[e], pr)], 1u);
+    for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(keys[e], pr)], 1u);
     __syncthreads();
     scan_cells(S);
     for (int e = tid; e < nb; e += IMG_THREADS) {
-      const uint32_t old = atomicAdd(&S.cells[cell_of_key(S.p.key[e], pr)], 1u);
+      const uint32_t old = atomicAdd(&S.cells[cell_of_key(keys[e], pr)], 1u);
       S.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)e;
     }
     __syncthreads();
@@ -810,7 +861,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     // the pixel owner walks its segment in neighbour order
     const int da = depth_axis(pr);
     const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
-    uint16_t *nz = &S.place[PT_CAP];
+    uint16_t *nz = &S.place[CAP];
     const int n_nz = list_nonempty_cells(S, nz);
     TICK(11);
     for (int c = tid; c < kPix; c += IMG_THREADS) {
@@ -830,7 +881,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
       float avg = 0.f, fc = 0.f;
       auto visit = [&](int e) {  // one in-box point, in neighbour order
-        const float a0 = S.p.a[0][e], a1 = S.p.a[1][e], a2 = S.p.a[2][e];
+        const float a0 = A(0, e), a1 = A(1, e), a2 = A(2, e);
         if (v0 == 0.f && v1 == 0.f && v2 == 0.f) {
           v0 = a0;
           v1 = a1;
@@ -843,11 +894,11 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
           v1 = v1 + (float)((double)d1 * inv);
           v2 = v2 + (float)((double)d2 * inv);
         }
-        const double d = div_len(S.p.t[da][e] - offd, da);
+        const double d = div_len(T(da, e) - offd, da);
         fc = (float)((double)fc + 1.0);
         avg = (float)((double)avg + (d - (double)avg) * recip_count<256>(S.recip, fc));
       };
-      sort_by_rank(&S.place[start], cn, S.p.key);
+      sort_by_rank<EB>(&S.place[start], cn, keys);
       for (int q = 0; q < cn; q++) visit((int)S.place[start + q]);
       S.raster[0][c] = v0;
       S.raster[1][c] = v1;
@@ -993,7 +1044,7 @@ void image_cell_thresholds(double len, double *out) {
 }
 
 void images_free(ImageState &im) {
-  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status, im.d_set_meta, im.d_set_bits, im.d_overflow};
+  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status, im.d_set_meta, im.d_set_bits, im.d_overflow, im.d_pts_overflow, im.d_pts_scratch};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   im = ImageState();
@@ -1066,12 +1117,14 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   im.num_candidates = n;
   im.channels = C;
   im.num_overflow = 0;
+  im.num_pts_overflow = 0;
   if (n == 0) return GPD_OK;
   if (n > im.capacity) {
-    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_overflow};
+    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_overflow, im.d_pts_overflow};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
     im.d_overflow = nullptr;
+    im.d_pts_overflow = nullptr;
     im.d_images = nullptr;
     im.d_images_hwc = nullptr;
     im.d_hands = nullptr;
@@ -1081,6 +1134,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
     HIP_RET(hipMalloc(&im.d_hands, (size_t)n * sizeof(gpd_hand)));
     HIP_RET(hipMalloc(&im.d_cand_meta, (size_t)n * 4 * sizeof(int32_t)));
     HIP_RET(hipMalloc(&im.d_overflow, (size_t)(n + 1) * sizeof(int32_t)));  // list + its counter
+    HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)(n + 1) * sizeof(int32_t)));
     im.capacity = n;
   }
   if (!im.d_status) HIP_RET(hipMalloc(&im.d_status, sizeof(int32_t)));
@@ -1233,8 +1287,36 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
       HIP_RET(hipGetLastError());
     }
   }
-  grasp_image_kernel<<<n, IMG_THREADS, 0, stream>>>(ip);
+  // normals + depth: nearly every box holds fewer than PT_CAP points; the others are queued and redone
+  // by the instantiation that keeps its point arrays in a global scratch row
+  ip.pts_overflow_list = im.d_pts_overflow;
+  ip.pts_overflow_count = im.d_pts_overflow + im.capacity;
+  ip.pts_scratch = nullptr;
+  HIP_RET(hipMemsetAsync(im.d_pts_overflow + im.capacity, 0, sizeof(int32_t), stream));
+  grasp_image_kernel<false><<<n, IMG_THREADS, 0, stream>>>(ip);
   HIP_RET(hipGetLastError());
+  if (check) {
+    int32_t n_over = 0;
+    HIP_RET(hipMemcpyAsync(&n_over, im.d_pts_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+    im.num_pts_overflow = n_over;
+    if (n_over > im.cap_pts_scratch) {
+      if (im.d_pts_scratch) (void)hipFree(im.d_pts_scratch);
+      im.d_pts_scratch = nullptr;
+      im.cap_pts_scratch = 0;
+      HIP_RET(hipMalloc(&im.d_pts_scratch, (size_t)n_over * PTS_SCRATCH_BYTES));
+      im.cap_pts_scratch = n_over;
+    }
+  }
+  if (im.num_pts_overflow > 0) {
+    ImgParams ib = ip;
+    ib.cand_list = im.d_pts_overflow;
+    ib.pts_overflow_list = nullptr;
+    ib.pts_overflow_count = nullptr;
+    ib.pts_scratch = im.d_pts_scratch;
+    grasp_image_kernel<true><<<im.num_pts_overflow, IMG_THREADS, 0, stream>>>(ib);
+    HIP_RET(hipGetLastError());
+  }
   if (ip.dbg) {
     unsigned long long h[32];
     HIP_RET(hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -1256,7 +1338,7 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
   HIP_RET(hipStreamSynchronize(stream));
   if (status) {
     set_error("images: kernel capacity exceeded (flags %d: 1 voxel AABB, 2 in-box points > %d, 4 shadow voxels > %d)", status,
-              PT_CAP, SH_CAP_BIG);
+              PT_CAP_BIG, SH_CAP_BIG);
     return GPD_ERR_CAPACITY;
   }
   return GPD_OK;

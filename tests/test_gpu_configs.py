@@ -215,3 +215,91 @@ def test_two_cameras_shadow_intersection(oracle_mod, cloud30k):
         assert not np.array_equal(one[..., 4], got[..., 4])
     finally:
         ctx.close()
+
+
+def _locally_dense_cloud(copies):
+    """The 30k cloud with `copies` jittered duplicates of everything within 6 cm of one object point."""
+    from scipy.spatial import cKDTree
+    cl = synth.make_cloud(1234, 30000)
+    obj = np.flatnonzero(cl["is_object"])
+    t = cKDTree(cl["xyz"].astype(np.float64))
+    centre = cl["xyz"][obj[len(obj) // 2]].astype(np.float64)
+    ball = np.array(t.query_ball_point(centre, 0.06))
+    rng = np.random.RandomState(3)
+    extra = [(cl["xyz"][ball] + rng.uniform(-0.0012, 0.0012, (len(ball), 3))).astype(np.float32) for _ in range(copies)]
+    xyz = np.concatenate([cl["xyz"]] + extra)
+    nrm = np.concatenate([cl["normals"]] + [cl["normals"][ball]] * copies)
+    near = np.array([i for i in t.query_ball_point(centre, 0.045) if cl["is_object"][i]], np.int32)
+    return cl, xyz, nrm, near
+
+
+def test_dense_cloud_overflow_fallbacks(oracle_mod):
+    """Neighbourhoods beyond 8192 points (the 16384-entry bitonic retry of the search) on a cloud of twice the
+    density, and image boxes with more than 2048 in-box points (the global-scratch instantiation of the points
+    kernel) on a locally five-fold cloud — both fallbacks against the oracle."""
+    w = _weights(15)
+    p = oracle_mod.default_params(15)
+    cl, xyz, nrm, near = _locally_dense_cloud(5)
+    cam = np.ones((1, len(xyz)), np.int32)
+    si = near[np.random.RandomState(9).choice(len(near), min(60, len(near)), replace=False)]
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(xyz, nrm, cam, cl["view_points"])
+        hands, n_cand = ctx.detect(si)
+        ohands, on_cand, _ = oracle_mod.detect(p, xyz, nrm, cam, cl["view_points"], si, w)
+        assert n_cand == on_cand and n_cand > 50
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes()
+        fw = oracle_mod.filter_workspace(p, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(p, xyz, nrm, cam, cl["view_points"], fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
+        # some box really holds more than 2048 points: count them for the valid hands (hand-frame box test)
+        worst = 0
+        flat = fw.reshape(-1)
+        for h in flat[cand][:: max(1, len(cand) // 40)]:
+            F = h["frame"].reshape(3, 3)
+            t = (xyz.astype(np.float64) - h["sample"]) @ F
+            inb = (t[:, 0] > h["bottom"]) & (t[:, 0] < h["bottom"] + 0.06) & (np.abs(t[:, 1] - h["center"]) < 0.05) & (np.abs(t[:, 2]) < 0.02)
+            worst = max(worst, int(inb.sum()))
+        assert worst > 2048, worst
+    finally:
+        ctx.close()
+    # twice the density everywhere: neighbourhoods of more than 8192 points
+    cl = synth.make_cloud(1234, 30000)
+    rng = np.random.RandomState(3)
+    jit = (cl["xyz"] + rng.uniform(-0.0012, 0.0012, cl["xyz"].shape)).astype(np.float32)
+    xyz = np.concatenate([cl["xyz"], jit])
+    nrm = np.concatenate([cl["normals"]] * 2)
+    cam = np.ones((1, len(xyz)), np.int32)
+    obj = np.flatnonzero(cl["is_object"])
+    si = obj[np.random.RandomState(9).choice(len(obj), 400, replace=False)].astype(np.int32)
+    w = _weights(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(xyz, nrm, cam, cl["view_points"])
+        hands, n_cand = ctx.detect(si)
+        p = oracle_mod.default_params(15)
+        ohands, on_cand, _ = oracle_mod.detect(p, xyz, nrm, cam, cl["view_points"], si, w)
+        assert n_cand == on_cand and n_cand > 100
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes()
+        fw = oracle_mod.filter_workspace(p, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(p, xyz, nrm, cam, cl["view_points"], fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
+        # the retry really ran: some neighbourhood holds more than 8192 points
+        from scipy.spatial import cKDTree
+        t = cKDTree(xyz.astype(np.float64))
+        assert max(len(x) for x in t.query_ball_point(xyz[si[:40]].astype(np.float64), 0.11)) > 8192
+        assert (img[..., 3] > 0).any()
+    finally:
+        ctx.close()
