@@ -225,3 +225,23 @@ def test_cem_detect_grasps_matches_oracle_replay(tmp_path, oracle_mod, lenet15_r
     gp = np.array([[float(x) for x in g[2:5]] for g in got])
     assert np.allclose(gp, want["position"], rtol=1e-9, atol=1e-12)
     assert [int(g[6]) for g in got] == want["finger_placement_index"].tolist()
+
+
+@pytest.mark.gpu
+def test_generate_candidates_cli_matches_oracle(tmp_path, oracle_mod, lenet15_real):
+    exe = os.path.join(ROOT, "gpd_amd", "host", "generate_candidates")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    cl = synth.make_cloud(99, 12000)
+    cfg, pcd = _write_case(tmp_path, cl, lenet15_real, 80, 5)
+    out = subprocess.run([exe, str(cfg), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    got = [l.split() for l in out.stdout.splitlines() if l.startswith("CANDIDATE ")]
+    si = _subsample_indices(len(cl["xyz"]), 80)
+    hands = oracle_mod.search(oracle_mod.default_params(15), cl["xyz"], cl["normals"], si)
+    want = [(s, j) for s in range(hands.shape[0]) for j in range(hands.shape[1]) if hands[s, j]["valid"]]
+    assert [(int(g[1]), int(g[2])) for g in got] == want and len(want) > 50
+    assert ("Generated %d grasp candidates." % len(want)) in out.stdout
+    for g, (s, j) in zip(got, want):
+        h = hands[s, j]
+        assert int(g[3]) == h["finger_placement_index"] and int(g[8]) == h["half_antipodal"] and int(g[9]) == h["full_antipodal"]
+        assert np.array_equal(np.array([float(x) for x in g[4:7]]), h["position"]) and float(g[7]) == h["grasp_width"]
