@@ -45,9 +45,13 @@ class GraspDetector {
   explicit GraspDetector(const std::string &config_filename);
   ~GraspDetector();
   std::vector<std::unique_ptr<candidate::Hand>> detectGrasps(const util::Cloud &cloud);
-  // CandidatesGenerator::preprocessPointCloud (candidates_generator.cpp:14-37): voxelise (cfg
-  // voxelize/voxel_size), normals on the GPU when the cloud has none (normals_radius), subsample.
+  // CandidatesGenerator::preprocessPointCloud (candidates_generator.cpp:14-37): workspace cut (cfg
+  // workspace), voxelise (voxelize/voxel_size), normals on the GPU when the cloud has none
+  // (normals_radius; normals that came with the cloud are kept), subsample.
   void preprocessPointCloud(util::Cloud &cloud);
+  // Cloud::calculateNormals (cloud.cpp:451-476) on the device: radius PCA, flipped to the view points,
+  // reverseNormals; replaces the cloud's normals.  False when the device call fails.
+  bool calculateNormals(util::Cloud &cloud, double radius);
   std::vector<std::unique_ptr<candidate::HandSet>> generateGraspCandidates(const util::Cloud &cloud);
   std::vector<std::unique_ptr<candidate::HandSet>> filterGraspsWorkspace(
       std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list, const std::vector<double> &workspace) const;
@@ -94,6 +98,7 @@ class GraspDetector {
   double voxel_size_ = 0.003, normals_radius_ = 0.03;
   int num_selected_ = 100;
   std::vector<double> workspace_grasps_;
+  std::vector<double> workspace_;  // cfg `workspace`: the cloud is cut to it in preprocessPointCloud
   bool filter_approach_direction_ = false;
   std::array<double, 3> direction_ = {1, 0, 0};
   double thresh_rad_ = 2.3;

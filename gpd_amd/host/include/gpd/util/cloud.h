@@ -35,6 +35,11 @@ class Cloud {
   // Cloud::setNormalsFromFile (cloud.cpp:622-641): a CSV of three rows (x, y, z components) with one
   // column per point.  The device boundary carries float32 normals (the reference keeps these doubles).
   void setNormalsFromFile(const std::string &filename);
+  // Cloud::filterWorkspace (cloud.cpp:206-267): keeps the points (normals, camera columns) strictly inside
+  // the box [x0 x1 y0 y1 z0 z1]; samples by coordinate likewise.  As in the reference the sample
+  // INDICES are replaced by the positions of the surviving entries (:215) and not remapped to the
+  // filtered cloud — call it before sampling, as preprocessPointCloud does.
+  void filterWorkspace(const std::vector<double> &workspace);
   // Cloud::voxelizeCloud (cloud.cpp:286-348), including what its std::set comparator (cloud.h:105-122,
   // not an ordering) keeps under libstdc++; drops normals like the reference's preprocessing order does.
   void voxelizeCloud(float cell_size);

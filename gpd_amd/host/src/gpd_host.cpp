@@ -211,6 +211,45 @@ struct VoxelDiffers {  // UniqueVector4First3Comparator (cloud.h:105-122)
 };
 }  // namespace
 
+void Cloud::filterWorkspace(const std::vector<double> &ws) {
+  if (ws.size() < 6) return;
+  auto inside = [&](double x, double y, double z) { return x > ws[0] && x < ws[1] && y > ws[2] && y < ws[3] && z > ws[4] && z < ws[5]; };
+  if (!sample_indices_.empty()) {
+    std::vector<int> keep;
+    for (int i = 0; i < (int)sample_indices_.size(); i++) {
+      const float *p = &xyz_[3 * (size_t)sample_indices_[i]];
+      if (inside(p[0], p[1], p[2])) keep.push_back(i);  // the position, as cloud.cpp:215 stores it
+    }
+    sample_indices_ = keep;
+    std::cout << sample_indices_.size() << " sample indices left after workspace filtering \n";
+  }
+  if (samples_.size() >= 3) {
+    std::vector<double> keep;
+    for (size_t i = 0; i + 2 < samples_.size(); i += 3)
+      if (inside(samples_[i], samples_[i + 1], samples_[i + 2])) keep.insert(keep.end(), samples_.begin() + i, samples_.begin() + i + 3);
+    samples_ = keep;
+    std::cout << samples_.size() / 3 << " samples left after workspace filtering \n";
+  }
+  const size_t n = size();
+  const int cams = numCameras();
+  const bool with_normals = hasNormals();
+  std::vector<size_t> idx;
+  for (size_t i = 0; i < n; i++)
+    if (inside(xyz_[3 * i], xyz_[3 * i + 1], xyz_[3 * i + 2])) idx.push_back(i);
+  std::vector<float> xyz(idx.size() * 3), normals(with_normals ? idx.size() * 3 : 0);
+  std::vector<int> cam((size_t)cams * idx.size());
+  for (size_t k = 0; k < idx.size(); k++) {
+    for (int r = 0; r < 3; r++) {
+      xyz[3 * k + r] = xyz_[3 * idx[k] + r];
+      if (with_normals) normals[3 * k + r] = normals_[3 * idx[k] + r];
+    }
+    for (int c = 0; c < cams; c++) cam[(size_t)c * idx.size() + k] = camera_source_[(size_t)c * n + idx[k]];
+  }
+  xyz_ = xyz;
+  normals_ = normals;
+  camera_source_ = cam;
+}
+
 void Cloud::setNormalsFromFile(const std::string &filename) {
   std::ifstream in(filename.c_str());
   std::string line;
@@ -405,6 +444,8 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   params_.init_bite = hand_cfg.getValueOfKey<double>("init_bite", 0.01);
   // candidate generation (grasp_detector.cpp:47-88)
   num_samples_ = config_file.getValueOfKey<int>("num_samples", 1000);
+  workspace_ = config_file.getValueOfKeyAsStdVectorDouble("workspace", "-1 1 -1 1 -1 1");
+  workspace_.resize(6, 0.0);
   voxelize_ = config_file.getValueOfKey<bool>("voxelize", true);
   voxel_size_ = config_file.getValueOfKey<double>("voxel_size", 0.003);
   normals_radius_ = config_file.getValueOfKey<double>("normals_radius", 0.03);
@@ -493,22 +534,28 @@ GraspDetector::~GraspDetector() {
   if (ctx_) gpd_hip_destroy(ctx_);
 }
 
+bool GraspDetector::calculateNormals(util::Cloud &cloud, double radius) {
+  if (!ctx_ || cloud.size() == 0) return false;
+  std::vector<float> zeros(cloud.size() * 3, 0.f), normals(cloud.size() * 3, 0.f);
+  printf("Calculating surface normals ...\n");
+  if (gpd_hip_upload_cloud(ctx_, cloud.getCloudProcessed().data(), zeros.data(), (int)cloud.size(), cloud.getCameraSource().data(),
+                           cloud.numCameras(), cloud.getViewPoints().data()) != GPD_OK ||
+      gpd_hip_estimate_normals(ctx_, radius, normals.data()) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return false;
+  }
+  last_num_sets_ = 0;
+  cloud.setNormals(normals);
+  return true;
+}
+
 void GraspDetector::preprocessPointCloud(util::Cloud &cloud) {
   printf("Processing cloud with %zu points.\n", cloud.size());
+  cloud.filterWorkspace(workspace_);  // candidates_generator.cpp:19 (NaN rows are dropped at load time)
   if (!cloud.hasNormals()) {
     // the reference's order: voxelise, then estimate normals on the voxelised cloud
     if (voxelize_) cloud.voxelizeCloud((float)voxel_size_);
-    if (ctx_ && cloud.size() > 0) {
-      std::vector<float> zeros(cloud.size() * 3, 0.f), normals(cloud.size() * 3, 0.f);
-      printf("Calculating surface normals ...\n");
-      if (gpd_hip_upload_cloud(ctx_, cloud.getCloudProcessed().data(), zeros.data(), (int)cloud.size(), cloud.getCameraSource().data(),
-                               cloud.numCameras(), cloud.getViewPoints().data()) != GPD_OK ||
-          gpd_hip_estimate_normals(ctx_, normals_radius_, normals.data()) != GPD_OK) {
-        printf("ERROR: %s\n", gpd_hip_last_error());
-        return;
-      }
-      cloud.setNormals(normals);
-    }
+    if (ctx_ && cloud.size() > 0 && !calculateNormals(cloud, normals_radius_)) return;
   }
   if (cloud.getSampleIndices().empty()) cloud.subsample(num_samples_);
 }

@@ -245,3 +245,28 @@ def test_generate_candidates_cli_matches_oracle(tmp_path, oracle_mod, lenet15_re
         h = hands[s, j]
         assert int(g[3]) == h["finger_placement_index"] and int(g[8]) == h["half_antipodal"] and int(g[9]) == h["full_antipodal"]
         assert np.array_equal(np.array([float(x) for x in g[4:7]]), h["position"]) and float(g[7]) == h["grasp_width"]
+
+
+@pytest.mark.gpu
+def test_label_grasps_cli_matches_oracle(tmp_path, oracle_mod, lenet15_real):
+    """label_grasps CONFIG PCD MESH: candidates on one cloud, every candidate checked again against the "mesh"
+    cloud (here the same scene, so the labels are the search's own full-antipodal flags — rare, but present).
+    Both files carry normals, which the tool negates like the reference does (so the files hold the inward
+    normals, and the tool ends up with the outward ones)."""
+    exe = os.path.join(ROOT, "gpd_amd", "host", "label_grasps")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    full = synth.make_cloud(1234, 30000)
+    neg = dict(full)
+    neg["normals"] = -full["normals"]
+    cfg, pcd = _write_case(tmp_path, neg, lenet15_real, 1000, 5)
+    out = subprocess.run([exe, str(cfg), str(pcd), str(pcd)], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    got = [int(l.split()[-1]) for l in out.stdout.splitlines() if l.startswith("(") and "label:" in l]
+    p = oracle_mod.default_params(15)
+    si = _subsample_indices(len(full["xyz"]), 1000)
+    hands = oracle_mod.filter_workspace(p, oracle_mod.search(p, full["xyz"], full["normals"], si))
+    v = hands.reshape(-1)[hands.reshape(-1)["valid"].astype(bool)]
+    labels, _ = oracle_mod.reevaluate(p, full["xyz"], full["normals"], v)
+    assert np.array_equal(labels, v["full_antipodal"].astype(np.int32)) and labels.sum() > 0
+    assert got == labels.tolist()
+    assert ("LABELS %d / %d" % (labels.sum(), len(labels))) in out.stdout
