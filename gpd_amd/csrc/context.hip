@@ -37,6 +37,7 @@ struct gpd_hip_ctx {
   int device = 0;
   gpd_params params;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // EXPERIMENT
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   float stage_ms[3] = {0.f, 0.f, 0.f};
   LeNetWeights lenet;
@@ -438,7 +439,7 @@ int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_
 }
 
 int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
-  if (!ctx || !(stages & 3)) {
+  if (!ctx || !(stages & 7)) {
     set_error("gpd_hip_replay: bad argument");
     return GPD_ERR_INVALID;
   }
@@ -462,6 +463,17 @@ int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
   hipEvent_t *ev = &ctx->replay_events[ctx->replay_used];
   ctx->replay_used += 6;
   HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+  if (stages & 4) {  // EXPERIMENT: images on a side stream, concurrently with the LeNet pass
+    if (!ctx->stream2) HIP_TRY(hipStreamCreate(&ctx->stream2));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream2, ev[0], 0));
+    rc = images_launch(ctx->search, ctx->images, ctx->stream2, false);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[1], ctx->stream2));
+    HIP_TRY(lenet_forward(ctx->lenet, ctx->lenet_scratch, ctx->images.d_images, n, ctx->d_scores, ctx->stream, ev + 2));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[1], 0));
+    HIP_TRY(hipEventRecord(ev[5], ctx->stream));
+    return GPD_OK;
+  }
   if (stages & 1) {
     rc = images_launch(ctx->search, ctx->images, ctx->stream, false);
     if (rc) return rc;

@@ -61,10 +61,9 @@ constexpr int C1_THREADS = 64 * (C1_MFMA_WAVES + C1_VALU_WAVES);
 // the LDS bytes and the weight column of step st+1 are requested, then the bytes of step st are
 // converted and multiplied; each stage is guarded by the liveness of ITS step (scalar branches).
 template <int C, int NT>
-__device__ __forceinline__ void conv1_unit(const uint8_t *s_imgq, const float *s_w, const uint16_t *s_off, int rp, int t0, uint32_t nzc,
+__device__ __forceinline__ void conv1_unit(const uint8_t *s_base, const uint32_t (&xa)[25], const float *wl, int rp, int t0, uint32_t nzc,
                                            int kq, int j, int img, int n, const float *__restrict__ bias, float *__restrict__ out) {
   constexpr int K = 25 * C, KP = (K + 3) & ~3, NS = KP / 4;
-  const uint8_t *xin = s_imgq + (2 * rp + (j >> 3)) * kImg + (j & 7) + 8 * t0;
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++)
@@ -74,6 +73,14 @@ __device__ __forceinline__ void conv1_unit(const uint8_t *s_imgq, const float *s
     if (st >= NS) return false;
     const int c0 = (4 * st) / 25, c1 = (4 * st + 3 < K ? 4 * st + 3 : K - 1) / 25;
     return (((nzc >> c0) | (nzc >> c1)) & 1u) != 0u;
+  };
+  // LDS address of the lane's tap of step st, tile 0: a per-lane register of the 25-step period (four
+  // channels) plus compile-time immediates; the padding taps of the last step (k >= K, weight 0) read
+  // the lane's first tap instead of running past the image
+  auto tap_ptr = [&](int st) -> const uint8_t * {
+    const uint8_t *p = s_base + xa[st % 25] + (st / 25) * (4 * kPix);
+    if (4 * st + 3 >= K) p = (4 * st + kq < K) ? p : s_base + xa[0];
+    return p;
   };
   // two register sets, step st computes from set st & 1 while the loads of step st+1 land in the
   // other one (no moves, no wait on the loads just issued).  Values of dead steps are never used:
@@ -87,16 +94,16 @@ __device__ __forceinline__ void conv1_unit(const uint8_t *s_imgq, const float *s
     a[z] = __builtin_nondeterministic_value(a[z]);
   }
   if (live(0)) {
-    a[0] = s_w[kq * 16 + j];
-    const uint8_t *x0 = xin + s_off[kq];
+    a[0] = wl[0];
+    const uint8_t *x0 = tap_ptr(0);
 #pragma unroll
     for (int t = 0; t < NT; t++) raw[0][t] = x0[8 * t];
   }
 #pragma unroll
   for (int st = 0; st < NS; st++) {
     if (live(st + 1)) {
-      a[(st + 1) & 1] = s_w[(4 * (st + 1) + kq) * 16 + j];
-      const uint8_t *x1 = xin + s_off[4 * (st + 1) + kq];
+      a[(st + 1) & 1] = wl[64 * (st + 1)];
+      const uint8_t *x1 = tap_ptr(st + 1);
 #pragma unroll
       for (int t = 0; t < NT; t++) raw[(st + 1) & 1][t] = x1[8 * t];
     }
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
   constexpr int K = 25 * C, KP = (K + 3) & ~3;
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
   __shared__ __attribute__((aligned(16))) float s_w[KP * 16];  // [k][16 filters], rows >= K are zero
-  __shared__ uint16_t s_off[KP];                                // byte offset of tap k in an image
+  __shared__ __attribute__((aligned(16))) float s_w4[4 * C * 28];  // filters 16..19: [f][c][25 taps + 3 pad]
   __shared__ uint32_t s_nz[2 * 28 * 2];  // per (image, band, half): channels with a non-zero byte in the input window
   const int tid = threadIdx.x;
   const int img0 = blockIdx.x * 2;
@@ -150,10 +157,10 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     const int k = i >> 4, f = i & 15;
     s_w[i] = k < K ? wt[k * 20 + f] : 0.f;
   }
-  for (int k = tid; k < KP; k += C1_THREADS) {
-    const int kk = k < K ? k : K - 1;
-    const int c = kk / 25, tap = kk - c * 25;
-    s_off[k] = (uint16_t)(c * kPix + (tap / 5) * kImg + tap % 5);
+  for (int i = tid; i < 4 * C * 28; i += C1_THREADS) {
+    const int fc = i / 28, tap = i - fc * 28;
+    const int f = fc / C, c = fc - f * C;
+    s_w4[i] = tap < 25 ? w[(size_t)(16 + f) * K + c * 25 + tap] : 0.f;
   }
   for (int i = tid; i < 2 * 28 * 2; i += C1_THREADS) s_nz[i] = 0u;
   __syncthreads();
@@ -176,32 +183,51 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     // the matrix waves win issue arbitration; the VALU waves of the same SIMD fill the gaps
     __builtin_amdgcn_s_setprio(3);
     const int kq = lane >> 4, j = lane & 15;
+    const float *wl = s_w + kq * 16 + j;  // the lane's weight column: step st reads wl[64 * st]
+    // byte offsets of the lane's taps over one 25-step period (k' = 4 s + kq covers four channels),
+    // relative to the first input byte of a unit; advanced from unit to unit by a wave-uniform step
+    uint32_t xa[25];
+#pragma unroll
+    for (int sp = 0; sp < 25; sp++) {
+      const int k = 4 * sp + kq, c = k / 25, tap = k - c * 25;
+      xa[sp] = (uint32_t)(c * kPix + (tap / 5) * kImg + tap % 5 + (j >> 3) * kImg + (j & 7));
+    }
+    uint32_t ubase = 0;
     // a wave owns seven of the pair's 56 bands and runs both halves of each (4 + 3 tiles)
     for (int i = 0; i < 14; i++) {
       const int band = wave + C1_MFMA_WAVES * (i >> 1);
       const int h = i & 1;
       const int q = band / 28, rp = band - q * 28;
       const uint32_t nzc = __builtin_amdgcn_readfirstlane(s_nz[band * 2 + h]);
+      const uint32_t ub = (uint32_t)(q * C * kPix + 2 * rp * kImg + 32 * h);
+      const uint32_t du = ub - ubase;
+      ubase = ub;
+#pragma unroll
+      for (int sp = 0; sp < 25; sp++) xa[sp] += du;
       if (h == 0)
-        conv1_unit<C, 4>(s_img[q], s_w, s_off, rp, 0, nzc, kq, j, img0 + q, n, bias, out);
+        conv1_unit<C, 4>(&s_img[0][0], xa, wl, rp, 0, nzc, kq, j, img0 + q, n, bias, out);
       else
-        conv1_unit<C, 3>(s_img[q], s_w, s_off, rp, 4, nzc, kq, j, img0 + q, n, bias, out);
+        conv1_unit<C, 3>(&s_img[0][0], xa, wl, rp, 4, nzc, kq, j, img0 + q, n, bias, out);
     }
   } else {
-    // filters 16..19: lane <-> pooled pixel, weights read as scalars in the file layout [f][k]
+    // filters 16..19: lane <-> pooled pixel; per tap one v_mfma_f32_4x4x1 (16 blocks of 4 filters x 4
+    // lanes, k = 1: D[f][lane] += w[f] * x[lane]) for each of the window's four conv pixels — the
+    // f32 pipe at its full rate instead of the half rate of plain v_fma_f32.  One k per instruction,
+    // so each output still is the k-ascending fmaf chain.  A operand: lane l carries the weight of
+    // filter 16 + (l & 3).
     const int vw = wave - C1_MFMA_WAVES;
-    const float *__restrict__ wf = w + (size_t)16 * K;
+    const float *wrow = s_w4 + (lane & 3) * C * 28;
     for (int task = vw; task < 2 * 13; task += C1_VALU_WAVES) {
       const int q = task / 13, chunk = task - q * 13;
       const int p = chunk * 64 + lane;
       const bool act = p < 784;
       const int pp = act ? p : 0;
       const int py = pp / 28, px = pp - py * 28;
-      float acc[4][4];
+      f32x4 acc[4];
 #pragma unroll
-      for (int f = 0; f < 4; f++)
+      for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) acc[f][e] = 0.f;
+        for (int f = 0; f < 4; f++) acc[e][f] = 0.f;
       const uint8_t *base = s_img[q] + (2 * py) * kImg + 2 * px;
       // channels that are zero under every window of this chunk (pooled rows chunk*64/28 ..) add
       // exact zeros to all sixteen chains: skipped
@@ -223,18 +249,24 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
             patch[r][2 * e + 1] = (float)(v >> 8);
           }
         }
+        float wv[28];
+#pragma unroll
+        for (int g = 0; g < 7; g++) {
+          const float4 t4 = *reinterpret_cast<const float4 *>(wrow + c * 28 + 4 * g);
+          wv[4 * g] = t4.x;
+          wv[4 * g + 1] = t4.y;
+          wv[4 * g + 2] = t4.z;
+          wv[4 * g + 3] = t4.w;
+        }
 #pragma unroll
         for (int kh = 0; kh < 5; kh++) {
 #pragma unroll
           for (int kw = 0; kw < 5; kw++) {
-#pragma unroll
-            for (int f = 0; f < 4; f++) {
-              const float wv = wf[f * K + c * 25 + kh * 5 + kw];
-              acc[f][0] = __builtin_fmaf(wv, patch[kh][kw], acc[f][0]);
-              acc[f][1] = __builtin_fmaf(wv, patch[kh][kw + 1], acc[f][1]);
-              acc[f][2] = __builtin_fmaf(wv, patch[kh + 1][kw], acc[f][2]);
-              acc[f][3] = __builtin_fmaf(wv, patch[kh + 1][kw + 1], acc[f][3]);
-            }
+            const float wk = wv[kh * 5 + kw];
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh][kw], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh][kw + 1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh + 1][kw], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh + 1][kw + 1], acc[3], 0, 0, 0);
           }
         }
       }
@@ -242,7 +274,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
       if (act && img < n) {
 #pragma unroll
         for (int f = 0; f < 4; f++) {
-          const float m = fmaxf(fmaxf(acc[f][0], acc[f][1]), fmaxf(acc[f][2], acc[f][3])) + bias[16 + f];
+          const float m = fmaxf(fmaxf(acc[0][f], acc[1][f]), fmaxf(acc[2][f], acc[3][f])) + bias[16 + f];
           out[((size_t)img * 20 + 16 + f) * 784 + p] = m;
         }
       }
