@@ -282,6 +282,145 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
   }
 }
 
+// conv1 + pool1, pixel-stationary form.  Two images per workgroup; a task is a chunk of 64 pooled
+// pixels, lane <-> pooled pixel.  Per live channel a lane converts ITS 6x6 input patch once (36
+// converts for 200 MFMAs) and keeps it in registers as the B operands; the weights stream from LDS
+// as the A operands of k = 1 MFMAs:
+//   v_mfma_f32_16x16x1 (4 blocks): D_b[f][j] += w[f][k] * x_b[j]   filters 0..15 x 64 pixels
+//   v_mfma_f32_4x4x1  (16 blocks): D_b[f][j] += w[16+f][k] * x_b[j] filters 16..19 x 64 pixels
+// once per tap and per conv pixel of the 2x2 pool window.  One k per instruction: every output is
+// the k-ascending fmaf chain of the oracle, and 16 + 4 filters fill the two tile shapes exactly.
+// Compared with the implicit GEMM on 16x16x4 (one byte read + one convert per MFMA, 54 % issue
+// overhead measured) the per-MFMA operand traffic drops to 0.3 LDS reads and 0.18 converts.
+// Zero skipping: grasp images are ~70 % zeros.  A channel in which the patches of all 64 lanes are
+// zero adds exact zeros to every chain (fmaf(w, 0, acc) == acc for finite w; acc is never -0) and
+// is skipped — decided from the patch bytes themselves (one ballot), which are fetched a channel
+// ahead anyway.  Pooled pixels are numbered strip-major (four strips of 7 columns), so a chunk is
+// a compact ~9 x 7 block: 28 % of the (chunk, channel) pairs drop out (17 % with row-major chunks).
+// Tasks are handed out through an LDS counter, so the four SIMDs stay balanced under skipping.
+constexpr int C1P_WAVES = 12, C1P_THREADS = 64 * C1P_WAVES, C1P_TASKS = 2 * 13, C1P_STRIP = 7;
+
+template <int C>
+__global__ __launch_bounds__(C1P_THREADS) void conv1_px_kernel(const uint8_t *__restrict__ images, const float *__restrict__ w,
+                                                               const float *__restrict__ bias, float *__restrict__ out, int n) {
+  constexpr int K = 25 * C;
+  __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
+  __shared__ __attribute__((aligned(16))) float s_wa[16 * C * 28];  // filters 0..15: [f][c][25 taps + 3 pad]
+  __shared__ __attribute__((aligned(16))) float s_wb[4 * C * 28];   // filters 16..19
+  __shared__ int s_next;
+  const int tid = threadIdx.x;
+  const int img0 = blockIdx.x * 2;
+  for (int q = 0; q < 2; q++) {
+    const int img = min(img0 + q, n - 1);
+    const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)img * kPix * C);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_img[q]);
+    for (int i = tid; i < kPix * C / 16; i += C1P_THREADS) dst[i] = src[i];
+  }
+  for (int i = tid; i < 20 * C * 28; i += C1P_THREADS) {
+    const int fc = i / 28, tap = i - fc * 28;
+    const int f = fc / C, c = fc - f * C;
+    const float v = tap < 25 ? w[(size_t)f * K + c * 25 + tap] : 0.f;
+    if (f < 16) s_wa[i] = v; else s_wb[i - 16 * C * 28] = v;
+  }
+  if (tid == 0) s_next = 0;
+  __syncthreads();
+  const int lane = tid & 63;
+  const float *wa_row = s_wa + (lane & 15) * C * 28;
+  const float *wb_row = s_wb + (lane & 3) * C * 28;
+  for (;;) {
+    int task = 0;
+    if (lane == 0) task = atomicAdd(&s_next, 1);
+    task = __builtin_amdgcn_readfirstlane(task);
+    if (task >= C1P_TASKS) break;
+    const int q = task / 13, chunk = task - q * 13;
+    // strip-major pixel number -> (row, column); the lanes past the image's last pixel redo pixel 783
+    const int pn = chunk * 64 + lane;
+    const int pc = pn < 784 ? pn : 783;
+    const int strip = pc / (28 * C1P_STRIP), within = pc - strip * (28 * C1P_STRIP);
+    const int py = within / C1P_STRIP, px = strip * C1P_STRIP + (within - py * C1P_STRIP);
+    const int opix = py * 28 + px;
+    const uint8_t *base = s_img[q] + (2 * py) * kImg + 2 * px;
+    f32x16 acc16[4];
+    f32x4 acc4[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc16[e][r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc4[e][r] = 0.f;
+    }
+    uint32_t raw[6][3];  // the patch of the next channel, as fetched: 6 rows x 3 byte pairs
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) raw[r][e] = *reinterpret_cast<const uint16_t *>(base + r * kImg + 2 * e);
+    for (int c = 0; c < C; c++) {
+      uint32_t any = 0;
+      float patch[6][6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+          any |= raw[r][e];
+          patch[r][2 * e] = (float)(raw[r][e] & 0xff);
+          patch[r][2 * e + 1] = (float)(raw[r][e] >> 8);
+        }
+      }
+      const bool live = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
+      if (c + 1 < C) {
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int e = 0; e < 3; e++) raw[r][e] = *reinterpret_cast<const uint16_t *>(base + (c + 1) * kPix + r * kImg + 2 * e);
+      }
+      if (!live) continue;
+      float wa[28], wb[28];
+#pragma unroll
+      for (int g = 0; g < 7; g++) {
+        const float4 ta = *reinterpret_cast<const float4 *>(wa_row + c * 28 + 4 * g);
+        const float4 tb = *reinterpret_cast<const float4 *>(wb_row + c * 28 + 4 * g);
+        wa[4 * g] = ta.x, wa[4 * g + 1] = ta.y, wa[4 * g + 2] = ta.z, wa[4 * g + 3] = ta.w;
+        wb[4 * g] = tb.x, wb[4 * g + 1] = tb.y, wb[4 * g + 2] = tb.z, wb[4 * g + 3] = tb.w;
+      }
+#pragma unroll
+      for (int kh = 0; kh < 5; kh++) {
+#pragma unroll
+        for (int kw = 0; kw < 5; kw++) {
+          const float ka = wa[kh * 5 + kw], kb = wb[kh * 5 + kw];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float x = patch[kh + (e >> 1)][kw + (e & 1)];
+            acc16[e] = __builtin_amdgcn_mfma_f32_16x16x1f32(ka, x, acc16[e], 0, 0, 0);
+            acc4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(kb, x, acc4[e], 0, 0, 0);
+          }
+        }
+      }
+    }
+    const int img = img0 + q;
+    if (img < n) {
+      // D of the 4-block 16x16x1: lane l, register 4 b + r  <->  the pixel of lane 16 b + (l & 15), filter 4 (l >> 4) + r
+      float *o = out + (size_t)img * 20 * 784;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int src = 16 * b + (lane & 15);
+        const int po = __shfl(opix, src);
+        if (chunk * 64 + src < 784) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int reg = 4 * b + r, f = 4 * (lane >> 4) + r;
+            o[f * 784 + po] = fmaxf(fmaxf(acc16[0][reg], acc16[1][reg]), fmaxf(acc16[2][reg], acc16[3][reg])) + bias[f];
+          }
+        }
+      }
+      if (pn < 784) {
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+          o[(16 + f) * 784 + opix] = fmaxf(fmaxf(acc4[0][f], acc4[1][f]), fmaxf(acc4[2][f], acc4[3][f])) + bias[16 + f];
+      }
+    }
+  }
+}
+
 // conv2 + pool2.  Persistent workgroups (one per CU) loop over images: the k-major weights of
 // filters 0..47 (96 KB) stay in LDS next to one image's pool1 planes (62.7 KB).
 //   waves 0-11  filters 0..47 on v_mfma_f32_16x16x4_f32: a wave owns one band of two output rows
@@ -603,16 +742,29 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     if (s.num_cus <= 0) s.num_cus = 256;
   }
   const int num_cus = s.num_cus;
+  static const bool old_c1 = getenv("GPD_C1_OLD") != nullptr;  // EXPERIMENT
   hipError_t e = lenet_scratch_reserve(s, n < kChunk ? n : kChunk);
   if (e != hipSuccess) return e;
   for (int off = 0; off < n; off += kChunk) {
     const int m = (n - off < kChunk) ? (n - off) : kChunk;
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
     switch (w.channels) {
-      case 15: conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
-      case 12: conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
-      case 3: conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
-      case 1: conv1_mfma_kernel<1><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m); break;
+      case 15:
+        if (old_c1) conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
+        else conv1_px_kernel<15><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
+        break;
+      case 12:
+        if (old_c1) conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
+        else conv1_px_kernel<12><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
+        break;
+      case 3:
+        if (old_c1) conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
+        else conv1_px_kernel<3><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
+        break;
+      case 1:
+        if (old_c1) conv1_mfma_kernel<1><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
+        else conv1_px_kernel<1><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
+        break;
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
