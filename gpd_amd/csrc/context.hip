@@ -137,7 +137,7 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   float **ws[] = {&ctx->lenet.c1w, &ctx->lenet.c1b, &ctx->lenet.c2w, &ctx->lenet.c2b,
-                  &ctx->lenet.f1w, &ctx->lenet.f1b, &ctx->lenet.f2w, &ctx->lenet.f2b, &ctx->lenet.c1wt, &ctx->lenet.c2wt};
+                  &ctx->lenet.f1w, &ctx->lenet.f1b, &ctx->lenet.f2w, &ctx->lenet.f2b, &ctx->lenet.c1wp, &ctx->lenet.c2wt};
   for (float **p : ws)
     if (*p) (void)hipFree(*p);
   lenet_scratch_free(ctx->lenet_scratch);
@@ -187,18 +187,20 @@ int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1
     HIP_TRY(hipMalloc(it.dst, it.n * sizeof(float)));
     HIP_TRY(hipMemcpy(*it.dst, it.src, it.n * sizeof(float), hipMemcpyHostToDevice));
   }
-  // k-major copies of the conv weights (file layout is [filter][k], conv_layer.cpp:35-36)
+  // device-side layouts of the conv weights (file layout is [filter][k], conv_layer.cpp:35-36):
+  // conv1 rows padded from 25 to 28 taps per channel, conv2 k-major
   {
     const int K1 = channels * 25;
-    std::vector<float> t1((size_t)K1 * 20), t2((size_t)500 * 50);
+    std::vector<float> t1((size_t)20 * channels * 28, 0.f), t2((size_t)500 * 50);
     for (int f = 0; f < 20; f++)
-      for (int k = 0; k < K1; k++) t1[(size_t)k * 20 + f] = conv1_w[(size_t)f * K1 + k];
+      for (int c = 0; c < channels; c++)
+        for (int t = 0; t < 25; t++) t1[((size_t)f * channels + c) * 28 + t] = conv1_w[(size_t)f * K1 + c * 25 + t];
     for (int f = 0; f < 50; f++)
       for (int k = 0; k < 500; k++) t2[(size_t)k * 50 + f] = conv2_w[(size_t)f * 500 + k];
     struct {
       float **dst;
       std::vector<float> *src;
-    } tr[] = {{&ctx->lenet.c1wt, &t1}, {&ctx->lenet.c2wt, &t2}};
+    } tr[] = {{&ctx->lenet.c1wp, &t1}, {&ctx->lenet.c2wt, &t2}};
     for (auto &it : tr) {
       if (*it.dst) (void)hipFree(*it.dst);
       *it.dst = nullptr;

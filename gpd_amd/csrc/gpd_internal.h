@@ -18,7 +18,8 @@ constexpr int kFc1Out = 500;
 struct LeNetWeights {
   int channels = 0;
   float *c1w = nullptr, *c1b = nullptr, *c2w = nullptr, *c2b = nullptr;
-  float *c1wt = nullptr, *c2wt = nullptr;  // k-major copies [K][F] for the implicit-GEMM A operand
+  float *c1wp = nullptr;  // conv1 weights padded to [20][C][28] (25 taps + 3 zeros): 16-byte rows for the LDS table
+  float *c2wt = nullptr;  // conv2 weights k-major [K][F] for the implicit-GEMM A operand
   float *f1w = nullptr, *f1b = nullptr, *f2w = nullptr, *f2b = nullptr;
 };
 

@@ -10,9 +10,11 @@
 // used for FC1 is bitwise such a chain (cdna_hip_programming.md §3).
 //
 // Kernels:
-//   conv1_mfma   planar u8 images + k-major weights in LDS -> implicit GEMM on f32 MFMA (+ 4
-//                filters on VALU waves), all-zero input windows skipped (exact), 2x2 max-pool
-//                fused                                           -> pool1 [n][20][28][28]
+//   conv1_mfma   planar u8 images + padded weight rows in LDS; pixel-stationary: every lane keeps
+//                the converted 6x6 patch of its pooled pixel in registers and k = 1 MFMAs
+//                (16x16x1 + 4x4x1 = 20 filters) stream the weights past it; channels whose
+//                patches are all zero are skipped (exact); 2x2 max-pool fused
+//                                                               -> pool1 [n][20][28][28]
 //   conv2_mfma   persistent; pool1 planes + 96 KB of weights in LDS, implicit GEMM + pool
 //                (+ 2 filters riding in the same waves on the VALU), output in the reference's
 //                flatten order j = pixel*50 + channel            -> flat  [n][7200]
@@ -25,262 +27,7 @@ namespace gpd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// ---------------------------------------------------------------------------
-// Convolutions: implicit GEMMs D[f][pix] = sum_k W[f][k] X[k][pix] on v_mfma_f32_16x16x4_f32,
-// k = c*25 + kh*5 + kw ascending — the MFMA accumulates k..k+3 in order, so each output is
-// still the oracle's fmaf chain (cdna_hip_programming.md §3, "bit-for-bit a k-ordered chain").
-//   A operand (lane l): W[f = l&15][k0 + (l>>4)]   (k-major weight copy in LDS)
-//   B operand (lane l): X[k0 + (l>>4)][pix = l&15] (image / pool1 planes in LDS)
-//   D (lane l, reg r):  pixel l&15, filter 4*(l>>4) + r
-// A pixel tile is 2 rows x 8 columns of conv outputs, so the 2x2 max-pool is two lane
-// exchanges (xor 1, xor 8).  max(a_i + b) == max(a_i) + b (rounding is monotone).
-// Filters that do not fill a 16-row tile (4 of conv1's 20, 2 of conv2's 50) run as direct
-// convolutions on otherwise idle VALU waves of the same workgroup.
-// ---------------------------------------------------------------------------
-// conv1 + pool1.  Two images per workgroup, 12 waves with two roles that use different pipes:
-//   waves 0-7  filters 0..15 as an implicit GEMM on v_mfma_f32_16x16x4_f32.  A wave owns a band
-//              of two output rows (7 tiles of 2x8 pixels) and keeps the 7 accumulators
-//              independent, so LDS reads and converts slot between MFMAs without stalling them;
-//              20 filters would pad a 32-row MFMA tile to 62 % efficiency, 16 fill it exactly.
-//   waves 8-11 filters 16..19 by direct convolution on the VALU (weights as wave-uniform
-//              scalars, 2x2 pool window per lane).
-// Both are k-ascending fmaf chains (16x16x4 accumulates k..k+3 in order), bias after the pool.
-// Zero skipping: grasp images are ~70 % zeros with large empty regions; a per-(band, half, channel)
-// zero map built from the LDS copy lets both roles drop the k-steps / channels whose inputs are
-// all zero — the dropped terms are exact zeros, results are bit-identical (see conv1_unit).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int C1_MFMA_WAVES = 8, C1_VALU_WAVES = 4;
-constexpr int C1_THREADS = 64 * (C1_MFMA_WAVES + C1_VALU_WAVES);
-
-// One MFMA work unit: NT pixel tiles (tiles t0 .. t0+NT-1 of the band's seven) x 16 filters over all
-// taps.  nzc has bit c set when channel c has a non-zero byte anywhere in the unit's input window:
-// a k-step whose taps all lie in all-zero channels is skipped — its products are exact zeros
-// (fmaf(w, 0, acc) == acc for finite w; acc is never -0), so the chain and every bit of the result
-// stay the same.  Grasp images are ~70 % zeros; at this granularity ~28 % of the steps drop out.
-// Software pipeline per step st (fully unrolled, the channels of a step are compile-time constants):
-// the LDS bytes and the weight column of step st+1 are requested, then the bytes of step st are
-// converted and multiplied; each stage is guarded by the liveness of ITS step (scalar branches).
-template <int C, int NT>
-__device__ __forceinline__ void conv1_unit(const uint8_t *s_base, const uint32_t (&xa)[25], const float *wl, int rp, int t0, uint32_t nzc,
-                                           int kq, int j, int img, int n, const float *__restrict__ bias, float *__restrict__ out) {
-  constexpr int K = 25 * C, KP = (K + 3) & ~3, NS = KP / 4;
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
-  auto live = [&](int st) -> bool {  // st is a compile-time constant after unrolling: two shifts, or, and
-    if (st >= NS) return false;
-    const int c0 = (4 * st) / 25, c1 = (4 * st + 3 < K ? 4 * st + 3 : K - 1) / 25;
-    return (((nzc >> c0) | (nzc >> c1)) & 1u) != 0u;
-  };
-  // LDS address of the lane's tap of step st, tile 0: a per-lane register of the 25-step period (four
-  // channels) plus compile-time immediates; the padding taps of the last step (k >= K, weight 0) read
-  // the lane's first tap instead of running past the image
-  auto tap_ptr = [&](int st) -> const uint8_t * {
-    const uint8_t *p = s_base + xa[st % 25] + (st / 25) * (4 * kPix);
-    if (4 * st + 3 >= K) p = (4 * st + kq < K) ? p : s_base + xa[0];
-    return p;
-  };
-  // two register sets, step st computes from set st & 1 while the loads of step st+1 land in the
-  // other one (no moves, no wait on the loads just issued).  Values of dead steps are never used:
-  // "some value" instead of a zero fill keeps selects out of the loop.
-  uint32_t raw[2][NT];
-  float a[2];
-#pragma unroll
-  for (int z = 0; z < 2; z++) {
-#pragma unroll
-    for (int t = 0; t < NT; t++) raw[z][t] = __builtin_nondeterministic_value(raw[z][t]);
-    a[z] = __builtin_nondeterministic_value(a[z]);
-  }
-  if (live(0)) {
-    a[0] = wl[0];
-    const uint8_t *x0 = tap_ptr(0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) raw[0][t] = x0[8 * t];
-  }
-#pragma unroll
-  for (int st = 0; st < NS; st++) {
-    if (live(st + 1)) {
-      a[(st + 1) & 1] = wl[64 * (st + 1)];
-      const uint8_t *x1 = tap_ptr(st + 1);
-#pragma unroll
-      for (int t = 0; t < NT; t++) raw[(st + 1) & 1][t] = x1[8 * t];
-    }
-    if (live(st)) {
-      float f[NT];
-#pragma unroll
-      for (int t = 0; t < NT; t++) f[t] = (float)raw[st & 1][t];
-      __builtin_amdgcn_sched_barrier(0);  // converts first, then the MFMAs back to back (no hazard nops in between)
-#pragma unroll
-      for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1], f[t], acc[t], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < NT; t++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      float x = acc[t][r];
-      x = fmaxf(x, __shfl_xor(x, 1));
-      x = fmaxf(x, __shfl_xor(x, 8));
-      acc[t][r] = x;
-    }
-    if (img < n && !(j & 1) && !(j & 8)) {
-      float *o = out + (size_t)img * 20 * 784 + rp * 28 + 4 * (t0 + t) + ((j & 7) >> 1);
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int f = kq * 4 + r;
-        o[f * 784] = acc[t][r] + bias[f];
-      }
-    }
-  }
-}
-
-template <int C>
-__global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wt,
-                                                                const float *__restrict__ w, const float *__restrict__ bias,
-                                                                float *__restrict__ out, int n) {
-  constexpr int K = 25 * C, KP = (K + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
-  __shared__ __attribute__((aligned(16))) float s_w[KP * 16];  // [k][16 filters], rows >= K are zero
-  __shared__ __attribute__((aligned(16))) float s_w4[4 * C * 28];  // filters 16..19: [f][c][25 taps + 3 pad]
-  __shared__ uint32_t s_nz[2 * 28 * 2];  // per (image, band, half): channels with a non-zero byte in the input window
-  const int tid = threadIdx.x;
-  const int img0 = blockIdx.x * 2;
-  for (int q = 0; q < 2; q++) {
-    const int img = min(img0 + q, n - 1);
-    const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)img * kPix * C);
-    uint4 *dst = reinterpret_cast<uint4 *>(s_img[q]);
-    for (int i = tid; i < kPix * C / 16; i += C1_THREADS) dst[i] = src[i];
-  }
-  for (int i = tid; i < KP * 16; i += C1_THREADS) {
-    const int k = i >> 4, f = i & 15;
-    s_w[i] = k < K ? wt[k * 20 + f] : 0.f;
-  }
-  for (int i = tid; i < 4 * C * 28; i += C1_THREADS) {
-    const int fc = i / 28, tap = i - fc * 28;
-    const int f = fc / C, c = fc - f * C;
-    s_w4[i] = tap < 25 ? w[(size_t)(16 + f) * K + c * 25 + tap] : 0.f;
-  }
-  for (int i = tid; i < 2 * 28 * 2; i += C1_THREADS) s_nz[i] = 0u;
-  __syncthreads();
-  // zero map: unit u = (image q, band rp, half h) reads input rows 2rp..2rp+5, columns 0..35 (tiles
-  // 0..3) or 32..59 (tiles 4..6); one (unit, channel) window per thread and turn, dword reads
-  for (int pr = tid; pr < 2 * 28 * 2 * C; pr += C1_THREADS) {
-    const int u = pr / C, c = pr - u * C;
-    const int q = u / 56, r2 = u - q * 56, rp = r2 >> 1, h = r2 & 1;
-    const uint8_t *base = s_img[q] + c * kPix + (2 * rp) * kImg + (h ? 32 : 0);
-    const int nd = h ? 7 : 9;
-    uint32_t any = 0;
-    for (int r = 0; r < 6; r++)
-      for (int d = 0; d < nd; d++) any |= *reinterpret_cast<const uint32_t *>(base + r * kImg + 4 * d);
-    if (any) atomicOr(&s_nz[u], 1u << c);
-  }
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
-  if (wave < C1_MFMA_WAVES) {
-    // the matrix waves win issue arbitration; the VALU waves of the same SIMD fill the gaps
-    __builtin_amdgcn_s_setprio(3);
-    const int kq = lane >> 4, j = lane & 15;
-    const float *wl = s_w + kq * 16 + j;  // the lane's weight column: step st reads wl[64 * st]
-    // byte offsets of the lane's taps over one 25-step period (k' = 4 s + kq covers four channels),
-    // relative to the first input byte of a unit; advanced from unit to unit by a wave-uniform step
-    uint32_t xa[25];
-#pragma unroll
-    for (int sp = 0; sp < 25; sp++) {
-      const int k = 4 * sp + kq, c = k / 25, tap = k - c * 25;
-      xa[sp] = (uint32_t)(c * kPix + (tap / 5) * kImg + tap % 5 + (j >> 3) * kImg + (j & 7));
-    }
-    uint32_t ubase = 0;
-    // a wave owns seven of the pair's 56 bands and runs both halves of each (4 + 3 tiles)
-    for (int i = 0; i < 14; i++) {
-      const int band = wave + C1_MFMA_WAVES * (i >> 1);
-      const int h = i & 1;
-      const int q = band / 28, rp = band - q * 28;
-      const uint32_t nzc = __builtin_amdgcn_readfirstlane(s_nz[band * 2 + h]);
-      const uint32_t ub = (uint32_t)(q * C * kPix + 2 * rp * kImg + 32 * h);
-      const uint32_t du = ub - ubase;
-      ubase = ub;
-#pragma unroll
-      for (int sp = 0; sp < 25; sp++) xa[sp] += du;
-      if (h == 0)
-        conv1_unit<C, 4>(&s_img[0][0], xa, wl, rp, 0, nzc, kq, j, img0 + q, n, bias, out);
-      else
-        conv1_unit<C, 3>(&s_img[0][0], xa, wl, rp, 4, nzc, kq, j, img0 + q, n, bias, out);
-    }
-  } else {
-    // filters 16..19: lane <-> pooled pixel; per tap one v_mfma_f32_4x4x1 (16 blocks of 4 filters x 4
-    // lanes, k = 1: D[f][lane] += w[f] * x[lane]) for each of the window's four conv pixels — the
-    // f32 pipe at its full rate instead of the half rate of plain v_fma_f32.  One k per instruction,
-    // so each output still is the k-ascending fmaf chain.  A operand: lane l carries the weight of
-    // filter 16 + (l & 3).
-    const int vw = wave - C1_MFMA_WAVES;
-    const float *wrow = s_w4 + (lane & 3) * C * 28;
-    for (int task = vw; task < 2 * 13; task += C1_VALU_WAVES) {
-      const int q = task / 13, chunk = task - q * 13;
-      const int p = chunk * 64 + lane;
-      const bool act = p < 784;
-      const int pp = act ? p : 0;
-      const int py = pp / 28, px = pp - py * 28;
-      f32x4 acc[4];
-#pragma unroll
-      for (int e = 0; e < 4; e++)
-#pragma unroll
-        for (int f = 0; f < 4; f++) acc[e][f] = 0.f;
-      const uint8_t *base = s_img[q] + (2 * py) * kImg + 2 * px;
-      // channels that are zero under every window of this chunk (pooled rows chunk*64/28 ..) add
-      // exact zeros to all sixteen chains: skipped
-      uint32_t nzc = 0;
-      {
-        const int r0 = (chunk * 64) / 28, r1 = (chunk * 64 + 63 < 783 ? chunk * 64 + 63 : 783) / 28;
-        for (int r = r0; r <= r1; r++) nzc |= s_nz[(q * 28 + r) * 2] | s_nz[(q * 28 + r) * 2 + 1];
-        nzc = __builtin_amdgcn_readfirstlane(nzc);
-      }
-      for (int c = 0; c < C; c++) {
-        if (!((nzc >> c) & 1u)) continue;
-        float patch[6][6];
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-#pragma unroll
-          for (int e = 0; e < 3; e++) {
-            const uint16_t v = *reinterpret_cast<const uint16_t *>(base + c * kPix + r * kImg + 2 * e);
-            patch[r][2 * e] = (float)(v & 0xff);
-            patch[r][2 * e + 1] = (float)(v >> 8);
-          }
-        }
-        float wv[28];
-#pragma unroll
-        for (int g = 0; g < 7; g++) {
-          const float4 t4 = *reinterpret_cast<const float4 *>(wrow + c * 28 + 4 * g);
-          wv[4 * g] = t4.x;
-          wv[4 * g + 1] = t4.y;
-          wv[4 * g + 2] = t4.z;
-          wv[4 * g + 3] = t4.w;
-        }
-#pragma unroll
-        for (int kh = 0; kh < 5; kh++) {
-#pragma unroll
-          for (int kw = 0; kw < 5; kw++) {
-            const float wk = wv[kh * 5 + kw];
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh][kw], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh][kw + 1], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh + 1][kw], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, patch[kh + 1][kw + 1], acc[3], 0, 0, 0);
-          }
-        }
-      }
-      const int img = img0 + q;
-      if (act && img < n) {
-#pragma unroll
-        for (int f = 0; f < 4; f++) {
-          const float m = fmaxf(fmaxf(acc[0][f], acc[1][f]), fmaxf(acc[2][f], acc[3][f])) + bias[16 + f];
-          out[((size_t)img * 20 + 16 + f) * 784 + p] = m;
-        }
-      }
-    }
-  }
-}
 
 // conv1 + pool1, pixel-stationary form.  Two images per workgroup; a task is a chunk of 64 pooled
 // pixels, lane <-> pooled pixel.  Per live channel a lane converts ITS 6x6 input patch once (36
@@ -292,18 +39,18 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
 // the k-ascending fmaf chain of the oracle, and 16 + 4 filters fill the two tile shapes exactly.
 // Compared with the implicit GEMM on 16x16x4 (one byte read + one convert per MFMA, 54 % issue
 // overhead measured) the per-MFMA operand traffic drops to 0.3 LDS reads and 0.18 converts.
+// max(a_i + b) == max(a_i) + b (rounding is monotone), so the bias is added after the pool.
 // Zero skipping: grasp images are ~70 % zeros.  A channel in which the patches of all 64 lanes are
 // zero adds exact zeros to every chain (fmaf(w, 0, acc) == acc for finite w; acc is never -0) and
 // is skipped — decided from the patch bytes themselves (one ballot), which are fetched a channel
 // ahead anyway.  Pooled pixels are numbered strip-major (four strips of 7 columns), so a chunk is
 // a compact ~9 x 7 block: 28 % of the (chunk, channel) pairs drop out (17 % with row-major chunks).
 // Tasks are handed out through an LDS counter, so the four SIMDs stay balanced under skipping.
-constexpr int C1P_WAVES = 12, C1P_THREADS = 64 * C1P_WAVES, C1P_TASKS = 2 * 13, C1P_STRIP = 7;
+constexpr int C1_WAVES = 8, C1_THREADS = 64 * C1_WAVES, C1_TASKS = 25, C1_STRIP = 7;
 
 template <int C>
-__global__ __launch_bounds__(C1P_THREADS) void conv1_px_kernel(const uint8_t *__restrict__ images, const float *__restrict__ w,
+__global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wp,
                                                                const float *__restrict__ bias, float *__restrict__ out, int n) {
-  constexpr int K = 25 * C;
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
   __shared__ __attribute__((aligned(16))) float s_wa[16 * C * 28];  // filters 0..15: [f][c][25 taps + 3 pad]
   __shared__ __attribute__((aligned(16))) float s_wb[4 * C * 28];   // filters 16..19
@@ -314,13 +61,13 @@ __global__ __launch_bounds__(C1P_THREADS) void conv1_px_kernel(const uint8_t *__
     const int img = min(img0 + q, n - 1);
     const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)img * kPix * C);
     uint4 *dst = reinterpret_cast<uint4 *>(s_img[q]);
-    for (int i = tid; i < kPix * C / 16; i += C1P_THREADS) dst[i] = src[i];
+    for (int i = tid; i < kPix * C / 16; i += C1_THREADS) dst[i] = src[i];
   }
-  for (int i = tid; i < 20 * C * 28; i += C1P_THREADS) {
-    const int fc = i / 28, tap = i - fc * 28;
-    const int f = fc / C, c = fc - f * C;
-    const float v = tap < 25 ? w[(size_t)f * K + c * 25 + tap] : 0.f;
-    if (f < 16) s_wa[i] = v; else s_wb[i - 16 * C * 28] = v;
+  {  // padded weight table [20][C][28] (built once on the host side of the C-ABI): filters 0..15, then 16..19
+    const uint4 *src = reinterpret_cast<const uint4 *>(wp);
+    uint4 *da = reinterpret_cast<uint4 *>(s_wa), *db = reinterpret_cast<uint4 *>(s_wb);
+    for (int i = tid; i < 16 * C * 7; i += C1_THREADS) da[i] = src[i];
+    for (int i = tid; i < 4 * C * 7; i += C1_THREADS) db[i] = src[16 * C * 7 + i];
   }
   if (tid == 0) s_next = 0;
   __syncthreads();
@@ -331,14 +78,16 @@ __global__ __launch_bounds__(C1P_THREADS) void conv1_px_kernel(const uint8_t *__
     int task = 0;
     if (lane == 0) task = atomicAdd(&s_next, 1);
     task = __builtin_amdgcn_readfirstlane(task);
-    if (task >= C1P_TASKS) break;
-    const int q = task / 13, chunk = task - q * 13;
-    // strip-major pixel number -> (row, column); the lanes past the image's last pixel redo pixel 783
-    const int pn = chunk * 64 + lane;
-    const int pc = pn < 784 ? pn : 783;
-    const int strip = pc / (28 * C1P_STRIP), within = pc - strip * (28 * C1P_STRIP);
-    const int py = within / C1P_STRIP, px = strip * C1P_STRIP + (within - py * C1P_STRIP);
-    const int opix = py * 28 + px;
+    if (task >= C1_TASKS) break;
+    // the pair's 2 x 784 pooled pixels are numbered through (24.5 chunks); per image strip-major
+    // pixel number -> (row, column).  Lanes past the last pixel redo it and store nothing.
+    const int g = task * 64 + lane;
+    const int gc = g < 2 * 784 ? g : 2 * 784 - 1;
+    const int q = gc >= 784 ? 1 : 0, pc = gc - q * 784;
+    const int strip = pc / (28 * C1_STRIP), within = pc - strip * (28 * C1_STRIP);
+    const int py = within / C1_STRIP, px = strip * C1_STRIP + (within - py * C1_STRIP);
+    // where the lane's pixel goes in pool1, relative to the pair's first image; -1: nothing to store
+    const int ooff = (g < 2 * 784 && img0 + q < n) ? q * 20 * 784 + py * 28 + px : -1;
     const uint8_t *base = s_img[q] + (2 * py) * kImg + 2 * px;
     f32x16 acc16[4];
     f32x4 acc4[4];
@@ -349,44 +98,62 @@ __global__ __launch_bounds__(C1P_THREADS) void conv1_px_kernel(const uint8_t *__
 #pragma unroll
       for (int r = 0; r < 4; r++) acc4[e][r] = 0.f;
     }
-    uint32_t raw[6][3];  // the patch of the next channel, as fetched: 6 rows x 3 byte pairs
+    uint32_t raw[6][3];  // the patch bytes of the channel about to be looked at: 6 rows x 3 byte pairs
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
       for (int e = 0; e < 3; e++) raw[r][e] = *reinterpret_cast<const uint16_t *>(base + r * kImg + 2 * e);
-    for (int c = 0; c < C; c++) {
-      uint32_t any = 0;
+    // Per channel three phases that are kept apart (sched_barrier): LDS requests, converts, then 200
+    // MFMAs back to back.  A VALU instruction between two MFMAs of one wave costs ~9 cycles of the
+    // matrix pipe, the same instruction issued by ANOTHER wave of the SIMD while this one streams
+    // MFMAs costs nothing (measured) — so each wave keeps its MFMA run pure and the waves of a SIMD
+    // fall out of phase.
+    for (int c = 0;;) {
+      // next live channel (the accumulators are not touched in this search loop)
+      bool live = false;
+      for (;;) {
+        uint32_t any = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int e = 0; e < 3; e++) any |= raw[r][e];
+        live = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
+        if (live || ++c >= C) break;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int e = 0; e < 3; e++) raw[r][e] = *reinterpret_cast<const uint16_t *>(base + c * kPix + r * kImg + 2 * e);
+      }
+      if (!live) break;
+      const uint8_t *nb = base + (c + 1 < C ? c + 1 : c) * kPix;
+      float4 ta[7], tb[7];
+#pragma unroll
+      for (int g = 0; g < 7; g++) {
+        ta[g] = *reinterpret_cast<const float4 *>(wa_row + c * 28 + 4 * g);
+        tb[g] = *reinterpret_cast<const float4 *>(wb_row + c * 28 + 4 * g);
+      }
       float patch[6][6];
 #pragma unroll
       for (int r = 0; r < 6; r++) {
 #pragma unroll
         for (int e = 0; e < 3; e++) {
-          any |= raw[r][e];
           patch[r][2 * e] = (float)(raw[r][e] & 0xff);
           patch[r][2 * e + 1] = (float)(raw[r][e] >> 8);
         }
       }
-      const bool live = __builtin_amdgcn_ballot_w64(any != 0u) != 0ull;
-      if (c + 1 < C) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+      for (int r = 0; r < 6; r++)
 #pragma unroll
-          for (int e = 0; e < 3; e++) raw[r][e] = *reinterpret_cast<const uint16_t *>(base + (c + 1) * kPix + r * kImg + 2 * e);
-      }
-      if (!live) continue;
-      float wa[28], wb[28];
-#pragma unroll
-      for (int g = 0; g < 7; g++) {
-        const float4 ta = *reinterpret_cast<const float4 *>(wa_row + c * 28 + 4 * g);
-        const float4 tb = *reinterpret_cast<const float4 *>(wb_row + c * 28 + 4 * g);
-        wa[4 * g] = ta.x, wa[4 * g + 1] = ta.y, wa[4 * g + 2] = ta.z, wa[4 * g + 3] = ta.w;
-        wb[4 * g] = tb.x, wb[4 * g + 1] = tb.y, wb[4 * g + 2] = tb.z, wb[4 * g + 3] = tb.w;
-      }
+        for (int e = 0; e < 3; e++) raw[r][e] = *reinterpret_cast<const uint16_t *>(nb + r * kImg + 2 * e);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kh = 0; kh < 5; kh++) {
 #pragma unroll
         for (int kw = 0; kw < 5; kw++) {
-          const float ka = wa[kh * 5 + kw], kb = wb[kh * 5 + kw];
+          const int t = kh * 5 + kw;
+          const float ka = t % 4 == 0 ? ta[t / 4].x : t % 4 == 1 ? ta[t / 4].y : t % 4 == 2 ? ta[t / 4].z : ta[t / 4].w;
+          const float kb = t % 4 == 0 ? tb[t / 4].x : t % 4 == 1 ? tb[t / 4].y : t % 4 == 2 ? tb[t / 4].z : tb[t / 4].w;
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const float x = patch[kh + (e >> 1)][kw + (e & 1)];
@@ -395,16 +162,16 @@ __global__ __launch_bounds__(C1P_THREADS) void conv1_px_kernel(const uint8_t *__
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (++c >= C) break;
     }
-    const int img = img0 + q;
-    if (img < n) {
+    {
       // D of the 4-block 16x16x1: lane l, register 4 b + r  <->  the pixel of lane 16 b + (l & 15), filter 4 (l >> 4) + r
-      float *o = out + (size_t)img * 20 * 784;
+      float *o = out + (size_t)img0 * 20 * 784;
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const int src = 16 * b + (lane & 15);
-        const int po = __shfl(opix, src);
-        if (chunk * 64 + src < 784) {
+        const int po = __shfl(ooff, 16 * b + (lane & 15));
+        if (po >= 0) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int reg = 4 * b + r, f = 4 * (lane >> 4) + r;
@@ -412,15 +179,26 @@ __global__ __launch_bounds__(C1P_THREADS) void conv1_px_kernel(const uint8_t *__
           }
         }
       }
-      if (pn < 784) {
+      if (ooff >= 0) {
 #pragma unroll
         for (int f = 0; f < 4; f++)
-          o[(16 + f) * 784 + opix] = fmaxf(fmaxf(acc4[0][f], acc4[1][f]), fmaxf(acc4[2][f], acc4[3][f])) + bias[16 + f];
+          o[(16 + f) * 784 + ooff] = fmaxf(fmaxf(acc4[0][f], acc4[1][f]), fmaxf(acc4[2][f], acc4[3][f])) + bias[16 + f];
       }
     }
   }
 }
 
+// ---------------------------------------------------------------------------
+// conv2 is an implicit GEMM D[f][pix] = sum_k W[f][k] X[k][pix] on v_mfma_f32_16x16x4_f32,
+// k = c*25 + kh*5 + kw ascending — the MFMA accumulates k..k+3 in order, so each output is
+// still the oracle's fmaf chain (cdna_hip_programming.md §3, "bit-for-bit a k-ordered chain").
+//   A operand (lane l): W[f = l&15][k0 + (l>>4)]   (k-major weight copy in LDS)
+//   B operand (lane l): X[k0 + (l>>4)][pix = l&15] (pool1 planes in LDS)
+//   D (lane l, reg r):  pixel l&15, filter 4*(l>>4) + r
+// A pixel tile is 2 rows x 8 columns of conv outputs, so the 2x2 max-pool is two lane
+// exchanges (xor 1, xor 8).  max(a_i + b) == max(a_i) + b (rounding is monotone).
+// The 2 filters that do not fill a 16-row tile run as a direct convolution on the VALU.
+// ---------------------------------------------------------------------------
 // conv2 + pool2.  Persistent workgroups (one per CU) loop over images: the k-major weights of
 // filters 0..47 (96 KB) stay in LDS next to one image's pool1 planes (62.7 KB).
 //   waves 0-11  filters 0..47 on v_mfma_f32_16x16x4_f32: a wave owns one band of two output rows
@@ -742,29 +520,16 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     if (s.num_cus <= 0) s.num_cus = 256;
   }
   const int num_cus = s.num_cus;
-  static const bool old_c1 = getenv("GPD_C1_OLD") != nullptr;  // EXPERIMENT
   hipError_t e = lenet_scratch_reserve(s, n < kChunk ? n : kChunk);
   if (e != hipSuccess) return e;
   for (int off = 0; off < n; off += kChunk) {
     const int m = (n - off < kChunk) ? (n - off) : kChunk;
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
     switch (w.channels) {
-      case 15:
-        if (old_c1) conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
-        else conv1_px_kernel<15><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
-        break;
-      case 12:
-        if (old_c1) conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
-        else conv1_px_kernel<12><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
-        break;
-      case 3:
-        if (old_c1) conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
-        else conv1_px_kernel<3><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
-        break;
-      case 1:
-        if (old_c1) conv1_mfma_kernel<1><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wt, w.c1w, w.c1b, s.pool1, m);
-        else conv1_px_kernel<1><<<(m + 1) / 2, C1P_THREADS, 0, stream>>>(img, w.c1w, w.c1b, s.pool1, m);
-        break;
+      case 15: conv1_mfma_kernel<15><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
+      case 12: conv1_mfma_kernel<12><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
+      case 3: conv1_mfma_kernel<3><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
+      case 1: conv1_mfma_kernel<1><<<(m + 1) / 2, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
