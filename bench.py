@@ -154,8 +154,8 @@ def main():
                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": kernels[dom]["achieved_TFLOPs"] / F32_PEAK_TFLOPS, "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
                         "flops_per_launch": kernels[dom]["algorithmic_flops"], "launch_ms": kernels[dom]["ms"],
-                        "note": "algorithmic (dense) FLOPs / measured time; conv1 drops k-steps whose input windows are all zero "
-                                "(exact, ~28 % of the steps on this workload), so the executed FLOP rate is lower"}
+                        "note": "algorithmic (dense) FLOPs / measured time; conv1 drops the (64-pixel chunk, channel) pairs whose "
+                                "input patches are all zero (exact, ~28 % on this workload), so the executed FLOP rate is lower"}
         else:
             roofline = {"kernel": "image stage (shadow_set + shadow_image + grasp_image kernels)", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}
