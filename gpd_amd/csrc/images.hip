@@ -55,7 +55,7 @@ namespace gpd {
 constexpr int IMG_THREADS = 512;   // 256 VGPRs per lane: no spills (1024 threads measured equally fast but spilled)
 constexpr int SET_THREADS = 1024;  // shadow_set_kernel
 constexpr int IMG_WAVES = IMG_THREADS / 64;
-constexpr int PT_CAP = 2048;  // in-box points per candidate (entry indices are packed into 11 bits by sort_by_rank)
+constexpr int PT_CAP = 2048;  // in-box points per candidate (entry indices are packed into 11 bits of the segment words)
 constexpr int PT_CAP_BIG = 16384;  // fallback instantiation of the points kernel: storage in a global scratch row
 constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
 constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
@@ -112,8 +112,8 @@ struct Box {
 constexpr size_t PTS_SCRATCH_BYTES = (size_t)PT_CAP_BIG * (3 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t));
 struct PointArrays {
   double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
-  float a[3][PT_CAP];   // |normal| in the hand frame
-  uint32_t key[PT_CAP]; // cx | cy << 6 | cz << 12 | neighbour rank << 18
+  float4 an[PT_CAP];    // |normal| in the hand frame (x, y, z) and, as bits in w, the key
+                        // cx | cy << 6 | cz << 12 | neighbour rank << 18: one 16-byte read per visit
 };
 struct NoPointArrays {};
 template <bool BIG>
@@ -121,7 +121,8 @@ struct __attribute__((aligned(16))) SmemPts {
   typename std::conditional<BIG, NoPointArrays, PointArrays>::type p;
   float raster[3][kPix];  // cell-index order (row flip applied at the store)
   uint32_t cells[kPix];   // (segment start << 16) | count; reused as the f32 depth plane
-  uint16_t place[(BIG ? PT_CAP_BIG : PT_CAP) + kPix];  // segment table + list of non-empty cells
+  uint32_t place[BIG ? PT_CAP_BIG : PT_CAP];  // segment table: neighbour rank << EB | entry (sorts without a gather)
+  uint16_t nzlist[kPix];                      // list of the non-empty cells
   double thr[3][kImg + 1];
   double recip[256];  // 1.0 / k
   float red_f[4 * IMG_WAVES];
@@ -471,31 +472,25 @@ __device__ inline void sort_u16_regs(uint16_t *p, int n) {
   for (int q = 0; q < N; q++)
     if (q < n) p[q] = (uint16_t)k[q];
 }
-// (rank << EB | entry) packed keys; entries are < 2^EB, rank = key[entry] >> 18 (14 bits)
-template <int N, int EB>
-__device__ inline void sort_by_rank_regs(uint16_t *p, int n, const uint32_t *key) {
+// segments of (rank << EB | entry) words, ascending
+template <int N>
+__device__ inline void sort_u32_regs(uint32_t *p, int n) {
   uint32_t k[N];
 #pragma unroll
-  for (int q = 0; q < N; q++) {
-    const uint32_t e = p[q];
-    k[q] = q < n ? ((key[e & ((1u << EB) - 1u)] >> 18) << EB) | e : 0xffffffffu;
-  }
+  for (int q = 0; q < N; q++) k[q] = q < n ? p[q] : 0xffffffffu;
   sort_regs<N>(k);
 #pragma unroll
   for (int q = 0; q < N; q++)
-    if (q < n) p[q] = (uint16_t)(k[q] & ((1u << EB) - 1u));
+    if (q < n) p[q] = k[q];
 }
-// sort entry indices by the neighbour rank stored in key[] (rank = key >> 18)
-template <int EB>
-__device__ inline void sort_by_rank(uint16_t *p, int n, const uint32_t *key) {
-  if (n <= 8) return sort_by_rank_regs<8, EB>(p, n, key);
-  if (n <= 16) return sort_by_rank_regs<16, EB>(p, n, key);
-  if (n <= 32) return sort_by_rank_regs<32, EB>(p, n, key);
+__device__ inline void sort_u32(uint32_t *p, int n) {
+  if (n <= 8) return sort_u32_regs<8>(p, n);
+  if (n <= 16) return sort_u32_regs<16>(p, n);
+  if (n <= 32) return sort_u32_regs<32>(p, n);
   for (int i = 1; i < n; i++) {
-    const uint16_t v = p[i];
-    const uint32_t kv = key[v] >> 18;
+    const uint32_t v = p[i];
     int j = i - 1;
-    while (j >= 0 && (key[p[j]] >> 18) > kv) {
+    while (j >= 0 && p[j] > v) {
       p[j + 1] = p[j];
       j--;
     }
@@ -767,25 +762,20 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   uint8_t *out = P.images + (size_t)cand * kPix * K.C;
   // the point arrays: LDS, or this workgroup's row of the global scratch
   double *gt = nullptr;
-  float *ga = nullptr;
-  uint32_t *gkey = nullptr;
+  float4 *gan = nullptr;
   if constexpr (BIG) {
     char *row = P.pts_scratch + (size_t)blockIdx.x * PTS_SCRATCH_BYTES;
     gt = reinterpret_cast<double *>(row);
-    ga = reinterpret_cast<float *>(row + (size_t)CAP * 3 * sizeof(double));
-    gkey = reinterpret_cast<uint32_t *>(row + (size_t)CAP * (3 * sizeof(double) + 3 * sizeof(float)));
+    gan = reinterpret_cast<float4 *>(row + (size_t)CAP * 3 * sizeof(double));
   }
   auto T = [&](int a, int e) -> double & {
     if constexpr (BIG) return gt[(size_t)a * CAP + e];
     else return S.p.t[a][e];
   };
-  auto A = [&](int a, int e) -> float & {
-    if constexpr (BIG) return ga[(size_t)a * CAP + e];
-    else return S.p.a[a][e];
+  auto AN = [&](int e) -> float4 & {
+    if constexpr (BIG) return gan[e];
+    else return S.p.an[e];
   };
-  uint32_t *keys;
-  if constexpr (BIG) keys = gkey;
-  else keys = S.p.key;
   Box B;
   load_box(P.hands[cand], B);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
@@ -815,10 +805,10 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
           T(0, e) = t[0];
           T(1, e) = t[1];
           T(2, e) = t[2];
-          A(0, e) = (float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2);
-          A(1, e) = (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2);
-          A(2, e) = (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2);
-          keys[e] = cells_of(S, B, t) | ((uint32_t)i << 18);
+          AN(e) = make_float4((float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2),
+                              (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2),
+                              (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2),
+                              __uint_as_float(cells_of(S, B, t) | ((uint32_t)i << 18)));
         }
       }
     }
@@ -849,19 +839,20 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   for (int pr = 0; pr < K.nproj; pr++) {
     for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
     __syncthreads();
-    for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(keys[e], pr)], 1u);
+    for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(__float_as_uint(AN(e).w), pr)], 1u);
     __syncthreads();
     scan_cells(S);
     for (int e = tid; e < nb; e += IMG_THREADS) {
-      const uint32_t old = atomicAdd(&S.cells[cell_of_key(keys[e], pr)], 1u);
-      S.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)e;
+      const uint32_t key = __float_as_uint(AN(e).w);
+      const uint32_t old = atomicAdd(&S.cells[cell_of_key(key, pr)], 1u);
+      S.place[(old >> 16) + (old & 0xffffu)] = ((key >> 18) << EB) | (uint32_t)e;
     }
     __syncthreads();
     TICK(6);
     // the pixel owner walks its segment in neighbour order
     const int da = depth_axis(pr);
     const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
-    uint16_t *nz = &S.place[CAP];
+    uint16_t *nz = S.nzlist;
     const int n_nz = list_nonempty_cells(S, nz);
     TICK(11);
     for (int c = tid; c < kPix; c += IMG_THREADS) {
@@ -881,7 +872,8 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
       float avg = 0.f, fc = 0.f;
       auto visit = [&](int e) {  // one in-box point, in neighbour order
-        const float a0 = A(0, e), a1 = A(1, e), a2 = A(2, e);
+        const float4 an = AN(e);
+        const float a0 = an.x, a1 = an.y, a2 = an.z;
         if (v0 == 0.f && v1 == 0.f && v2 == 0.f) {
           v0 = a0;
           v1 = a1;
@@ -898,8 +890,8 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
         fc = (float)((double)fc + 1.0);
         avg = (float)((double)avg + (d - (double)avg) * recip_count<256>(S.recip, fc));
       };
-      sort_by_rank<EB>(&S.place[start], cn, keys);
-      for (int q = 0; q < cn; q++) visit((int)S.place[start + q]);
+      sort_u32(&S.place[start], cn);  // neighbour order: the rank sits above the entry index
+      for (int q = 0; q < cn; q++) visit((int)(S.place[start + q] & ((1u << EB) - 1u)));
       S.raster[0][c] = v0;
       S.raster[1][c] = v1;
       S.raster[2][c] = v2;
