@@ -136,6 +136,15 @@ def test_edge_cases_and_errors(oracle_mod, cloud30k):
             else:
                 img[i] = rng.randint(0, 256, (60, 60, 15)) * (rng.rand(60, 60, 15) < 0.05)
         assert np.array_equal(ctx.score(img), oracle_mod.lenet(img, w))
+        # image counts around the pair size of a conv1 workgroup (the pair's pixels share 64-lane chunks)
+        for n in (1, 2, 3):
+            assert np.array_equal(ctx.score(img[:n]), oracle_mod.lenet(img[:n], w))
+        # one lit pixel at the image corners and at the seams of conv1's 7-column strips / 64-pixel chunks
+        spots = [(0, 0), (59, 59), (0, 59), (59, 0), (17, 13), (18, 14), (35, 27), (36, 28), (19, 41), (20, 42)]
+        img = np.zeros((len(spots), 60, 60, 15), np.uint8)
+        for i, (y, x) in enumerate(spots):
+            img[i, y, x, (0, 14)[i % 2]] = 255 - i
+        assert np.array_equal(ctx.score(img), oracle_mod.lenet(img, w))
         # the skipping is exact for finite weights only: anything else is refused
         bad = {k: v.copy() for k, v in w.items()}
         bad["c1w"][7] = np.inf
