@@ -26,7 +26,6 @@
 namespace gpd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // conv1 + pool1, pixel-stationary form.  Two images per workgroup; a task is a chunk of 64 pooled
@@ -44,7 +43,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // zero adds exact zeros to every chain (fmaf(w, 0, acc) == acc for finite w; acc is never -0) and
 // is skipped — decided from the patch bytes themselves (one ballot), which are fetched a channel
 // ahead anyway.  Pooled pixels are numbered strip-major (four strips of 7 columns), so a chunk is
-// a compact ~9 x 7 block: 28 % of the (chunk, channel) pairs drop out (17 % with row-major chunks).
+// a compact ~9 x 7 block: 28 % of the (chunk, channel) pairs drop out (14 % with row-major chunks;
+// profiles/r01m_conv1_skip_stats.txt).
 // Tasks are handed out through an LDS counter, so the four SIMDs stay balanced under skipping.
 constexpr int C1_WAVES = 8, C1_THREADS = 64 * C1_WAVES, C1_TASKS = 25, C1_STRIP = 7;
 
