@@ -90,7 +90,8 @@ struct ImgParams {
   const uint32_t *set_bits;  // [live sets][SETWORDS] shadow voxel bitsets (shadow_set_kernel)
   uint8_t *images;        // planar [n][C][3600]
   int32_t *status;
-  const int32_t *cand_list;  // shadow kernel: candidates to process (nullptr: blockIdx)
+  int num_cand;              // candidates of the launch (the kernels that do not take a list)
+  const int32_t *cand_list;  // shadow kernel: candidates to process (nullptr: all, in XCD-aware order)
   int32_t *overflow_list;    // shadow kernel: candidates whose box exceeds SHC voxels
   int32_t *overflow_count;
   unsigned long long *dbg;  // profiling aid (GPD_IMG_TIMING=1): per-phase cycle sums
@@ -531,12 +532,24 @@ __device__ inline void load_box(const gpd_hand &H, Box &B) {
 // shadow_image_kernel: the shadow channel of the three projections of one candidate
 // (createShadowImage, image_strategy.cpp:192-233; 15 channels only).
 // ---------------------------------------------------------------------------
+// XCD-aware candidate order (workgroup L runs on XCD L % 8, one L2 per XCD): XCD x takes the x-th
+// eighth of the candidate list, so the candidates of one hand set — which read the same neighbourhood
+// rows / the same shadow bitset — meet in ONE L2 instead of being dealt out over all eight.
+// Launch with 8 * ceil(n / 8) workgroups; returns -1 for the padding ones.
+__device__ __forceinline__ int xcd_candidate(int n) {
+  const int per = (n + 7) >> 3;
+  const int L = blockIdx.x, slot = L >> 3;
+  const int cand = (L & 7) * per + slot;
+  return cand < n ? cand : -1;
+}
+
 template <int SHC>
 __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_image_kernel(ImgParams P) {
   __shared__ SmemShadow<SHC> S;
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
-  const int cand = P.cand_list ? P.cand_list[blockIdx.x] : (int)blockIdx.x;
+  const int cand = P.cand_list ? P.cand_list[blockIdx.x] : xcd_candidate(P.num_cand);
+  if (cand < 0) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int set_ord = P.meta[4 * cand + 2];
@@ -753,7 +766,8 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   constexpr int EB = BIG ? 14 : 11;  // bits of an entry index
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
-  const int cand = BIG ? P.cand_list[blockIdx.x] : (int)blockIdx.x;
+  const int cand = BIG ? P.cand_list[blockIdx.x] : xcd_candidate(P.num_cand);
+  if (cand < 0) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int slot_s = P.meta[4 * cand + 0];
@@ -1256,13 +1270,14 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     HIP_RET(hipGetLastError());
   }
   ip.cand_list = nullptr;
+  ip.num_cand = n;
   ip.overflow_list = im.d_overflow;
   ip.overflow_count = im.d_overflow + im.capacity;
   if (im.channels == 15) {
     // most boxes fit the two-per-CU instantiation; the few that do not are queued by it and
     // redone by the large one
     HIP_RET(hipMemsetAsync(im.d_overflow + im.capacity, 0, sizeof(int32_t), stream));
-    shadow_image_kernel<SH_CAP><<<n, IMG_THREADS, 0, stream>>>(ip);
+    shadow_image_kernel<SH_CAP><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
     HIP_RET(hipGetLastError());
     if (check) {
       int32_t n_over = 0;
@@ -1285,7 +1300,7 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
   ip.pts_overflow_count = im.d_pts_overflow + im.capacity;
   ip.pts_scratch = nullptr;
   HIP_RET(hipMemsetAsync(im.d_pts_overflow + im.capacity, 0, sizeof(int32_t), stream));
-  grasp_image_kernel<false><<<n, IMG_THREADS, 0, stream>>>(ip);
+  grasp_image_kernel<false><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
   HIP_RET(hipGetLastError());
   if (check) {
     int32_t n_over = 0;
