@@ -563,19 +563,31 @@ __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_ima
   if (tid == 0) {
     S.flag = 0;
     // voxel AABB of the image box: corners sample + F * (bx, by, bz)
-    double lo0 = DBL_MAX, lo1 = DBL_MAX, lo2 = DBL_MAX;
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const double bx = (k & 1) ? B.hi[0] : B.lo[0];
       const double by = (k & 2) ? B.hi[1] : B.lo[1];
       const double bz = (k & 4) ? B.hi[2] : B.lo[2];
-      lo0 = fmin(lo0, B.sample[0] + B.F[0] * bx + B.F[1] * by + B.F[2] * bz);
-      lo1 = fmin(lo1, B.sample[1] + B.F[3] * bx + B.F[4] * by + B.F[5] * bz);
-      lo2 = fmin(lo2, B.sample[2] + B.F[6] * bx + B.F[7] * by + B.F[8] * bz);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double w = B.sample[a] + B.F[3 * a] * bx + B.F[3 * a + 1] * by + B.F[3 * a + 2] * bz;
+        lo[a] = fmin(lo[a], w);
+        hi[a] = fmax(hi[a], w);
+      }
     }
-    S.vorg[0] = (int)floor(lo0 * K.voxel_mult) - 1;
-    S.vorg[1] = (int)floor(lo1 * K.voxel_mult) - 1;
-    S.vorg[2] = (int)floor(lo2 * K.voxel_mult) - 1;
+    // capacity: the box must fit the VDIM^3 voxel window of this kernel and the SD^3 region that
+    // shadow_set_kernel voxelised around the sample; a larger image volume is reported
+    // (GPD_ERR_CAPACITY, flag 1) instead of silently losing shadow voxels
+    int bad = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int v0 = (int)floor(lo[a] * K.voxel_mult) - 1, v1 = (int)floor(hi[a] * K.voxel_mult) + 1;
+      const int o = (int)floor(B.sample[a] * K.voxel_mult) - SR;
+      S.vorg[a] = v0;
+      if (v1 - v0 >= VDIM || v0 < o || v1 >= o + SD) bad = 1;
+    }
+    S.flag = bad;
   }
   __syncthreads();
   const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];

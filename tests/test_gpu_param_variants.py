@@ -69,3 +69,21 @@ def test_detect_matches_oracle_under_parameter_variant(oracle_mod, name):
         assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_oversized_image_volume_is_refused_not_truncated(oracle_mod):
+    """An image volume whose box does not fit the shadow kernel's voxel window (46^3 voxels of 3 mm) must come
+    back as GPD_ERR_CAPACITY — the kernel would otherwise lose shadow voxels without a trace.  A volume that
+    still fits is computed and matches the oracle (covered by `other_image_volume` above)."""
+    cl = synth.make_cloud(4242, 20000)
+    si = synth.sample_indices(cl, 40)
+    gp = _set(api.default_params(15), volume_width=0.16, volume_depth=0.10)
+    ctx = api.Context(gp)
+    try:
+        ctx.set_lenet_weights(_weights(15))
+        ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+        with pytest.raises(api.GpdHipError, match="capacity"):
+            ctx.detect(si)
+    finally:
+        ctx.close()
