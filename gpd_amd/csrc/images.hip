@@ -62,9 +62,11 @@ constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per 
 constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
 constexpr int VBITS = VDIM * VDIM * VDIM;
 constexpr int VWORDS = (VBITS + 31) / 32;
-constexpr int SD = 88;        // per-set shadow region edge in voxels (2*43 + 1, rounded up)
-constexpr int SR = 43;        // region reach: every image box of a set lies within 0.1233 m of the sample
-constexpr int SETWORDS = SD * SD * SD / 32;
+constexpr int SR = 43;        // region reach: every image box of a set lies within 0.1233 m (41.1 voxels, so 42 whole
+                              // voxels) of the sample; one more on the low side, where the box window starts
+constexpr int SD = 86;        // per-set shadow region edge in voxels: offsets -43 .. +42 from the sample's voxel.
+                              // 86^3 bits = 79.5 KB: two shadow_set workgroups per CU (88^3 = 85 KB allowed one)
+constexpr int SETWORDS = (SD * SD * SD + 31) / 32;
 
 struct ImgConsts {
   double vol_depth, vol_width, vol_height, half_od, dbl_h;
@@ -585,7 +587,8 @@ __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_ima
       const int v0 = (int)floor(lo[a] * K.voxel_mult) - 1, v1 = (int)floor(hi[a] * K.voxel_mult) + 1;
       const int o = (int)floor(B.sample[a] * K.voxel_mult) - SR;
       S.vorg[a] = v0;
-      if (v1 - v0 >= VDIM || v0 < o || v1 >= o + SD) bad = 1;
+      // (the window's one-voxel margins may stick out of the region: they hold no voxel of the box)
+      if (v1 - v0 >= VDIM || v0 + 1 < o || v1 - 1 >= o + SD) bad = 1;
     }
     S.flag = bad;
   }
