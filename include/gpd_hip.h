@@ -100,7 +100,9 @@ const char *gpd_hip_last_error(void);
  * EigenClassifier::EigenClassifier (net/eigen_classifier.cpp:28-50):
  * conv1 [20][C*25] row-major, conv2 [50][500] row-major, ip1 column-major
  * 500 x 7200 over the pixel-major flatten (eigen_classifier.cpp:103-107,
- * dense_layer.cpp:7), ip2 column-major 2 x 500.  Copied to the device once. */
+ * dense_layer.cpp:7), ip2 column-major 2 x 500.  Copied to the device once.
+ * The conv1 weights must be finite (GPD_ERR_INVALID otherwise): conv1 skips input
+ * patches that are all zero, which is exact for finite weights only (0 * inf = NaN). */
 int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels,
                               const float *conv1_w, const float *conv1_b,
                               const float *conv2_w, const float *conv2_b,
