@@ -43,6 +43,10 @@ struct ImageGeometry {
 class GraspDetector {
  public:
   explicit GraspDetector(const std::string &config_filename);
+  // From the parameter objects the reference hands to CandidatesGenerator / HandSearch and ImageGenerator
+  // directly (src/tests/test_grasp_image.cpp:50-108): no classifier, no voxelisation, workspaces +-1 m.
+  GraspDetector(const candidate::HandSearch::Parameters &hand_search_params, const descriptor::ImageGeometry &image_geom,
+                int hip_device = 0);
   ~GraspDetector();
   std::vector<std::unique_ptr<candidate::Hand>> detectGrasps(const util::Cloud &cloud);
   // CandidatesGenerator::preprocessPointCloud (candidates_generator.cpp:14-37): workspace cut (cfg
@@ -68,6 +72,11 @@ class GraspDetector {
   // grasp_detector.cpp:522-526 -> HandSearch::reevaluateHypotheses (hand_search.cpp:66-134): labels
   // (1 = full antipodal on cloud_gt) and rewritten half/full flags of `hands`.  Uploads cloud_gt.
   std::vector<int> evalGroundTruth(const util::Cloud &cloud_gt, std::vector<std::unique_ptr<candidate::Hand>> &hands);
+  // ImageGenerator::createImages (descriptor/image_generator.cpp:17-99): one image per valid hand of the
+  // given sets, set-major / slot-minor, no filtering.  The sets must come from the last
+  // generateGraspCandidates on this cloud (their neighbourhoods are still on the device).
+  bool createImages(const util::Cloud &cloud, const std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list,
+                    std::vector<std::unique_ptr<net::Image>> &images_out, std::vector<std::unique_ptr<candidate::Hand>> &hands_out);
   bool createGraspImages(util::Cloud &cloud, std::vector<std::unique_ptr<candidate::Hand>> &hands_out,
                          std::vector<std::unique_ptr<net::Image>> &images_out);
   std::vector<std::unique_ptr<candidate::Hand>> selectGrasps(std::vector<std::unique_ptr<candidate::Hand>> &hands) const;

@@ -515,6 +515,38 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   }
 }
 
+GraspDetector::GraspDetector(const candidate::HandSearch::Parameters &hs, const descriptor::ImageGeometry &ig, int hip_device) {
+  gpd_hip_default_params(&params_);
+  params_.finger_width = hs.hand_geometry_.finger_width_;
+  params_.hand_outer_diameter = hs.hand_geometry_.outer_diameter_;
+  params_.hand_depth = hs.hand_geometry_.depth_;
+  params_.hand_height = hs.hand_geometry_.height_;
+  params_.init_bite = hs.hand_geometry_.init_bite_;
+  params_.nn_radius_frames = hs.nn_radius_frames_;
+  params_.num_orientations = hs.num_orientations_;
+  params_.num_finger_placements = hs.num_finger_placements_;
+  params_.deepen_hand = hs.deepen_hand_ ? 1 : 0;
+  params_.num_hand_axes = (int)std::min<size_t>(hs.hand_axes_.size(), 3);
+  for (int i = 0; i < params_.num_hand_axes; i++) params_.hand_axes[i] = hs.hand_axes_[i];
+  params_.friction_coeff = hs.friction_coeff_;
+  params_.min_viable = hs.min_viable_;
+  params_.volume_width = ig.outer_diameter_;
+  params_.volume_depth = ig.depth_;
+  params_.volume_height = ig.height_;
+  params_.image_size = ig.size_;
+  params_.image_num_channels = ig.num_channels_;
+  num_samples_ = hs.num_samples_;
+  voxelize_ = false;
+  workspace_ = {-1.0, 1.0, -1.0, 1.0, -1.0, 1.0};
+  workspace_grasps_ = workspace_;
+  for (int i = 0; i < 6; i++) params_.workspace_grasps[i] = workspace_grasps_[i];
+  clustering_ = std::make_unique<Clustering>(0);
+  if (gpd_hip_create(hip_device, &params_, &ctx_) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    ctx_ = nullptr;
+  }
+}
+
 candidate::HandSearch::Parameters GraspDetector::getHandSearchParameters() const {
   candidate::HandSearch::Parameters p;
   p.nn_radius_frames_ = params_.nn_radius_frames;
@@ -806,6 +838,47 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::pruneGraspCandidate
     }
   }
   return hands_out;
+}
+
+bool GraspDetector::createImages(const util::Cloud &cloud, const std::vector<std::unique_ptr<candidate::HandSet>> &hand_set_list,
+                                 std::vector<std::unique_ptr<net::Image>> &images_out,
+                                 std::vector<std::unique_ptr<candidate::Hand>> &hands_out) {
+  (void)cloud;
+  images_out.clear();
+  hands_out.clear();
+  if (!ctx_) return false;
+  if (hand_set_list.empty()) return true;
+  if ((int)hand_set_list.size() != last_num_sets_) {
+    printf("ERROR: createImages: the hand sets are not those of the last generateGraspCandidates call\n");
+    return false;
+  }
+  for (size_t s = 0; s < hand_set_list.size(); s++) {
+    const auto &hs = hand_set_list[s];
+    bool same = hs && !hs->getHands().empty() && hs->getHands()[0]->record().set_index == (int)s;
+    for (int r = 0; r < 3 && same; r++) same = last_samples_[3 * s + r] == hs->getHands()[0]->record().sample[r];
+    if (!same) {
+      printf("ERROR: createImages: the hand sets are not those of the last generateGraspCandidates call\n");
+      return false;
+    }
+  }
+  std::vector<gpd_hand> recs = flatten(hand_set_list);
+  const size_t bytes = (size_t)60 * 60 * params_.image_num_channels;
+  size_t nv = 0;
+  for (const gpd_hand &r : recs) nv += r.valid;
+  std::vector<uint8_t> pix(nv * bytes);
+  std::vector<int32_t> cand(nv);
+  int n_cand = 0;
+  if (gpd_hip_images(ctx_, recs.data(), last_num_sets_, pix.data(), cand.data(), &n_cand) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return false;
+  }
+  for (int k = 0; k < n_cand; k++) {
+    auto im = std::make_unique<net::Image>(60, 60, params_.image_num_channels);
+    std::memcpy(im->data.data(), pix.data() + (size_t)k * bytes, bytes);
+    images_out.push_back(std::move(im));
+    hands_out.push_back(std::make_unique<candidate::Hand>(recs[cand[k]]));
+  }
+  return true;
 }
 
 bool GraspDetector::createGraspImages(util::Cloud &cloud, std::vector<std::unique_ptr<candidate::Hand>> &hands_out,

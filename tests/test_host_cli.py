@@ -270,3 +270,54 @@ def test_label_grasps_cli_matches_oracle(tmp_path, oracle_mod, lenet15_real):
     assert np.array_equal(labels, v["full_antipodal"].astype(np.int32)) and labels.sum() > 0
     assert got == labels.tolist()
     assert ("LABELS %d / %d" % (labels.sum(), len(labels))) in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,axes", [(15, None), (3, None), (15, [0, 1, 2])])
+def test_test_grasp_image_tool_on_krylon_sample_3456(tmp_path, oracle_mod, channels, axes):
+    """The reference's only built test program and its documented invocation (src/tests/test_grasp_image.cpp,
+    README: `test_grasp_image ../tutorials/krylon.pcd 3456 1 ...`): raw krylon cloud, normals with radius 0.03
+    then negated, sample index 3456, ONE orientation about axis 2 (or the axes given), an image per valid hand.
+    The tool's frame / position / flags / images against the oracle on the same steps."""
+    exe = os.path.join(ROOT, "gpd_amd", "host", "test_grasp_image")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    xyz = np.load(os.path.join(ROOT, "tests", "golden", "krylon_xyz.npz"))["xyz"]
+    pcd = tmp_path / "krylon.pcd"
+    with open(str(pcd), "w") as f:
+        f.write("# .PCD v.7 - Point Cloud Data file format\nVERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\n"
+                "WIDTH %d\nHEIGHT 1\nPOINTS %d\nDATA ascii\n" % (len(xyz), len(xyz)))
+        for p in xyz:
+            f.write("%.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+    dump = tmp_path / "images.bin"
+    argv = [exe, str(pcd), "3456", "0", str(channels)] + [str(a) for a in (axes or [])]
+    out = subprocess.run(argv, capture_output=True, text=True, cwd=str(tmp_path), timeout=300,
+                         env=dict(os.environ, GPD_DUMP_IMAGES=str(dump)))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = out.stdout.splitlines()
+    assert ("hand_axes: " + "".join("%d " % a for a in (axes or [2]))) in lines
+    # ---- the oracle on the same steps
+    p = oracle_mod.default_params(channels)
+    p.num_orientations = 1
+    p.num_hand_axes = len(axes or [2])
+    for i, a in enumerate(axes or [2]):
+        p.hand_axes[i] = a
+    normals = -oracle_mod.estimate_normals(xyz, radius=0.03)
+    cam, vp = np.ones((1, len(xyz)), np.int32), np.zeros((1, 3))
+    hands = oracle_mod.search(p, xyz, normals, np.array([3456], np.int32))
+    assert hands.shape == (1, len(axes or [2]))
+    h = hands[0, 0]
+    k = lines.index("grasp orientation:")
+    frame = np.array([[float(v) for v in lines[k + 1 + r].split()] for r in range(3)])
+    assert np.array_equal(frame, h["frame"].reshape(3, 3))
+    assert np.array_equal(np.array([float(v) for v in lines[k - 1].split()[1:]]), h["sample"])
+    assert np.array_equal(np.array([float(v) for v in lines[k + 4].split()[2:]]), h["position"])
+    oimg, ocand = oracle_mod.images(p, xyz, normals, cam, vp, hands.copy())
+    valid = [hands[0, j] for j in range(hands.shape[1]) if hands[0, j]["valid"]]
+    got = [l.split() for l in lines if l.startswith("IMAGE ")]
+    assert len(got) == len(ocand) == len(valid) >= 1
+    raw = np.fromfile(str(dump), np.uint8).reshape(len(got), 60, 60, channels)
+    assert np.array_equal(raw, oimg)
+    for g, v in zip(got, valid):
+        assert (int(g[3]), int(g[4]), int(g[5]), int(g[6])) == (v["slot"], v["finger_placement_index"], v["half_antipodal"], v["full_antipodal"])
+    anti = [l for l in lines if l.startswith("Antipodal:")][0].split()[1:]
+    assert [int(x) for x in anti] == [int(v["full_antipodal"]) for v in valid]
