@@ -72,3 +72,24 @@ def test_normals_csv(tmp_path):
     L.gpd_host_load_normals_csv.restype = C.c_int
     n = L.gpd_host_load_normals_csv(str(pcd).encode(), str(csv).encode(), out.ctypes.data_as(C.c_void_p), 40)
     assert n == 40 and np.array_equal(out, nrm)
+
+
+def test_cli_argument_errors_without_a_gpu(tmp_path):
+    """The host tools check their arguments and inputs before they touch the device, with the reference's
+    messages and its -1 exit status (src/tests/test_grasp_image.cpp:20-44, src/detect_grasps.cpp)."""
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpd_amd", "host")
+    tool = os.path.join(host, "test_grasp_image")
+    assert os.path.exists(tool), "run __graft_entry__.build()"
+    out = subprocess.run([tool], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 255 and "ERROR: Not enough arguments given!" in out.stdout
+    out = subprocess.run([tool, str(tmp_path / "missing.pcd"), "0", "0"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 255 and "Input point cloud is empty or does not exist" in out.stdout
+    pcd = tmp_path / "three.pcd"
+    _write(str(pcd), np.eye(3, dtype=np.float32), None, False)
+    out = subprocess.run([tool, str(pcd), "7", "0"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 255 and "Sample index is larger than the number of points" in out.stdout
+    for name in ("detect_grasps", "generate_candidates", "label_grasps", "cem_detect_grasps"):
+        out = subprocess.run([os.path.join(host, name)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 255 and "Not enough input arguments" in out.stdout, name
