@@ -53,3 +53,49 @@ def test_hip_reproduces_golden(C):
         assert np.abs(ctx.score(img) - d["scores"]).max() <= 1e-4
     finally:
         ctx.close()
+
+
+def _krylon_3456(mod_params):
+    d = np.load(os.path.join(GOLD, "krylon_3456.npz"))
+    xyz = np.load(os.path.join(GOLD, "krylon_xyz.npz"))["xyz"]
+    p = mod_params(15)
+    p.num_orientations = 1
+    p.num_hand_axes = 3
+    for i in range(3):
+        p.hand_axes[i] = i
+    return d, xyz, p
+
+
+def test_oracle_reproduces_krylon_sample_3456(oracle_mod):
+    """README.md:223 / src/tests/test_grasp_image.cpp: krylon.pcd, flipped radius-0.03 normals, sample 3456."""
+    d, xyz, p = _krylon_3456(oracle_mod.default_params)
+    normals = -oracle_mod.estimate_normals(xyz, radius=0.03)
+    assert np.array_equal(normals[3456], d["normal_3456"]) and float(normals.astype(np.float64).sum()) == float(d["normals_checksum"])
+    hands = oracle_mod.search(p, xyz, normals, np.array([3456], np.int32))
+    assert hands.view(np.uint8).tobytes() == d["hands"].tobytes()
+    assert hands["valid"].tolist() == [[1, 0, 1]]
+    img, cand = oracle_mod.images(p, xyz, normals, np.ones((1, len(xyz)), np.int32), np.zeros((1, 3)), hands.copy())
+    assert np.array_equal(cand, d["cand_index"]) and np.array_equal(img, d["images"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_krylon_sample_3456():
+    from gpd_amd import api
+    d, xyz, p = _krylon_3456(api.default_params)
+    ctx = api.Context(p)
+    try:
+        ctx.upload_cloud(xyz, np.zeros_like(xyz), np.ones((1, len(xyz)), np.int32), np.zeros((1, 3)))
+        normals = -ctx.estimate_normals(0.03)
+        assert np.array_equal(normals[3456], d["normal_3456"])
+        ctx.upload_cloud(xyz, normals, np.ones((1, len(xyz)), np.int32), np.zeros((1, 3)))
+        hands = ctx.search(np.array([3456], np.int32))
+        want = d["hands"].view(api.HAND_DTYPE).reshape(hands.shape)
+        assert np.array_equal(hands["valid"], want["valid"])
+        v = want["valid"].astype(bool)
+        assert np.array_equal(hands["finger_placement_index"][v], want["finger_placement_index"][v])
+        for f in ("frame", "position", "top", "bottom", "center", "grasp_width"):
+            assert np.allclose(hands[f][v], want[f][v], rtol=1e-12, atol=1e-15)
+        img, cand = ctx.images(hands)
+        assert np.array_equal(cand, d["cand_index"]) and np.array_equal(img, d["images"])
+    finally:
+        ctx.close()
