@@ -127,7 +127,7 @@ struct ImageState {
   gpd_hand *d_hands = nullptr;        // candidate hand records
   int32_t *d_cand_meta = nullptr;     // [n][4]: sample slot, N_images, shadow-set ordinal, -
   int32_t *d_set_meta = nullptr;      // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera
-  uint32_t *d_set_bits = nullptr;     // [sets][88^3/32] shadow voxel bitsets
+  uint32_t *d_set_bits = nullptr;     // [sets][SETWORDS] shadow voxel bitsets
   int num_shadow_sets = 0, cap_shadow_sets = 0;
   int channels = 0;
   int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
@@ -139,6 +139,7 @@ struct ImageState {
   int32_t *d_status = nullptr;        // error flags from the kernel
   int cap_hands = 0;
   long long stat_sets = 0, stat_sum_set_ni = 0, stat_sum_cand_ni = 0;  // for the algorithmic byte count
+  std::vector<unsigned char> consts;  // the constant block (geometry, view points) the candidate list was built with
 };
 int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageState &im, const gpd_hand *hands, int num_sets,
                int32_t *cand_index, hipStream_t stream);

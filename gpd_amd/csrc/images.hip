@@ -1248,15 +1248,39 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
     k.stride_a = A;
     k.stride_c = Cc;
   }
-  // stream-ordered after the kernels of an earlier call that still read the old constants
-  HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_img), &k, sizeof(k), 0, hipMemcpyHostToDevice, stream));
+  im.consts.assign(reinterpret_cast<const unsigned char *>(&k), reinterpret_cast<const unsigned char *>(&k) + sizeof(k));
   return images_launch(s, im, stream, true);
+}
+
+// c_img is ONE block per device, shared by every context of the process on that device.  Under the
+// lock: a context whose block (geometry, view points of its cloud) differs from the loaded one waits
+// for the device — kernels of another context, on another stream, may still be reading it — and
+// loads its own; the caller keeps the lock until its kernels are enqueued.  Same-stream order covers
+// the context's own earlier kernels.
+static std::mutex g_img_mutex;
+static std::vector<unsigned char> g_img_loaded[64];
+
+static int load_img_consts(const std::vector<unsigned char> &want, hipStream_t stream) {
+  if (want.size() != sizeof(ImgConsts)) return GPD_ERR_STATE;
+  int dev = 0;
+  HIP_RET(hipGetDevice(&dev));
+  std::vector<unsigned char> &loaded = g_img_loaded[dev & 63];
+  if (loaded == want) return GPD_OK;
+  if (!loaded.empty()) HIP_RET(hipDeviceSynchronize());
+  HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_img), want.data(), sizeof(ImgConsts), 0, hipMemcpyHostToDevice, stream));
+  loaded = want;
+  return GPD_OK;
 }
 
 // Launches grasp_image_kernel over the candidate list resident on the device.
 int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool check) {
   const int n = im.num_candidates;
   if (n <= 0) return GPD_OK;
+  std::lock_guard<std::mutex> consts_lock(g_img_mutex);
+  {
+    const int rc = load_img_consts(im.consts, stream);
+    if (rc) return rc;
+  }
   ImgParams ip;
   ip.nn = s.d_nn;
   ip.cap = s.nn_cap;

@@ -34,6 +34,8 @@
 
 #include <type_traits>
 
+#include <mutex>
+
 #include "gpd_internal.h"
 
 namespace gpd {
@@ -1485,7 +1487,15 @@ static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, c
   return GPD_OK;
 }
 
-static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slots, hipStream_t stream) {
+// c_hand is ONE block per device, shared by every context of the process on that device.  A context
+// whose constants differ from the loaded ones waits for the device (kernels of another context, on
+// another stream, may still be reading the block) before it overwrites them; the lock is handed
+// back to the caller, who keeps it until its kernels that read the block are enqueued.
+static std::mutex g_hand_mutex;
+static std::vector<unsigned char> g_hand_loaded[64];
+
+static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slots, hipStream_t stream,
+                              std::unique_lock<std::mutex> &lock) {
   HandConsts hk;
   std::memset(&hk, 0, sizeof(hk));
   std::memcpy(hk.rot, hc.rot, sizeof(hk.rot));
@@ -1502,7 +1512,15 @@ static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slo
   hk.hand_depth = p.hand_depth;
   hk.hand_height = p.hand_height;
   hk.init_bite = p.init_bite;
+  lock = std::unique_lock<std::mutex>(g_hand_mutex);
+  int dev = 0;
+  HIP_RET(hipGetDevice(&dev));
+  std::vector<unsigned char> &loaded = g_hand_loaded[dev & 63];
+  const unsigned char *bytes = reinterpret_cast<const unsigned char *>(&hk);
+  if (loaded.size() == sizeof(hk) && std::memcmp(loaded.data(), bytes, sizeof(hk)) == 0) return GPD_OK;
+  if (!loaded.empty()) HIP_RET(hipDeviceSynchronize());
   HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_hand), &hk, sizeof(hk), 0, hipMemcpyHostToDevice, stream));
+  loaded.assign(bytes, bytes + sizeof(hk));
   return GPD_OK;
 }
 
@@ -1514,7 +1532,8 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   int cap = 0;
   int rc = neighbourhoods(p, c, s, hc, sample_idx, sample_xyz, S, slots, &cap, stream);
   if (rc) return rc;
-  rc = upload_hand_consts(p, hc, slots, stream);
+  std::unique_lock<std::mutex> consts_lock;  // held until the kernels that read c_hand are enqueued
+  rc = upload_hand_consts(p, hc, slots, stream, consts_lock);
   if (rc) return rc;
   HandParams hp;
   hp.counts = s.d_counts;
@@ -1544,7 +1563,8 @@ int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand
   int cap = 0;
   int rc = neighbourhoods(p, c, s, hc, nullptr, xyz.data(), n, slots, &cap, stream);
   if (rc) return rc;
-  rc = upload_hand_consts(p, hc, slots, stream);
+  std::unique_lock<std::mutex> consts_lock;  // held until the kernels that read c_hand are enqueued
+  rc = upload_hand_consts(p, hc, slots, stream, consts_lock);
   if (rc) return rc;
   HIP_RET(hipMemcpyAsync(s.d_hands, hands, (size_t)n * sizeof(gpd_hand), hipMemcpyHostToDevice, stream));
   HandParams hp;

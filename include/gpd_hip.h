@@ -3,12 +3,13 @@
  * GPD hot path: candidate search -> grasp image -> LeNet score.
  *
  * Everything here is `extern "C"`, plain pointers and sizes.  Host buffers are
- * owned by the caller, device memory is owned by the context.  One context per
- * device (the hand / image geometry lives in the device's constant memory: two
- * contexts with DIFFERENT parameters on one device must not run concurrently);
- * a context is not thread-safe (the reference's GraspDetector is not either:
- * grasp_detector.cpp:192-328 is called from one thread).  Contexts on different
- * devices may be driven from different threads.
+ * owned by the caller, device memory is owned by the context.  A context is not
+ * thread-safe (the reference's GraspDetector is not either: grasp_detector.cpp:192-328
+ * is called from one thread); different contexts — on different devices or on the
+ * same one — may be driven from different threads.  The hand / image geometry and
+ * the view points live in one constant block per device: contexts on a device
+ * that agree on them overlap freely, a context with different values waits for
+ * the device before it loads its own (correct, but serialising).
  *
  * Each entry point names the reference interface it replaces (paths relative to
  * the reference tree).  Return value: 0 on success, <0 on error

@@ -312,3 +312,60 @@ def test_dense_cloud_overflow_fallbacks(oracle_mod):
         assert (img[..., 3] > 0).any()
     finally:
         ctx.close()
+
+
+def test_two_contexts_with_different_constants_on_one_device(oracle_mod):
+    """The device constant blocks (image geometry + view points, hand constants) are one per device: two
+    contexts with DIFFERENT geometry and cameras on the same device must not see each other's values —
+    neither when their calls interleave (replay after the other context ran) nor from two host threads."""
+    import threading
+    w = _weights(15)
+    clA, clB = synth.make_cloud(11, 12000), synth.make_cloud(12, 12000)
+    clB = dict(clB)
+    clB["view_points"] = np.array([[0.3, -0.2, 0.9]])  # another camera: other shadows, other constants
+    pA, pB = api.default_params(15), api.default_params(15)
+    pB.volume_width, pB.volume_depth, pB.volume_height = 0.08, 0.05, 0.03
+    pB.finger_width, pB.num_finger_placements = 0.015, 6
+    opA, opB = oracle_mod.default_params(15), oracle_mod.default_params(15)
+    opB.volume_width, opB.volume_depth, opB.volume_height = 0.08, 0.05, 0.03
+    opB.finger_width, opB.num_finger_placements = 0.015, 6
+    siA, siB = synth.sample_indices(clA, 60), synth.sample_indices(clB, 60)
+    wantA = oracle_mod.detect(opA, clA["xyz"], clA["normals"], clA["cam_source"], clA["view_points"], siA, w)
+    wantB = oracle_mod.detect(opB, clB["xyz"], clB["normals"], clB["cam_source"], clB["view_points"], siB, w)
+    A, B = api.Context(pA), api.Context(pB)
+    try:
+        for c, cl in ((A, clA), (B, clB)):
+            c.set_lenet_weights(w)
+            c.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+
+        def same(got, want):
+            h, n = got
+            return n == want[1] and np.array_equal(h["valid"], want[0]["valid"]) and np.array_equal(h["score"], want[0]["score"])
+
+        assert same(A.detect(siA), wantA) and same(B.detect(siB), wantB) and wantA[1] > 20 and wantB[1] > 20
+        # A's candidate list is still on the device; B ran in between: the replay must reload A's constants
+        hA = A.search(siA)
+        hA = oracle_mod.filter_workspace(opA, hA)
+        imgA, candA = A.images(hA)
+        scoresA = A.score(imgA)
+        assert same(B.detect(siB), wantB)
+        A.replay(3)
+        _, _, _, rs = A.replay_times(len(candA))
+        assert np.array_equal(rs, scoresA)
+        # two host threads, one context each
+        bad = []
+
+        def run(c, si, want):
+            for _ in range(6):
+                if not same(c.detect(si), want):
+                    bad.append(1)
+
+        ts = [threading.Thread(target=run, args=(A, siA, wantA)), threading.Thread(target=run, args=(B, siB, wantB))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not bad
+    finally:
+        A.close()
+        B.close()
