@@ -1268,6 +1268,9 @@ static int load_img_consts(const std::vector<unsigned char> &want, hipStream_t s
   if (loaded == want) return GPD_OK;
   if (!loaded.empty()) HIP_RET(hipDeviceSynchronize());
   HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_img), want.data(), sizeof(ImgConsts), 0, hipMemcpyHostToDevice, stream));
+  // the block counts as loaded only once the copy has landed: a context with the same values skips
+  // the copy and launches on ITS stream, which is not ordered after this one
+  HIP_RET(hipStreamSynchronize(stream));
   loaded = want;
   return GPD_OK;
 }

@@ -1520,6 +1520,9 @@ static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slo
   if (loaded.size() == sizeof(hk) && std::memcmp(loaded.data(), bytes, sizeof(hk)) == 0) return GPD_OK;
   if (!loaded.empty()) HIP_RET(hipDeviceSynchronize());
   HIP_RET(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_hand), &hk, sizeof(hk), 0, hipMemcpyHostToDevice, stream));
+  // the block counts as loaded only once the copy has landed: a context with the same values skips
+  // the copy and launches on ITS stream, which is not ordered after this one
+  HIP_RET(hipStreamSynchronize(stream));
   loaded.assign(bytes, bytes + sizeof(hk));
   return GPD_OK;
 }
