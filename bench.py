@@ -2,18 +2,28 @@
 """bench.py — BASELINE.json's metric on MI355X: 15-channel grasp candidates generated +
 scored per second (grasp-image generation + LeNet), N GPUs of one node.
 
-A step = one pass of the hot path (image generation + LeNet scoring) over the candidate
-batch of one synthetic cloud; candidates, neighbourhoods and weights are already resident
-in HBM when the timed region starts.  Workload = BASELINE.json configs[1]: a single 30k-point
-synthetic cloud, its first 5000 valid candidates, 15 channels.  With N > 1 every rank owns
-its own cloud (cloud_id = rank, as config 5 shards 256 clouds over 8 GPUs): no data-path
-collective, weak scaling; torch.distributed (RCCL) is used for the barrier and the
-max-over-ranks time only.
+Default (--mode replay), the headline: a step = one pass of the hot path (image generation + LeNet
+scoring) over the candidate batch of one synthetic cloud; candidates, neighbourhoods and weights are
+already resident in HBM when the timed region starts.  Workload = BASELINE.json configs[1]: a single
+30k-point synthetic cloud, its first 5000 valid candidates, 15 channels.  With N > 1 every rank owns
+its own cloud (cloud_id = rank): no data-path collective, weak scaling; torch.distributed (RCCL) is
+used for the barrier and the max-over-ranks time only.  The same line also carries, measured after the
+timed region: `detect_end_to_end` (one gpd_hip_detect call, host buffers in and out) and
+`batch_end_to_end` (gpd_hip_detect_batch over a few clouds per rank: upload + search + filter + images +
+LeNet + records back, two clouds in flight) — the product path, whole job over all ranks.
+
+--config {2,3a,3b,4} selects the other single-GPU BASELINE configs (3a/3b: 3 / 12 channels on the same
+cloud, 4: 300k-point clutter cloud, 50000 candidates).
+
+--mode batch: BASELINE configs[4] end to end — `--clouds` synthetic 30k-point clouds (default 256), cloud i ->
+rank i mod N, every cloud uploaded, searched, imaged, scored and its candidates returned to the host
+(gpd_hip_detect_batch); a step = one pass over the rank's clouds; value = candidates of all ranks / time.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel), "kernels"
 (both stages), "cpu_baseline" (the CPU oracle on a bounded sample, all host cores).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,19 +36,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # f32 vector == f32-input MFMA peak
+LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk x 2.4 GHz = 78.6 TB/s aggregate LDS bandwidth (MI355X_MICROARCH.md)
 LENET_MFLOP = {15: 83.04, 12: 73.63, 3: 45.41, 1: 39.14}  # SURVEY.md §8d (+ the 1-channel strategy)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+KERNEL_SOURCES = ("gpd_amd/csrc/lenet.hip", "gpd_amd/csrc/images.hip", "gpd_amd/csrc/search.hip")
+
+CONFIGS = {  # BASELINE.json configs[1..3]
+    "2": dict(points=30000, candidates=5000, channels=15, clutter=False),
+    "3a": dict(points=30000, candidates=5000, channels=3, clutter=False),
+    "3b": dict(points=30000, candidates=5000, channels=12, clutter=False),
+    "4": dict(points=300000, candidates=50000, channels=15, clutter=True),
+}
+
+
+def source_hashes():
+    out = {}
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            out[rel] = hashlib.sha1(f.read()).hexdigest()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=30000)
-    ap.add_argument("--candidates", type=int, default=5000)
-    ap.add_argument("--channels", type=int, default=15)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (replay) / 2 passes over the rank's clouds (batch)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (replay) / 1 (batch)")
+    ap.add_argument("--mode", choices=("replay", "batch"), default="replay")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE config preset (default: 2)")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--candidates", type=int, default=None)
+    ap.add_argument("--channels", type=int, default=None)
+    ap.add_argument("--clutter", action="store_true")
+    ap.add_argument("--clouds", type=int, default=256, help="--mode batch: clouds of the whole job (cloud i -> rank i mod N)")
+    ap.add_argument("--batch-samples", type=int, default=2564, help="samples per cloud of the batch legs")
+    ap.add_argument("--batch-clouds", type=int, default=12, help="replay mode: clouds per rank of the batch_end_to_end leg (0 disables)")
     ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.mode == "replay" else 2
+    if args.warmup is None:
+        args.warmup = 3 if args.mode == "replay" else 1
+    preset = CONFIGS[args.config or "2"]
+    points = args.points if args.points is not None else preset["points"]
+    candidates = args.candidates if args.candidates is not None else preset["candidates"]
+    C = args.channels if args.channels is not None else preset["channels"]
+    clutter = args.clutter or preset["clutter"]
 
     # stdout carries exactly ONE line (the JSON of rank 0): everything else that libraries print to
     # fd 1 (RCCL's start-up banner, HIP warnings) goes to stderr
@@ -57,19 +100,89 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gpd_amd import api, synth
-    C = args.channels
+    from gpd_amd import dist as gdist
     real = None
     gold = os.path.join(ROOT, "tests", "golden", "lenet%d_params.npz" % C)
     if os.path.exists(gold):
         real = dict(np.load(gold))
     w = synth.lenet_weights(C, real=real)
 
-    # --- workload: one cloud per rank (seed 1234 + rank), first `candidates` valid hands
-    cloud = synth.make_cloud(1234 + rank, args.points)
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def reduce(elapsed, units):
+        if dist is None:
+            return float(elapsed), float(units)
+        t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax[0:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
+        return float(tmax[0]), float(t[1])
+
     ctx = api.Context(api.default_params(C), device=local_rank)
     ctx.set_lenet_weights(w)                       # weights copied once per device at init
+
+    def batch_leg(cloud_ids, passes, warm):
+        """gpd_hip_detect_batch over the listed clouds (seed 1234 + id), `passes` times, barrier-bracketed."""
+        clouds = [synth.make_cloud(1234 + cid, 30000) for cid in cloud_ids]
+        samples = [synth.sample_indices(cl, args.batch_samples) for cl in clouds]
+        for _ in range(warm):
+            ctx.detect_batch(clouds[: max(2, len(clouds) // 4)], samples[: max(2, len(clouds) // 4)], 0)
+        barrier()
+        t0 = time.perf_counter()
+        n_cand = 0
+        stage = np.zeros(3)
+        for _ in range(passes):
+            for hands, ns, nc, ms in ctx.detect_batch(clouds, samples, 0):
+                n_cand += nc
+                stage += ms
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        el, tot = reduce(elapsed, n_cand)
+        _, ncl = reduce(elapsed, len(clouds) * passes)
+        return dict(clouds=int(ncl), candidates=int(tot), wall_s=el, clouds_per_s=ncl / el, cand_per_s=tot / el,
+                    kernel_ms_rank0={"search": float(stage[0]), "images": float(stage[1]), "lenet": float(stage[2])},
+                    kernel_bound_cand_per_s_rank0=n_cand / (stage.sum() / 1e3) if stage.sum() > 0 else None)
+
+    if args.mode == "batch":
+        mine = gdist.clouds_of_rank(args.clouds, rank, world)
+        assert mine, "more ranks than clouds"
+        leg = batch_leg(mine, args.steps, args.warmup)
+        if rank == 0:
+            net_s = leg["kernel_ms_rank0"]["lenet"] / 1e3
+            n0 = leg["candidates"] / world
+            net_tflops = LENET_MFLOP[C] * 1e6 * n0 / net_s / 1e12 if net_s > 0 else None
+            out = {
+                "metric": "15-ch grasp candidates generated+scored/sec, end to end over a batch of clouds (configs[4])",
+                "value": leg["cand_per_s"], "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": leg["wall_s"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64 geometry / f32 LeNet / u8 images", "data": "synthetic",
+                "config": {"workload": "%d synthetic 30k-point clouds x %d samples (~%d candidates each), 15-channel, cloud i -> rank i mod %d; "
+                                       "per cloud: host buffers in, upload, grid, search, filter, images, LeNet, scored candidates out"
+                           % (args.clouds, args.batch_samples, leg["candidates"] // max(1, leg["clouds"]), world),
+                           "clouds": args.clouds, "samples_per_cloud": args.batch_samples, "channels": C,
+                           "sharding": "independent clouds, no collective"},
+                "batch_end_to_end": leg,
+                "roofline": {"kernel": "LeNet stage of the batch (conv1+conv2+ip1+ip2), rank 0", "bound": "mfma", "achieved": net_tflops,
+                             "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tflops / F32_PEAK_TFLOPS if net_tflops else None,
+                             "traffic": None},
+            }
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        ctx.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # --- replay mode.  Workload: one cloud per rank (seed 1234 + rank), first `candidates` valid hands
+    cloud = synth.make_cloud(1234 + rank, points, clutter=clutter)
     ctx.upload_cloud(cloud["xyz"], cloud["normals"], cloud["cam_source"], cloud["view_points"])
-    n_samples = min(int(args.candidates / 2.0) + 64, int(cloud["is_object"].sum()))
+    n_samples = min(int(candidates / 2.0) + 64, int(cloud["is_object"].sum()))
     si = synth.sample_indices(cloud, n_samples)
     t0 = time.perf_counter()
     hands = ctx.search(si)
@@ -81,23 +194,30 @@ def main():
     _filter_workspace(hands_f, ctx.params)
     flat = hands_f.reshape(-1)
     vidx = np.flatnonzero(flat["valid"])
-    if len(vidx) > args.candidates:
-        flat["valid"][vidx[args.candidates:]] = 0
-    _, cand = ctx.images(hands_f, download=False)   # uploads the candidate list, first pass
-    n_cand = len(cand)
-    ni = ctx.images_stats()
+    if len(vidx) > candidates:
+        flat["valid"][vidx[candidates:]] = 0
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    # end-to-end latency of the fused entry point (search + filter + images + LeNet + host hops)
+    # end-to-end latency of the fused entry point (search + filter + images + LeNet, host buffers in / out)
     ctx.detect(si)
     t0 = time.perf_counter()
     _, n_detect = ctx.detect(si)
     detect_wall = time.perf_counter() - t0
-    ctx.images(hands_f, download=False)  # restore the benchmark's candidate list
+    detect_kernel_ms = [float(x) for x in ctx.stage_ms()]
+
+    # a sample of the images for conv1's zero-skip statistics (the executed-FLOP fraction of the roofline line)
+    live_frac = None
+    if C in (12, 15):
+        sub = hands_f.copy()
+        sflat = sub.reshape(-1)
+        keep = np.flatnonzero(sflat["valid"])[::max(1, len(vidx) // 256)][:256]
+        sflat["valid"] = 0
+        sflat["valid"][keep] = 1
+        imgs, _ = ctx.images(sub, download=True)
+        live_frac = _conv1_live_fraction(imgs)
+
+    _, cand = ctx.images(hands_f, download=False)   # the benchmark's candidate list, first pass
+    n_cand = len(cand)
+    ni = ctx.images_stats()
 
     for _ in range(args.warmup):
         ctx.replay(3)
@@ -112,15 +232,12 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed, float(n_cand)], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax[0:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        total_cand = float(t[1])
-    else:
-        total_cand = float(n_cand)
+    elapsed, total_cand = reduce(elapsed, n_cand)
     assert launches == args.steps
+
+    batch = None
+    if args.batch_clouds > 0 and C == 15 and not clutter:
+        batch = batch_leg([rank + world * k for k in range(args.batch_clouds)], 1, 1)
 
     if rank == 0:
         value = total_cand * args.steps / elapsed
@@ -145,17 +262,23 @@ def main():
         for (name, fl), ms_sum in zip(kflops.items(), kernel_ms):
             k_s = ms_sum / 1e3 / args.steps
             kernels[name] = {"ms": k_s * 1e3, "algorithmic_flops": fl * n_cand,
-                             "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None}
+                             "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None,
+                             "frac_f32": fl * n_cand / k_s / 1e12 / F32_PEAK_TFLOPS if k_s > 0 else None}
         traffic = _pmc_traffic()
         dom = max(kflops, key=lambda k: kernels[k]["ms"])
         if kernels[dom]["ms"] >= img_s * 1e3 / 3.0:
             # the dominant single kernel of the step (conv1 + pool1 at 15 channels): f32 MFMA bound
+            frac = kernels[dom]["achieved_TFLOPs"] / F32_PEAK_TFLOPS
             roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
-                        "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": kernels[dom]["achieved_TFLOPs"] / F32_PEAK_TFLOPS, "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
+                        "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": frac,
+                        "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
                         "flops_per_launch": kernels[dom]["algorithmic_flops"], "launch_ms": kernels[dom]["ms"],
-                        "note": "algorithmic (dense) FLOPs / measured time; conv1 drops the (64-pixel chunk, channel) pairs whose "
-                                "input patches are all zero (exact, ~28 % on this workload), so the executed FLOP rate is lower"}
+                        "note": "frac = algorithmic (dense) FLOPs / measured time / peak.  conv1 drops the (64-pixel chunk, channel) pairs "
+                                "whose input patches are all zero (exact): frac_executed = frac x live pair fraction is the rate "
+                                "the matrix pipe actually sustains"}
+            if dom == "conv1_mfma_kernel" and live_frac is not None:
+                roofline["live_pair_fraction"] = live_frac
+                roofline["frac_executed"] = frac * live_frac
         else:
             roofline = {"kernel": "image stage (shadow_set + shadow_image + grasp_image kernels)", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}
@@ -164,15 +287,23 @@ def main():
             "value": value, "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 geometry / f32 LeNet / u8 images", "data": "synthetic",
-            "config": {"workload": "single %dk-point synthetic cloud per GPU (seed 1234+rank), first %d valid candidates, %d-channel LeNet"
-                       % (args.points // 1000, n_cand, C), "points": args.points, "candidates_per_gpu": n_cand,
+            "config": {"workload": "single %dk-point synthetic %scloud per GPU (seed 1234+rank), first %d valid candidates, %d-channel LeNet"
+                       % (points // 1000, "clutter " if clutter else "", n_cand, C), "points": points, "candidates_per_gpu": n_cand,
                        "samples": int(n_samples), "channels": C, "sharding": "one cloud per GPU, no collective"},
             "roofline": roofline, "kernels": kernels, "pmc_traffic": traffic,
             "search": {"samples": int(n_samples), "hand_sets": int(hands.shape[0]), "kernel_ms": search_ms,
                        "wall_ms_incl_download": search_wall * 1e3},
             "detect_end_to_end": {"candidates": int(n_detect), "wall_ms": detect_wall * 1e3,
-                                  "note": "gpd_hip_detect: all candidates of the sample set, host buffers in, scored hands out"},
+                                  "kernel_ms": {"search": detect_kernel_ms[0], "images": detect_kernel_ms[1], "lenet": detect_kernel_ms[2]},
+                                  "kernel_sum_over_wall": sum(detect_kernel_ms) / (detect_wall * 1e3),
+                                  "cand_per_s": n_detect / detect_wall,
+                                  "note": "gpd_hip_detect: all candidates of the sample set, host buffers in, scored hands out; "
+                                          "filter / compaction / score scatter on the device"},
         }
+        if batch is not None:
+            batch["note"] = ("gpd_hip_detect_batch, %d clouds per rank x %d samples, two clouds in flight per context: upload + grid + "
+                             "search + filter + images + LeNet + scored candidates back to the host" % (args.batch_clouds, args.batch_samples))
+            out["batch_end_to_end"] = batch
         if args.cpu_samples > 0 and args.gpus == 1:  # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = _cpu_baseline(cloud, w, C, args.cpu_samples)
         sys.stdout.flush()
@@ -181,6 +312,28 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _conv1_live_fraction(imgs):
+    """Fraction of the (64-pooled-pixel chunk, channel) pairs conv1_mfma_kernel executes: a pair is dropped when the
+    6x6 input patches of all 64 pooled pixels of the chunk are zero in that channel.  Chunks as the kernel numbers
+    them: image pairs, 2 x 784 pooled pixels, strips of 7 columns (lenet.hip: C1_STRIP)."""
+    imgs = np.asarray(imgs)
+    n, Cc = imgs.shape[0] & ~1, imgs.shape[3]
+    if n < 2:
+        return None
+    nz = imgs[:n] != 0
+    win = np.zeros((n, 28, 28, Cc), bool)
+    for dy in range(6):
+        for dx in range(6):
+            win |= nz[:, dy:dy + 56:2, dx:dx + 56:2, :]
+    order = np.array([r * 28 + c for s in range(0, 28, 7) for r in range(28) for c in range(s, s + 7)])
+    seq = win[:, order // 28, order % 28, :].reshape(n // 2, 2 * 784, Cc)   # the pair's pixels, numbered through
+    live = tot = 0
+    for s in range(0, 2 * 784, 64):
+        live += seq[:, s:s + 64].any(axis=1).sum()
+        tot += (n // 2) * Cc
+    return float(live) / float(tot)
 
 
 def _filter_workspace(hands, p):
@@ -203,15 +356,19 @@ def _filter_workspace(hands, p):
 
 
 def _pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json, produced by
-    profiles/run_profile.sh + summarize.py --traffic on the same workload).  None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
-        return {}
-    d = json.load(open(path))["kernels"]
-    out = {"source": "profiles/r01_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes; reads x2 per gfx950 note)"}
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json, produced by
+    profiles/run_profile.sh + summarize.py --traffic on the default workload).  The file carries the SHA-1 of the
+    kernel sources it was measured on: when a kernel file has changed since, the numbers are stale and dropped."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return {"note": "no PMC traffic file"}
+    d = json.load(open(TRAFFIC_FILE))
+    if d.get("source_hashes") != source_hashes():
+        return {"note": "%s was measured on other kernel sources: stale, not reported" % os.path.relpath(TRAFFIC_FILE, ROOT)}
+    d = d["kernels"]
+    out = {"source": "profiles/r02_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes; reads x2 per the gfx950 note; "
+                     "same kernel sources as this run, by SHA-1)"}
     img = [v["hbm_bytes_per_launch"] for k, v in d.items()
-           if any(s in k for s in ("grasp_image_kernel", "shadow_image_kernel<6144>", "shadow_set_kernel"))]
+           if any(s in k for s in ("grasp_image_kernel<false>", "grasp_image_kernel<0>", "shadow_image_kernel<6144>", "shadow_set_kernel"))]
     if img:
         out["image"] = float(sum(img))
     net = [v["hbm_bytes_per_launch"] for k, v in d.items() if any(s in k for s in ("conv1", "conv2", "fc1_mfma", "fc2_score"))]

@@ -35,6 +35,17 @@ class Params(C.Structure):
     ]
 
 
+class DetectJob(C.Structure):
+    """Mirror of `gpd_detect_job` (include/gpd_hip.h)."""
+    _fields_ = [
+        ("xyz", C.c_void_p), ("normals", C.c_void_p), ("cam_source", C.c_void_p), ("view_points", C.c_void_p),
+        ("sample_indices", C.c_void_p), ("hands", C.c_void_p),
+        ("num_points", C.c_int32), ("num_cams", C.c_int32), ("num_samples", C.c_int32), ("num_selected", C.c_int32),
+        ("hands_capacity", C.c_int32), ("num_sets", C.c_int32), ("num_candidates", C.c_int32), ("num_hands", C.c_int32),
+        ("status", C.c_int32), ("stage_ms", C.c_float * 3),
+    ]
+
+
 class GpdHipError(RuntimeError):
     pass
 
@@ -42,7 +53,8 @@ class GpdHipError(RuntimeError):
 EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
-           "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms"]
+           "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
+           "gpd_hip_detect_select", "gpd_hip_detect_batch"]
 
 
 def build():
@@ -70,6 +82,9 @@ def lib():
         L.gpd_hip_reevaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.gpd_hip_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.gpd_hip_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.gpd_hip_detect_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.gpd_hip_detect_batch.argtypes = [C.c_void_p, C.POINTER(DetectJob), C.c_int]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
         L.gpd_hip_estimate_normals.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
@@ -187,7 +202,42 @@ class Context:
         hands = np.empty((len(si), self.n_slots), HAND_DTYPE)  # rows [0, num_sets) are written by the call
         ns, nc = C.c_int(0), C.c_int(0)
         self._check(lib().gpd_hip_detect(self._h, _ptr(si), len(si), _ptr(hands), C.byref(ns), C.byref(nc)))
-        return hands[: ns.value].copy(), nc.value
+        return hands[: ns.value], nc.value
+
+    def detect_select(self, sample_indices, num_selected=0):
+        """detectGrasps steps 1-4 (+ selectGrasps when num_selected > 0) -> (hands[k], n_sets, n_candidates):
+        only the scored candidates (or the num_selected best, score descending) come back."""
+        si = np.ascontiguousarray(sample_indices, np.int32)
+        cap = len(si) * self.n_slots if num_selected == 0 else min(num_selected, len(si) * self.n_slots)
+        hands = np.empty(max(cap, 1), HAND_DTYPE)
+        ns, nc, nh = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(lib().gpd_hip_detect_select(self._h, _ptr(si), len(si), int(num_selected), _ptr(hands), cap,
+                                                C.byref(ns), C.byref(nc), C.byref(nh)))
+        return hands[: nh.value], ns.value, nc.value
+
+    def detect_batch(self, clouds, samples, num_selected=0):
+        """detect_grasps over independent clouds (two in flight per context).  clouds: dicts with xyz, normals,
+        cam_source, view_points; samples: one int32 index array per cloud.
+        -> list of (hands[k], n_sets, n_candidates, stage_ms[3]) in cloud order."""
+        jobs = (DetectJob * len(clouds))()
+        keep = []
+        for j, cl, si in zip(jobs, clouds, samples):
+            xyz = np.ascontiguousarray(cl["xyz"], np.float32)
+            nrm = np.ascontiguousarray(cl["normals"], np.float32)
+            P = len(xyz)
+            cam = np.ascontiguousarray(cl["cam_source"], np.int32).reshape(-1, P)
+            vp = np.ascontiguousarray(cl["view_points"], np.float64).reshape(-1, 3)
+            si = np.ascontiguousarray(si, np.int32)
+            cap = len(si) * self.n_slots if num_selected == 0 else min(num_selected, len(si) * self.n_slots)
+            hands = np.empty(max(cap, 1), HAND_DTYPE)
+            keep.append((xyz, nrm, cam, vp, si, hands))
+            j.xyz, j.normals, j.cam_source, j.view_points = _ptr(xyz), _ptr(nrm), _ptr(cam), _ptr(vp)
+            j.sample_indices, j.hands = _ptr(si), _ptr(hands)
+            j.num_points, j.num_cams, j.num_samples = P, cam.shape[0], len(si)
+            j.num_selected, j.hands_capacity = int(num_selected), cap
+        self._check(lib().gpd_hip_detect_batch(self._h, jobs, len(clouds)))
+        return [(k[5][: j.num_hands], j.num_sets, j.num_candidates, [float(x) for x in j.stage_ms])
+                for j, k in zip(jobs, keep)]
 
     def stage_ms(self):
         ms = np.zeros(3, np.float32)

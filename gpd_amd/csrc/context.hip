@@ -1,11 +1,26 @@
 // C-ABI of libgpd_hip.so (include/gpd_hip.h): context, uploads, stage launches.
+//
+// A context owns two LANES — each a HIP stream with its own cloud, search buffers, candidate plan,
+// image buffers and LeNet scratch.  Every single-cloud entry point runs on lane 0.
+// gpd_hip_detect_batch alternates the lanes: while the image + LeNet kernels of cloud i run on one
+// lane, the upload + grid + search of cloud i+1 is already enqueued on the other, so host hops and
+// the host-device copies of one cloud hide behind the kernels of its neighbour.
+//
+// A fused detect is three steps per cloud:
+//   begin   enqueue sample upload, neighbourhood / centre / hand_eval kernels (incl. the workspace filter)
+//           and plan_kernel (candidate list, shadow LCG offsets) + the 48-byte summary copy — no waiting
+//   middle  wait for the summary (the only mid-pipeline wait: the launch sizes), enqueue image kernels,
+//           LeNet, the record gather (all sets / candidates / the num_selected best) and ONE device-to-host
+//           copy into pinned memory
+//   end     wait, hand the records to the caller
+// Between the stages nothing crosses PCIe but that summary.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <vector>
-
-#include <chrono>
-#include <cmath>
 
 #include "gpd_internal.h"
 
@@ -33,36 +48,269 @@ using namespace gpd;
     }                                                                                   \
   } while (0)
 
-struct gpd_hip_ctx {
-  int device = 0;
-  gpd_params params;
+namespace {
+
+constexpr int kLanes = 2;
+
+struct HostFlags {  // pinned; written by the last copies of a job
+  int32_t status;   // capacity flags of the image kernels
+  int32_t tie;      // select_topk: equal scores among the winners or at the cut
+  int32_t pad_[2];
+};
+
+struct Lane {
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;  // EXPERIMENT
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // search start / end, images end, LeNet end, images start
   float stage_ms[3] = {0.f, 0.f, 0.f};
-  LeNetWeights lenet;
-  LeNetScratch lenet_scratch;
   Cloud cloud;
   SearchState search;
+  Plan plan;
   ImageState images;
+  LeNetScratch lenet_scratch;
+  float *d_scores = nullptr;
+  int d_scores_cap = 0;
+  gpd_hand *d_out = nullptr;  // hand records gathered for the caller
+  size_t d_out_cap = 0;       // records
+  char *h_out = nullptr;      // pinned: records, then scores
+  size_t h_out_bytes = 0;
+  HostFlags *h_flags = nullptr;  // pinned
+  int32_t *d_sel = nullptr;      // [SEL capacity] candidate ordinals of the selection, then the tie flag
+  int d_sel_cap = 0;
   // staging for gpd_hip_score with host images
   uint8_t *d_img_in = nullptr;      // HWC images handed to gpd_hip_score
   uint8_t *d_img_planar = nullptr;  // their planar copy
   size_t d_img_in_bytes = 0;
-  float *d_scores = nullptr;
-  int d_scores_cap = 0;
+};
+
+// one fused detect in flight on a lane
+struct Job {
+  const int32_t *sample_idx = nullptr;
+  const double *sample_xyz = nullptr;
+  int S = 0;
+  int mode = 0;          // 0: all hand sets [num_sets][slots]; 1: candidates only (num_selected > 0: the best ones)
+  int num_selected = 0;
+  gpd_hand *hands = nullptr;
+  long long capacity = 0;  // records `hands` can take
+  int num_sets = 0, num_candidates = 0, num_hands = 0;
+  bool live = false;       // device work enqueued, end() still has to collect it
+  int out_records = 0;
+};
+
+}  // namespace
+
+struct gpd_hip_ctx {
+  int device = 0;
+  gpd_params params;
+  LeNetWeights lenet;
+  Lane lane[kLanes];
   std::vector<hipEvent_t> replay_events;  // 6 per gpd_hip_replay call: start, images done, conv1, conv2, fc1, end
   float replay_kernel_ms[4] = {0, 0, 0, 0};  // conv1, conv2, fc1, fc2 sums of the replays of the last gpd_hip_replay_times
   size_t replay_used = 0;
 };
 
-static int reserve_scores(gpd_hip_ctx *ctx, int n) {
-  if (n <= ctx->d_scores_cap) return GPD_OK;
-  if (ctx->d_scores) (void)hipFree(ctx->d_scores);
-  ctx->d_scores = nullptr;
-  ctx->d_scores_cap = 0;
-  HIP_TRY(hipMalloc(&ctx->d_scores, (size_t)n * sizeof(float)));
-  ctx->d_scores_cap = n;
+static int lane_init(Lane &L) {
+  if (L.stream) return GPD_OK;
+  HIP_TRY(hipStreamCreate(&L.stream));
+  for (auto &e : L.ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&L.h_flags), sizeof(HostFlags), 0));
+  std::memset(L.h_flags, 0, sizeof(HostFlags));
+  return GPD_OK;
+}
+
+static void lane_free(Lane &L) {
+  if (L.stream) (void)hipStreamSynchronize(L.stream);
+  lenet_scratch_free(L.lenet_scratch);
+  cloud_free(L.cloud);
+  search_free(L.search);
+  plan_free(L.plan);
+  images_free(L.images);
+  void *dev[] = {L.d_scores, L.d_out, L.d_sel, L.d_img_in, L.d_img_planar};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  if (L.h_out) (void)hipHostFree(L.h_out);
+  if (L.h_flags) (void)hipHostFree(L.h_flags);
+  for (auto &e : L.ev)
+    if (e) (void)hipEventDestroy(e);
+  if (L.stream) (void)hipStreamDestroy(L.stream);
+  L = Lane();
+}
+
+static int reserve_scores(Lane &L, int n) {
+  if (n <= L.d_scores_cap) return GPD_OK;
+  if (L.d_scores) (void)hipFree(L.d_scores);
+  L.d_scores = nullptr;
+  L.d_scores_cap = 0;
+  const int cap = n + n / 8;
+  HIP_TRY(hipMalloc(&L.d_scores, (size_t)cap * sizeof(float)));
+  L.d_scores_cap = cap;
+  return GPD_OK;
+}
+
+static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
+  if (records > L.d_out_cap) {
+    if (L.d_out) (void)hipFree(L.d_out);
+    L.d_out = nullptr;
+    L.d_out_cap = 0;
+    const size_t cap = records + records / 8;
+    HIP_TRY(hipMalloc(&L.d_out, cap * sizeof(gpd_hand)));
+    L.d_out_cap = cap;
+  }
+  const size_t bytes = L.d_out_cap * sizeof(gpd_hand) + extra_bytes;
+  if (bytes > L.h_out_bytes) {
+    if (L.h_out) (void)hipHostFree(L.h_out);
+    L.h_out = nullptr;
+    L.h_out_bytes = 0;
+    const size_t cap = bytes + bytes / 8;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&L.h_out), cap, 0));
+    L.h_out_bytes = cap;
+  }
+  return GPD_OK;
+}
+
+// ---- the three steps of a fused detect -------------------------------------------------------
+static int job_begin(gpd_hip_ctx *ctx, Lane &L, Job &J) {
+  J.live = false;
+  J.num_sets = J.num_candidates = J.num_hands = 0;
+  if (J.S == 0) return GPD_OK;
+  HIP_TRY(hipEventRecord(L.ev[0], L.stream));
+  int rc = search_run(ctx->params, L.cloud, L.search, J.sample_idx, J.sample_xyz, J.S, L.stream, /*sync_counts=*/false);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(L.ev[1], L.stream));
+  rc = plan_build(ctx->params, L.cloud, L.search, L.plan, L.stream);
+  if (rc) return rc;
+  J.live = true;
+  return GPD_OK;
+}
+
+static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
+  if (!J.live) return GPD_OK;
+  J.live = false;  // set again once everything is enqueued
+  HIP_TRY(hipStreamSynchronize(L.stream));
+  if (L.plan.h_summary->worst_found > L.search.nn_cap) {
+    // a neighbourhood overflowed the list capacity of the search kernel: once more with the large lists
+    const int cap = search_next_capacity(L.search, L.plan.h_summary->worst_found);
+    if (!cap) {
+      set_error("search: a neighbourhood holds %d points, more than the LDS list capacity 16384", L.plan.h_summary->worst_found);
+      return GPD_ERR_CAPACITY;
+    }
+    int rc = search_force_capacity(L.search, cap);
+    if (rc) return rc;
+    rc = job_begin(ctx, L, J);
+    if (rc) return rc;
+    J.live = false;
+    HIP_TRY(hipStreamSynchronize(L.stream));
+  }
+  const PlanSummary sm = *L.plan.h_summary;
+  const int slots = ctx->params.num_hand_axes * ctx->params.num_orientations;
+  J.num_sets = sm.num_sets;
+  J.num_candidates = sm.num_candidates;
+  const int n = sm.num_candidates;
+  int k = 0;
+  if (J.mode == 0)
+    J.out_records = sm.num_sets * slots;
+  else if (J.num_selected > 0)
+    J.out_records = k = std::min(J.num_selected, n);
+  else
+    J.out_records = n;
+  J.num_hands = J.out_records;
+  if ((long long)J.out_records > J.capacity) {
+    set_error("detect: %d hand records to return, the caller's buffer holds %lld", J.out_records, J.capacity);
+    return GPD_ERR_INVALID;
+  }
+  (void)hipEventElapsedTime(&L.stage_ms[0], L.ev[0], L.ev[1]);  // here: the next job on this lane records them again
+  HIP_TRY(hipEventRecord(L.ev[4], L.stream));
+  int rc = images_run(ctx->params, L.cloud, L.search, L.plan, L.images, L.stream);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(L.ev[2], L.stream));
+  if (n > 0) {
+    rc = reserve_scores(L, n);
+    if (rc) return rc;
+    HIP_TRY(lenet_forward(ctx->lenet, L.lenet_scratch, L.images.d_images, n, L.d_scores, L.stream));
+  }
+  HIP_TRY(hipEventRecord(L.ev[3], L.stream));
+  rc = reserve_out(L, (size_t)J.out_records, k ? (size_t)n * sizeof(float) : 0);
+  if (rc) return rc;
+  L.h_flags->tie = 0;
+  if (J.mode == 0) {
+    rc = plan_emit_hands(ctx->params, L.search, L.plan, n > 0 ? L.d_scores : nullptr, L.d_out, false, L.stream);
+  } else if (k > 0) {
+    if (k + 1 > L.d_sel_cap) {
+      if (L.d_sel) (void)hipFree(L.d_sel);
+      L.d_sel = nullptr;
+      L.d_sel_cap = 0;
+      HIP_TRY(hipMalloc(&L.d_sel, (size_t)(k + 1) * sizeof(int32_t)));
+      L.d_sel_cap = k + 1;
+    }
+    rc = select_topk(L.d_scores, n, k, L.d_sel, L.d_sel + k, L.stream);
+    if (rc) return rc;
+    rc = gather_hands(ctx->params, L.search, L.plan, L.d_scores, L.d_sel, k, L.d_out, L.stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(&L.h_flags->tie, L.d_sel + k, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+    // the scores (4 bytes per candidate) ride along: equal scores are settled with std::partial_sort on the host
+    HIP_TRY(hipMemcpyAsync(L.h_out + L.d_out_cap * sizeof(gpd_hand), L.d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost,
+                           L.stream));
+  } else {
+    rc = plan_emit_hands(ctx->params, L.search, L.plan, L.d_scores, L.d_out, true, L.stream);
+  }
+  if (rc) return rc;
+  if (J.out_records > 0)
+    HIP_TRY(hipMemcpyAsync(L.h_out, L.d_out, (size_t)J.out_records * sizeof(gpd_hand), hipMemcpyDeviceToHost, L.stream));
+  HIP_TRY(hipMemcpyAsync(&L.h_flags->status, L.images.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+  J.live = true;
+  return GPD_OK;
+}
+
+static bool score_greater(const std::pair<float, int32_t> &a, const std::pair<float, int32_t> &b) { return a.first > b.first; }
+
+static int job_end(gpd_hip_ctx *ctx, Lane &L, Job &J) {
+  if (!J.live) return GPD_OK;
+  J.live = false;
+  HIP_TRY(hipStreamSynchronize(L.stream));
+  (void)hipEventElapsedTime(&L.stage_ms[1], L.ev[4], L.ev[2]);
+  (void)hipEventElapsedTime(&L.stage_ms[2], L.ev[2], L.ev[3]);
+  if (L.h_flags->status) {
+    images_status_text(L.h_flags->status, g_err, sizeof(g_err));
+    return GPD_ERR_CAPACITY;
+  }
+  const int n = J.num_candidates;
+  if (J.mode == 1 && J.num_selected > 0 && J.out_records > 0 && L.h_flags->tie) {
+    // equal scores among the winners: the reference's result is whatever std::partial_sort leaves
+    // (grasp_detector.cpp:409), which depends on the history of its heap — so run exactly that, on
+    // (score, candidate) pairs in candidate order, and gather the winners again
+    const float *sc = reinterpret_cast<const float *>(L.h_out + L.d_out_cap * sizeof(gpd_hand));
+    std::vector<std::pair<float, int32_t>> v((size_t)n);
+    for (int i = 0; i < n; i++) v[i] = {sc[i], i};
+    const int k = J.out_records;
+    std::partial_sort(v.begin(), v.begin() + k, v.end(), score_greater);
+    std::vector<int32_t> sel((size_t)k);
+    for (int i = 0; i < k; i++) sel[i] = v[i].second;
+    HIP_TRY(hipMemcpyAsync(L.d_sel, sel.data(), (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, L.stream));
+    int rc = gather_hands(ctx->params, L.search, L.plan, L.d_scores, L.d_sel, k, L.d_out, L.stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(L.h_out, L.d_out, (size_t)k * sizeof(gpd_hand), hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
+  }
+  if (J.out_records > 0) std::memcpy(J.hands, L.h_out, (size_t)J.out_records * sizeof(gpd_hand));
+  return GPD_OK;
+}
+
+static int check_samples(gpd_hip_ctx *ctx, const Lane &L, const char *who, const int32_t *sample_indices, const double *sample_xyz,
+                         int num_samples, int num_points) {
+  (void)ctx;
+  (void)L;
+  if (sample_indices) {
+    for (int i = 0; i < num_samples; i++)
+      if (sample_indices[i] < 0 || sample_indices[i] >= num_points) {
+        set_error("%s: sample index %d out of range", who, sample_indices[i]);
+        return GPD_ERR_INVALID;
+      }
+  } else {
+    for (int i = 0; i < 3 * num_samples; i++)
+      if (!std::isfinite(sample_xyz[i])) {
+        set_error("%s: sample %d is not finite", who, i / 3);
+        return GPD_ERR_INVALID;
+      }
+  }
   return GPD_OK;
 }
 
@@ -105,16 +353,55 @@ int gpd_hip_create(int device, const gpd_params *params, gpd_hip_ctx **out) {
     set_error("gpd_hip_create: null argument");
     return GPD_ERR_INVALID;
   }
+  *out = nullptr;
   const int C = params->image_num_channels;
   if (params->image_size != kImg || (C != 1 && C != 3 && C != 12 && C != 15)) {
     set_error("gpd_hip_create: image_size must be 60 and image_num_channels one of 1/3/12/15");
     return GPD_ERR_INVALID;
   }
   const int slots = params->num_hand_axes * params->num_orientations;
-  if (params->num_hand_axes < 1 || params->num_hand_axes > 3 || slots < 1 || slots > GPD_MAX_SLOTS ||
+  if (params->num_hand_axes < 1 || params->num_hand_axes > 3 || params->num_orientations < 1 || slots < 1 || slots > GPD_MAX_SLOTS ||
       params->num_finger_placements < 1 || params->num_finger_placements > 16) {
     set_error("gpd_hip_create: unsupported num_hand_axes/num_orientations/num_finger_placements");
     return GPD_ERR_INVALID;
+  }
+  for (int a = 0; a < params->num_hand_axes; a++)
+    if (params->hand_axes[a] < 0 || params->hand_axes[a] > 2) {  // index into the unit axes (hand_set.cpp:52-53)
+      set_error("gpd_hip_create: hand_axes[%d] = %d is not one of 0, 1, 2", a, params->hand_axes[a]);
+      return GPD_ERR_INVALID;
+    }
+  {
+    // lengths that end up as divisors, box extents and radii
+    const double pos[] = {params->finger_width,  params->hand_outer_diameter, params->hand_depth,       params->hand_height,
+                          params->init_bite,     params->volume_width,        params->volume_depth,     params->volume_height,
+                          params->nn_radius_frames};
+    static const char *names[] = {"finger_width", "hand_outer_diameter", "hand_depth",   "hand_height",     "init_bite",
+                                  "volume_width", "volume_depth",        "volume_height", "nn_radius_frames"};
+    for (size_t i = 0; i < sizeof(pos) / sizeof(pos[0]); i++)
+      if (!(pos[i] > 0.0) || !std::isfinite(pos[i])) {
+        set_error("gpd_hip_create: %s must be positive and finite", names[i]);
+        return GPD_ERR_INVALID;
+      }
+    const double fin[] = {params->friction_coeff,      params->min_aperture,        params->max_aperture,
+                          params->workspace_grasps[0], params->workspace_grasps[1], params->workspace_grasps[2],
+                          params->workspace_grasps[3], params->workspace_grasps[4], params->workspace_grasps[5]};
+    for (double v : fin)
+      if (std::isnan(v)) {
+        set_error("gpd_hip_create: NaN in friction_coeff / apertures / workspace_grasps");
+        return GPD_ERR_INVALID;
+      }
+    if (!(params->hand_outer_diameter > params->finger_width)) {
+      set_error("gpd_hip_create: hand_outer_diameter must exceed finger_width");
+      return GPD_ERR_INVALID;
+    }
+    // deepenHand's steps (finger_hand.cpp:116-121) are evaluated all at once from a 32-entry table
+    int steps = 0;
+    for (double d = params->init_bite + 0.005; d <= params->hand_depth && steps <= 32; d += 0.005) steps++;
+    if (params->deepen_hand && steps > 32) {
+      set_error("gpd_hip_create: hand_depth %.3f needs more than 32 deepening steps of 5 mm from init_bite %.3f", params->hand_depth,
+                params->init_bite);
+      return GPD_ERR_CAPACITY;
+    }
   }
   int count = 0;
   HIP_TRY(hipGetDeviceCount(&count));
@@ -126,8 +413,11 @@ int gpd_hip_create(int device, const gpd_params *params, gpd_hip_ctx **out) {
   gpd_hip_ctx *ctx = new gpd_hip_ctx();
   ctx->device = device;
   ctx->params = *params;
-  HIP_TRY(hipStreamCreate(&ctx->stream));
-  for (auto &e : ctx->ev) HIP_TRY(hipEventCreate(&e));
+  const int rc = lane_init(ctx->lane[0]);
+  if (rc) {
+    gpd_hip_destroy(ctx);
+    return rc;
+  }
   *out = ctx;
   return GPD_OK;
 }
@@ -135,22 +425,12 @@ int gpd_hip_create(int device, const gpd_params *params, gpd_hip_ctx **out) {
 void gpd_hip_destroy(gpd_hip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &L : ctx->lane) lane_free(L);
   float **ws[] = {&ctx->lenet.c1w, &ctx->lenet.c1b, &ctx->lenet.c2w, &ctx->lenet.c2b,
                   &ctx->lenet.f1w, &ctx->lenet.f1b, &ctx->lenet.f2w, &ctx->lenet.f2b, &ctx->lenet.c1wp, &ctx->lenet.c2wt};
   for (float **p : ws)
     if (*p) (void)hipFree(*p);
-  lenet_scratch_free(ctx->lenet_scratch);
-  cloud_free(ctx->cloud);
-  search_free(ctx->search);
-  images_free(ctx->images);
-  if (ctx->d_img_in) (void)hipFree(ctx->d_img_in);
-  if (ctx->d_img_planar) (void)hipFree(ctx->d_img_planar);
-  if (ctx->d_scores) (void)hipFree(ctx->d_scores);
-  for (auto &e : ctx->ev)
-    if (e) (void)hipEventDestroy(e);
   for (auto &e : ctx->replay_events) (void)hipEventDestroy(e);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
@@ -181,6 +461,8 @@ int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1
       set_error("gpd_hip_set_lenet_weights: conv1 weight %zu is not finite", i);
       return GPD_ERR_INVALID;
     }
+  for (auto &L : ctx->lane)
+    if (L.stream) HIP_TRY(hipStreamSynchronize(L.stream));  // no kernel still reads the old weights
   for (auto &it : items) {
     if (*it.dst) (void)hipFree(*it.dst);
     *it.dst = nullptr;
@@ -223,37 +505,38 @@ int gpd_hip_score(gpd_hip_ctx *ctx, const uint8_t *images, int n, float *scores)
   }
   if (n == 0) return GPD_OK;
   HIP_TRY(hipSetDevice(ctx->device));
+  Lane &L = ctx->lane[0];
   const size_t bytes = (size_t)n * kPix * ctx->lenet.channels;
   const uint8_t *d_img = nullptr;
   if (images) {
-    if (bytes > ctx->d_img_in_bytes) {
-      if (ctx->d_img_in) (void)hipFree(ctx->d_img_in);
-      if (ctx->d_img_planar) (void)hipFree(ctx->d_img_planar);
-      ctx->d_img_in = nullptr;
-      ctx->d_img_planar = nullptr;
-      ctx->d_img_in_bytes = 0;
-      HIP_TRY(hipMalloc(&ctx->d_img_in, bytes));
-      HIP_TRY(hipMalloc(&ctx->d_img_planar, bytes));
-      ctx->d_img_in_bytes = bytes;
+    if (bytes > L.d_img_in_bytes) {
+      if (L.d_img_in) (void)hipFree(L.d_img_in);
+      if (L.d_img_planar) (void)hipFree(L.d_img_planar);
+      L.d_img_in = nullptr;
+      L.d_img_planar = nullptr;
+      L.d_img_in_bytes = 0;
+      HIP_TRY(hipMalloc(&L.d_img_in, bytes));
+      HIP_TRY(hipMalloc(&L.d_img_planar, bytes));
+      L.d_img_in_bytes = bytes;
     }
-    HIP_TRY(hipMemcpyAsync(ctx->d_img_in, images, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hwc_to_planar(ctx->d_img_in, ctx->d_img_planar, n, ctx->lenet.channels, ctx->stream));
-    d_img = ctx->d_img_planar;
+    HIP_TRY(hipMemcpyAsync(L.d_img_in, images, bytes, hipMemcpyHostToDevice, L.stream));
+    HIP_TRY(hwc_to_planar(L.d_img_in, L.d_img_planar, n, ctx->lenet.channels, L.stream));
+    d_img = L.d_img_planar;
   } else {
-    if (n != ctx->images.num_candidates || !ctx->images.d_images) {
-      set_error("gpd_hip_score: no device images for n=%d (gpd_hip_images produced %d)", n, ctx->images.num_candidates);
+    if (n != L.images.num_candidates || !L.images.d_images) {
+      set_error("gpd_hip_score: no device images for n=%d (gpd_hip_images produced %d)", n, L.images.num_candidates);
       return GPD_ERR_STATE;
     }
-    d_img = ctx->images.d_images;
+    d_img = L.images.d_images;
   }
-  int rc = reserve_scores(ctx, n);
+  int rc = reserve_scores(L, n);
   if (rc) return rc;
-  HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-  HIP_TRY(lenet_forward(ctx->lenet, ctx->lenet_scratch, d_img, n, ctx->d_scores, ctx->stream));
-  HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-  HIP_TRY(hipMemcpyAsync(scores, ctx->d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipEventElapsedTime(&ctx->stage_ms[2], ctx->ev[2], ctx->ev[3]));
+  HIP_TRY(hipEventRecord(L.ev[2], L.stream));
+  HIP_TRY(lenet_forward(ctx->lenet, L.lenet_scratch, d_img, n, L.d_scores, L.stream));
+  HIP_TRY(hipEventRecord(L.ev[3], L.stream));
+  HIP_TRY(hipMemcpyAsync(scores, L.d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, L.stream));
+  HIP_TRY(hipStreamSynchronize(L.stream));
+  HIP_TRY(hipEventElapsedTime(&L.stage_ms[2], L.ev[2], L.ev[3]));
   return GPD_OK;
 }
 
@@ -264,8 +547,8 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
     return GPD_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(cloud_upload(ctx->cloud, xyz, normals, num_points, cam_source, num_cams, view_points, ctx->stream));
-  return GPD_OK;
+  Lane &L = ctx->lane[0];
+  return cloud_upload(L.cloud, xyz, normals, num_points, cam_source, num_cams, view_points, L.stream, /*sync=*/true);
 }
 
 int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals) {
@@ -273,12 +556,13 @@ int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals) {
     set_error("gpd_hip_estimate_normals: bad argument");
     return GPD_ERR_INVALID;
   }
-  if (!ctx->cloud.num_points) {
+  Lane &L = ctx->lane[0];
+  if (!L.cloud.num_points) {
     set_error("gpd_hip_estimate_normals: no cloud uploaded");
     return GPD_ERR_STATE;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  return normals_run(ctx->cloud, radius, normals, ctx->stream);
+  return normals_run(L.cloud, radius, normals, L.stream);
 }
 
 // samples by index (sample_xyz == nullptr) or by coordinates (sample_indices == nullptr)
@@ -288,33 +572,23 @@ static int search_any(gpd_hip_ctx *ctx, const char *who, const int32_t *sample_i
     set_error("%s: bad argument", who);
     return GPD_ERR_INVALID;
   }
-  if (!ctx->cloud.num_points) {
+  Lane &L = ctx->lane[0];
+  if (!L.cloud.num_points) {
     set_error("%s: no cloud uploaded", who);
     return GPD_ERR_STATE;
   }
   *num_sets = 0;
   if (num_samples == 0) return GPD_OK;
-  if (sample_indices) {
-    for (int i = 0; i < num_samples; i++)
-      if (sample_indices[i] < 0 || sample_indices[i] >= ctx->cloud.num_points) {
-        set_error("%s: sample index %d out of range", who, sample_indices[i]);
-        return GPD_ERR_INVALID;
-      }
-  } else {
-    for (int i = 0; i < 3 * num_samples; i++)
-      if (!std::isfinite(sample_xyz[i])) {
-        set_error("%s: sample %d is not finite", who, i / 3);
-        return GPD_ERR_INVALID;
-      }
-  }
+  int rc = check_samples(ctx, L, who, sample_indices, sample_xyz, num_samples, L.cloud.num_points);
+  if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-  int rc = search_run(ctx->params, ctx->cloud, ctx->search, sample_indices, sample_xyz, num_samples, ctx->stream);
+  HIP_TRY(hipEventRecord(L.ev[0], L.stream));
+  rc = search_run(ctx->params, L.cloud, L.search, sample_indices, sample_xyz, num_samples, L.stream);
   if (rc) return rc;
-  HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-  rc = search_download(ctx->params, ctx->search, hands, num_sets, ctx->stream);
+  HIP_TRY(hipEventRecord(L.ev[1], L.stream));
+  rc = search_download(ctx->params, L.search, hands, num_sets, L.stream);
   if (rc) return rc;
-  HIP_TRY(hipEventElapsedTime(&ctx->stage_ms[0], ctx->ev[0], ctx->ev[1]));
+  HIP_TRY(hipEventElapsedTime(&L.stage_ms[0], L.ev[0], L.ev[1]));
   return GPD_OK;
 }
 
@@ -339,7 +613,8 @@ int gpd_hip_reevaluate(gpd_hip_ctx *ctx, gpd_hand *hands, int num_hands, int32_t
     set_error("gpd_hip_reevaluate: bad argument");
     return GPD_ERR_INVALID;
   }
-  if (!ctx->cloud.num_points) {
+  Lane &L = ctx->lane[0];
+  if (!L.cloud.num_points) {
     set_error("gpd_hip_reevaluate: no cloud uploaded");
     return GPD_ERR_STATE;
   }
@@ -351,7 +626,8 @@ int gpd_hip_reevaluate(gpd_hip_ctx *ctx, gpd_hand *hands, int num_hands, int32_t
         return GPD_ERR_INVALID;
       }
   HIP_TRY(hipSetDevice(ctx->device));
-  return reevaluate_run(ctx->params, ctx->cloud, ctx->search, hands, num_hands, labels, ctx->stream);
+  L.images.num_candidates = 0;  // the search buffers the resident candidate list points into are reused
+  return reevaluate_run(ctx->params, L.cloud, L.search, hands, num_hands, labels, L.stream);
 }
 
 int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets, uint8_t *images, int32_t *cand_index,
@@ -360,65 +636,114 @@ int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets, uint8_
     set_error("gpd_hip_images: bad argument");
     return GPD_ERR_INVALID;
   }
-  if (!ctx->cloud.num_points) {
+  Lane &L = ctx->lane[0];
+  if (!L.cloud.num_points) {
     set_error("gpd_hip_images: no cloud uploaded");
     return GPD_ERR_STATE;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-  int rc = images_run(ctx->params, ctx->cloud, ctx->search, ctx->images, hands, num_sets, cand_index, ctx->stream);
-  if (rc) return rc;
-  HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-  *num_candidates = ctx->images.num_candidates;
-  if (images && ctx->images.num_candidates > 0) {
-    // the caller wants cv::Mat-layout pixels: planar -> HWC on the device, then one copy
-    const size_t bytes = (size_t)ctx->images.capacity * kPix * ctx->params.image_num_channels;
-    if (!ctx->images.d_images_hwc) HIP_TRY(hipMalloc(&ctx->images.d_images_hwc, bytes));
-    HIP_TRY(planar_to_hwc(ctx->images.d_images, ctx->images.d_images_hwc, ctx->images.num_candidates,
-                          ctx->params.image_num_channels, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(images, ctx->images.d_images_hwc,
-                           (size_t)ctx->images.num_candidates * kPix * ctx->params.image_num_channels, hipMemcpyDeviceToHost,
-                           ctx->stream));
+  SearchState &s = L.search;
+  const int slots = ctx->params.num_hand_axes * ctx->params.num_orientations;
+  *num_candidates = 0;
+  if (s.cloud_generation != L.cloud.generation || s.num_samples == 0) {
+    set_error("images: hands must come from gpd_hip_search / gpd_hip_detect on this context and cloud");
+    return GPD_ERR_STATE;
   }
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipEventElapsedTime(&ctx->stage_ms[1], ctx->ev[0], ctx->ev[1]));
+  if (num_sets > s.num_samples) {
+    set_error("images: %d sets passed, the search had %d samples", num_sets, s.num_samples);
+    return GPD_ERR_INVALID;
+  }
+  // the caller's validity flags (the host filters between the stages clear them: grasp_detector.cpp:238-255)
+  // replace the ones the search left on the device; everything else about the hands is already there.  The
+  // sets' samples travel along: plan_kernel checks them against the search's (a moved hand set is refused).
+  std::vector<uint8_t> fv((size_t)num_sets * slots + 1, 0);
+  std::vector<double> smp((size_t)num_sets * 3 + 1, 0.0);
+  for (int si = 0; si < num_sets; si++) {
+    for (int j = 0; j < slots; j++) fv[(size_t)si * slots + j] = hands[(size_t)si * slots + j].valid ? 1 : 0;
+    for (int r = 0; r < 3; r++) smp[3 * (size_t)si + r] = hands[(size_t)si * slots].sample[r];
+  }
+  HIP_TRY(hipEventRecord(L.ev[0], L.stream));
+  int rc = plan_build(ctx->params, L.cloud, s, L.plan, L.stream, fv.data(), smp.data(), num_sets);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(L.stream));  // fv / smp are pageable: their copies have left them by now as well
+  if (L.plan.h_summary->mismatch_set >= 0) {
+    set_error("images: set %d does not match the last search (sample moved, or more sets than the search produced)",
+              L.plan.h_summary->mismatch_set);
+    return GPD_ERR_STATE;
+  }
+  rc = images_run(ctx->params, L.cloud, s, L.plan, L.images, L.stream);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(L.ev[1], L.stream));
+  const int n = L.images.num_candidates;
+  *num_candidates = n;
+  if (cand_index && n > 0)
+    HIP_TRY(hipMemcpyAsync(cand_index, L.plan.d_cand_out, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+  if (images && n > 0) {
+    // the caller wants cv::Mat-layout pixels: planar -> HWC on the device, then one copy
+    const size_t bytes = (size_t)L.images.capacity * kPix * ctx->params.image_num_channels;
+    if (!L.images.d_images_hwc) HIP_TRY(hipMalloc(&L.images.d_images_hwc, bytes));
+    HIP_TRY(planar_to_hwc(L.images.d_images, L.images.d_images_hwc, n, ctx->params.image_num_channels, L.stream));
+    HIP_TRY(hipMemcpyAsync(images, L.images.d_images_hwc, (size_t)n * kPix * ctx->params.image_num_channels, hipMemcpyDeviceToHost,
+                           L.stream));
+  }
+  HIP_TRY(hipMemcpyAsync(&L.h_flags->status, L.images.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+  HIP_TRY(hipStreamSynchronize(L.stream));
+  HIP_TRY(hipEventElapsedTime(&L.stage_ms[1], L.ev[0], L.ev[1]));
+  if (L.h_flags->status) {
+    images_status_text(L.h_flags->status, g_err, sizeof(g_err));
+    return GPD_ERR_CAPACITY;
+  }
   return GPD_OK;
 }
 
-static int detect_any(gpd_hip_ctx *ctx, const int32_t *sample_indices, const double *sample_xyz, int num_samples, gpd_hand *hands,
-                      int *num_sets, int *num_candidates) {
-  if (!ctx || !hands || !num_sets || !num_candidates || (!sample_indices && !sample_xyz)) {
-    set_error("gpd_hip_detect: bad argument");
+static int detect_any(gpd_hip_ctx *ctx, const char *who, const int32_t *sample_indices, const double *sample_xyz, int num_samples,
+                      int mode, int num_selected, gpd_hand *hands, long long capacity, int *num_sets, int *num_candidates,
+                      int *num_hands) {
+  if (!ctx || !hands || !num_sets || !num_candidates || (!sample_indices && !sample_xyz) || num_samples < 0 || num_selected < 0) {
+    set_error("%s: bad argument", who);
     return GPD_ERR_INVALID;
   }
   if (!ctx->lenet.channels) {
-    set_error("gpd_hip_detect: LeNet weights not set");
+    set_error("%s: LeNet weights not set", who);
     return GPD_ERR_STATE;
   }
+  Lane &L = ctx->lane[0];
+  if (!L.cloud.num_points) {
+    set_error("%s: no cloud uploaded", who);
+    return GPD_ERR_STATE;
+  }
+  *num_sets = 0;
   *num_candidates = 0;
-  // GPD_DETECT_TIMING=1: wall time of the stages incl. their host hops, to stderr
+  if (num_hands) *num_hands = 0;
+  int rc = check_samples(ctx, L, who, sample_indices, sample_xyz, num_samples, L.cloud.num_points);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  // GPD_DETECT_TIMING=1: wall time of the three steps, to stderr
   const bool timing = getenv("GPD_DETECT_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  int rc = search_any(ctx, "gpd_hip_detect", sample_indices, sample_xyz, num_samples, hands, num_sets);
+  Job J;
+  J.sample_idx = sample_indices;
+  J.sample_xyz = sample_xyz;
+  J.S = num_samples;
+  J.mode = mode;
+  J.num_selected = num_selected;
+  J.hands = hands;
+  J.capacity = capacity;
+  rc = job_begin(ctx, L, J);
   if (rc) return rc;
-  if (*num_sets == 0) return GPD_OK;
   const double t1 = now();
-  filter_workspace_host(ctx->params, hands, *num_sets);
+  rc = job_middle(ctx, L, J);
+  if (rc) return rc;
   const double t2 = now();
-  std::vector<int32_t> cand((size_t)(*num_sets) * ctx->params.num_hand_axes * ctx->params.num_orientations);
-  rc = gpd_hip_images(ctx, hands, *num_sets, nullptr, cand.data(), num_candidates);
+  rc = job_end(ctx, L, J);
   if (rc) return rc;
-  if (*num_candidates == 0) return GPD_OK;
-  const double t3 = now();
-  std::vector<float> scores(*num_candidates);
-  rc = gpd_hip_score(ctx, nullptr, *num_candidates, scores.data());
-  if (rc) return rc;
-  const double t4 = now();
-  for (int i = 0; i < *num_candidates; i++) hands[cand[i]].score = scores[i];
+  *num_sets = J.num_sets;
+  *num_candidates = J.num_candidates;
+  if (num_hands) *num_hands = J.num_hands;
   if (timing)
-    fprintf(stderr, "[detect-timing] search %.2f ms (kernels %.2f)  filter %.2f  images %.2f (kernels %.2f)  score %.2f (kernels %.2f)  scatter %.2f\n",
-            t1 - t0, ctx->stage_ms[0], t2 - t1, t3 - t2, ctx->stage_ms[1], t4 - t3, ctx->stage_ms[2], now() - t4);
+    fprintf(stderr, "[detect-timing] enqueue search+plan %.3f ms, wait+enqueue images/LeNet/gather %.3f, wait+copy out %.3f; kernels: search %.3f images %.3f LeNet %.3f\n",
+            t1 - t0, t2 - t1, now() - t2, L.stage_ms[0], L.stage_ms[1], L.stage_ms[2]);
   return GPD_OK;
 }
 
@@ -428,7 +753,8 @@ int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samp
     set_error("gpd_hip_detect: bad argument");
     return GPD_ERR_INVALID;
   }
-  return detect_any(ctx, sample_indices, nullptr, num_samples, hands, num_sets, num_candidates);
+  const long long cap = ctx ? (long long)num_samples * ctx->params.num_hand_axes * ctx->params.num_orientations : 0;
+  return detect_any(ctx, "gpd_hip_detect", sample_indices, nullptr, num_samples, 0, 0, hands, cap, num_sets, num_candidates, nullptr);
 }
 
 int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples, gpd_hand *hands, int *num_sets,
@@ -437,16 +763,107 @@ int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_
     set_error("gpd_hip_detect_samples: bad argument");
     return GPD_ERR_INVALID;
   }
-  return detect_any(ctx, nullptr, samples_xyz, num_samples, hands, num_sets, num_candidates);
+  const long long cap = ctx ? (long long)num_samples * ctx->params.num_hand_axes * ctx->params.num_orientations : 0;
+  return detect_any(ctx, "gpd_hip_detect_samples", nullptr, samples_xyz, num_samples, 0, 0, hands, cap, num_sets, num_candidates,
+                    nullptr);
+}
+
+int gpd_hip_detect_select(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, int num_selected, gpd_hand *hands,
+                          int hands_capacity, int *num_sets, int *num_candidates, int *num_hands) {
+  if (!sample_indices || !num_hands || hands_capacity < 0) {
+    set_error("gpd_hip_detect_select: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  return detect_any(ctx, "gpd_hip_detect_select", sample_indices, nullptr, num_samples, 1, num_selected, hands, hands_capacity, num_sets,
+                    num_candidates, num_hands);
+}
+
+int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
+  if (!ctx || num_jobs < 0 || (num_jobs > 0 && !jobs)) {
+    set_error("gpd_hip_detect_batch: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  if (!ctx->lenet.channels) {
+    set_error("gpd_hip_detect_batch: LeNet weights not set");
+    return GPD_ERR_STATE;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int i = 0; i < num_jobs; i++) {
+    gpd_detect_job &j = jobs[i];
+    j.status = GPD_OK;
+    j.num_sets = j.num_candidates = j.num_hands = 0;
+    j.stage_ms[0] = j.stage_ms[1] = j.stage_ms[2] = 0.f;
+    if (!j.xyz || !j.normals || j.num_points <= 0 || !j.cam_source || j.num_cams < 1 || !j.view_points || !j.sample_indices ||
+        j.num_samples < 0 || !j.hands || j.hands_capacity < 0 || j.num_selected < 0) {
+      set_error("gpd_hip_detect_batch: job %d has a bad argument", i);
+      return GPD_ERR_INVALID;
+    }
+  }
+  for (int l = 0; l < kLanes; l++) {
+    const int rc = lane_init(ctx->lane[l]);
+    if (rc) return rc;
+  }
+  std::vector<Job> J((size_t)num_jobs);
+  int first_error = GPD_OK;
+  char first_text[sizeof(g_err)] = "";
+  auto fail = [&](int i, int rc) {
+    jobs[i].status = rc;
+    J[i].live = false;
+    if (!first_error) {
+      first_error = rc;
+      std::memcpy(first_text, g_err, sizeof(g_err));
+    }
+  };
+  auto begin = [&](int i) {
+    gpd_detect_job &j = jobs[i];
+    Lane &L = ctx->lane[i % kLanes];
+    int rc = check_samples(ctx, L, "gpd_hip_detect_batch", j.sample_indices, nullptr, j.num_samples, j.num_points);
+    if (!rc) rc = cloud_upload(L.cloud, j.xyz, j.normals, j.num_points, j.cam_source, j.num_cams, j.view_points, L.stream, /*sync=*/false);
+    if (rc) return fail(i, rc);
+    J[i].sample_idx = j.sample_indices;
+    J[i].S = j.num_samples;
+    J[i].mode = 1;
+    J[i].num_selected = j.num_selected;
+    J[i].hands = j.hands;
+    J[i].capacity = j.hands_capacity;
+    rc = job_begin(ctx, L, J[i]);
+    if (rc) fail(i, rc);
+  };
+  auto end = [&](int i) {
+    Lane &L = ctx->lane[i % kLanes];
+    const int rc = job_end(ctx, L, J[i]);
+    if (rc) return fail(i, rc);
+    jobs[i].num_sets = J[i].num_sets;
+    jobs[i].num_candidates = J[i].num_candidates;
+    jobs[i].num_hands = J[i].num_hands;
+    for (int k = 0; k < 3; k++) jobs[i].stage_ms[k] = L.stage_ms[k];
+  };
+  // cloud i+1's upload + search are enqueued (other lane) before the host waits for cloud i's plan;
+  // cloud i-1's results are collected after cloud i's image / LeNet kernels are in the queue
+  // (stream order keeps cloud i+1's kernels behind cloud i-1's on their shared lane; of the pinned host buffers,
+  //  begin touches the cloud / summary staging only, which job i-1 is done with since its own middle step)
+  if (num_jobs > 0) begin(0);
+  for (int i = 0; i < num_jobs; i++) {
+    if (i + 1 < num_jobs) begin(i + 1);
+    if (jobs[i].status == GPD_OK) {
+      const int rc = job_middle(ctx, ctx->lane[i % kLanes], J[i]);
+      if (rc) fail(i, rc);
+    }
+    if (i >= 1) end(i - 1);
+  }
+  if (num_jobs > 0) end(num_jobs - 1);
+  if (first_error) std::memcpy(g_err, first_text, sizeof(g_err));
+  return first_error;
 }
 
 int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
-  if (!ctx || !(stages & 7)) {
+  if (!ctx || !(stages & 3) || (stages & ~3)) {
     set_error("gpd_hip_replay: bad argument");
     return GPD_ERR_INVALID;
   }
-  if (ctx->images.num_candidates <= 0 || !ctx->images.d_images) {
-    set_error("gpd_hip_replay: no candidate list on the device (call gpd_hip_images first)");
+  Lane &L = ctx->lane[0];
+  if (L.images.num_candidates <= 0 || !L.images.d_images || L.search.num_samples == 0) {
+    set_error("gpd_hip_replay: no candidate list on the device (call gpd_hip_images / gpd_hip_detect first)");
     return GPD_ERR_STATE;
   }
   if ((stages & 2) && !ctx->lenet.channels) {
@@ -454,8 +871,8 @@ int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
     return GPD_ERR_STATE;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  const int n = ctx->images.num_candidates;
-  int rc = reserve_scores(ctx, n);
+  const int n = L.images.num_candidates;
+  int rc = reserve_scores(L, n);
   if (rc) return rc;
   while (ctx->replay_events.size() < ctx->replay_used + 6) {
     hipEvent_t e;
@@ -464,36 +881,26 @@ int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
   }
   hipEvent_t *ev = &ctx->replay_events[ctx->replay_used];
   ctx->replay_used += 6;
-  HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-  if (stages & 4) {  // EXPERIMENT: images on a side stream, concurrently with the LeNet pass
-    if (!ctx->stream2) HIP_TRY(hipStreamCreate(&ctx->stream2));
-    HIP_TRY(hipStreamWaitEvent(ctx->stream2, ev[0], 0));
-    rc = images_launch(ctx->search, ctx->images, ctx->stream2, false);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[1], ctx->stream2));
-    HIP_TRY(lenet_forward(ctx->lenet, ctx->lenet_scratch, ctx->images.d_images, n, ctx->d_scores, ctx->stream, ev + 2));
-    HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[1], 0));
-    HIP_TRY(hipEventRecord(ev[5], ctx->stream));
-    return GPD_OK;
-  }
+  HIP_TRY(hipEventRecord(ev[0], L.stream));
   if (stages & 1) {
-    rc = images_launch(ctx->search, ctx->images, ctx->stream, false);
+    rc = images_launch(L.search, L.plan, L.images, L.stream);
     if (rc) return rc;
   }
-  HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[1], L.stream));
   if (stages & 2) {
-    HIP_TRY(lenet_forward(ctx->lenet, ctx->lenet_scratch, ctx->images.d_images, n, ctx->d_scores, ctx->stream, ev + 2));
+    HIP_TRY(lenet_forward(ctx->lenet, L.lenet_scratch, L.images.d_images, n, L.d_scores, L.stream, ev + 2));
   } else {
-    for (int i = 2; i < 5; i++) HIP_TRY(hipEventRecord(ev[i], ctx->stream));
+    for (int i = 2; i < 5; i++) HIP_TRY(hipEventRecord(ev[i], L.stream));
   }
-  HIP_TRY(hipEventRecord(ev[5], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[5], L.stream));
   return GPD_OK;
 }
 
 int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *scores) {
   if (!ctx || !ms) return GPD_ERR_INVALID;
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  Lane &L = ctx->lane[0];
+  HIP_TRY(hipStreamSynchronize(L.stream));
   ms[0] = ms[1] = 0.f;
   for (int k = 0; k < 4; k++) ctx->replay_kernel_ms[k] = 0.f;
   for (size_t i = 0; i + 5 < ctx->replay_used; i += 6) {
@@ -510,12 +917,12 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
   }
   if (launches) *launches = (int)(ctx->replay_used / 6);
   ctx->replay_used = 0;
-  if (scores && ctx->images.num_candidates > 0 && ctx->d_scores)
-    HIP_TRY(hipMemcpy(scores, ctx->d_scores, (size_t)ctx->images.num_candidates * sizeof(float), hipMemcpyDeviceToHost));
+  if (scores && L.images.num_candidates > 0 && L.d_scores)
+    HIP_TRY(hipMemcpy(scores, L.d_scores, (size_t)L.images.num_candidates * sizeof(float), hipMemcpyDeviceToHost));
   int32_t status = 0;
-  if (ctx->images.d_status) HIP_TRY(hipMemcpy(&status, ctx->images.d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (L.images.d_status) HIP_TRY(hipMemcpy(&status, L.images.d_status, sizeof(int32_t), hipMemcpyDeviceToHost));
   if (status) {
-    set_error("gpd_hip_replay_times: image kernel reported capacity flags %d", status);
+    images_status_text(status, g_err, sizeof(g_err));
     return GPD_ERR_CAPACITY;
   }
   return GPD_OK;
@@ -529,16 +936,17 @@ int gpd_hip_replay_kernel_ms(gpd_hip_ctx *ctx, float ms[4]) {
 
 int gpd_hip_last_images_stats(gpd_hip_ctx *ctx, long long out[4]) {
   if (!ctx || !out) return GPD_ERR_INVALID;
-  out[0] = ctx->images.num_candidates;
-  out[1] = ctx->images.stat_sets;
-  out[2] = ctx->images.stat_sum_set_ni;
-  out[3] = ctx->images.stat_sum_cand_ni;
+  const Lane &L = ctx->lane[0];
+  out[0] = L.images.num_candidates;
+  out[1] = L.images.stat_sets;
+  out[2] = L.images.stat_sum_set_ni;
+  out[3] = L.images.stat_sum_cand_ni;
   return GPD_OK;
 }
 
 int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]) {
   if (!ctx || !ms) return GPD_ERR_INVALID;
-  for (int i = 0; i < 3; i++) ms[i] = ctx->stage_ms[i];
+  for (int i = 0; i < 3; i++) ms[i] = ctx->lane[0].stage_ms[i];
   return GPD_OK;
 }
 

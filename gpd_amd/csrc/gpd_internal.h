@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
+
 #include <vector>
 
 #include "../../include/gpd_hip.h"
@@ -43,7 +45,8 @@ void set_error(const char *fmt, ...);
 // Device copy of what the path reads from util::Cloud, as SoA for coalesced streaming.
 constexpr int kMaxCams = 8;
 struct Cloud {
-  int num_points = 0, num_cams = 0, capacity = 0;
+  int num_points = 0, num_cams = 0, capacity = 0, cap_cams = 0;
+  char *h_pin = nullptr;              // pinned staging of the caller's arrays (xyz, normals, cam_source)
   uint64_t generation = 0;            // bumped by every upload
   float *px = nullptr, *py = nullptr, *pz = nullptr;
   float *nx = nullptr, *ny = nullptr, *nz = nullptr;
@@ -85,8 +88,8 @@ inline GridView grid_view(const Cloud &c) {
   g.z = c.g_z;
   return g;
 }
-hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
-                        const double *view_points, hipStream_t stream);
+int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
+                 const double *view_points, hipStream_t stream, bool sync);
 void cloud_free(Cloud &c);
 int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream);
 
@@ -103,20 +106,106 @@ struct SearchState {
   double *d_frames = nullptr;         // [S][12] sample, normal, binormal, curvature
   double *d_centers = nullptr;        // [S][3] mean of the image neighbourhood
   gpd_hand *d_hands = nullptr;        // [S][slots]
-  std::vector<int32_t> h_counts;      // host copy of d_counts
+  uint8_t *d_fvalid = nullptr;        // [S][slots] is_valid after filterGraspsWorkspace (hand_eval_kernel writes it; the
+                                      // unfused gpd_hip_images overwrites it with the caller's flags)
+  std::vector<int32_t> h_counts;      // host copy of d_counts (unfused entry points only)
   std::vector<int32_t> h_set_sample;  // set -> sample slot
   std::vector<double> h_samples;      // [S][3] sample coordinates (to validate hands passed to images)
 };
-// samples by index (sample_xyz == nullptr) or by coordinates (sample_idx == nullptr)
+// samples by index (sample_xyz == nullptr) or by coordinates (sample_idx == nullptr).  sync_counts: download the
+// neighbourhood sizes and grow the list capacity when one overflows (the unfused entry points); without it nothing
+// waits for the device and the caller checks `worst found` in the plan summary (search_retry_needed).
 int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, const double *sample_xyz, int S,
-               hipStream_t stream);
+               hipStream_t stream, bool sync_counts = true);
+// list capacity the next search_run would use after a neighbourhood of `worst` entries; 0: beyond every capacity
+int search_next_capacity(const SearchState &s, int worst);
+int search_force_capacity(SearchState &s, int cap);
 // HandSearch::reevaluateHypotheses on the uploaded cloud; invalidates the search state
 int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand *hands, int n, int32_t *labels, hipStream_t stream);
 int search_download(const gpd_params &p, SearchState &s, gpd_hand *hands, int *num_sets, hipStream_t stream);
 void search_free(SearchState &s);
 
-// GraspDetector::filterGraspsWorkspace (grasp_detector.cpp:334-398) on the host.
+// GraspDetector::filterGraspsWorkspace (grasp_detector.cpp:334-398) for one valid hand: aperture and the
+// workspace box around the hand's outline.  The reference computes right_top from left_bottom
+// (:360-363); kept.  Evaluated with the same unfused fp64 operations on the host and on the device.
+struct FilterConsts {
+  double min_aperture, max_aperture, half_width, hand_depth;
+  double workspace[6];
+};
+inline FilterConsts filter_consts(const gpd_params &p) {
+  FilterConsts f;
+  f.min_aperture = p.min_aperture;
+  f.max_aperture = p.max_aperture;
+  f.half_width = 0.5 * p.hand_outer_diameter;
+  f.hand_depth = p.hand_depth;
+  for (int i = 0; i < 6; i++) f.workspace[i] = p.workspace_grasps[i];
+  return f;
+}
+__host__ __device__ inline bool workspace_ok(const FilterConsts &f, const gpd_hand &h) {
+  bool ok = h.grasp_width >= f.min_aperture && h.grasp_width <= f.max_aperture;
+  for (int r = 0; r < 3 && ok; r++) {
+    const double bin = h.frame[3 * r + 1], app = h.frame[3 * r + 0];
+    const double lb = h.position[r] + f.half_width * bin;
+    const double rb = h.position[r] - f.half_width * bin;
+    const double lt = lb + f.hand_depth * app;
+    const double rt = lb + f.hand_depth * app;
+    const double ap = h.position[r] - 0.05 * app;
+    const double mn = fmin(fmin(fmin(lb, rb), fmin(lt, rt)), ap);
+    const double mx = fmax(fmax(fmax(lb, rb), fmax(lt, rt)), ap);
+    ok = mn >= f.workspace[2 * r] && mx <= f.workspace[2 * r + 1];
+  }
+  return ok;
+}
 void filter_workspace_host(const gpd_params &p, gpd_hand *hands, int num_sets);
+
+// ---- Candidate plan (plan.hip) -----------------------------------------------------
+// What GraspDetector::detectGrasps does between its stages on the host — filterGraspsWorkspace
+// dropping hand sets (grasp_detector.cpp:238, 334-398), createImageList's set-major / slot-minor
+// gather of the valid hands (image_generator.cpp:91-98), the per-set shadow LCG offsets
+// (hand_set.cpp:263-266 is one global stream) and the score write-back (:269-273) — as device
+// tables, built by one plan_kernel launch from the search results.
+struct PlanSummary {  // copied to the host once per call (pinned)
+  int32_t num_sets;          // samples with a frame neighbourhood (frame_estimator.cpp:24-29)
+  int32_t num_candidates;    // valid hands after the filter
+  int32_t num_shadow_sets;   // (live set, camera) voxel bitsets
+  int32_t worst_found;       // largest neighbourhood found by the search (list capacity check)
+  int32_t live_sets;         // sets with at least one candidate
+  int32_t mismatch_set;      // gpd_hip_images: first set whose sample differs from the search's (or that the search does
+                             // not have), -1: none
+  int32_t pad_[2];
+  long long sum_set_ni, sum_cand_ni;  // for the algorithmic byte count of SURVEY §8d
+};
+struct Plan {
+  int cap_samples = 0, cap_slots = 0, cap_cams = 0;
+  int32_t *d_sample_of_set = nullptr;  // [S]
+  int32_t *d_hand_cand = nullptr;      // [S][slots] candidate ordinal of a hand, -1: none
+  int32_t *d_cand_hand = nullptr;      // [S*slots] hand (sample slot * slots + slot) of a candidate
+  int32_t *d_cand_out = nullptr;       // [S*slots] index of the candidate in the set-major hand array handed to the caller
+  int32_t *d_cand_meta = nullptr;      // [S*slots][4]: sample slot, N_images, first shadow bitset (< 0: none), number of bitsets
+  int32_t *d_set_meta = nullptr;       // [S*cams][8]: sample slot, N_images, lcg offset lo, hi, camera
+  PlanSummary *d_summary = nullptr;
+  PlanSummary *h_summary = nullptr;    // pinned
+  uint8_t *d_set_flags = nullptr;      // gpd_hip_images: the caller's is_valid flags, [sets][slots] ...
+  double *d_set_samples = nullptr;     // ... and the samples of its hand sets, [sets][3]
+  int cap_set_flags = 0;
+};
+void plan_free(Plan &pl);
+// Enqueues plan_kernel + the summary copy on `stream`; the caller waits for the stream before reading pl.h_summary.
+// set_flags == nullptr: the validity flags are the ones hand_eval_kernel left (search + workspace filter).
+// Otherwise (gpd_hip_images) the caller's flags, set-major [num_sets_given][slots], and the samples of its sets
+// [num_sets_given][3] (host pointers, copied asynchronously: keep them alive until the stream has been waited for).
+int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &pl, hipStream_t stream,
+               const uint8_t *set_flags = nullptr, const double *set_samples = nullptr, int num_sets_given = 0);
+// set-major hand records of the last search with `valid` = the filtered flag and the scores written back
+// (out: [num_sets][slots], device); candidates_only: the scored valid hands in candidate order instead.
+int plan_emit_hands(const gpd_params &p, const SearchState &s, const Plan &pl, const float *d_scores, gpd_hand *d_out,
+                    bool candidates_only, hipStream_t stream);
+// GraspDetector::selectGrasps (grasp_detector.cpp:405-420) over the device score array: the k best candidates,
+// score descending; *tie: equal scores among them or at the cut (the caller then falls back to std::partial_sort)
+int select_topk(const float *d_scores, int n, int k, int32_t *d_sel /* [k] candidate ordinals */, int32_t *d_tie,
+                hipStream_t stream);
+int gather_hands(const gpd_params &p, const SearchState &s, const Plan &pl, const float *d_scores, const int32_t *d_sel, int k,
+                 gpd_hand *d_out, hipStream_t stream);
 
 // ---- Grasp images (images.hip) ---------------------------------------------------
 struct ImageState {
@@ -124,26 +213,22 @@ struct ImageState {
   int capacity = 0;                   // images
   uint8_t *d_images = nullptr;        // planar [n][C][60][60]
   uint8_t *d_images_hwc = nullptr;    // [n][60][60][C], only when the caller downloads pixels
-  gpd_hand *d_hands = nullptr;        // candidate hand records
-  int32_t *d_cand_meta = nullptr;     // [n][4]: sample slot, N_images, shadow-set ordinal, -
-  int32_t *d_set_meta = nullptr;      // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera
   uint32_t *d_set_bits = nullptr;     // [sets][SETWORDS] shadow voxel bitsets
   int num_shadow_sets = 0, cap_shadow_sets = 0;
   int channels = 0;
   int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
-  int num_overflow = 0;               // as found by the last checked launch (replays reuse it)
   int32_t *d_pts_overflow = nullptr;  // [capacity + 1]: candidates for the large points instantiation, then their count
-  int num_pts_overflow = 0;
-  char *d_pts_scratch = nullptr;      // point arrays of the large instantiation, one row per listed candidate
-  int cap_pts_scratch = 0;            // rows
-  int32_t *d_status = nullptr;        // error flags from the kernel
-  int cap_hands = 0;
+  char *d_pts_scratch = nullptr;      // point arrays of the large instantiation, one row per workgroup of its grid
+  int32_t *d_status = nullptr;        // error flags from the kernels
   long long stat_sets = 0, stat_sum_set_ni = 0, stat_sum_cand_ni = 0;  // for the algorithmic byte count
-  std::vector<unsigned char> consts;  // the constant block (geometry, view points) the candidate list was built with
+  std::vector<unsigned char> consts;  // the constant block (image geometry) the candidate list was built with
+  double view_points[3 * kMaxCams] = {0};  // of the cloud the list was built on (shadow_set_kernel argument)
 };
-int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageState &im, const gpd_hand *hands, int num_sets,
-               int32_t *cand_index, hipStream_t stream);
-int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool check);
+// Sizes the image buffers for the plan's candidate list (summary already on the host) and launches the image kernels.
+int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream);
+// Re-launches them on the resident list.  Nothing waits for the device: capacity flags accumulate in im.d_status.
+int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream);
+void images_status_text(int status, char *buf, size_t len);
 hipError_t planar_to_hwc(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream);
 hipError_t hwc_to_planar(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream);
 void image_cell_thresholds(double len, double *out);  // 61 doubles

@@ -56,27 +56,13 @@ void host_consts(const gpd_params &p, HostConsts &h) {
   h.nn_radius_images = std::fmax(std::fmax(p.volume_depth, p.volume_height / 2.0), p.volume_width);
 }
 
-// GraspDetector::filterGraspsWorkspace — grasp_detector.cpp:334-398.  The reference
-// computes right_top from left_bottom (line 360-363); kept.
+// GraspDetector::filterGraspsWorkspace — grasp_detector.cpp:334-398 (workspace_ok in gpd_internal.h).
 void filter_workspace_host(const gpd_params &p, gpd_hand *hands, int num_sets) {
   const int slots = p.num_hand_axes * p.num_orientations;
-  const double half_width = 0.5 * p.hand_outer_diameter;
+  const FilterConsts f = filter_consts(p);
   for (long i = 0; i < (long)num_sets * slots; i++) {
     gpd_hand &h = hands[i];
-    if (!h.valid) continue;
-    bool ok = h.grasp_width >= p.min_aperture && h.grasp_width <= p.max_aperture;
-    for (int r = 0; r < 3 && ok; r++) {
-      const double bin = h.frame[3 * r + 1], app = h.frame[3 * r + 0];
-      const double lb = h.position[r] + half_width * bin;
-      const double rb = h.position[r] - half_width * bin;
-      const double lt = lb + p.hand_depth * app;
-      const double rt = lb + p.hand_depth * app;
-      const double ap = h.position[r] - 0.05 * app;
-      const double mn = std::fmin(std::fmin(std::fmin(lb, rb), std::fmin(lt, rt)), ap);
-      const double mx = std::fmax(std::fmax(std::fmax(lb, rb), std::fmax(lt, rt)), ap);
-      ok = mn >= p.workspace_grasps[2 * r] && mx <= p.workspace_grasps[2 * r + 1];
-    }
-    h.valid = ok ? 1 : 0;
+    if (h.valid) h.valid = workspace_ok(f, h) ? 1 : 0;
   }
 }
 

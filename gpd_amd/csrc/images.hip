@@ -71,7 +71,6 @@ constexpr int SETWORDS = (SD * SD * SD + 31) / 32;
 struct ImgConsts {
   double vol_depth, vol_width, vol_height, half_od, dbl_h;
   int C, nproj, per;
-  double view_point[3 * kMaxCams];
   double shadow_length, voxel, voxel_mult, rand_inv;
   int num_shadow;
   uint32_t stride_a, stride_c;  // LCG jump by SET_THREADS * num_shadow draws
@@ -87,13 +86,15 @@ struct ImgParams {
   const float *nn;
   int cap;
   const double *centers;
-  const gpd_hand *hands;  // one per candidate
+  const gpd_hand *hands;      // [S][slots] records of the search
+  const int32_t *cand_hand;   // [n] record of a candidate (plan_kernel)
   const int32_t *meta;    // [n][4]: sample slot, N_images, first shadow bitset (< 0: no shadow), number of bitsets (cameras)
   const uint32_t *set_bits;  // [live sets][SETWORDS] shadow voxel bitsets (shadow_set_kernel)
   uint8_t *images;        // planar [n][C][3600]
   int32_t *status;
   int num_cand;              // candidates of the launch (the kernels that do not take a list)
-  const int32_t *cand_list;  // shadow kernel: candidates to process (nullptr: all, in XCD-aware order)
+  const int32_t *cand_list;  // large instantiations: the queued candidates (nullptr: all, in XCD-aware order) ...
+  const int32_t *cand_count; // ... and how many there are (device side: nothing waits for the count)
   int32_t *overflow_list;    // shadow kernel: candidates whose box exceeds SHC voxels
   int32_t *overflow_count;
   unsigned long long *dbg;  // profiling aid (GPD_IMG_TIMING=1): per-phase cycle sums
@@ -546,19 +547,16 @@ __device__ __forceinline__ int xcd_candidate(int n) {
 }
 
 template <int SHC>
-__global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_image_kernel(ImgParams P) {
-  __shared__ SmemShadow<SHC> S;
+__device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow<SHC> &S, const int cand) {
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
-  const int cand = P.cand_list ? P.cand_list[blockIdx.x] : xcd_candidate(P.num_cand);
-  if (cand < 0) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int set_ord = P.meta[4 * cand + 2];
   const int set_nb = P.meta[4 * cand + 3];
   uint8_t *out = P.images + (size_t)cand * kPix * K.C;
   Box B;
-  load_box(P.hands[cand], B);
+  load_box(P.hands[P.cand_hand[cand]], B);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
   for (int i = tid; i < 128; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
   for (int w = tid; w < VWORDS; w += IMG_THREADS) S.bp.bits[w] = 0u;
@@ -770,19 +768,36 @@ __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_ima
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
 
+// LGRID workgroups of the large instantiations walk the queue of the small one; the queue length is read
+// on the device, so the host enqueues them without waiting for it (an empty queue costs an empty launch)
+constexpr int LGRID = 256;
+
+template <int SHC>
+__global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_image_kernel(ImgParams P) {
+  __shared__ SmemShadow<SHC> S;
+  if constexpr (SHC > SH_CAP) {
+    const int count = *P.cand_count;
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+      __syncthreads();  // the previous candidate's LDS is dead
+      shadow_image_body<SHC>(P, S, P.cand_list[q]);
+    }
+  } else {
+    const int cand = xcd_candidate(P.num_cand);
+    if (cand < 0) return;
+    shadow_image_body<SHC>(P, S, cand);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // grasp_image_kernel: normals (3) and depth (1) channels per projection of one candidate
 // (createNormalsImage / createDepthImage, image_strategy.cpp:124-190).
 // ---------------------------------------------------------------------------
 template <bool BIG>
-__global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
-  __shared__ SmemPts<BIG> S;
+__device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG> &S, const int cand) {
   constexpr int CAP = BIG ? PT_CAP_BIG : PT_CAP;
   constexpr int EB = BIG ? 14 : 11;  // bits of an entry index
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
-  const int cand = BIG ? P.cand_list[blockIdx.x] : xcd_candidate(P.num_cand);
-  if (cand < 0) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int slot_s = P.meta[4 * cand + 0];
@@ -806,7 +821,7 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
     else return S.p.an[e];
   };
   Box B;
-  load_box(P.hands[cand], B);
+  load_box(P.hands[P.cand_hand[cand]], B);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
   for (int i = tid; i < 256; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
   if (tid == 0) {
@@ -943,6 +958,22 @@ __global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
 
+template <bool BIG>
+__global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
+  __shared__ SmemPts<BIG> S;
+  if constexpr (BIG) {
+    const int count = *P.cand_count;
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+      __syncthreads();  // the previous candidate's LDS is dead
+      grasp_image_body<true>(P, S, P.cand_list[q]);
+    }
+  } else {
+    const int cand = xcd_candidate(P.num_cand);
+    if (cand < 0) return;
+    grasp_image_body<false>(P, S, cand);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // shadow_set_kernel: HandSet::calculateShadow / calculateShadowForCamera (hand_set.cpp:118-233)
 // for one camera, once per hand set.  The 33 * N_i LCG draws of the set (stream offset given by
@@ -957,6 +988,8 @@ struct SetParams {
   const double *frames;     // [S][12], sample first
   const int32_t *set_meta;  // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera, -
   uint32_t *set_bits;       // [sets][SETWORDS]
+  double view_point[3 * kMaxCams];  // of the cloud (a kernel argument, not a device constant: clouds of a batch
+                                    // with different cameras run side by side)
 };
 
 __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
@@ -978,7 +1011,7 @@ __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
   // shadow_vec = shadow_length * (center - view_point) / norm (hand_set.cpp:147-150)
   const double *cen = P.centers + 3 * (size_t)slot_s;
   double vec[3];
-  for (int r = 0; r < 3; r++) vec[r] = cen[r] - K.view_point[3 * cam + r];
+  for (int r = 0; r < 3; r++) vec[r] = cen[r] - P.view_point[3 * cam + r];
   const double nrm = sqrt(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
   for (int r = 0; r < 3; r++) vec[r] = K.shadow_length * vec[r] / nrm;
   uint32_t state = lcg_jump(0u, off + (unsigned long long)tid * (unsigned)K.num_shadow);
@@ -1065,116 +1098,55 @@ void image_cell_thresholds(double len, double *out) {
 }
 
 void images_free(ImageState &im) {
-  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_status, im.d_set_meta, im.d_set_bits, im.d_overflow, im.d_pts_overflow, im.d_pts_scratch};
+  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_status, im.d_set_bits, im.d_overflow, im.d_pts_overflow, im.d_pts_scratch};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   im = ImageState();
 }
 
-int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageState &im, const gpd_hand *hands, int num_sets,
-               int32_t *cand_index, hipStream_t stream) {
-  const int slots = p.num_hand_axes * p.num_orientations;
+// The candidate list itself (which hands, in which order, where each hand set starts in the LCG stream) is
+// built on the device by plan_kernel; its sizes are in pl.h_summary by now.  This sizes the image buffers,
+// prepares the constant block of the image geometry and launches the kernels.
+int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream) {
   const int C = p.image_num_channels;
-  if (s.cloud_generation != c.generation || s.num_samples == 0) {
-    set_error("images: hands must come from gpd_hip_search on this context and cloud");
-    return GPD_ERR_STATE;
-  }
-  if (num_sets > (int)s.h_set_sample.size()) {
-    set_error("images: %d sets passed, search produced %zu", num_sets, s.h_set_sample.size());
-    return GPD_ERR_INVALID;
-  }
-  // candidate list in set-major, slot-minor order; LCG offsets over live sets
-  std::vector<gpd_hand> cand;
-  std::vector<int32_t> meta, set_meta;
-  unsigned long long lcg = 0;
-  im.stat_sets = 0;
-  im.stat_sum_set_ni = 0;
-  im.stat_sum_cand_ni = 0;
-  for (int si = 0; si < num_sets; si++) {
-    int nv = 0;
-    for (int j = 0; j < slots; j++) nv += hands[(size_t)si * slots + j].valid ? 1 : 0;
-    if (!nv) continue;
-    const int samp = s.h_set_sample[si];
-    const gpd_hand &h0 = hands[(size_t)si * slots];
-    for (int r = 0; r < 3; r++)
-      if (h0.sample[r] != s.h_samples[3 * (size_t)si + r]) {
-        set_error("images: set %d does not match the last search (sample moved)", si);
-        return GPD_ERR_STATE;
-      }
-    const int Ni = s.h_counts[8 * samp + 1];
-    const int seen_mask = s.h_counts[8 * samp + 4];
-    // HandSet::calculateShadow (hand_set.cpp:118-185): every camera that sees a neighbourhood point
-    // casts 33*N_i draws, in camera order.  One camera: its set (empty if it sees nothing).  Several:
-    // start from camera 0's set (empty if camera 0 sees nothing) and intersect with the seen others.
-    int first_bits = -1, n_bits = 0;
-    if (C == 15 && Ni > 0) {
-      const bool cam0 = (seen_mask & 1) != 0;
-      for (int cam = 0; cam < c.num_cams; cam++) {
-        if (!(seen_mask >> cam & 1)) continue;
-        if (cam0) {
-          if (first_bits < 0) first_bits = (int)(set_meta.size() / 8);
-          n_bits++;
-          const int32_t row[8] = {samp, Ni, (int32_t)(uint32_t)(lcg & 0xffffffffull), (int32_t)(lcg >> 32), cam, 0, 0, 0};
-          set_meta.insert(set_meta.end(), row, row + 8);
-        }
-        lcg += (unsigned long long)Ni * 33ull;  // the draws are consumed even when the result is discarded
-      }
-    }
-    for (int j = 0; j < slots; j++) {
-      const gpd_hand &h = hands[(size_t)si * slots + j];
-      if (!h.valid) continue;
-      if (cand_index) cand_index[cand.size()] = si * slots + j;
-      cand.push_back(h);
-      meta.push_back(samp);
-      meta.push_back(Ni);
-      meta.push_back(first_bits);
-      meta.push_back(n_bits);
-    }
-    im.stat_sets++;
-    im.stat_sum_set_ni += Ni;
-    im.stat_sum_cand_ni += (long long)Ni * nv;
-  }
-  const int n = (int)cand.size();
+  const PlanSummary &sm = *pl.h_summary;
+  const int n = sm.num_candidates;
   im.num_candidates = n;
   im.channels = C;
-  im.num_overflow = 0;
-  im.num_pts_overflow = 0;
+  im.stat_sets = sm.live_sets;
+  im.stat_sum_set_ni = sm.sum_set_ni;
+  im.stat_sum_cand_ni = sm.sum_cand_ni;
+  im.num_shadow_sets = sm.num_shadow_sets;
+  std::memcpy(im.view_points, c.view_points, sizeof(im.view_points));
+  if (!im.d_status) {
+    HIP_RET(hipMalloc(&im.d_status, sizeof(int32_t)));
+    HIP_RET(hipMalloc(&im.d_pts_scratch, (size_t)LGRID * PTS_SCRATCH_BYTES));
+  }
+  HIP_RET(hipMemsetAsync(im.d_status, 0, sizeof(int32_t), stream));
   if (n == 0) return GPD_OK;
   if (n > im.capacity) {
-    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_hands, im.d_cand_meta, im.d_overflow, im.d_pts_overflow};
+    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_overflow, im.d_pts_overflow};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
     im.d_overflow = nullptr;
     im.d_pts_overflow = nullptr;
     im.d_images = nullptr;
     im.d_images_hwc = nullptr;
-    im.d_hands = nullptr;
-    im.d_cand_meta = nullptr;
     im.capacity = 0;
-    HIP_RET(hipMalloc(&im.d_images, (size_t)n * kPix * C));
-    HIP_RET(hipMalloc(&im.d_hands, (size_t)n * sizeof(gpd_hand)));
-    HIP_RET(hipMalloc(&im.d_cand_meta, (size_t)n * 4 * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&im.d_overflow, (size_t)(n + 1) * sizeof(int32_t)));  // list + its counter
-    HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)(n + 1) * sizeof(int32_t)));
-    im.capacity = n;
+    const int cap = n + n / 8;  // slack: the clouds of a batch differ a little
+    HIP_RET(hipMalloc(&im.d_images, (size_t)cap * kPix * C));
+    HIP_RET(hipMalloc(&im.d_overflow, (size_t)(cap + 1) * sizeof(int32_t)));  // list + its counter
+    HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)(cap + 1) * sizeof(int32_t)));
+    im.capacity = cap;
   }
-  if (!im.d_status) HIP_RET(hipMalloc(&im.d_status, sizeof(int32_t)));
-  HIP_RET(hipMemsetAsync(im.d_status, 0, sizeof(int32_t), stream));
-  HIP_RET(hipMemcpyAsync(im.d_hands, cand.data(), (size_t)n * sizeof(gpd_hand), hipMemcpyHostToDevice, stream));
-  HIP_RET(hipMemcpyAsync(im.d_cand_meta, meta.data(), (size_t)n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  im.num_shadow_sets = (int)(set_meta.size() / 8);
   if (im.num_shadow_sets > im.cap_shadow_sets) {
-    if (im.d_set_meta) (void)hipFree(im.d_set_meta);
     if (im.d_set_bits) (void)hipFree(im.d_set_bits);
-    im.d_set_meta = nullptr;
     im.d_set_bits = nullptr;
     im.cap_shadow_sets = 0;
-    HIP_RET(hipMalloc(&im.d_set_meta, (size_t)im.num_shadow_sets * 8 * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&im.d_set_bits, (size_t)im.num_shadow_sets * SETWORDS * sizeof(uint32_t)));
-    im.cap_shadow_sets = im.num_shadow_sets;
+    const int cap = im.num_shadow_sets + im.num_shadow_sets / 8;
+    HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * SETWORDS * sizeof(uint32_t)));
+    im.cap_shadow_sets = cap;
   }
-  if (im.num_shadow_sets)
-    HIP_RET(hipMemcpyAsync(im.d_set_meta, set_meta.data(), set_meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   ImgConsts k;
   std::memset(&k, 0, sizeof(k));
   k.vol_depth = p.volume_depth;
@@ -1185,13 +1157,12 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
   k.C = C;
   k.nproj = (C <= 3) ? 1 : 3;
   k.per = (C == 15) ? 5 : (C == 12 ? 4 : C);
-  for (int r = 0; r < 3 * c.num_cams; r++) k.view_point[r] = c.view_points[r];
   // shadow_length_ = max(volume_depth, volume_height/2, volume_width) (image_15_channels_strategy.h:70-75)
   k.shadow_length = std::fmax(std::fmax(p.volume_depth, p.volume_height / 2.0), p.volume_width);
   k.voxel = 0.003;
   k.voxel_mult = 1.0 / 0.003;
   k.rand_inv = 1.0 / 32767.0;
-  k.num_shadow = (int)std::floor(k.shadow_length / k.voxel);
+  k.num_shadow = (int)std::floor(k.shadow_length / k.voxel);  // plan_kernel places the sets in the LCG stream with the same count
   k.len[0] = k.vol_depth;
   k.len[1] = k.vol_width;
   k.len[2] = k.dbl_h;
@@ -1248,8 +1219,9 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, ImageS
     k.stride_a = A;
     k.stride_c = Cc;
   }
-  im.consts.assign(reinterpret_cast<const unsigned char *>(&k), reinterpret_cast<const unsigned char *>(&k) + sizeof(k));
-  return images_launch(s, im, stream, true);
+  const unsigned char *kb = reinterpret_cast<const unsigned char *>(&k);
+  if (im.consts.size() != sizeof(k) || std::memcmp(im.consts.data(), kb, sizeof(k)) != 0) im.consts.assign(kb, kb + sizeof(k));
+  return images_launch(s, pl, im, stream);
 }
 
 // c_img is ONE block per device, shared by every context of the process on that device.  Under the
@@ -1275,8 +1247,10 @@ static int load_img_consts(const std::vector<unsigned char> &want, hipStream_t s
   return GPD_OK;
 }
 
-// Launches grasp_image_kernel over the candidate list resident on the device.
-int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool check) {
+// Launches the image kernels over the candidate list resident on the device.  Nothing here waits for the
+// device: the large instantiations read the length of their queues on the device, capacity flags
+// accumulate in im.d_status (read by the caller with its results).
+int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream) {
   const int n = im.num_candidates;
   if (n <= 0) return GPD_OK;
   std::lock_guard<std::mutex> consts_lock(g_img_mutex);
@@ -1285,11 +1259,13 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     if (rc) return rc;
   }
   ImgParams ip;
+  std::memset(&ip, 0, sizeof(ip));
   ip.nn = s.d_nn;
   ip.cap = s.nn_cap;
   ip.centers = s.d_centers;
-  ip.hands = im.d_hands;
-  ip.meta = im.d_cand_meta;
+  ip.hands = s.d_hands;
+  ip.cand_hand = pl.d_cand_hand;
+  ip.meta = pl.d_cand_meta;
   ip.images = im.d_images;
   ip.status = im.d_status;
   static unsigned long long *d_dbg = nullptr;
@@ -1306,12 +1282,14 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     sp.cap = s.nn_cap;
     sp.centers = s.d_centers;
     sp.frames = s.d_frames;
-    sp.set_meta = im.d_set_meta;
+    sp.set_meta = pl.d_set_meta;
     sp.set_bits = im.d_set_bits;
+    std::memcpy(sp.view_point, im.view_points, sizeof(sp.view_point));
     shadow_set_kernel<<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
     HIP_RET(hipGetLastError());
   }
   ip.cand_list = nullptr;
+  ip.cand_count = nullptr;
   ip.num_cand = n;
   ip.overflow_list = im.d_overflow;
   ip.overflow_count = im.d_overflow + im.capacity;
@@ -1321,20 +1299,13 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     HIP_RET(hipMemsetAsync(im.d_overflow + im.capacity, 0, sizeof(int32_t), stream));
     shadow_image_kernel<SH_CAP><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
     HIP_RET(hipGetLastError());
-    if (check) {
-      int32_t n_over = 0;
-      HIP_RET(hipMemcpyAsync(&n_over, im.d_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-      HIP_RET(hipStreamSynchronize(stream));
-      im.num_overflow = n_over;
-    }
-    if (im.num_overflow > 0) {
-      ImgParams ib = ip;
-      ib.cand_list = im.d_overflow;
-      ib.overflow_list = nullptr;
-      ib.overflow_count = nullptr;
-      shadow_image_kernel<SH_CAP_BIG><<<im.num_overflow, IMG_THREADS, 0, stream>>>(ib);
-      HIP_RET(hipGetLastError());
-    }
+    ImgParams ib = ip;
+    ib.cand_list = im.d_overflow;
+    ib.cand_count = im.d_overflow + im.capacity;
+    ib.overflow_list = nullptr;
+    ib.overflow_count = nullptr;
+    shadow_image_kernel<SH_CAP_BIG><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
+    HIP_RET(hipGetLastError());
   }
   // normals + depth: nearly every box holds fewer than PT_CAP points; the others are queued and redone
   // by the instantiation that keeps its point arrays in a global scratch row
@@ -1344,26 +1315,14 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
   HIP_RET(hipMemsetAsync(im.d_pts_overflow + im.capacity, 0, sizeof(int32_t), stream));
   grasp_image_kernel<false><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
   HIP_RET(hipGetLastError());
-  if (check) {
-    int32_t n_over = 0;
-    HIP_RET(hipMemcpyAsync(&n_over, im.d_pts_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipStreamSynchronize(stream));
-    im.num_pts_overflow = n_over;
-    if (n_over > im.cap_pts_scratch) {
-      if (im.d_pts_scratch) (void)hipFree(im.d_pts_scratch);
-      im.d_pts_scratch = nullptr;
-      im.cap_pts_scratch = 0;
-      HIP_RET(hipMalloc(&im.d_pts_scratch, (size_t)n_over * PTS_SCRATCH_BYTES));
-      im.cap_pts_scratch = n_over;
-    }
-  }
-  if (im.num_pts_overflow > 0) {
+  {
     ImgParams ib = ip;
     ib.cand_list = im.d_pts_overflow;
+    ib.cand_count = im.d_pts_overflow + im.capacity;
     ib.pts_overflow_list = nullptr;
     ib.pts_overflow_count = nullptr;
     ib.pts_scratch = im.d_pts_scratch;
-    grasp_image_kernel<true><<<im.num_pts_overflow, IMG_THREADS, 0, stream>>>(ib);
+    grasp_image_kernel<true><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
     HIP_RET(hipGetLastError());
   }
   if (ip.dbg) {
@@ -1381,16 +1340,13 @@ int images_launch(const SearchState &s, ImageState &im, hipStream_t stream, bool
     fprintf(stderr, "[img-timing] shadow voxels in box: max %llu mean %.0f; in-box points: max %llu mean %.0f\n", h[28],
             (double)h[29] / n, h[30], (double)h[31] / n);
   }
-  if (!check) return GPD_OK;
-  int32_t status = 0;
-  HIP_RET(hipMemcpyAsync(&status, im.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  HIP_RET(hipStreamSynchronize(stream));
-  if (status) {
-    set_error("images: kernel capacity exceeded (flags %d: 1 voxel AABB, 2 in-box points > %d, 4 shadow voxels > %d)", status,
-              PT_CAP_BIG, SH_CAP_BIG);
-    return GPD_ERR_CAPACITY;
-  }
   return GPD_OK;
+}
+
+// text of the capacity flags an image kernel left in d_status
+void images_status_text(int status, char *buf, size_t len) {
+  snprintf(buf, len, "images: kernel capacity exceeded (flags %d: 1 voxel AABB, 2 in-box points > %d, 4 shadow voxels > %d)", status,
+           PT_CAP_BIG, SH_CAP_BIG);
 }
 
 }  // namespace gpd

@@ -1,0 +1,529 @@
+// The host glue of GraspDetector::detectGrasps between its stages, as device tables.
+//
+// Replaces, for the fused entry points (gpd_hip_detect, gpd_hip_detect_batch) and for
+// gpd_hip_images:
+//   * filterGraspsWorkspace dropping hand sets without a valid hand (grasp_detector.cpp:238, 334-398;
+//     the per-hand test itself runs at the end of hand_eval_kernel),
+//   * the compaction of the frames (frame_estimator.cpp:24-29: samples without a 0.01 m neighbour are
+//     dropped before the sets are numbered),
+//   * createImageList's set-major, slot-minor gather of the valid hands (image_generator.cpp:91-98),
+//   * the position of every hand set in the single LCG stream of the shadow draws
+//     (hand_set.cpp:118-185, 263-266: every camera that sees a neighbourhood point consumes
+//     N * num_shadow_points draws, in set order),
+//   * the score write-back hands[i]->setScore(scores[i]) (grasp_detector.cpp:269-273),
+//   * selectGrasps (grasp_detector.cpp:405-420) over the device score array.
+//
+// plan_kernel is ONE workgroup: the tables are prefix sums over the samples in order (a few thousand
+// entries), a serial dependency that a single 1024-lane scan resolves in microseconds.
+#include <cstddef>
+#include <cstring>
+
+#include "gpd_internal.h"
+
+namespace gpd {
+
+#define HIP_RET(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GPD_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+constexpr int PLAN_THREADS = 1024;
+
+struct PlanParams {
+  const int32_t *counts;   // [S][8]: N_hands, N_images, k_frames, found, mask of cameras that see the image neighbourhood
+  const uint8_t *fvalid;   // [S][slots]
+  const uint8_t *set_flags;   // non-null: use these instead, [num_sets_given][slots] in SET order (sets beyond: invalid)
+  const double *set_samples;  // ... whose samples [num_sets_given][3] must equal the search's
+  const double *frames;       // [S][12], sample first
+  int num_sets_given;
+  int S, slots, num_cams;
+  int shadow;              // 15 channels: the shadow draws are consumed
+  int num_shadow;          // draws per neighbourhood point and camera (hand_set.cpp:127: floor(shadow_length / 0.003))
+  int32_t *sample_of_set, *hand_cand, *cand_hand, *cand_out, *cand_meta, *set_meta;
+  PlanSummary *summary;
+};
+
+// exclusive scan of (a, b, c, d) over the workgroup; totals returned through the references
+struct Scan4 {
+  int a, b, c;
+  unsigned long long d;
+};
+__device__ inline Scan4 block_scan4(Scan4 v, Scan4 &total, Scan4 *s_part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Scan4 incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int xa = __shfl_up(incl.a, o), xb = __shfl_up(incl.b, o), xc = __shfl_up(incl.c, o);
+    const unsigned lo = __shfl_up((unsigned)incl.d, o), hi = __shfl_up((unsigned)(incl.d >> 32), o);
+    if (lane >= o) {
+      incl.a += xa;
+      incl.b += xb;
+      incl.c += xc;
+      incl.d += ((unsigned long long)hi << 32) | lo;
+    }
+  }
+  __syncthreads();
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  Scan4 base = {0, 0, 0, 0ull};
+  total = base;
+  for (int w = 0; w < PLAN_THREADS / 64; w++) {
+    const Scan4 x = s_part[w];
+    if (w < wave) {
+      base.a += x.a;
+      base.b += x.b;
+      base.c += x.c;
+      base.d += x.d;
+    }
+    total.a += x.a;
+    total.b += x.b;
+    total.c += x.c;
+    total.d += x.d;
+  }
+  Scan4 excl = {base.a + incl.a - v.a, base.b + incl.b - v.b, base.c + incl.c - v.c, base.d + incl.d - v.d};
+  return excl;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(PlanParams P) {
+  __shared__ Scan4 s_part[PLAN_THREADS / 64];
+  __shared__ int s_worst, s_live, s_mismatch;
+  __shared__ unsigned long long s_sum[2];
+  const int tid = threadIdx.x;
+  if (tid == 0) s_mismatch = 0x7fffffff;
+  Scan4 carry = {0, 0, 0, 0ull};  // sets, candidates, shadow bitsets, LCG draws before this chunk
+  int worst = 0, live_sets = 0;
+  long long sum_set_ni = 0, sum_cand_ni = 0;
+  const unsigned cam_mask = P.num_cams >= 32 ? 0xffffffffu : ((1u << P.num_cams) - 1u);
+  for (int base = 0; base < P.S; base += PLAN_THREADS) {
+    const int s = base + tid;
+    int has_set = 0, nv = 0, n_bits = 0, Ni = 0, ncam = 0;
+    unsigned seen = 0;
+    unsigned vmask = 0;  // valid slots (slots <= GPD_MAX_SLOTS = 24)
+    if (s < P.S) {
+      const int32_t *cn = P.counts + 8 * (size_t)s;
+      has_set = cn[2] > 0;
+      Ni = cn[1];
+      seen = (unsigned)cn[4] & cam_mask;
+      worst = max(worst, cn[3]);
+    }
+    int ns_pre = 0;
+    if (P.set_flags) {
+      // the caller's flags are numbered by hand set: the set number of a sample first (its own scan)
+      Scan4 v0 = {has_set, 0, 0, 0ull};
+      Scan4 t0;
+      ns_pre = carry.a + block_scan4(v0, t0, s_part).a;
+    }
+    if (s < P.S) {
+      if (has_set && !P.set_flags) {
+        for (int j = 0; j < P.slots; j++)
+          if (P.fvalid[(size_t)s * P.slots + j]) vmask |= 1u << j;
+      } else if (has_set && ns_pre < P.num_sets_given) {
+        for (int j = 0; j < P.slots; j++)
+          if (P.set_flags[(size_t)ns_pre * P.slots + j]) vmask |= 1u << j;
+        bool same = true;
+        for (int r = 0; r < 3; r++) same &= P.set_samples[3 * (size_t)ns_pre + r] == P.frames[12 * (size_t)s + r];
+        if (!same) atomicMin(&s_mismatch, ns_pre);
+      }
+      nv = __popc(vmask);
+      if (nv && P.shadow && Ni > 0) {
+        // HandSet::calculateShadow (hand_set.cpp:118-185): every camera that sees a neighbourhood point casts
+        // Ni * num_shadow draws, in camera order.  One camera: its voxel set (empty if it sees nothing).  Several:
+        // camera 0's set (empty if camera 0 sees nothing) intersected with the sets of the other seeing cameras —
+        // the draws are consumed even when the result is discarded.
+        ncam = __popc(seen);
+        n_bits = (seen & 1u) ? ncam : 0;
+      }
+      if (nv) {
+        live_sets++;
+        sum_set_ni += Ni;
+        sum_cand_ni += (long long)Ni * nv;
+      }
+    }
+    Scan4 v = {has_set, nv, n_bits, (unsigned long long)Ni * (unsigned long long)P.num_shadow * (unsigned long long)ncam};
+    Scan4 total;
+    const Scan4 ex = block_scan4(v, total, s_part);
+    if (s < P.S) {
+      const int ns = carry.a + ex.a;
+      if (has_set) P.sample_of_set[ns] = s;
+      int cand = carry.b + ex.b;
+      const int first_bits = n_bits ? carry.c + ex.c : -1;
+      for (int j = 0; j < P.slots; j++) {
+        int hc = -1;
+        if (vmask >> j & 1u) {
+          hc = cand++;
+          P.cand_hand[hc] = s * P.slots + j;
+          P.cand_out[hc] = ns * P.slots + j;
+          int32_t *m = P.cand_meta + 4 * (size_t)hc;
+          m[0] = s;
+          m[1] = Ni;
+          m[2] = first_bits;
+          m[3] = n_bits;
+        }
+        P.hand_cand[(size_t)s * P.slots + j] = hc;
+      }
+      if (ncam) {
+        unsigned long long lcg = carry.d + ex.d;
+        int row = carry.c + ex.c;
+        for (int cam = 0; cam < P.num_cams; cam++) {
+          if (!(seen >> cam & 1u)) continue;
+          if (n_bits) {
+            int32_t *m = P.set_meta + 8 * (size_t)row++;
+            m[0] = s;
+            m[1] = Ni;
+            m[2] = (int32_t)(uint32_t)(lcg & 0xffffffffull);
+            m[3] = (int32_t)(uint32_t)(lcg >> 32);
+            m[4] = cam;
+            m[5] = m[6] = m[7] = 0;
+          }
+          lcg += (unsigned long long)Ni * (unsigned long long)P.num_shadow;
+        }
+      }
+    }
+    carry.a += total.a;
+    carry.b += total.b;
+    carry.c += total.c;
+    carry.d += total.d;
+  }
+  // reductions of the per-thread statistics
+  if (tid == 0) {
+    s_worst = 0;
+    s_live = 0;
+    s_sum[0] = 0ull;
+    s_sum[1] = 0ull;
+  }
+  __syncthreads();
+  atomicMax(&s_worst, worst);
+  if (live_sets) {
+    atomicAdd(&s_live, live_sets);
+    atomicAdd(&s_sum[0], (unsigned long long)sum_set_ni);
+    atomicAdd(&s_sum[1], (unsigned long long)sum_cand_ni);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    PlanSummary sm;
+    sm.num_sets = carry.a;
+    sm.num_candidates = carry.b;
+    sm.num_shadow_sets = carry.c;
+    sm.worst_found = s_worst;
+    sm.live_sets = s_live;
+    sm.mismatch_set = s_mismatch != 0x7fffffff ? s_mismatch : -1;
+    if (P.set_flags && P.num_sets_given > carry.a && sm.mismatch_set < 0) sm.mismatch_set = carry.a;  // more sets than the search has
+    sm.pad_[0] = sm.pad_[1] = 0;
+    sm.sum_set_ni = (long long)s_sum[0];
+    sm.sum_cand_ni = (long long)s_sum[1];
+    *P.summary = sm;
+  }
+}
+
+void plan_free(Plan &pl) {
+  void *ptrs[] = {pl.d_sample_of_set, pl.d_hand_cand, pl.d_cand_hand, pl.d_cand_out, pl.d_cand_meta, pl.d_set_meta, pl.d_summary,
+                  pl.d_set_flags, pl.d_set_samples};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (pl.h_summary) (void)hipHostFree(pl.h_summary);
+  pl = Plan();
+}
+
+int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &pl, hipStream_t stream, const uint8_t *set_flags,
+               const double *set_samples, int num_sets_given) {
+  const int slots = p.num_hand_axes * p.num_orientations;
+  const int S = s.num_samples;
+  if (s.capacity_samples > pl.cap_samples || slots > pl.cap_slots || c.num_cams > pl.cap_cams) {
+    const int capS = s.capacity_samples > pl.cap_samples ? s.capacity_samples : pl.cap_samples;
+    const int capC = c.num_cams > pl.cap_cams ? c.num_cams : pl.cap_cams;
+    const int capL = slots > pl.cap_slots ? slots : pl.cap_slots;
+    plan_free(pl);
+    const size_t H = (size_t)capS * capL;
+    HIP_RET(hipMalloc(&pl.d_sample_of_set, (size_t)capS * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&pl.d_hand_cand, H * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&pl.d_cand_hand, H * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&pl.d_cand_out, H * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&pl.d_cand_meta, H * 4 * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&pl.d_set_meta, (size_t)capS * capC * 8 * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&pl.d_summary, sizeof(PlanSummary)));
+    HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&pl.h_summary), sizeof(PlanSummary), 0));
+    pl.cap_samples = capS;
+    pl.cap_slots = capL;
+    pl.cap_cams = capC;
+  }
+  PlanParams pp;
+  pp.set_flags = nullptr;
+  pp.set_samples = nullptr;
+  pp.num_sets_given = 0;
+  if (set_flags) {
+    if (num_sets_given > pl.cap_set_flags || !pl.d_set_flags) {
+      if (pl.d_set_flags) (void)hipFree(pl.d_set_flags);
+      if (pl.d_set_samples) (void)hipFree(pl.d_set_samples);
+      pl.d_set_flags = nullptr;
+      pl.d_set_samples = nullptr;
+      pl.cap_set_flags = 0;
+      const int cap = num_sets_given > pl.cap_samples ? num_sets_given : pl.cap_samples;
+      HIP_RET(hipMalloc(&pl.d_set_flags, (size_t)cap * pl.cap_slots + 16));
+      HIP_RET(hipMalloc(&pl.d_set_samples, ((size_t)cap * 3 + 1) * sizeof(double)));
+      pl.cap_set_flags = cap;
+    }
+    if (num_sets_given > 0) {
+      HIP_RET(hipMemcpyAsync(pl.d_set_flags, set_flags, (size_t)num_sets_given * slots, hipMemcpyHostToDevice, stream));
+      HIP_RET(hipMemcpyAsync(pl.d_set_samples, set_samples, (size_t)num_sets_given * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
+    pp.set_flags = pl.d_set_flags;
+    pp.set_samples = pl.d_set_samples;
+    pp.num_sets_given = num_sets_given;
+  }
+  pp.frames = s.d_frames;
+  pp.counts = s.d_counts;
+  pp.fvalid = s.d_fvalid;
+  pp.S = S;
+  pp.slots = slots;
+  pp.num_cams = c.num_cams;
+  pp.shadow = p.image_num_channels == 15 ? 1 : 0;
+  // shadow_length_ = max(volume_depth, volume_height/2, volume_width) (image_15_channels_strategy.h:70-75);
+  // num_shadow_points = floor(shadow_length / voxel_grid_size), voxel_grid_size = 0.003 (hand_set.cpp:125-127)
+  const double shadow_length = std::fmax(std::fmax(p.volume_depth, p.volume_height / 2.0), p.volume_width);
+  pp.num_shadow = (int)std::floor(shadow_length / 0.003);
+  pp.sample_of_set = pl.d_sample_of_set;
+  pp.hand_cand = pl.d_hand_cand;
+  pp.cand_hand = pl.d_cand_hand;
+  pp.cand_out = pl.d_cand_out;
+  pp.cand_meta = pl.d_cand_meta;
+  pp.set_meta = pl.d_set_meta;
+  pp.summary = pl.d_summary;
+  plan_kernel<<<1, PLAN_THREADS, 0, stream>>>(pp);
+  HIP_RET(hipGetLastError());
+  HIP_RET(hipMemcpyAsync(pl.h_summary, pl.d_summary, sizeof(PlanSummary), hipMemcpyDeviceToHost, stream));
+  return GPD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Hand records for the caller
+// ---------------------------------------------------------------------------
+struct EmitParams {
+  const gpd_hand *hands;  // [S][slots] as the search wrote them
+  const uint8_t *fvalid;
+  const int32_t *sample_of_set, *hand_cand, *cand_hand, *cand_out;
+  const float *scores;    // per candidate (may be null: scores stay 0)
+  const int32_t *sel;     // gather mode: candidate ordinals
+  gpd_hand *out;
+  int n, slots;
+};
+// 11 x 16 bytes per record, one lane per 16-byte piece: coalesced in and out
+__device__ inline void copy_hand(const gpd_hand *src, gpd_hand *dst, int set_index, int valid, float score, int piece) {
+  uint4 v = reinterpret_cast<const uint4 *>(src)[piece];
+  if (piece == 9) {         // bytes 144..159: grasp_width (8), score (4), finger_placement_index (4)
+    v.z = __float_as_uint(score);
+  } else if (piece == 10) { // bytes 160..175: set_index, slot, valid | half | full | pad, pad
+    v.x = (uint32_t)set_index;
+    v.z = (v.z & 0xffffff00u) | (uint32_t)(valid & 0xff);
+  }
+  reinterpret_cast<uint4 *>(dst)[piece] = v;
+}
+static_assert(sizeof(gpd_hand) == 176, "copy_hand assumes the 176-byte record");
+static_assert(offsetof(gpd_hand, score) == 152 && offsetof(gpd_hand, set_index) == 160 && offsetof(gpd_hand, valid) == 168,
+              "copy_hand field offsets");
+
+// all sets: out[ns][slot]
+__global__ __launch_bounds__(256) void emit_sets_kernel(EmitParams P) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int rec = g >> 4, piece = g & 15;
+  if (rec >= P.n || piece >= 11) return;
+  const int ns = rec / P.slots, j = rec - ns * P.slots;
+  const int h = P.sample_of_set[ns] * P.slots + j;
+  const int c = P.hand_cand[h];
+  const float score = (c >= 0 && P.scores) ? P.scores[c] : P.hands[h].score;
+  copy_hand(P.hands + h, P.out + rec, ns, P.fvalid[h], score, piece);
+}
+// candidates only (sel == nullptr: all, in candidate order; else the listed ones)
+__global__ __launch_bounds__(256) void emit_cands_kernel(EmitParams P) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int rec = g >> 4, piece = g & 15;
+  if (rec >= P.n || piece >= 11) return;
+  const int c = P.sel ? P.sel[rec] : rec;
+  const int h = P.cand_hand[c];
+  copy_hand(P.hands + h, P.out + rec, P.cand_out[c] / P.slots, 1, P.scores ? P.scores[c] : 0.f, piece);
+}
+
+int plan_emit_hands(const gpd_params &p, const SearchState &s, const Plan &pl, const float *d_scores, gpd_hand *d_out,
+                    bool candidates_only, hipStream_t stream) {
+  EmitParams ep;
+  ep.hands = s.d_hands;
+  ep.fvalid = s.d_fvalid;
+  ep.sample_of_set = pl.d_sample_of_set;
+  ep.hand_cand = pl.d_hand_cand;
+  ep.cand_hand = pl.d_cand_hand;
+  ep.cand_out = pl.d_cand_out;
+  ep.scores = d_scores;
+  ep.sel = nullptr;
+  ep.out = d_out;
+  ep.slots = p.num_hand_axes * p.num_orientations;
+  ep.n = candidates_only ? pl.h_summary->num_candidates : pl.h_summary->num_sets * ep.slots;
+  if (ep.n <= 0) return GPD_OK;
+  const unsigned grid = (unsigned)(((size_t)ep.n * 16 + 255) / 256);
+  if (candidates_only)
+    emit_cands_kernel<<<grid, 256, 0, stream>>>(ep);
+  else
+    emit_sets_kernel<<<grid, 256, 0, stream>>>(ep);
+  HIP_RET(hipGetLastError());
+  return GPD_OK;
+}
+
+int gather_hands(const gpd_params &p, const SearchState &s, const Plan &pl, const float *d_scores, const int32_t *d_sel, int k,
+                 gpd_hand *d_out, hipStream_t stream) {
+  if (k <= 0) return GPD_OK;
+  EmitParams ep;
+  ep.hands = s.d_hands;
+  ep.fvalid = s.d_fvalid;
+  ep.sample_of_set = pl.d_sample_of_set;
+  ep.hand_cand = pl.d_hand_cand;
+  ep.cand_hand = pl.d_cand_hand;
+  ep.cand_out = pl.d_cand_out;
+  ep.scores = d_scores;
+  ep.sel = d_sel;
+  ep.out = d_out;
+  ep.slots = p.num_hand_axes * p.num_orientations;
+  ep.n = k;
+  emit_cands_kernel<<<(unsigned)(((size_t)k * 16 + 255) / 256), 256, 0, stream>>>(ep);
+  HIP_RET(hipGetLastError());
+  return GPD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// selectGrasps (grasp_detector.cpp:405-420): std::partial_sort of the hands by score, descending, first
+// num_selected kept.  One workgroup: radix select of the k-th largest score (four 8-bit passes over the
+// order-preserving integer image of the floats), then the k winners are sorted in LDS by
+// (score descending, candidate ordinal ascending).  Equal scores make the reference's result depend on
+// libstdc++'s heap-select history; they are reported through *tie and the caller reruns the selection with
+// std::partial_sort itself on the downloaded scores (4 bytes per candidate) — the records still stay on
+// the device until the winners are gathered.
+// ---------------------------------------------------------------------------
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAX_K = 8192;  // keys sorted in LDS (64 KB)
+
+__device__ inline uint32_t score_key(float f) {  // larger float <-> larger key; -0 and +0 stay distinct (as they compare equal,
+                                                 // they count as a tie below via the float comparison)
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(const float *__restrict__ scores, int n, int k, int32_t *sel,
+                                                                  int32_t *tie) {
+  __shared__ unsigned long long s_keys[SEL_MAX_K];
+  __shared__ int s_hist[256];
+  __shared__ uint32_t s_prefix;
+  __shared__ int s_remaining, s_count_gt, s_count_eq, s_tie;
+  __shared__ int s_wcount[SEL_THREADS / 64];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_prefix = 0u;
+    s_remaining = k;
+    s_count_gt = 0;
+    s_count_eq = 0;
+    s_tie = 0;
+  }
+  __syncthreads();
+  // the k-th largest key, most significant byte first
+  for (int pass = 0; pass < 4; pass++) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) s_hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+    const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < n; i += SEL_THREADS) {
+      const uint32_t key = score_key(scores[i]);
+      if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 0xffu], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int rem = s_remaining;
+      int b = 255;
+      for (; b > 0; b--) {
+        if (s_hist[b] >= rem) break;
+        rem -= s_hist[b];
+      }
+      s_prefix = prefix | ((uint32_t)b << shift);
+      s_remaining = rem;
+    }
+    __syncthreads();
+  }
+  const uint32_t kth = s_prefix;  // key of the k-th largest score
+  const int need_eq = s_remaining;  // how many entries equal to it belong to the selection
+  // entries above the threshold, then the first need_eq equal ones by candidate ordinal
+  for (int base = 0; base < n; base += SEL_THREADS) {
+    const int i = base + tid;
+    const uint32_t key = i < n ? score_key(scores[i]) : 0u;
+    const bool gt = i < n && key > kth;
+    if (gt) {
+      const int pos = atomicAdd(&s_count_gt, 1);
+      s_keys[pos] = ((unsigned long long)(~key) << 32) | (unsigned)i;  // ascending sort of ~key = descending score
+    }
+  }
+  __syncthreads();
+  const int n_gt = s_count_gt;
+  // equal entries in ordinal order: chunked ballot scan
+  for (int base = 0; base < n; base += SEL_THREADS) {
+    const int i = base + tid;
+    const bool eq = i < n && score_key(scores[i]) == kth;
+    const unsigned long long ballot = __ballot(eq);
+    if ((tid & 63) == 0) s_wcount[tid >> 6] = __popcll(ballot);
+    __syncthreads();
+    int off = s_count_eq;
+    for (int w = 0; w < (tid >> 6); w++) off += s_wcount[w];
+    if (eq) {
+      const int r = off + __popcll(ballot & ((1ull << (tid & 63)) - 1ull));
+      if (r < need_eq) s_keys[n_gt + r] = ((unsigned long long)(~kth) << 32) | (unsigned)i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < SEL_THREADS / 64; w++) t += s_wcount[w];
+      s_count_eq += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && s_count_eq > need_eq) s_tie = 1;  // a tie at the cut
+  // bitonic sort of the k keys
+  int m = 1;
+  while (m < k) m <<= 1;
+  for (int i = k + tid; i < m; i += SEL_THREADS) s_keys[i] = ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= m; size <<= 1) {
+    for (int j = size >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (m >> 1); t += SEL_THREADS) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = s_keys[lo], b = s_keys[hi];
+        if ((a > b) == up) {
+          s_keys[lo] = b;
+          s_keys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += SEL_THREADS) {
+    const int idx = (int)(unsigned)(s_keys[i] & 0xffffffffull);
+    sel[i] = idx;
+    // equal scores next to each other (float comparison: -0 == +0)
+    if (i + 1 < k && scores[idx] == scores[(int)(unsigned)(s_keys[i + 1] & 0xffffffffull)]) s_tie = 1;
+  }
+  __syncthreads();
+  if (tid == 0) *tie = s_tie;
+}
+
+int select_topk(const float *d_scores, int n, int k, int32_t *d_sel, int32_t *d_tie, hipStream_t stream) {
+  if (k <= 0 || n <= 0) return GPD_OK;
+  if (k > n) k = n;
+  if (k > SEL_MAX_K) {
+    set_error("select_topk: k = %d exceeds the device selection capacity %d", k, SEL_MAX_K);
+    return GPD_ERR_CAPACITY;
+  }
+  select_topk_kernel<<<1, SEL_THREADS, 0, stream>>>(d_scores, n, k, d_sel, d_tie);
+  HIP_RET(hipGetLastError());
+  return GPD_OK;
+}
+
+}  // namespace gpd

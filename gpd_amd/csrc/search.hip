@@ -146,56 +146,71 @@ void cloud_free(Cloud &c) {
   void *ptrs[] = {c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.cam_source, c.staging, c.g_start, c.g_cursor, c.g_idx, c.g_x, c.g_y, c.g_z};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (c.h_pin) (void)hipHostFree(c.h_pin);
   c = Cloud();
 }
 
-hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
-                        const double *view_points, hipStream_t stream) {
-  if (num_cams > kMaxCams) return hipErrorInvalidValue;
-  hipError_t e;
-  if (n > c.capacity || num_cams > c.num_cams) {
-    uint64_t gen = c.generation;
-    cloud_free(c);
-    c.generation = gen;
-    float **planes[] = {&c.px, &c.py, &c.pz, &c.nx, &c.ny, &c.nz};
-    for (float **p : planes)
-      if ((e = hipMalloc(p, (size_t)n * sizeof(float))) != hipSuccess) return e;
-    if ((e = hipMalloc(&c.cam_source, (size_t)n * num_cams * sizeof(int32_t))) != hipSuccess) return e;
-    if ((e = hipMalloc(&c.staging, (size_t)n * 6 * sizeof(float))) != hipSuccess) return e;
-    if ((e = hipMalloc(&c.g_idx, (size_t)n * sizeof(int32_t))) != hipSuccess) return e;
-    float **gp[] = {&c.g_x, &c.g_y, &c.g_z};
-    for (float **p : gp)
-      if ((e = hipMalloc(p, (size_t)n * sizeof(float))) != hipSuccess) return e;
-    c.capacity = n;
+// The caller's arrays are copied into a pinned staging buffer (one pass that also takes the bounds of the
+// uniform grid and rejects non-finite coordinates), so the three host-to-device copies are truly
+// asynchronous: with sync == false nothing here waits for the device and the upload of the next cloud
+// overlaps the kernels of the current one (gpd_hip_detect_batch).
+int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
+                 const double *view_points, hipStream_t stream, bool sync) {
+  if (num_cams > kMaxCams) {
+    set_error("upload_cloud: at most %d cameras are supported", kMaxCams);
+    return GPD_ERR_INVALID;
   }
+  if (n > c.capacity || num_cams > c.cap_cams) {
+    const uint64_t gen = c.generation;
+    const int cap = n > c.capacity ? n + n / 4 : c.capacity;  // slack: clouds of a batch differ by a few points
+    const int cams = num_cams > c.cap_cams ? num_cams : c.cap_cams;
+    cloud_free(c);  // hipFree waits for the device: kernels of an earlier cloud on this stream are done
+    c.generation = gen;
+    float **planes[] = {&c.px, &c.py, &c.pz, &c.nx, &c.ny, &c.nz, &c.g_x, &c.g_y, &c.g_z};
+    for (float **p : planes) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float)));
+    HIP_RET(hipMalloc(&c.cam_source, (size_t)cap * cams * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&c.staging, (size_t)cap * 6 * sizeof(float)));
+    HIP_RET(hipMalloc(&c.g_idx, (size_t)cap * sizeof(int32_t)));
+    HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&c.h_pin), (size_t)cap * (6 * sizeof(float) + cams * sizeof(int32_t)), 0));
+    c.capacity = cap;
+    c.cap_cams = cams;
+  }
+  float *hx = reinterpret_cast<float *>(c.h_pin), *hn = hx + (size_t)3 * n;
+  int32_t *hc = reinterpret_cast<int32_t *>(hx + (size_t)6 * n);
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  bool finite = true;
+  for (int i = 0; i < n; i++)
+    for (int a = 0; a < 3; a++) {
+      const float v = xyz[3 * (size_t)i + a];
+      hx[3 * (size_t)i + a] = v;
+      finite &= std::isfinite(v);
+      lo[a] = v < lo[a] ? v : lo[a];
+      hi[a] = v > hi[a] ? v : hi[a];
+    }
+  if (!finite) {  // pcl::removeNaNFromPointCloud runs before the path (candidates_generator.cpp:17); an Inf would
+                  // make the grid dimensions undefined
+    set_error("upload_cloud: the cloud holds non-finite coordinates (remove NaN/Inf points first)");
+    return GPD_ERR_INVALID;
+  }
+  std::memcpy(hn, normals, (size_t)n * 3 * sizeof(float));
+  std::memcpy(hc, cam_source, (size_t)n * num_cams * sizeof(int32_t));
   c.num_points = n;
   c.num_cams = num_cams;
   c.generation++;
   std::memcpy(c.view_points, view_points, sizeof(double) * 3 * num_cams);
-  if ((e = hipMemcpyAsync(c.staging, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(c.staging + (size_t)n * 3, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, stream)) !=
-      hipSuccess)
-    return e;
-  if ((e = hipMemcpyAsync(c.cam_source, cam_source, (size_t)n * num_cams * sizeof(int32_t), hipMemcpyHostToDevice, stream)) !=
-      hipSuccess)
-    return e;
+  HIP_RET(hipMemcpyAsync(c.staging, hx, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, stream));
+  HIP_RET(hipMemcpyAsync(c.cam_source, hc, (size_t)n * num_cams * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   split_soa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c.staging, c.staging + (size_t)n * 3, n, c.px, c.py, c.pz, c.nx, c.ny,
                                                          c.nz);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  // uniform grid: bounds on the host, counting sort on the device
-  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = 0; i < n; i++)
-    for (int a = 0; a < 3; a++) {
-      lo[a] = xyz[3 * i + a] < lo[a] ? xyz[3 * i + a] : lo[a];
-      hi[a] = xyz[3 * i + a] > hi[a] ? xyz[3 * i + a] : hi[a];
-    }
+  HIP_RET(hipGetLastError());
+  // uniform grid: bounds from the pass above, counting sort on the device
   c.g_cell = 0.02f;
   for (;;) {  // at most 256 cells per axis
     bool ok = true;
     for (int a = 0; a < 3; a++) {
       c.g_lo[a] = lo[a];
       c.g_dim[a] = (int)std::floor((hi[a] - lo[a]) / c.g_cell) + 1;
-      if (c.g_dim[a] > 256) ok = false;
+      if (c.g_dim[a] > 256 || c.g_dim[a] < 1) ok = false;
     }
     if (ok) break;
     c.g_cell *= 2.f;
@@ -206,17 +221,20 @@ hipError_t cloud_upload(Cloud &c, const float *xyz, const float *normals, int n,
     if (c.g_cursor) (void)hipFree(c.g_cursor);
     c.g_start = nullptr;
     c.g_cursor = nullptr;
-    if ((e = hipMalloc(&c.g_start, (size_t)(cells + 1) * sizeof(int32_t))) != hipSuccess) return e;
-    if ((e = hipMalloc(&c.g_cursor, (size_t)cells * sizeof(int32_t))) != hipSuccess) return e;
-    c.g_cells_cap = cells;
+    c.g_cells_cap = 0;
+    const int want = cells + cells / 2;
+    HIP_RET(hipMalloc(&c.g_start, (size_t)(want + 1) * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&c.g_cursor, (size_t)want * sizeof(int32_t)));
+    c.g_cells_cap = want;
   }
   GridView g = grid_view(c);
-  if ((e = hipMemsetAsync(c.g_cursor, 0, (size_t)cells * sizeof(int32_t), stream)) != hipSuccess) return e;
+  HIP_RET(hipMemsetAsync(c.g_cursor, 0, (size_t)cells * sizeof(int32_t), stream));
   grid_count_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor);
   grid_scan_kernel<<<1, 1024, 0, stream>>>(c.g_cursor, c.g_start, c.g_cursor, cells);
   grid_scatter_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor, c.g_idx, c.g_x, c.g_y, c.g_z);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  return hipStreamSynchronize(stream);
+  HIP_RET(hipGetLastError());
+  if (sync) HIP_RET(hipStreamSynchronize(stream));
+  return GPD_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -948,6 +966,7 @@ struct HandConsts {
   int min_viable;
   double cos_friction;
   double fw, hand_depth, hand_height, init_bite;
+  FilterConsts filter;  // filterGraspsWorkspace (grasp_detector.cpp:334-398), applied to the valid hands
 };
 
 struct HandParams {
@@ -956,6 +975,7 @@ struct HandParams {
   const double *frames;
   int cap;
   gpd_hand *hands;
+  uint8_t *fvalid;  // hand_eval_kernel: [S][slots] is_valid after filterGraspsWorkspace
   int num_samples;
   int32_t *labels;  // reeval_kernel only: [n][8] rows of the counts table, column 5
 };
@@ -1227,6 +1247,7 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
       z.finger_placement_index = -1;
       z.slot = slot;
       *H = z;
+      P.fvalid[(size_t)s * K.slots + slot] = 0;
     }
     return;
   }
@@ -1390,6 +1411,9 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
     h.half_antipodal = label >= 1;
     h.full_antipodal = label == 2;
     *H = h;
+    // detectGrasps step 2 (grasp_detector.cpp:238): the workspace / aperture filter only clears is_valid, the
+    // record itself stays as the search produced it
+    P.fvalid[(size_t)s * K.slots + slot] = (valid && workspace_ok(K.filter, h)) ? 1 : 0;
   }
 }
 
@@ -1397,7 +1421,7 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
 // Host side
 // ---------------------------------------------------------------------------
 void search_free(SearchState &s) {
-  void *ptrs[] = {s.d_sample_idx, s.d_sample_xyz, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands};
+  void *ptrs[] = {s.d_sample_idx, s.d_sample_xyz, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands, s.d_fvalid};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   s = SearchState();
@@ -1405,7 +1429,7 @@ void search_free(SearchState &s) {
 
 static int search_reserve(SearchState &s, int S, int cap, int slots) {
   if (S <= s.capacity_samples && cap == s.nn_cap) return GPD_OK;
-  const int newS = S > s.capacity_samples ? S : s.capacity_samples;
+  const int newS = S > s.capacity_samples ? S + S / 8 : s.capacity_samples;  // slack: the clouds of a batch differ a little
   search_free(s);
   HIP_RET(hipMalloc(&s.d_sample_idx, (size_t)newS * sizeof(int32_t)));
   HIP_RET(hipMalloc(&s.d_sample_xyz, (size_t)newS * 3 * sizeof(double)));
@@ -1415,13 +1439,14 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
   HIP_RET(hipMalloc(&s.d_frames, (size_t)newS * 12 * sizeof(double)));
   HIP_RET(hipMalloc(&s.d_centers, (size_t)newS * 3 * sizeof(double)));
   HIP_RET(hipMalloc(&s.d_hands, (size_t)newS * slots * sizeof(gpd_hand)));
+  HIP_RET(hipMalloc(&s.d_fvalid, (size_t)newS * slots));
   s.capacity_samples = newS;
   s.nn_cap = cap;
   return GPD_OK;
 }
 
 static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, int S, int cap, bool by_xyz,
-                              hipStream_t stream) {
+                              hipStream_t stream, bool sync_counts) {
   NbParams np;
   np.px = c.px; np.py = c.py; np.pz = c.pz; np.nx = c.nx; np.ny = c.ny; np.nz = c.nz;
   np.num_points = c.num_points;
@@ -1453,15 +1478,18 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   HIP_RET(hipGetLastError());
   centre_kernel<<<(3 * S + 63) / 64, 64, 0, stream>>>(s.d_nn, s.d_counts, cap, S, s.d_centers);
   HIP_RET(hipGetLastError());
-  s.h_counts.resize((size_t)S * 8);
-  HIP_RET(hipMemcpyAsync(s.h_counts.data(), s.d_counts, (size_t)S * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  HIP_RET(hipStreamSynchronize(stream));
+  s.h_counts.clear();
+  if (sync_counts) {
+    s.h_counts.resize((size_t)S * 8);
+    HIP_RET(hipMemcpyAsync(s.h_counts.data(), s.d_counts, (size_t)S * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+  }
   return GPD_OK;
 }
 
 // neighbourhoods of S samples (by index or by coordinates), list capacity grown once if needed
 static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, const int32_t *sample_idx,
-                          const double *sample_xyz, int S, int slots, int *cap_out, hipStream_t stream) {
+                          const double *sample_xyz, int S, int slots, int *cap_out, hipStream_t stream, bool sync_counts = true) {
   int cap = s.nn_cap ? s.nn_cap : 8192;
   int rc = search_reserve(s, S, cap, slots);
   if (rc) return rc;
@@ -1470,8 +1498,9 @@ static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, c
       HIP_RET(hipMemcpyAsync(s.d_sample_xyz, sample_xyz, (size_t)S * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
     else
       HIP_RET(hipMemcpyAsync(s.d_sample_idx, sample_idx, (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    rc = run_neighbourhoods(p, c, s, hc, S, cap, sample_xyz != nullptr, stream);
+    rc = run_neighbourhoods(p, c, s, hc, S, cap, sample_xyz != nullptr, stream, sync_counts);
     if (rc) return rc;
+    if (!sync_counts) break;  // the caller reads `worst found` from the plan summary and retries (search_next_capacity)
     int worst = 0;
     for (int i = 0; i < S; i++) worst = s.h_counts[8 * i + 3] > worst ? s.h_counts[8 * i + 3] : worst;
     if (worst <= cap) break;
@@ -1512,6 +1541,7 @@ static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slo
   hk.hand_depth = p.hand_depth;
   hk.hand_height = p.hand_height;
   hk.init_bite = p.init_bite;
+  hk.filter = filter_consts(p);
   lock = std::unique_lock<std::mutex>(g_hand_mutex);
   int dev = 0;
   HIP_RET(hipGetDevice(&dev));
@@ -1527,13 +1557,26 @@ static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slo
   return GPD_OK;
 }
 
+int search_next_capacity(const SearchState &s, int worst) {
+  if (worst <= s.nn_cap) return s.nn_cap;
+  return worst <= 16384 ? 16384 : 0;
+}
+int search_force_capacity(SearchState &s, int cap) {
+  if (cap == s.nn_cap) return GPD_OK;
+  const int S = s.capacity_samples;
+  search_free(s);
+  s.nn_cap = cap;  // search_reserve allocates on the next run (capacity_samples is 0 now)
+  (void)S;
+  return GPD_OK;
+}
+
 int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, const double *sample_xyz, int S,
-               hipStream_t stream) {
+               hipStream_t stream, bool sync_counts) {
   const int slots = p.num_hand_axes * p.num_orientations;
   HostConsts hc;
   host_consts(p, hc);
   int cap = 0;
-  int rc = neighbourhoods(p, c, s, hc, sample_idx, sample_xyz, S, slots, &cap, stream);
+  int rc = neighbourhoods(p, c, s, hc, sample_idx, sample_xyz, S, slots, &cap, stream, sync_counts);
   if (rc) return rc;
   std::unique_lock<std::mutex> consts_lock;  // held until the kernels that read c_hand are enqueued
   rc = upload_hand_consts(p, hc, slots, stream, consts_lock);
@@ -1544,6 +1587,7 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   hp.frames = s.d_frames;
   hp.cap = cap;
   hp.hands = s.d_hands;
+  hp.fvalid = s.d_fvalid;
   hp.labels = nullptr;
   hp.num_samples = S;
   hand_eval_kernel<<<((S + 7) / 8) * 8 * slots, 256, 0, stream>>>(hp);
@@ -1576,6 +1620,7 @@ int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand
   hp.frames = s.d_frames;
   hp.cap = cap;
   hp.hands = s.d_hands;
+  hp.fvalid = nullptr;
   hp.labels = s.d_counts;
   hp.num_samples = n;
   reeval_kernel<<<n, 256, 0, stream>>>(hp);

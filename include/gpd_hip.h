@@ -157,8 +157,9 @@ int gpd_hip_search_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_
 int gpd_hip_reevaluate(gpd_hip_ctx *ctx, gpd_hand *hands, int num_hands, int32_t *labels);
 
 /* Replaces ImageGenerator::createImages (image_generator.cpp:17-99) for hand
- * sets produced by gpd_hip_search (optionally after the host workspace filter,
- * grasp_detector.cpp:334-398, which clears `valid`).  One image per valid hand
+ * sets produced by the last gpd_hip_search / gpd_hip_detect on this context (optionally after
+ * the host filters, grasp_detector.cpp:334-398 / :422-453, which clear `valid`: only the `valid`
+ * flags and the sets' samples are read from `hands`, the records themselves are on the device).  One image per valid hand
  * in set-major, slot-minor order; sets without a valid hand are skipped like
  * filterGraspsWorkspace drops them.  images (may be NULL: keep on device) holds
  * n_cand * 60*60*C bytes HWC.  cand_index (may be NULL) receives for each image
@@ -167,11 +168,54 @@ int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets,
                    uint8_t *images, int32_t *cand_index, int *num_candidates);
 
 /* Fused path used by GraspDetector::detectGrasps steps 1-4
- * (grasp_detector.cpp:222-273): search, workspace/aperture filter, images,
- * scores; everything stays on the device between the stages.  hands receives
- * num_samples*num_slots records with `score` set on the valid ones. */
+ * (grasp_detector.cpp:222-273): search, workspace/aperture filter
+ * (filterGraspsWorkspace, :238, :334-398), images, scores, score write-back (:269-273).
+ * Everything stays on the device between the stages: the filter runs at the end of the
+ * hand kernel, one small kernel builds the candidate list (set-major, slot-minor, as
+ * image_generator.cpp:91-98) and places every hand set in the shadow LCG stream, and the
+ * only host hop in the middle is a 48-byte summary that sizes the launches.  One copy in
+ * (the samples), one copy out (the records).  hands receives num_sets*num_slots records
+ * (room for num_samples*num_slots is required): `valid` is the flag after the filter,
+ * `score` is set on the valid ones. */
 int gpd_hip_detect(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples,
                    gpd_hand *hands, int *num_sets, int *num_candidates);
+
+/* The same, returning what detectGrasps keeps after step 4 / step 5 instead of every slot:
+ * num_selected == 0: the scored candidates — the `hands` list ImageGenerator::createImages moves
+ *   out of the hand sets (image_generator.cpp:91-98), in that order;
+ * num_selected  > 0: GraspDetector::selectGrasps (grasp_detector.cpp:405-420): the
+ *   min(num_selected, candidates) best, score descending, picked on the device so that only those
+ *   records cross PCIe (equal scores: the arrangement std::partial_sort leaves, as the reference).
+ * hands holds hands_capacity records; *num_hands receives how many were written. */
+int gpd_hip_detect_select(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, int num_selected,
+                          gpd_hand *hands, int hands_capacity, int *num_sets, int *num_candidates,
+                          int *num_hands);
+
+/* One independent cloud of a batch: the arguments of gpd_hip_upload_cloud + gpd_hip_detect_select. */
+typedef struct gpd_detect_job {
+  const float *xyz;            /* in */
+  const float *normals;
+  const int32_t *cam_source;
+  const double *view_points;
+  const int32_t *sample_indices;
+  gpd_hand *hands;             /* out: hands_capacity records */
+  int32_t num_points, num_cams, num_samples;
+  int32_t num_selected;        /* 0: all candidates; > 0: selectGrasps */
+  int32_t hands_capacity;
+  int32_t num_sets, num_candidates, num_hands; /* out */
+  int32_t status;              /* out: GPD_OK or the error of this cloud */
+  float stage_ms[3];           /* out: search, images, LeNet kernel time of this cloud */
+} gpd_detect_job;
+
+/* detect_grasps over a batch of independent clouds (src/detect_grasps.cpp:20-86 called once per
+ * cloud; BASELINE configs[4]).  The context keeps two clouds in flight on two streams: upload, grid
+ * and candidate search of cloud i+1 are enqueued while the image and LeNet kernels of cloud i run,
+ * and the records of cloud i-1 are handed over meanwhile — the host hops of one cloud hide behind
+ * the kernels of its neighbour.  Results are those of num_jobs separate
+ * gpd_hip_upload_cloud + gpd_hip_detect_select calls (the shadow LCG restarts per cloud).  Returns
+ * the first error; each job carries its own status.  The cloud uploaded with gpd_hip_upload_cloud
+ * is replaced. */
+int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs);
 
 /* gpd_hip_detect for samples given by coordinates (see gpd_hip_search_samples). */
 int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples,
@@ -187,7 +231,7 @@ int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]);
  * neighbourhood size N_i, out[3] sum over candidates of N_i. */
 int gpd_hip_last_images_stats(gpd_hip_ctx *ctx, long long out[4]);
 
-/* Re-run stage 3 (stages & 1: grasp images) and/or stage 4 (stages & 2: LeNet) on the
+/* Re-run stage 3 (stages == 1: grasp images), stage 4 (2: LeNet) or both (3) on the
  * candidate list that the last gpd_hip_images / gpd_hip_detect left resident on the
  * device — what calling ImageGenerator::createImages + Classifier::classifyImages
  * again on the same hand sets does (grasp_detector.cpp:261-273), without host hops.

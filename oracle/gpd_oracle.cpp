@@ -1239,6 +1239,7 @@ int gpd_oracle_images(const gpd_params *P, const float *xyz, const float *normal
     radiusSearch(g, q, radius, nbrs[k]);
   }
   std::vector<uint64_t> lcg_off(live.size() + 1, 0);
+  const int num_shadow = (int)std::floor(radius / 0.003);  // as calculateShadow evaluates it
   if (C == 15)
     for (size_t k = 0; k < live.size(); k++) {
       uint64_t d = 0;
@@ -1246,7 +1247,9 @@ int gpd_oracle_images(const gpd_params *P, const float *xyz, const float *normal
       for (int c = 0; c < n_cams; c++) {
         long seen = 0;
         for (int i = 0; i < N; i++) seen += cam_source[(size_t)c * np + nbrs[k][i].idx];
-        if (seen >= 1) d += (uint64_t)N * 33u;
+        // calculateShadowForCamera draws N * num_shadow_points values (hand_set.cpp:202-212),
+        // num_shadow_points = floor(shadow_length / 0.003): 33 only for the default 0.10 m volume
+        if (seen >= 1) d += (uint64_t)N * (uint64_t)num_shadow;
       }
       lcg_off[k + 1] = lcg_off[k] + d;
     }
@@ -1506,6 +1509,21 @@ int gpd_oracle_find_clusters(const gpd_hand *hands, const double *scores, int n,
     }
   }
   return n_out;
+}
+
+// GraspDetector::selectGrasps — grasp_detector.cpp:405-420: std::partial_sort of the hands by
+// isScoreGreater (grasp_detector.h: hand1->getScore() > hand2->getScore()), the first
+// min(num_selected, n) kept.  The algorithm only sees comparator outcomes, so sorting (score, index)
+// pairs in the hands' order reproduces the arrangement the reference's libstdc++ build leaves — also
+// among equal scores.  out_idx receives the indices of the kept hands, in the kept order.
+int gpd_oracle_select(const float *scores, int n, int num_selected, int32_t *out_idx) {
+  std::vector<std::pair<float, int32_t>> v((size_t)n);
+  for (int i = 0; i < n; i++) v[i] = {scores[i], i};
+  const int middle = std::min(n, num_selected);
+  std::partial_sort(v.begin(), v.begin() + middle, v.end(),
+                    [](const std::pair<float, int32_t> &a, const std::pair<float, int32_t> &b) { return a.first > b.first; });
+  for (int i = 0; i < middle; i++) out_idx[i] = v[i].second;
+  return middle;
 }
 
 }  // extern "C"

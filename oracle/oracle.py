@@ -229,6 +229,14 @@ def find_clusters(hands, scores, min_inliers=1, remove_inliers=False):
     return out[:k].copy(), osc[:k].copy(), src[:k].copy()
 
 
+def select(scores, num_selected):
+    """GraspDetector::selectGrasps over a score list -> indices of the kept hands, in the kept order."""
+    sc = np.ascontiguousarray(scores, np.float32)
+    out = np.zeros(max(min(len(sc), num_selected), 1), np.int32)
+    k = lib().gpd_oracle_select(_p(sc), len(sc), int(num_selected), _p(out))
+    return out[:k].copy()
+
+
 def search_xyz(params, xyz, normals, samples):
     """HandSearch::searchHands for samples given by coordinates (f64 [S,3]) -> hands [n_sets, n_slots]."""
     xyz = np.ascontiguousarray(xyz, np.float32)

@@ -1,0 +1,189 @@
+"""The device-resident detect path: workspace filter, candidate compaction, score write-back and
+selectGrasps on the GPU (gpd_hip_detect / gpd_hip_detect_select), and the two-clouds-in-flight batch entry
+(gpd_hip_detect_batch, BASELINE configs[4]) — against the oracle and against the unfused
+search -> host filter -> images -> score route through the same C-ABI."""
+import numpy as np
+import pytest
+
+from gpd_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(C=15):
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden", "lenet%d_params.npz" % C)
+    return synth.lenet_weights(C, real=dict(np.load(g)) if os.path.exists(g) else None)
+
+
+@pytest.fixture(scope="module")
+def ctx(lenet15_real):
+    c = api.Context(api.default_params(15))
+    c.set_lenet_weights(lenet15_real)
+    yield c
+    c.close()
+
+
+def _oracle_candidates(oracle_mod, cl, si, w, p=None):
+    p = p or oracle_mod.default_params(15)
+    oh, on, _ = oracle_mod.detect(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, w)
+    flat = oh.reshape(-1)
+    return oh, flat[flat["valid"].astype(bool)].copy(), on
+
+
+def _same_records(a, b):
+    """byte for byte except the float score (asserted to 1e-4, observed identical)"""
+    assert a.shape == b.shape
+    assert np.abs(a["score"] - b["score"]).max() <= 1e-4 if len(a) else True
+    x, y = a.copy(), b.copy()
+    x["score"] = 0
+    y["score"] = 0
+    assert x.tobytes() == y.tobytes()
+
+
+def test_fused_detect_equals_unfused_route(ctx, oracle_mod, cloud30k, lenet15_real):
+    """gpd_hip_detect (filter + compaction + scatter on the device) against search -> oracle's
+    filterGraspsWorkspace on the host -> images -> score through the same C-ABI."""
+    cl = cloud30k
+    si = synth.sample_indices(cl, 260)
+    ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+    fused, n = ctx.detect(si)
+    hands = oracle_mod.filter_workspace(oracle_mod.default_params(15), ctx.search(si))
+    _, cand = ctx.images(hands, download=False)
+    scores = ctx.score(None, n=len(cand))
+    flat = hands.reshape(-1)
+    flat["score"][cand] = scores
+    assert n == len(cand) and n > 300
+    assert fused.tobytes() == hands.tobytes()
+    # the tight workspace really filters something on the device too
+    p = api.default_params(15)
+    p.workspace_grasps[:] = [-0.1, 0.1, -0.1, 0.12, -1.0, 1.0]
+    op = oracle_mod.default_params(15)
+    op.workspace_grasps[:] = [-0.1, 0.1, -0.1, 0.12, -1.0, 1.0]
+    c2 = api.Context(p)
+    try:
+        c2.set_lenet_weights(lenet15_real)
+        c2.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+        f2, n2 = c2.detect(si)
+        oh, on, _ = oracle_mod.detect(op, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, lenet15_real)
+        assert n2 == on and 0 < n2 < n
+        _same_records(f2.reshape(-1), oh.reshape(-1))
+    finally:
+        c2.close()
+
+
+def test_detect_select_all_and_topk(ctx, oracle_mod, cloud30k, lenet15_real):
+    cl = cloud30k
+    si = synth.sample_indices(cl, 300)
+    ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+    oh, ocand, on = _oracle_candidates(oracle_mod, cl, si, lenet15_real)
+    # every candidate, in (set, slot) order
+    got, ns, nc = ctx.detect_select(si, 0)
+    assert ns == oh.shape[0] and nc == on == len(got) and nc > 400
+    _same_records(got, ocand)
+    # selectGrasps(k): the oracle's std::partial_sort restatement and, scores being distinct here, plain argsort
+    assert len(np.unique(ocand["score"])) == len(ocand)
+    for k in (1, 7, 100, 1000, nc, nc + 5):
+        sel, _, nc2 = ctx.detect_select(si, k)
+        want = oracle_mod.select(ocand["score"], k)
+        assert nc2 == nc and len(sel) == min(k, nc)
+        assert np.array_equal(want, np.argsort(-ocand["score"], kind="stable")[: len(want)])
+        _same_records(sel, ocand[want])
+
+
+def test_detect_select_with_tied_scores(oracle_mod, cloud30k, lenet15_real):
+    """Equal scores: the reference's selectGrasps returns whatever arrangement std::partial_sort leaves
+    (grasp_detector.cpp:409).  With ip2 = 0 every score is the same; with most ip2 weights zeroed and a
+    ReLU-dead ip1 many are — both must come back in exactly that arrangement."""
+    cl = cloud30k
+    si = synth.sample_indices(cl, 200)
+    for variant in ("all_equal", "many_equal"):
+        w = {k: v.copy() for k, v in lenet15_real.items()}
+        if variant == "all_equal":
+            w["f2w"][:] = 0.0
+        else:
+            w["f1b"][:] = -1e6  # ReLU kills every ip1 unit ...
+            w["f1b"][:3] = 0.0  # ... but three
+            w["f1w"] = np.round(w["f1w"] * 8.0) / 8.0
+            w["f2w"] = np.round(w["f2w"] * 4.0) / 4.0
+        c = api.Context(api.default_params(15))
+        try:
+            c.set_lenet_weights(w)
+            c.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+            allc, _, nc = c.detect_select(si, 0)
+            _, ocand, on = _oracle_candidates(oracle_mod, cl, si, w)
+            assert nc == on and np.array_equal(allc["score"], ocand["score"])
+            if variant == "all_equal":
+                assert len(np.unique(ocand["score"])) == 1
+            for k in (5, 64, 300):
+                sel, _, _ = c.detect_select(si, k)
+                want = oracle_mod.select(ocand["score"], k)
+                _same_records(sel, ocand[want])
+        finally:
+            c.close()
+
+
+def test_detect_batch_equals_separate_calls(ctx, oracle_mod, lenet15_real):
+    """configs[4] shape: independent clouds, two in flight on the context's two streams.  Results are those
+    of separate upload + detect calls, whatever the cloud's lane, camera set-up or neighbours in the batch."""
+    clouds, samples = [], []
+    for cid in range(5):
+        cl = dict(synth.make_cloud(300 + cid, 14000 + 1500 * cid))
+        if cid == 2:  # two cameras, another view point: other shadows than its neighbours in the batch
+            P = len(cl["xyz"])
+            cam = np.zeros((2, P), np.int32)
+            cam[0] = cl["xyz"][:, 0] < 0.05
+            cam[1] = cl["xyz"][:, 0] > -0.05
+            cl["cam_source"] = cam
+            cl["view_points"] = np.array([[0.0, 0.0, 0.0], [0.3, 0.1, 0.05]])
+        clouds.append(cl)
+        samples.append(synth.sample_indices(cl, 90 + 10 * cid))
+    samples[3] = samples[3][:0]  # a cloud without samples
+    res = ctx.detect_batch(clouds, samples, 0)
+    assert len(res) == 5
+    for cid, (cl, si) in enumerate(zip(clouds, samples)):
+        hands, ns, nc, ms = res[cid]
+        ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+        one, ns1, nc1 = ctx.detect_select(si, 0)
+        assert (ns, nc) == (ns1, nc1) and hands.tobytes() == one.tobytes()
+        if cid in (0, 2):
+            _, ocand, on = _oracle_candidates(oracle_mod, cl, si, lenet15_real)
+            assert on == nc and nc > 50
+            _same_records(hands, ocand)
+        if cid == 3:
+            assert nc == 0 and len(hands) == 0
+    # selectGrasps inside the batch, twice the same batch -> the same bytes (lanes reuse their buffers)
+    a = ctx.detect_batch(clouds, samples, 25)
+    b = ctx.detect_batch(clouds[::-1], samples[::-1], 25)[::-1]
+    for cid in range(5):
+        assert a[cid][0].tobytes() == b[cid][0].tobytes() and a[cid][1:3] == b[cid][1:3]
+        want = res[cid][0][oracle_mod.select(res[cid][0]["score"], 25)] if len(res[cid][0]) else res[cid][0]
+        assert a[cid][0].tobytes() == want.tobytes()
+
+
+def test_detect_batch_reports_a_bad_cloud(ctx, cloud30k):
+    cl = cloud30k
+    si = synth.sample_indices(cl, 40)
+    bad = dict(cl)
+    bad["xyz"] = cl["xyz"].copy()
+    bad["xyz"][17, 1] = np.inf
+    with pytest.raises(api.GpdHipError, match="non-finite"):
+        ctx.detect_batch([cl, bad, cl], [si, si, si], 0)
+    with pytest.raises(api.GpdHipError, match="non-finite"):
+        ctx.upload_cloud(bad["xyz"], bad["normals"], bad["cam_source"], bad["view_points"])
+    # the context is still usable
+    ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+    _, n = ctx.detect(si)
+    assert n > 20
+
+
+def test_create_rejects_bad_parameters():
+    for field, value in (("hand_axes", 3), ("volume_width", 0.0), ("hand_depth", -0.06), ("finger_width", float("nan")),
+                         ("hand_depth", 0.5)):
+        p = api.default_params(15)
+        if field == "hand_axes":
+            p.hand_axes[0] = value
+        else:
+            setattr(p, field, value)
+        with pytest.raises(api.GpdHipError):
+            api.Context(p)

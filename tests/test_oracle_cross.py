@@ -231,3 +231,40 @@ def test_multi_camera_shadow_against_python_reference(oracle_mod):
                     first = False
                 k += 1
         assert k == len(cand)
+
+
+def test_shadow_lcg_stream_for_another_image_volume(oracle_mod, small_cloud):
+    """HandSet::calculateShadowForCamera draws N * num_shadow_points values per camera and hand set from ONE
+    LCG stream (hand_set.cpp:202-212, 263-266), num_shadow_points = floor(shadow_length / 0.003): 33 for the
+    default 0.10 m volume, 26 for a 0.08 m one.  The oracle (and the HIP path) place every set in the stream by
+    jump-ahead; here the SECOND and later sets are checked against a plain sequential run of the generator."""
+    cl = small_cloud
+    p = oracle_mod.default_params(15)
+    p.volume_width, p.volume_depth, p.volume_height = 0.08, 0.05, 0.03
+    assert int(np.floor(0.08 / 0.003)) == 26
+    si = synth.sample_indices(cl, 8)
+    hands = oracle_mod.filter_workspace(p, oracle_mod.search(p, cl["xyz"], cl["normals"], si))
+    img, cand = oracle_mod.images(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], hands)
+    flat = hands.reshape(-1)
+    rng = pyref.Lcg(0)
+    k = 0
+    live = 0
+    checked = 0
+    for s in range(hands.shape[0]):
+        if not hands[s]["valid"].any():
+            continue
+        nbr = pyref.radius_neighbours(cl["xyz"], hands[s, 0]["sample"].astype(np.float32), 0.08)
+        vox = pyref.shadow_voxels(cl["xyz"][nbr], cl["view_points"][0], rng, shadow_length=0.08)
+        first = True
+        for j in range(hands.shape[1]):
+            if not hands[s, j]["valid"]:
+                continue
+            if live >= 1 and first and checked < 3:  # sets after the first: their stream offset matters
+                want = pyref.grasp_image(p, flat[cand[k]], cl["xyz"], cl["normals"], nbr, vox)
+                assert want[..., 4].any()
+                assert np.array_equal(img[k], want), "set %d: %d pixels differ" % (s, (img[k] != want).sum())
+                checked += 1
+            first = False
+            k += 1
+        live += 1
+    assert checked >= 2
