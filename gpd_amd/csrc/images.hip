@@ -599,6 +599,13 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     const int ox = (int)floor(B.sample[0] * K.voxel_mult) - SR, oy = (int)floor(B.sample[1] * K.voxel_mult) - SR,
               oz = (int)floor(B.sample[2] * K.voxel_mult) - SR;
     const int zlo = z0 - oz;
+    // t_a(z + 1) - t_a(z) = F[6 + a] * voxel, the same for every row
+    double invBz[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const double bz = B.F[6 + a] * K.voxel;
+      invBz[a] = uniform_f64(fabs(bz) > 1e-9 ? 1.0 / bz : 0.0);
+    }
     for (int row = tid; row < VDIM * VDIM; row += IMG_THREADS) {
       const int ix = row / VDIM, iy = row - ix * VDIM;
       const int sx = x0 + ix - ox, sy = y0 + iy - oy;
@@ -619,6 +626,32 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
       }
       const int nbits = zb - za;
       field &= (nbits >= 64) ? ~0ull : ((1ull << nbits) - 1ull);
+      if (field) {
+        // The row is a line along world z: its hand-frame coordinates are affine in z, so the part that can lie in
+        // the box is an interval, found from the three slabs and widened by 1.5 voxels.  It only spares work — the
+        // exact f64 box test below decides for every voxel that is left (the set voxels of the rows around a box
+        // are ~3x those inside it, and a lane's trip count is what its whole wave waits for).
+        double tb[3];
+        to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(za - zlo + z0) * K.voxel, tb);
+        double dmin = 0.0, dmax = (double)(nbits - 1);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          if (invBz[a] != 0.0) {
+            const double d0 = (B.lo[a] - tb[a]) * invBz[a], d1 = (B.hi[a] - tb[a]) * invBz[a];
+            dmin = fmax(dmin, fmin(d0, d1) - 1.5);
+            dmax = fmin(dmax, fmax(d0, d1) + 1.5);
+          } else if (tb[a] < B.lo[a] - 1e-6 || tb[a] > B.hi[a] + 1e-6) {
+            dmax = -1.0;  // the row runs parallel to this slab, outside it
+          }
+        }
+        if (dmax < dmin) {
+          field = 0ull;
+        } else {
+          const int t0 = (int)ceil(dmin), t1 = (int)floor(dmax);
+          if (t0 > 0) field &= ~((1ull << t0) - 1ull);
+          if (t1 < 63) field &= (2ull << t1) - 1ull;
+        }
+      }
       while (field) {
         const int t = __ffsll((long long)field) - 1;
         field &= field - 1;

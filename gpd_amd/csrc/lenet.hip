@@ -18,7 +18,7 @@
 //   conv2_mfma   persistent; pool1 planes + 96 KB of weights in LDS, implicit GEMM + pool
 //                (+ 2 filters riding in the same waves on the VALU), output in the reference's
 //                flatten order j = pixel*50 + channel            -> flat  [n][7200]
-//   fc1_mfma     [500 x 7200] x [7200 x n] on v_mfma_f32_32x32x2_f32, + bias, ReLU
+//   fc1_mfma     [500 x 7200] x [7200 x n] on v_mfma_f32_16x16x4_f32, 128 x 16..128 tiles picked per launch, + bias, ReLU
 //                                                               -> fc1t  [500][n]
 //   fc2_score    2 x 500 chains per image, score = y1 - y0       -> scores[n]
 #include "gpd_internal.h"
@@ -378,97 +378,154 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
 #undef C2_EACH
 
 // ---------------------------------------------------------------------------
-// FC1 on f32 MFMA:  D[u][m] = sum_k W[k][u] * X[m][k]   (W = ip1 weights, column-
-// major 500x7200 == row-major [7200][500]; X = flat).  Block tile FC_BU(u) x FC_BM(m),
-// one 32x32 tile per wave, K stepped by 16 through LDS.
-// A operand (lane l): W[k0 + (l>>5)][u0 + (l&31)],  B operand: X[m0 + (l&31)][k0 + (l>>5)].
-// D layout: col(m) = lane&31, row(u) = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// FC1 on f32 MFMA:  D[u][m] = sum_k W[k][u] * X[m][k]   (W = ip1 weights, column-major 500x7200 ==
+// row-major [7200][500], dense_layer.cpp:7; X = flat, the pixel-major flatten of eigen_classifier.cpp:103-107).
+//
+// Workgroup tile 128 (u) x 16*NT (m), eight waves, each 16 (u) x 16*NT (m) on v_mfma_f32_16x16x4_f32:
+//   A operand (lane l): W[k0 + (l >> 4)][u = l & 15]   B operand: X[m = l & 15][k0 + (l >> 4)]
+//   D (lane l, reg r):  u = 4 * (l >> 4) + r, m = l & 15
+// K is walked in order, 4 per MFMA, so every output is still the k-ascending fmaf chain of the oracle.
+//
+// The GEMM is small (36 GFLOP at n = 5000) against 1024 SIMDs, so the tile shape decides the balance:
+// 4 u-tiles x ceil(n / (16 NT)) m-tiles, NT picked per launch so that the m-tiles fill the 64 workgroup
+// columns of the chip in whole rounds (n = 5000: NT = 5, 4 x 63 = 252 workgroups on 256 CUs, one round —
+// the 64 x 64 tiles of round 1 left a 3-tile makespan on 2.47 tiles per SIMD).  128-wide u-tiles also halve
+// the operand traffic per flop from L2 (2.3 GB per launch at 64 x 64).  The four u-tiles of an m-tile run
+// on ONE XCD (workgroup L runs on XCD L % 8), so the image rows are fetched from HBM once.
+// LDS: three stages of K = 32 (W rows padded to 144 floats, X k-major with a row stride = 17 mod 32: both the
+// transposing writes and the MFMA operand reads are bank-conflict free); global loads run two stages ahead
+// through two register sets.
 // ---------------------------------------------------------------------------
-constexpr int FC_BU = 64, FC_BM = 64, FC_BK = 32;  // 16 x 79 = 1264 two-wave tiles at n = 5000: ~5 per CU, balanced
-constexpr int FC_THREADS = 64 * (FC_BU / 32) * (FC_BM / 32);
+constexpr int FC_BU = 128, FC_BK = 32, FC_THREADS = 512, FC_SW = FC_BU + 16, FC_STEPS = kFc1In / FC_BK;
+static_assert(kFc1In % FC_BK == 0, "K steps");
+__host__ __device__ constexpr int fc_sx(int bm) { return (bm % 32 == 16) ? bm + 1 : bm + 17; }
 
+template <int NT>
 __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__restrict__ W, const float *__restrict__ bias,
-                                                              const float *__restrict__ X, float *__restrict__ out_t, int n, int ld_out,
-                                                              int n_u_tiles) {
-  __shared__ __attribute__((aligned(16))) float s_w[2][FC_BK][FC_BU];  // double-buffered: one barrier per K step
-  __shared__ __attribute__((aligned(16))) float s_x[2][FC_BK][FC_BM + 1];
+                                                              const float *__restrict__ X, float *__restrict__ out_t, int n, int ld_out) {
+  constexpr int BM = 16 * NT, SX = fc_sx(BM);
+  constexpr int STAGE = FC_BK * FC_SW + FC_BK * SX;  // floats per stage: W tile, then X tile
+  __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];
   const int tid = threadIdx.x;
-  // XCD-aware tile order (workgroup L runs on XCD L % 8, each XCD has its own L2): the output
-  // tiles of one image tile get consecutive slots on ONE XCD, so the image rows (64 x 7200 floats)
-  // are fetched from HBM once instead of once per XCD (1.26 GB -> ~0.2 GB per launch).
   const int L = blockIdx.x;
   const int xcd = L & 7, slot = L >> 3;
-  const int u_tile = slot % n_u_tiles;
-  const int m_tile = (slot / n_u_tiles) * 8 + xcd;
-  const int u0 = u_tile * FC_BU;
-  const int m0 = m_tile * FC_BM;
+  const int u0 = (slot & 3) * FC_BU;
+  const int m0 = ((slot >> 2) * 8 + xcd) * BM;
   if (m0 >= n) return;
   const int wave = tid >> 6, lane = tid & 63;
-  constexpr int WU = FC_BU / 32;
-  const int wu = (wave % WU) * 32, wm = (wave / WU) * 32;
-  f32x16 acc;
+  const int g = lane >> 4, j = lane & 15;
+  f32x4 acc[NT];
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
-  // loader roles: W tile FC_BK x FC_BU and X tile FC_BM x FC_BK as float4, round-robin over the threads
-  constexpr int W_V = FC_BK * FC_BU / 4, X_V = FC_BM * FC_BK / 4;
-  constexpr int W_PT = (W_V + FC_THREADS - 1) / FC_THREADS, X_PT = (X_V + FC_THREADS - 1) / FC_THREADS;
-  // register prefetch: the loads of step k0 + FC_BK are in flight during the MFMAs of step k0
-  float4 wv[W_PT], xv[X_PT];
-  auto fetch = [&](int k0) {
+  for (int t = 0; t < NT; t++)
 #pragma unroll
-    for (int i = 0; i < W_PT; i++) {
-      const int v = tid + i * FC_THREADS;
-      const int k = v / (FC_BU / 4), u = (v % (FC_BU / 4)) * 4;
-      wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v < W_V && u0 + u < kFc1Out) wv[i] = *reinterpret_cast<const float4 *>(W + (size_t)(k0 + k) * kFc1Out + u0 + u);
-    }
+    for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
+  // loader roles.  W tile: 32 rows x 32 float4 -> two per thread.  X tile: BM rows x 8 float4 (eight lanes
+  // per image row: 128-byte segments), ceil(BM * 8 / 512) per thread.
+  constexpr int XV = BM * 8, X_PT = (XV + FC_THREADS - 1) / FC_THREADS;
+  const int wk = tid >> 5, wuq = tid & 31;  // + 16 rows for the second float4
+  // every load is unconditional (out-of-range lanes read a clamped address and their value is dropped at the
+  // LDS store): straight-line loads let the compiler count them, so the wait before a stage's LDS stores
+  // covers only ITS loads, not the ones issued for the stage after it
+  const bool w_ok = u0 + 4 * wuq < kFc1Out;
+  const float *wsrc = W + (size_t)wk * kFc1Out + min(u0 + 4 * wuq, kFc1Out - 4);
+  const float *xsrc[X_PT];
+  int xm[X_PT], xkq[X_PT];
 #pragma unroll
-    for (int i = 0; i < X_PT; i++) {
-      const int v = tid + i * FC_THREADS;
-      const int m = v / (FC_BK / 4), k = (v % (FC_BK / 4)) * 4;
-      xv[i] = *reinterpret_cast<const float4 *>(X + (size_t)min(m0 + m, n - 1) * kFc1In + k0 + k);
-    }
-  };
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < W_PT; i++) {
-      const int v = tid + i * FC_THREADS;
-      if (v < W_V) *reinterpret_cast<float4 *>(&s_w[buf][v / (FC_BU / 4)][(v % (FC_BU / 4)) * 4]) = wv[i];
-    }
-#pragma unroll
-    for (int i = 0; i < X_PT; i++) {
-      const int v = tid + i * FC_THREADS;
-      const int m = v / (FC_BK / 4), k = (v % (FC_BK / 4)) * 4;
-      if (v < X_V) {
-        s_x[buf][k + 0][m] = xv[i].x;
-        s_x[buf][k + 1][m] = xv[i].y;
-        s_x[buf][k + 2][m] = xv[i].z;
-        s_x[buf][k + 3][m] = xv[i].w;
-      }
-    }
-  };
-  fetch(0);
-  stage(0);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = 0; k0 < kFc1In; k0 += FC_BK) {
-    const bool more = k0 + FC_BK < kFc1In;
-    if (more) fetch(k0 + FC_BK);
-#pragma unroll
-    for (int kk = 0; kk < FC_BK; kk += 2) {
-      const float a = s_w[cur][kk + (lane >> 5)][wu + (lane & 31)];
-      const float bb = s_x[cur][kk + (lane >> 5)][wm + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
-    }
-    if (more) stage(cur ^ 1);  // the other buffer was last read before the previous barrier
-    __syncthreads();
-    cur ^= 1;
+  for (int i = 0; i < X_PT; i++) {
+    const int v = min(tid + i * FC_THREADS, XV - 1);
+    xm[i] = v >> 3;
+    xkq[i] = v & 7;
+    xsrc[i] = X + (size_t)min(m0 + xm[i], n - 1) * kFc1In + 4 * xkq[i];
   }
-  const int m = m0 + wm + (lane & 31);
+  float4 rw[2][2], rx[2][X_PT];
+  auto fetch = [&](int step, float4(&w2)[2], float4(&x2)[X_PT]) {
+    const size_t k0 = (size_t)step * FC_BK;
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int u = u0 + wu + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (u < kFc1Out && m < n) out_t[(size_t)u * ld_out + m] = fmaxf(acc[r] + bias[u], 0.f);
+    for (int i = 0; i < 2; i++) w2[i] = *reinterpret_cast<const float4 *>(wsrc + (k0 + 16 * i) * kFc1Out);
+#pragma unroll
+    for (int i = 0; i < X_PT; i++) x2[i] = *reinterpret_cast<const float4 *>(xsrc[i] + k0);
+  };
+  auto stage = [&](int buf, const float4(&w2)[2], const float4(&x2)[X_PT]) {
+    float *sw = smem + buf * STAGE, *sx = sw + FC_BK * FC_SW;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      *reinterpret_cast<float4 *>(sw + (wk + 16 * i) * FC_SW + 4 * wuq) = w_ok ? w2[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < X_PT; i++)
+      if (tid + i * FC_THREADS < XV) {
+        float *d = sx + (4 * xkq[i]) * SX + xm[i];
+        d[0] = x2[i].x;
+        d[SX] = x2[i].y;
+        d[2 * SX] = x2[i].z;
+        d[3 * SX] = x2[i].w;
+      }
+  };
+  auto compute = [&](int buf) {
+    const float *sw = smem + buf * STAGE + g * FC_SW + wave * 16 + j;
+    const float *sx = smem + buf * STAGE + FC_BK * FC_SW + g * SX + j;
+    float a_cur = sw[0], a_nxt = 0.f, b_cur[NT], b_nxt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) b_cur[t] = sx[16 * t];
+#pragma unroll
+    for (int ks = 0; ks < FC_BK / 4; ks++) {
+      if (ks + 1 < FC_BK / 4) {  // operands of the next four k are requested before this step's MFMAs ...
+        a_nxt = sw[(4 * (ks + 1)) * FC_SW];
+#pragma unroll
+        for (int t = 0; t < NT; t++) b_nxt[t] = sx[(4 * (ks + 1)) * SX + 16 * t];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // ... and arrive while they run (the scheduler would sink the reads to their uses)
+#pragma unroll
+      for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+#pragma unroll
+      for (int t = 0; t < NT; t++) b_cur[t] = b_nxt[t];
+    }
+  };
+  // prologue: stage 0 in LDS, stage 1 in register set 1
+  fetch(0, rw[0], rx[0]);
+  stage(0, rw[0], rx[0]);
+  fetch(1, rw[1], rx[1]);
+  __syncthreads();
+  // step t: loads of step t + 2 go out first (register set t % 2), the MFMAs of stage t % 3 run, the loads of
+  // step t + 1 (issued a whole step ago) are written to stage (t + 1) % 3, whose readers finished before the
+  // last barrier
+  auto step = [&](int t, float4(&w_far)[2], float4(&x_far)[X_PT], const float4(&w_near)[2], const float4(&x_near)[X_PT]) {
+    if (t + 2 < FC_STEPS) fetch(t + 2, w_far, x_far);
+    compute(t % 3);
+    if (t + 1 < FC_STEPS) stage((t + 1) % 3, w_near, x_near);
+    __syncthreads();
+  };
+  int t = 0;
+  for (; t + 1 < FC_STEPS; t += 2) {
+    step(t, rw[0], rx[0], rw[1], rx[1]);
+    step(t + 1, rw[1], rx[1], rw[0], rx[0]);
+  }
+  if (t < FC_STEPS) step(t, rw[0], rx[0], rw[1], rx[1]);
+  // bias, ReLU (eigen_classifier.cpp:113), transposed store for ip2
+#pragma unroll
+  for (int tt = 0; tt < NT; tt++) {
+    const int m = m0 + 16 * tt + j;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int u = u0 + wave * 16 + 4 * g + r;
+      if (u < kFc1Out && m < n) out_t[(size_t)u * ld_out + m] = fmaxf(acc[tt][r] + bias[u], 0.f);
+    }
+  }
+}
+
+template <int NT>
+static void fc1_launch(const float *W, const float *bias, const float *X, float *out_t, int n, int ld_out, hipStream_t stream) {
+  const int m_tiles = (n + 16 * NT - 1) / (16 * NT);
+  const int groups = (m_tiles + 7) / 8;
+  fc1_mfma_kernel<NT><<<groups * 4 * 8, FC_THREADS, 0, stream>>>(W, bias, X, out_t, n, ld_out);
+}
+// m-tile width: the smallest multiple of 16 (at most 128) whose tiles fill the chip's 64 workgroup columns
+// (256 CUs / 4 u-tiles) in r whole rounds, r as small as possible
+static int fc1_pick_nt(int n) {
+  for (int r = 1;; r++) {
+    const int nt = (n + 64 * r * 16 - 1) / (64 * r * 16);
+    if (nt <= 8) return nt < 1 ? 1 : nt;
   }
 }
 
@@ -535,8 +592,16 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
     conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m);
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[1], stream);
-    const int n_u_tiles = (kFc1Out + FC_BU - 1) / FC_BU, n_m_groups = ((m + FC_BM - 1) / FC_BM + 7) / 8;
-    fc1_mfma_kernel<<<n_u_tiles * n_m_groups * 8, FC_THREADS, 0, stream>>>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, n_u_tiles);
+    switch (fc1_pick_nt(m)) {
+      case 1: fc1_launch<1>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+      case 2: fc1_launch<2>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+      case 3: fc1_launch<3>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+      case 4: fc1_launch<4>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+      case 5: fc1_launch<5>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+      case 6: fc1_launch<6>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+      case 7: fc1_launch<7>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+      default: fc1_launch<8>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
+    }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[2], stream);
     fc2_score_kernel<<<(m + 255) / 256, 256, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
   }

@@ -124,9 +124,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(PlanParams P) {
       } else if (has_set && ns_pre < P.num_sets_given) {
         for (int j = 0; j < P.slots; j++)
           if (P.set_flags[(size_t)ns_pre * P.slots + j]) vmask |= 1u << j;
-        bool same = true;
+        bool same = true;  // checked for the sets that contribute a candidate (the caller may pass husks for the others)
         for (int r = 0; r < 3; r++) same &= P.set_samples[3 * (size_t)ns_pre + r] == P.frames[12 * (size_t)s + r];
-        if (!same) atomicMin(&s_mismatch, ns_pre);
+        if (vmask && !same) atomicMin(&s_mismatch, ns_pre);
       }
       nv = __popc(vmask);
       if (nv && P.shadow && Ni > 0) {

@@ -101,7 +101,10 @@ class GraspDetector {
   std::vector<gpd_hand> flatten(const std::vector<std::unique_ptr<candidate::HandSet>> &sets) const;
   gpd_params params_;
   gpd_hip_ctx *ctx_ = nullptr;
+  std::shared_ptr<net::Classifier> classifier_;  // grasp_detector.h: classifier_, made by net::Classifier::create
   bool has_classifier_ = false;
+  bool fused_classifier_ = false;  // the classifier is the HIP back-end and its parameters are loaded in ctx_
+  bool plugin_route_ = false;      // cfg classifier_plugin_route: score through Classifier::classifyImages
   int num_samples_ = 1000;
   bool voxelize_ = true;
   double voxel_size_ = 0.003, normals_radius_ = 0.03;

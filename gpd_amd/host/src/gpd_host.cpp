@@ -332,10 +332,9 @@ namespace net {
 
 std::shared_ptr<Classifier> Classifier::create(const std::string &model_file, const std::string &weights_file, Device device,
                                                int batch_size) {
-  if (device != Device::eGPU) {
-    printf("ERROR: this build only has the HIP classifier (device = 1); no CPU back-end is linked.\n");
-    return nullptr;
-  }
+  // one back-end is compiled in, as in the reference's builds (classifier.cpp:46-62); see classifier.h
+  if (device != Device::eGPU)
+    printf("NOTE: classifier device = %d requested; this build's only back-end (HipClassifier) runs on the GPU.\n", (int)device);
   auto c = std::make_shared<HipClassifier>(model_file, weights_file, device, batch_size);
   if (!c->ok()) return nullptr;
   return c;
@@ -356,12 +355,12 @@ std::vector<float> HipClassifier::readBinaryFileIntoVector(const std::string &lo
 HipClassifier::HipClassifier(const std::string &, const std::string &weights_file, Classifier::Device, int batch_size)
     : batch_size_(batch_size) {
   const std::string &dir = weights_file;
-  auto c1w = readBinaryFileIntoVector(dir + "conv1_weights.bin"), c1b = readBinaryFileIntoVector(dir + "conv1_biases.bin");
-  auto c2w = readBinaryFileIntoVector(dir + "conv2_weights.bin"), c2b = readBinaryFileIntoVector(dir + "conv2_biases.bin");
-  auto f1w = readBinaryFileIntoVector(dir + "ip1_weights.bin"), f1b = readBinaryFileIntoVector(dir + "ip1_biases.bin");
-  auto f2w = readBinaryFileIntoVector(dir + "ip2_weights.bin"), f2b = readBinaryFileIntoVector(dir + "ip2_biases.bin");
-  if (c1w.size() % 500 != 0 || c1w.empty() || c1b.size() != 20 || c2w.size() != 25000 || c2b.size() != 50 ||
-      f1w.size() != 3600000 || f1b.size() != 500 || f2w.size() != 1000 || f2b.size() != 2) {
+  static const char *files[8] = {"conv1_weights.bin", "conv1_biases.bin", "conv2_weights.bin", "conv2_biases.bin",
+                                 "ip1_weights.bin",   "ip1_biases.bin",   "ip2_weights.bin",   "ip2_biases.bin"};
+  for (int i = 0; i < 8; i++) params_[i] = readBinaryFileIntoVector(dir + files[i]);
+  const auto &c1w = params_[0];
+  if (c1w.size() % 500 != 0 || c1w.empty() || params_[1].size() != 20 || params_[2].size() != 25000 || params_[3].size() != 50 ||
+      params_[4].size() != 3600000 || params_[5].size() != 500 || params_[6].size() != 1000 || params_[7].size() != 2) {
     printf("ERROR: LeNet parameter files in %s are missing or have unexpected sizes\n", dir.c_str());
     return;
   }
@@ -374,8 +373,8 @@ HipClassifier::HipClassifier(const std::string &, const std::string &weights_fil
     ctx_ = nullptr;
     return;
   }
-  if (gpd_hip_set_lenet_weights(ctx_, channels_, c1w.data(), c1b.data(), c2w.data(), c2b.data(), f1w.data(), f1b.data(), f2w.data(),
-                                f2b.data()) != GPD_OK) {
+  if (gpd_hip_set_lenet_weights(ctx_, channels_, params_[0].data(), params_[1].data(), params_[2].data(), params_[3].data(),
+                                params_[4].data(), params_[5].data(), params_[6].data(), params_[7].data()) != GPD_OK) {
     printf("ERROR: %s\n", gpd_hip_last_error());
     return;
   }
@@ -492,26 +491,39 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
     ctx_ = nullptr;
     return;
   }
-  // classifier (grasp_detector.cpp:129-145): weights_file is the parameter directory
+  // classifier (grasp_detector.cpp:129-145): created through the plugin factory, as the reference does.  For the
+  // Eigen-layout parameters weights_file is the parameter directory.
+  std::string model_file = config_file.getValueOfKeyAsString("model_file", "");
   std::string weights_file = config_file.getValueOfKeyAsString("weights_file", "");
-  if (!weights_file.empty()) {
+  if (!model_file.empty() || !weights_file.empty()) {
+    const int device = config_file.getValueOfKey<int>("device", 0);
+    const int batch_size = config_file.getValueOfKey<int>("batch_size", 1);
     const std::string dir = resolve(weights_file, cfg_dir);
-    typedef net::HipClassifier HC;
-    auto c1w = HC::readBinaryFileIntoVector(dir + "conv1_weights.bin"), c1b = HC::readBinaryFileIntoVector(dir + "conv1_biases.bin");
-    auto c2w = HC::readBinaryFileIntoVector(dir + "conv2_weights.bin"), c2b = HC::readBinaryFileIntoVector(dir + "conv2_biases.bin");
-    auto f1w = HC::readBinaryFileIntoVector(dir + "ip1_weights.bin"), f1b = HC::readBinaryFileIntoVector(dir + "ip1_biases.bin");
-    auto f2w = HC::readBinaryFileIntoVector(dir + "ip2_weights.bin"), f2b = HC::readBinaryFileIntoVector(dir + "ip2_biases.bin");
-    const size_t want_c1 = (size_t)20 * 25 * params_.image_num_channels;
-    if (c1w.size() == want_c1 && c1b.size() == 20 && c2w.size() == 25000 && c2b.size() == 50 && f1w.size() == 3600000 &&
-        f1b.size() == 500 && f2w.size() == 1000 && f2b.size() == 2 &&
-        gpd_hip_set_lenet_weights(ctx_, params_.image_num_channels, c1w.data(), c1b.data(), c2w.data(), c2b.data(), f1w.data(),
-                                  f1b.data(), f2w.data(), f2b.data()) == GPD_OK) {
+    classifier_ = net::Classifier::create(model_file, dir, static_cast<net::Classifier::Device>(device), batch_size);
+    printf("============ CLASSIFIER ======================\nmodel_file: %s\nweights_file: %s\nbatch_size: %d\n"
+           "==============================================\n",
+           model_file.c_str(), dir.c_str(), batch_size);
+    // detectGrasps normally runs search -> images -> scores fused on the device, in ctx_: the HIP back-end's
+    // parameters are loaded there as well.  Any other Classifier (or cfg classifier_plugin_route = 1) is driven
+    // through classifyImages, the reference's own sequence (grasp_detector.cpp:261-273).
+    auto *hc = dynamic_cast<net::HipClassifier *>(classifier_.get());
+    if (!classifier_) {
+      printf("ERROR: could not create the classifier from %s\n", dir.c_str());
+    } else if (!hc) {
+      has_classifier_ = true;  // a foreign back-end: plugin route only
+    } else if (hc->channels() != params_.image_num_channels) {
+      printf("ERROR: the classifier's %d channels do not match image_num_channels = %d\n", hc->channels(), params_.image_num_channels);
+      classifier_.reset();
+    } else if (gpd_hip_set_lenet_weights(ctx_, hc->channels(), hc->parameter(0).data(), hc->parameter(1).data(),
+                                         hc->parameter(2).data(), hc->parameter(3).data(), hc->parameter(4).data(),
+                                         hc->parameter(5).data(), hc->parameter(6).data(), hc->parameter(7).data()) == GPD_OK) {
       has_classifier_ = true;
+      fused_classifier_ = true;
     } else {
-      printf("ERROR: could not load the LeNet parameters from %s\n", dir.c_str());
+      printf("ERROR: %s\n", gpd_hip_last_error());
+      classifier_.reset();
     }
-    printf("============ CLASSIFIER ======================\nweights_file: %s\n==============================================\n",
-           dir.c_str());
+    plugin_route_ = config_file.getValueOfKey<int>("classifier_plugin_route", 0) != 0;
   }
 }
 
@@ -897,6 +909,8 @@ bool GraspDetector::createGraspImages(util::Cloud &cloud, std::vector<std::uniqu
     std::vector<std::vector<bool>> keep(n_sets, std::vector<bool>(slots, false));
     for (int s = 0; s < n_sets; s++) sets[s]->sample_[0] = s;  // remember the set number through the move
     auto filtered = filterGraspsWorkspace(sets, workspace_grasps_);
+    if (filter_approach_direction_)  // grasp_detector.cpp:505-512
+      filtered = filterGraspsDirection(filtered, direction_, thresh_rad_);
     for (auto &hs : filtered) keep[(int)hs->sample_[0]] = hs->getIsValid();
     for (int s = 0; s < n_sets; s++)
       for (int j = 0; j < slots; j++) recs[(size_t)s * slots + j].valid = keep[s][j] ? 1 : 0;
@@ -944,7 +958,22 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
   int n_sets = 0, n_cand = 0;
   std::vector<std::unique_ptr<candidate::Hand>> hands;
   float ms[3] = {0, 0, 0};
-  if (!filter_approach_direction_) {
+  if (plugin_route_ || !fused_classifier_) {
+    // the reference's own sequence through the plugin interface (grasp_detector.cpp:222-273): candidates ->
+    // filterGraspsWorkspace [-> filterGraspsDirection] -> ImageGenerator::createImages -> classifier_->classifyImages
+    // -> hands[i]->setScore
+    util::Cloud work = cloud;
+    std::vector<std::unique_ptr<net::Image>> images;
+    if (!createGraspImages(work, hands, images)) return hands_out;
+    float t[3];
+    gpd_hip_last_stage_ms(ctx_, t);
+    ms[0] = t[0];
+    ms[1] = t[1];
+    const double tc = now_s();
+    const std::vector<float> scores = classifier_->classifyImages(images);
+    ms[2] = (float)((now_s() - tc) * 1e3);
+    for (size_t i = 0; i < hands.size(); i++) hands[i]->setScore(scores[i]);
+  } else if (!filter_approach_direction_) {
     // steps 1-4 fused on the device (grasp_detector.cpp:222-273)
     if (!searchDevice(cloud, true, recs, n_sets, n_cand)) return hands_out;
     printf("Generated %d hand sets.\n", n_sets);
