@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpd_hip.so")
+# GPD_HIP_LIB: another build of the same library (A/B timing of a kernel change on one GPU box)
+LIB_PATH = os.environ.get("GPD_HIP_LIB") or os.path.join(_HERE, "libgpd_hip.so")
 _LIB = None
 
 # numpy mirror of `gpd_hand` (include/gpd_hip.h)

@@ -55,7 +55,8 @@ namespace gpd {
 constexpr int IMG_THREADS = 512;   // 256 VGPRs per lane: no spills (1024 threads measured equally fast but spilled)
 constexpr int SET_THREADS = 1024;  // shadow_set_kernel
 constexpr int IMG_WAVES = IMG_THREADS / 64;
-constexpr int PT_CAP = 2048;  // in-box points per candidate (entry indices are packed into 11 bits of the segment words)
+constexpr int PT_CAP = 1024;  // in-box points per candidate on the two-per-CU instantiation (mean ~380 on the 3 mm benchmark clouds; entry
+                              // indices are packed into 11 bits of the segment words); fuller boxes go to the large instantiation
 constexpr int PT_CAP_BIG = 16384;  // fallback instantiation of the points kernel: storage in a global scratch row
 constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
 constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
@@ -120,15 +121,21 @@ struct PointArrays {
                         // cx | cy << 6 | cz << 12 | neighbour rank << 18: one 16-byte read per visit
 };
 struct NoPointArrays {};
+// Under 80 KB for the small instantiation, so that two workgroups — two grasp_image ones, or one of them next to a
+// shadow_image one of another stream — share a CU (the kernels wait on LDS round trips and barriers most of their
+// time; the second resident workgroup fills those gaps).  What made it 155 KB before: three normal planes + a depth
+// plane held at once (57.6 KB) and 2048-point arrays.  Now the walks leave their four values per NON-EMPTY pixel
+// (at most one per in-box point) and the planes are rebuilt one after the other in the storage of the segment
+// counters, dilated straight into registers.
 template <bool BIG>
 struct __attribute__((aligned(16))) SmemPts {
   typename std::conditional<BIG, NoPointArrays, PointArrays>::type p;
-  float raster[3][kPix];  // cell-index order (row flip applied at the store)
-  uint32_t cells[kPix];   // (segment start << 16) | count; reused as the f32 depth plane
+  uint32_t cells[kPix];   // (segment start << 16) | count of a pixel; after the walks: the f32 plane being finished
   uint32_t place[BIG ? PT_CAP_BIG : PT_CAP];  // segment table: neighbour rank << EB | entry (sorts without a gather)
-  uint16_t nzlist[kPix];                      // list of the non-empty cells
+  float4 nzv[BIG ? kPix : PT_CAP];            // per non-empty pixel: the three normal values and the depth value
+  uint16_t nzlist[BIG ? kPix : PT_CAP];       // the non-empty pixels, longest segment first
   double thr[3][kImg + 1];
-  double recip[256];  // 1.0 / k
+  double recip[128];  // 1.0 / k
   float red_f[4 * IMG_WAVES];
   int red_i[IMG_WAVES];
   int counter;
@@ -425,6 +432,83 @@ __device__ void finalize_planes(SM &S, const float *p012, const float *p3, uint8
     }
   }
   __syncthreads();
+}
+
+// ---- one plane at a time (grasp_image_kernel): the same arithmetic as finalize_planes, with the dilated values
+//      of a thread's pixel groups kept in registers across the planes that are normalised together
+constexpr int GPT = (900 + IMG_THREADS - 1) / IMG_THREADS;  // groups of 4 pixels per thread and plane
+__device__ inline void dilate_plane(const float *pl, float (&d)[GPT][4], float &mn, float &mx) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < GPT; k++) {
+    const int g = tid + k * IMG_THREADS;
+    if (g < 900) {
+      const int r = g / 15, c0 = (g - r * 15) * 4;
+      const int rm = r > 0 ? r - 1 : 0, rp = r < kImg - 1 ? r + 1 : kImg - 1;
+      const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + 4 < kImg ? c0 + 4 : kImg - 1;
+      const float4 a = *reinterpret_cast<const float4 *>(pl + rm * kImg + c0);
+      const float4 b = *reinterpret_cast<const float4 *>(pl + r * kImg + c0);
+      const float4 c = *reinterpret_cast<const float4 *>(pl + rp * kImg + c0);
+      const float el = fmaxf(fmaxf(pl[rm * kImg + cl], pl[r * kImg + cl]), pl[rp * kImg + cl]);
+      const float er = fmaxf(fmaxf(pl[rm * kImg + cr], pl[r * kImg + cr]), pl[rp * kImg + cr]);
+      const float m0 = fmaxf(fmaxf(a.x, b.x), c.x), m1 = fmaxf(fmaxf(a.y, b.y), c.y);
+      const float m2 = fmaxf(fmaxf(a.z, b.z), c.z), m3 = fmaxf(fmaxf(a.w, b.w), c.w);
+      d[k][0] = fmaxf(fmaxf(el, m0), m1);
+      d[k][1] = fmaxf(fmaxf(m0, m1), m2);
+      d[k][2] = fmaxf(fmaxf(m1, m2), m3);
+      d[k][3] = fmaxf(fmaxf(m2, m3), er);
+      mn = fminf(mn, fminf(fminf(d[k][0], d[k][1]), fminf(d[k][2], d[k][3])));
+      mx = fmaxf(mx, fmaxf(fmaxf(d[k][0], d[k][1]), fmaxf(d[k][2], d[k][3])));
+    }
+  }
+}
+// block-wide min / max -> the scale and shift of cv::normalize(NORM_MINMAX) as floats (image_strategy.cpp:144-153)
+template <class SM>
+__device__ inline void minmax_scale(SM &S, float mn, float mx, float &fs, float &fb) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    S.red_f[2 * (tid >> 6)] = mn;
+    S.red_f[2 * (tid >> 6) + 1] = mx;
+  }
+  __syncthreads();
+  float a = S.red_f[0], b = S.red_f[1];
+#pragma unroll
+  for (int w = 1; w < IMG_WAVES; w++) {
+    a = fminf(a, S.red_f[2 * w]);
+    b = fmaxf(b, S.red_f[2 * w + 1]);
+  }
+  const double smin = (double)a, smax = (double)b;
+  const double scale = 1.0 * ((smax - smin) > DBL_EPSILON ? 1.0 / (smax - smin) : 0.0);
+  const double shift = 0.0 - smin * scale;
+  fs = (float)scale;
+  fb = (float)shift;
+}
+__device__ inline void store_plane(const float (&d)[GPT][4], float fs, float fb, uint8_t *out) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < GPT; k++) {
+    const int g = tid + k * IMG_THREADS;
+    if (g < 900) {
+      const int r = g / 15, c0 = (g - r * 15) * 4;
+      uint32_t packed = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float v = d[k][j] * fs + fb;
+        const float u = v * 255.0f + 0.0f;
+        float t = rintf(u);
+        t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+        packed |= (uint32_t)(int)t << (8 * j);
+      }
+      // image row = 59 - cell row (image_strategy.cpp:128-129)
+      *reinterpret_cast<uint32_t *>(out + (kImg - 1 - r) * kImg + c0) = packed;
+    }
+  }
 }
 
 template <int N>
@@ -856,7 +940,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
   Box B;
   load_box(P.hands[P.cand_hand[cand]], B);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
-  for (int i = tid; i < 256; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
+  for (int i = tid; i < 128; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
   if (tid == 0) {
     S.flag = 0;
     S.counter = 0;
@@ -932,16 +1016,6 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     uint16_t *nz = S.nzlist;
     const int n_nz = list_nonempty_cells(S, nz);
     TICK(11);
-    for (int c = tid; c < kPix; c += IMG_THREADS) {
-      if (!(S.cells[c] & 0xffffu)) {
-        S.raster[0][c] = 0.f;
-        S.raster[1][c] = 0.f;
-        S.raster[2][c] = 0.f;
-        S.cells[c] = 0u;  // depth plane: 0.0f
-      }
-    }
-    __syncthreads();
-    TICK(12);
     for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
       const int c = nz[qn];
       const uint32_t w = S.cells[c];
@@ -965,34 +1039,60 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
         }
         const double d = div_len(T(da, e) - offd, da);
         fc = (float)((double)fc + 1.0);
-        avg = (float)((double)avg + (d - (double)avg) * recip_count<256>(S.recip, fc));
+        avg = (float)((double)avg + (d - (double)avg) * recip_count<128>(S.recip, fc));
       };
       sort_u32(&S.place[start], cn);  // neighbour order: the rank sits above the entry index
       for (int q = 0; q < cn; q++) visit((int)(S.place[start + q] & ((1u << EB) - 1u)));
-      S.raster[0][c] = v0;
-      S.raster[1][c] = v1;
-      S.raster[2][c] = v2;
-      S.cells[c] = __float_as_uint((float)(1.0 - (double)avg));  // the depth plane, in place of the segment table
+      S.nzv[qn] = make_float4(v0, v1, v2, (float)(1.0 - (double)avg));
     }
     TICK(13);
     __syncthreads();
     TICK(7);
-    if (K.C == 1)  // Image1ChannelsStrategy: the depth image alone (image_1_channels_strategy.cpp:25-40)
-      finalize_planes<1>(S, reinterpret_cast<const float *>(S.cells), nullptr, out);
-    else if (K.C >= 12) {
-      // two passes (normals, then depth): one 4-plane pass keeps 32 dilated values per lane and spills
-      finalize_planes<3>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per) * kPix);
-      finalize_planes<1>(S, reinterpret_cast<const float *>(S.cells), nullptr, out + (size_t)(pr * K.per + 3) * kPix);
+    // ---- the planes, one after the other in the storage of the (dead) segment counters: empty pixels are 0 in all of
+    //      them, the non-empty pixels of a projection are the same for its normal and depth planes
+    float *raster = reinterpret_cast<float *>(S.cells);
+    for (int c = tid; c < kPix; c += IMG_THREADS) raster[c] = 0.f;
+    __syncthreads();
+    TICK(12);
+    const bool with_normals = K.C != 1, with_depth = K.C == 1 || K.C >= 12;
+    if (with_normals) {
+      // createNormalsImage: the three planes are dilated and normalised as ONE 3-channel image (image_strategy.cpp:144-153)
+      float d[3][GPT][4];
+      float mn = FLT_MAX, mx = -FLT_MAX;
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) {
+        for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
+          const float4 v = S.nzv[qn];
+          raster[nz[qn]] = pl == 0 ? v.x : (pl == 1 ? v.y : v.z);
+        }
+        __syncthreads();
+        dilate_plane(raster, d[pl], mn, mx);
+        __syncthreads();
+      }
+      float fs, fb;
+      minmax_scale(S, mn, mx, fs, fb);
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) store_plane(d[pl], fs, fb, out + (size_t)(pr * K.per + pl) * kPix);
     }
-    else
-      finalize_planes<3>(S, &S.raster[0][0], nullptr, out + (size_t)(pr * K.per) * kPix);
+    if (with_depth) {
+      // createDepthImage (image_strategy.cpp:178-187); Image1ChannelsStrategy is this plane alone
+      float d[GPT][4];
+      float mn = FLT_MAX, mx = -FLT_MAX;
+      for (int qn = tid; qn < n_nz; qn += IMG_THREADS) raster[nz[qn]] = S.nzv[qn].w;
+      __syncthreads();
+      dilate_plane(raster, d, mn, mx);
+      float fs, fb;
+      minmax_scale(S, mn, mx, fs, fb);
+      store_plane(d, fs, fb, out + (size_t)(K.C == 1 ? 0 : pr * K.per + 3) * kPix);
+    }
+    __syncthreads();
     TICK(8);
   }
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(IMG_THREADS) void grasp_image_kernel(ImgParams P) {
+__global__ __launch_bounds__(IMG_THREADS, BIG ? 2 : 4) void grasp_image_kernel(ImgParams P) {
   __shared__ SmemPts<BIG> S;
   if constexpr (BIG) {
     const int count = *P.cand_count;
