@@ -184,10 +184,13 @@ def main():
     ctx.upload_cloud(cloud["xyz"], cloud["normals"], cloud["cam_source"], cloud["view_points"])
     n_samples = min(int(candidates / 2.0) + 64, int(cloud["is_object"].sum()))
     si = synth.sample_indices(cloud, n_samples)
-    t0 = time.perf_counter()
-    hands = ctx.search(si)
-    search_wall = time.perf_counter() - t0
-    search_ms = float(ctx.stage_ms()[0])
+    hands = ctx.search(si)  # first call: allocations
+    search_ms, search_wall = 1e30, 1e30
+    for _ in range(3):     # the stage kernels by HIP events / the unfused call incl. the download of every hand record
+        t0 = time.perf_counter()
+        hands = ctx.search(si)
+        search_wall = min(search_wall, time.perf_counter() - t0)
+        search_ms = min(search_ms, float(ctx.stage_ms()[0]))
     # host workspace/aperture filter through the product path is part of detect(); here the
     # candidate list is cut to exactly `candidates` hands in (set, slot) order
     hands_f = hands.copy()
@@ -199,10 +202,14 @@ def main():
 
     # end-to-end latency of the fused entry point (search + filter + images + LeNet, host buffers in / out)
     ctx.detect(si)
-    t0 = time.perf_counter()
-    _, n_detect = ctx.detect(si)
-    detect_wall = time.perf_counter() - t0
-    detect_kernel_ms = [float(x) for x in ctx.stage_ms()]
+    walls, kms = [], []
+    for _ in range(5):  # median of five calls
+        t0 = time.perf_counter()
+        _, n_detect = ctx.detect(si)
+        walls.append(time.perf_counter() - t0)
+        kms.append([float(x) for x in ctx.stage_ms()])
+    mid = int(np.argsort(walls)[len(walls) // 2])
+    detect_wall, detect_kernel_ms = walls[mid], kms[mid]
 
     # a sample of the images for conv1's zero-skip statistics (the executed-FLOP fraction of the roofline line)
     live_frac = None

@@ -405,6 +405,9 @@ struct NbParams {
 // d2 is recomputed from the coordinates (bit-identical, L2 hits) instead of being stored twice.
 // Five barriers instead of the 78 barrier-separated bitonic stages (648 of the kernel's 1320 us).
 constexpr int NB_BUCKETS = 1024;
+// 512 threads: sixteen waves per CU at two workgroups (72 KB of LDS each) — the kernel waits on dependent global
+// loads (cell bounds -> points) and on its barriers, more waves in flight is what hides them
+constexpr int NB_THREADS = 512, NB_WAVES = NB_THREADS / 64, NB_PER = NB_BUCKETS / NB_THREADS;
 template <int N>
 __device__ inline void sort_regs64(unsigned long long (&k)[N]) {
 #pragma unroll
@@ -425,7 +428,7 @@ __device__ inline void sort_regs64(unsigned long long (&k)[N]) {
     }
   }
 }
-__global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
+__global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
   __shared__ int s_count;
   __shared__ int s_bounds[3];
@@ -481,11 +484,11 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     return b < NB_BUCKETS - 1 ? b : NB_BUCKETS - 1;
   };
   if (P.bucket)
-    for (int i = tid; i < NB_BUCKETS; i += 256) s_hist[i] = 0;
+    for (int i = tid; i < NB_BUCKETS; i += NB_THREADS) s_hist[i] = 0;
   __syncthreads();
   // 1. visit the grid cells around the sample; FLANN L2_Simple<float>: d2 accumulated over
   //    x,y,z, strict <
-  grid_visit(P.grid, qx, qy, qz, P.reach, tid >> 6, 4, lane, [&](bool in, int i, float x, float y, float z) {
+  grid_visit(P.grid, qx, qy, qz, P.reach, tid >> 6, NB_WAVES, lane, [&](bool in, int i, float x, float y, float z) {
     float d = qx - x;
     float d2 = 0.f;
     d2 += d * d;
@@ -516,12 +519,12 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   const int found = s_count;
   const int n = found < P.cap ? found : P.cap;
   if (P.bucket) {
-    // 2. bucket sort: exclusive scan of the counters (four buckets per lane) ...
-    __shared__ int s_wsum[4];
-    int c4[4], sum = 0;
+    // 2. bucket sort: exclusive scan of the counters (NB_PER buckets per lane) ...
+    __shared__ int s_wsum[NB_WAVES];
+    int c4[NB_PER], sum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      c4[q] = s_hist[4 * tid + q];
+    for (int q = 0; q < NB_PER; q++) {
+      c4[q] = s_hist[NB_PER * tid + q];
       sum += c4[q];
     }
     int incl = sum;
@@ -535,15 +538,15 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     int run = incl - sum;
     for (int w = 0; w < (tid >> 6); w++) run += s_wsum[w];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      s_start[4 * tid + q] = run;
-      s_hist[4 * tid + q] = run;  // the scatter cursor
+    for (int q = 0; q < NB_PER; q++) {
+      s_start[NB_PER * tid + q] = run;
+      s_hist[NB_PER * tid + q] = run;  // the scatter cursor
       run += c4[q];
     }
-    if (tid == 255) s_start[NB_BUCKETS] = run;
+    if (tid == NB_THREADS - 1) s_start[NB_BUCKETS] = run;
     __syncthreads();
     // ... indices grouped bucket by bucket ...
-    for (int t = tid; t < n; t += 256) {
+    for (int t = tid; t < n; t += NB_THREADS) {
       const uint32_t i = s_a[t];
       const int pos = atomicAdd(&s_hist[bucket_of(d2_of((int)i))], 1);
       if (pos < n) s_b[pos] = i;  // always true (the counters come from the same d2 values); keeps a corrupted table out of LDS
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     __syncthreads();
     // ... and every bucket ordered by (d2 bits, index); non-negative floats order as unsigned.
     // s_a (dead) receives the sorted d2 bits.
-    for (int b = tid; b < NB_BUCKETS; b += 256) {
+    for (int b = tid; b < NB_BUCKETS; b += NB_THREADS) {
       const int st = s_start[b], nb = s_start[b + 1] - st;
       if (nb <= 0) continue;
       auto run = [&](auto tag) {
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
     }
     __syncthreads();
     const int ncrowd = s_ncrowd < NB_BUCKETS ? s_ncrowd : NB_BUCKETS;
-    for (int c = tid >> 6; c < ncrowd; c += 4) {
+    for (int c = tid >> 6; c < ncrowd; c += NB_WAVES) {
       const int b = s_hist[c];
       const int st = s_start[b], nb = s_start[b + 1] - st;
       if (nb <= 64) {
@@ -630,12 +633,12 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   } else {
     int m = 1;
     while (m < n) m <<= 1;
-    for (int i = n + tid; i < m; i += 256) s_keys[i] = ~0ull;
+    for (int i = n + tid; i < m; i += NB_THREADS) s_keys[i] = ~0ull;
     __syncthreads();
     // 2. bitonic sort ascending by (d2 bits, index); non-negative floats order as unsigned
     for (int k = 2; k <= m; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < (m >> 1); t += 256) {
+        for (int t = tid; t < (m >> 1); t += NB_THREADS) {
           const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
           const int hi = lo | j;
           const bool up = (lo & k) == 0;
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   auto index_at = [&](int t) { return P.bucket ? (int)s_b[t] : (int)(unsigned)(s_keys[t] & 0xffffffffull); };
   // 3. prefix lengths of the image, frame and hand-search neighbourhoods
   const unsigned ri = __float_as_uint(P.r2_images), rf = __float_as_uint(P.r2_frames), rh = __float_as_uint(P.r2_hands);
-  for (int t = tid; t < n; t += 256) {
+  for (int t = tid; t < n; t += NB_THREADS) {
     const unsigned d = d2bits_at(t);
     const unsigned dn = (t + 1 < n) ? d2bits_at(t + 1) : 0xffffffffu;
     if (d < ri && dn >= ri) s_bounds[0] = t + 1;
@@ -668,7 +671,7 @@ __global__ __launch_bounds__(256) void neighbourhood_kernel(NbParams P) {
   float *on = P.nn + (size_t)s * 6 * P.cap;
   const int n_img = s_bounds[0];
   int seen = 0;
-  for (int t = tid; t < n; t += 256) {
+  for (int t = tid; t < n; t += NB_THREADS) {
     const int i = index_at(t);
     oi[t] = i;
     const float x = P.px[i], y = P.py[i];
@@ -1474,7 +1477,7 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   const size_t lds = (size_t)cap * sizeof(unsigned long long) + (np.bucket ? (2 * NB_BUCKETS + 1) * sizeof(int) : 0);
   HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds));
-  neighbourhood_kernel<<<S, 256, lds, stream>>>(np);
+  neighbourhood_kernel<<<S, NB_THREADS, lds, stream>>>(np);
   HIP_RET(hipGetLastError());
   centre_kernel<<<(3 * S + 63) / 64, 64, 0, stream>>>(s.d_nn, s.d_counts, cap, S, s.d_centers);
   HIP_RET(hipGetLastError());
