@@ -190,7 +190,7 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
     // a neighbourhood overflowed the list capacity of the search kernel: once more with the large lists
     const int cap = search_next_capacity(L.search, L.plan.h_summary->worst_found);
     if (!cap) {
-      set_error("search: a neighbourhood holds %d points, more than the LDS list capacity 16384", L.plan.h_summary->worst_found);
+      set_error("search: a neighbourhood holds %d points, more than the list capacity %d", L.plan.h_summary->worst_found, kNnCapMax);
       return GPD_ERR_CAPACITY;
     }
     int rc = search_force_capacity(L.search, cap);

@@ -44,6 +44,8 @@ void set_error(const char *fmt, ...);
 // ---- Cloud (search.hip) -----------------------------------------------------
 // Device copy of what the path reads from util::Cloud, as SoA for coalesced streaming.
 constexpr int kMaxCams = 8;
+// largest neighbourhood the search handles: hand_eval_kernel keeps neighbour ranks in 16 bits
+constexpr int kNnCapMax = 65535;
 struct Cloud {
   int num_points = 0, num_cams = 0, capacity = 0, cap_cams = 0;
   char *h_pin = nullptr;              // pinned staging of the caller's arrays (xyz, normals, cam_source)
@@ -96,7 +98,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
 // ---- Candidate search (search.hip) -----------------------------------------------
 struct SearchState {
   int num_samples = 0, capacity_samples = 0;
-  int nn_cap = 0;                     // entries per neighbourhood list (8192 or 16384)
+  int nn_cap = 0;                     // entries per neighbourhood list: 8192 / 16384 (LDS sorts) or up to kNnCapMax (global-memory sort)
   uint64_t cloud_generation = 0;
   int32_t *d_sample_idx = nullptr;    // [S]
   double *d_sample_xyz = nullptr;     // [S][3] samples given by coordinates (used instead of the indices)

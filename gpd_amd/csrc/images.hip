@@ -114,11 +114,11 @@ struct Box {
 // points kernel: in-box points cached once, one projection's normals (3 planes) + depth at a time.
 // BIG (the overflow fallback, up to PT_CAP_BIG in-box points): the point arrays live in a global
 // scratch row instead of LDS.
-constexpr size_t PTS_SCRATCH_BYTES = (size_t)PT_CAP_BIG * (3 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t));
+constexpr size_t PTS_SCRATCH_BYTES = (size_t)PT_CAP_BIG * (3 * sizeof(double) + sizeof(float4));
 struct PointArrays {
   double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
-  float4 an[PT_CAP];    // |normal| in the hand frame (x, y, z) and, as bits in w, the key
-                        // cx | cy << 6 | cz << 12 | neighbour rank << 18: one 16-byte read per visit
+  float4 an[PT_CAP];    // |normal| in the hand frame (x, y, z) and, as bits in w, the cell key
+                        // cx | cy << 6 | cz << 12: one 16-byte read per visit
 };
 struct NoPointArrays {};
 // Under 80 KB for the small instantiation, so that two workgroups — two grasp_image ones, or one of them next to a
@@ -131,7 +131,7 @@ template <bool BIG>
 struct __attribute__((aligned(16))) SmemPts {
   typename std::conditional<BIG, NoPointArrays, PointArrays>::type p;
   uint32_t cells[kPix];   // (segment start << 16) | count of a pixel; after the walks: the f32 plane being finished
-  uint32_t place[BIG ? PT_CAP_BIG : PT_CAP];  // segment table: neighbour rank << EB | entry (sorts without a gather)
+  uint16_t place[BIG ? PT_CAP_BIG : PT_CAP];  // segment table: entry numbers (entries are numbered in neighbour order)
   float4 nzv[BIG ? kPix : PT_CAP];            // per non-empty pixel: the three normal values and the depth value
   uint16_t nzlist[BIG ? kPix : PT_CAP];       // the non-empty pixels, longest segment first
   double thr[3][kImg + 1];
@@ -560,32 +560,6 @@ __device__ inline void sort_u16_regs(uint16_t *p, int n) {
   for (int q = 0; q < N; q++)
     if (q < n) p[q] = (uint16_t)k[q];
 }
-// segments of (rank << EB | entry) words, ascending
-template <int N>
-__device__ inline void sort_u32_regs(uint32_t *p, int n) {
-  uint32_t k[N];
-#pragma unroll
-  for (int q = 0; q < N; q++) k[q] = q < n ? p[q] : 0xffffffffu;
-  sort_regs<N>(k);
-#pragma unroll
-  for (int q = 0; q < N; q++)
-    if (q < n) p[q] = k[q];
-}
-__device__ inline void sort_u32(uint32_t *p, int n) {
-  if (n <= 8) return sort_u32_regs<8>(p, n);
-  if (n <= 16) return sort_u32_regs<16>(p, n);
-  if (n <= 32) return sort_u32_regs<32>(p, n);
-  for (int i = 1; i < n; i++) {
-    const uint32_t v = p[i];
-    int j = i - 1;
-    while (j >= 0 && p[j] > v) {
-      p[j + 1] = p[j];
-      j--;
-    }
-    p[j + 1] = v;
-  }
-}
-
 #define TICK(k)                                                     \
   do {                                                              \
     if (P.dbg && tid == 0) {                                        \
@@ -912,7 +886,6 @@ __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_ima
 template <bool BIG>
 __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG> &S, const int cand) {
   constexpr int CAP = BIG ? PT_CAP_BIG : PT_CAP;
-  constexpr int EB = BIG ? 14 : 11;  // bits of an entry index
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
   const int tid = threadIdx.x;
@@ -946,6 +919,10 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     S.counter = 0;
   }
   __syncthreads();
+  // The in-box points are numbered IN NEIGHBOUR ORDER (an ordered compaction: per 512 neighbours one ballot per wave
+  // and a prefix over the eight wave counts), so that an entry's number is its rank among the in-box points: the
+  // walks order a pixel's segment by entry number alone — no rank bits to carry, whatever the neighbourhood size.
+  int n_before = 0;  // in-box points of the earlier rounds (the same in every thread)
   for (int i0 = 0; i0 < N; i0 += IMG_THREADS) {
     const int i = i0 + tid;
     double t[3] = {0, 0, 0};
@@ -955,25 +932,31 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       in = in_box(B, t);
     }
     const unsigned long long ballot = __ballot(in);
-    if (ballot) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&S.counter, __popcll(ballot));
-      base = __shfl(base, 0);
-      if (in) {
-        const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (e < CAP) {
-          const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
-          T(0, e) = t[0];
-          T(1, e) = t[1];
-          T(2, e) = t[2];
-          AN(e) = make_float4((float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2),
-                              (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2),
-                              (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2),
-                              __uint_as_float(cells_of(S, B, t) | ((uint32_t)i << 18)));
-        }
+    if (lane == 0) S.red_i[tid >> 6] = __popcll(ballot);
+    __syncthreads();
+    int base = n_before, round_total = 0;
+#pragma unroll
+    for (int w = 0; w < IMG_WAVES; w++) {
+      const int c = S.red_i[w];
+      if (w < (tid >> 6)) base += c;
+      round_total += c;
+    }
+    if (in) {
+      const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
+      if (e < CAP) {
+        const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
+        T(0, e) = t[0];
+        T(1, e) = t[1];
+        T(2, e) = t[2];
+        AN(e) = make_float4((float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2),
+                            (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2),
+                            (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2), __uint_as_float(cells_of(S, B, t)));
       }
     }
+    n_before += round_total;
+    __syncthreads();  // red_i is rewritten by the next round
   }
+  if (tid == 0) S.counter = n_before;
   __syncthreads();
   const int n_box_all = S.counter;
   if (n_box_all > CAP) {
@@ -1006,7 +989,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     for (int e = tid; e < nb; e += IMG_THREADS) {
       const uint32_t key = __float_as_uint(AN(e).w);
       const uint32_t old = atomicAdd(&S.cells[cell_of_key(key, pr)], 1u);
-      S.place[(old >> 16) + (old & 0xffffu)] = ((key >> 18) << EB) | (uint32_t)e;
+      S.place[(old >> 16) + (old & 0xffffu)] = (uint16_t)e;
     }
     __syncthreads();
     TICK(6);
@@ -1041,8 +1024,8 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
         fc = (float)((double)fc + 1.0);
         avg = (float)((double)avg + (d - (double)avg) * recip_count<128>(S.recip, fc));
       };
-      sort_u32(&S.place[start], cn);  // neighbour order: the rank sits above the entry index
-      for (int q = 0; q < cn; q++) visit((int)(S.place[start + q] & ((1u << EB) - 1u)));
+      sort_u16(&S.place[start], cn);  // neighbour order = entry order
+      for (int q = 0; q < cn; q++) visit((int)S.place[start + q]);
       S.nzv[qn] = make_float4(v0, v1, v2, (float)(1.0 - (double)avg));
     }
     TICK(13);

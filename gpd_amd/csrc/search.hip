@@ -407,7 +407,7 @@ struct NbParams {
 constexpr int NB_BUCKETS = 1024;
 // 512 threads: sixteen waves per CU at two workgroups (72 KB of LDS each) — the kernel waits on dependent global
 // loads (cell bounds -> points) and on its barriers, more waves in flight is what hides them
-constexpr int NB_THREADS = 512, NB_WAVES = NB_THREADS / 64, NB_PER = NB_BUCKETS / NB_THREADS;
+constexpr int NB_THREADS = 512, NB_WAVES = NB_THREADS / 64;
 template <int N>
 __device__ inline void sort_regs64(unsigned long long (&k)[N]) {
 #pragma unroll
@@ -428,7 +428,19 @@ __device__ inline void sort_regs64(unsigned long long (&k)[N]) {
     }
   }
 }
+// GLOBAL: the slow path for neighbourhoods beyond the LDS list capacities (the reference has no limit:
+// hand_search.cpp:178 takes whatever radiusSearch returns).  The same bucket sort with the two index arrays in
+// global memory — they live in the output rows themselves (sorted indices in nn_idx, d2 bits in the last nn row until
+// the gather overwrites it) — and, LDS being free, 8192 buckets.
+template <bool GLOBAL>
 __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
+  constexpr int NBK = GLOBAL ? 8192 : NB_BUCKETS;  // buckets
+  constexpr int PER = NBK / NB_THREADS;           // per lane in the scan
+  // workgroup-wide hand-over of the index arrays: a barrier, plus a fence when they are global memory
+  auto hand_over = [] {
+    if constexpr (GLOBAL) __threadfence_block();
+    __syncthreads();
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_keys[];
   __shared__ int s_count;
   __shared__ int s_bounds[3];
@@ -464,10 +476,18 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     s_ncrowd = 0;
   }
   // bucket mode: two u32 arrays in the key storage, counters behind them
-  uint32_t *s_a = reinterpret_cast<uint32_t *>(s_keys);  // indices in visit order, then sorted d2 bits
-  uint32_t *s_b = s_a + P.cap;                           // indices in bucket order, then sorted
-  int *s_hist = reinterpret_cast<int *>(s_keys + P.cap);
-  int *s_start = s_hist + NB_BUCKETS;  // NB_BUCKETS + 1 entries
+  uint32_t *s_a, *s_b;  // indices in visit order, then sorted d2 bits / indices in bucket order, then sorted
+  int *s_hist;
+  if constexpr (GLOBAL) {
+    s_a = reinterpret_cast<uint32_t *>(P.nn + ((size_t)s * 6 + 5) * P.cap);
+    s_b = reinterpret_cast<uint32_t *>(P.nn_idx + (size_t)s * P.cap);
+    s_hist = reinterpret_cast<int *>(s_keys);
+  } else {
+    s_a = reinterpret_cast<uint32_t *>(s_keys);
+    s_b = s_a + P.cap;
+    s_hist = reinterpret_cast<int *>(s_keys + P.cap);
+  }
+  int *s_start = s_hist + NBK;  // NBK + 1 entries
   auto d2_of = [&](int i) {  // FLANN L2_Simple<float>, the same operation order as in the visit
     float d = qx - P.px[i];
     float d2 = 0.f;
@@ -478,13 +498,13 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     d2 += d * d;
     return d2;
   };
-  const float bscale = (float)NB_BUCKETS / P.r2_all;
+  const float bscale = (float)NBK / P.r2_all;
   auto bucket_of = [&](float d2) {
     const int b = (int)(d2 * bscale);
-    return b < NB_BUCKETS - 1 ? b : NB_BUCKETS - 1;
+    return b < NBK - 1 ? b : NBK - 1;
   };
   if (P.bucket)
-    for (int i = tid; i < NB_BUCKETS; i += NB_THREADS) s_hist[i] = 0;
+    for (int i = tid; i < NBK; i += NB_THREADS) s_hist[i] = 0;
   __syncthreads();
   // 1. visit the grid cells around the sample; FLANN L2_Simple<float>: d2 accumulated over
   //    x,y,z, strict <
@@ -515,16 +535,16 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       }
     }
   });
-  __syncthreads();
+  hand_over();
   const int found = s_count;
   const int n = found < P.cap ? found : P.cap;
   if (P.bucket) {
-    // 2. bucket sort: exclusive scan of the counters (NB_PER buckets per lane) ...
+    // 2. bucket sort: exclusive scan of the counters (PER buckets per lane) ...
     __shared__ int s_wsum[NB_WAVES];
-    int c4[NB_PER], sum = 0;
+    int c4[PER], sum = 0;
 #pragma unroll
-    for (int q = 0; q < NB_PER; q++) {
-      c4[q] = s_hist[NB_PER * tid + q];
+    for (int q = 0; q < PER; q++) {
+      c4[q] = s_hist[PER * tid + q];
       sum += c4[q];
     }
     int incl = sum;
@@ -538,12 +558,12 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     int run = incl - sum;
     for (int w = 0; w < (tid >> 6); w++) run += s_wsum[w];
 #pragma unroll
-    for (int q = 0; q < NB_PER; q++) {
-      s_start[NB_PER * tid + q] = run;
-      s_hist[NB_PER * tid + q] = run;  // the scatter cursor
+    for (int q = 0; q < PER; q++) {
+      s_start[PER * tid + q] = run;
+      s_hist[PER * tid + q] = run;  // the scatter cursor
       run += c4[q];
     }
-    if (tid == NB_THREADS - 1) s_start[NB_BUCKETS] = run;
+    if (tid == NB_THREADS - 1) s_start[NBK] = run;
     __syncthreads();
     // ... indices grouped bucket by bucket ...
     for (int t = tid; t < n; t += NB_THREADS) {
@@ -551,10 +571,10 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       const int pos = atomicAdd(&s_hist[bucket_of(d2_of((int)i))], 1);
       if (pos < n) s_b[pos] = i;  // always true (the counters come from the same d2 values); keeps a corrupted table out of LDS
     }
-    __syncthreads();
+    hand_over();
     // ... and every bucket ordered by (d2 bits, index); non-negative floats order as unsigned.
     // s_a (dead) receives the sorted d2 bits.
-    for (int b = tid; b < NB_BUCKETS; b += NB_THREADS) {
+    for (int b = tid; b < NBK; b += NB_THREADS) {
       const int st = s_start[b], nb = s_start[b + 1] - st;
       if (nb <= 0) continue;
       auto run = [&](auto tag) {
@@ -583,11 +603,11 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
         // crowded bucket (lattice clouds put dozens of points at exactly the same distance): left
         // to a whole wave below
         const int c = atomicAdd(&s_ncrowd, 1);
-        if (c < NB_BUCKETS) s_hist[c] = b;  // the scatter cursors are dead: their storage lists the crowded buckets
+        if (c < NBK) s_hist[c] = b;  // the scatter cursors are dead: their storage lists the crowded buckets
       }
     }
     __syncthreads();
-    const int ncrowd = s_ncrowd < NB_BUCKETS ? s_ncrowd : NB_BUCKETS;
+    const int ncrowd = s_ncrowd < NBK ? s_ncrowd : NBK;
     for (int c = tid >> 6; c < ncrowd; c += NB_WAVES) {
       const int b = s_hist[c];
       const int st = s_start[b], nb = s_start[b + 1] - st;
@@ -610,26 +630,47 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
           s_b[st + lane] = (uint32_t)k;
         }
       } else {
-        // more than 64 equal-ish distances: d2 column first (all lanes), then one lane sorts in LDS
+        // more than 64 keys in one bucket (dense clouds; lattice clouds put many points at exactly the same distance):
+        // the d2 column first, then a bitonic network over the two arrays by the whole wave.  Every comparison
+        // sorts upwards (the first step of each merge pairs x with its mirror image), so positions past the end
+        // would hold +inf and never move: those comparisons are simply left out.
         for (int x = lane; x < nb; x += 64) s_a[st + x] = __float_as_uint(d2_of((int)s_b[st + x]));
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-          for (int x = 1; x < nb; x++) {
-            const uint32_t vd = s_a[st + x], vi = s_b[st + x];
-            const unsigned long long v = ((unsigned long long)vd << 32) | vi;
-            int j = x - 1;
-            while (j >= 0 && (((unsigned long long)s_a[st + j] << 32) | s_b[st + j]) > v) {
-              s_a[st + j + 1] = s_a[st + j];
-              s_b[st + j + 1] = s_b[st + j];
-              j--;
+        int m = 1;
+        while (m < nb) m <<= 1;
+        auto exchange = [&](int lo, int hi) {
+          if (hi < nb) {
+            const unsigned long long klo = ((unsigned long long)s_a[st + lo] << 32) | s_b[st + lo];
+            const unsigned long long khi = ((unsigned long long)s_a[st + hi] << 32) | s_b[st + hi];
+            if (klo > khi) {
+              s_a[st + lo] = (uint32_t)(khi >> 32);
+              s_b[st + lo] = (uint32_t)khi;
+              s_a[st + hi] = (uint32_t)(klo >> 32);
+              s_b[st + hi] = (uint32_t)klo;
             }
-            s_a[st + j + 1] = vd;
-            s_b[st + j + 1] = vi;
+          }
+        };
+        auto wave_sync = [] {
+          __threadfence_block();
+          __builtin_amdgcn_wave_barrier();
+        };
+        for (int size = 2; size <= m; size <<= 1) {
+          wave_sync();
+          const int half = size >> 1;
+          for (int t = lane; t < (m >> 1); t += 64) {
+            const int blk = t / half, off = t - blk * half;
+            exchange(blk * size + off, blk * size + size - 1 - off);
+          }
+          for (int stride = size >> 2; stride > 0; stride >>= 1) {
+            wave_sync();
+            for (int t = lane; t < (m >> 1); t += 64) {
+              const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+              exchange(lo, lo + stride);
+            }
           }
         }
       }
     }
-    __syncthreads();
+    hand_over();
   } else {
     int m = 1;
     while (m < n) m <<= 1;
@@ -1472,12 +1513,21 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.grid = grid_view(c);
   np.reach = (float)r_all * 1.001f + 1e-5f;
   // 8192-entry lists are bucket-sorted (64 + 8 KB of LDS: two workgroups per CU); the 16384-entry
-  // retry of an overfull neighbourhood sorts in place (bitonic, 128 KB)
-  np.bucket = cap < 16384 ? 1 : 0;
-  const size_t lds = (size_t)cap * sizeof(unsigned long long) + (np.bucket ? (2 * NB_BUCKETS + 1) * sizeof(int) : 0);
-  HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds));
-  neighbourhood_kernel<<<S, NB_THREADS, lds, stream>>>(np);
+  // retry of an overfull neighbourhood sorts in place (bitonic, 128 KB); anything larger (up to kNnCapMax) is
+  // bucket-sorted in global memory
+  if (cap > 16384) {
+    np.bucket = 1;
+    const size_t lds = (size_t)(2 * 8192 + 1) * sizeof(int);
+    HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    neighbourhood_kernel<true><<<S, NB_THREADS, lds, stream>>>(np);
+  } else {
+    np.bucket = cap < 16384 ? 1 : 0;
+    const size_t lds = (size_t)cap * sizeof(unsigned long long) + (np.bucket ? (2 * NB_BUCKETS + 1) * sizeof(int) : 0);
+    HIP_RET(hipFuncSetAttribute(reinterpret_cast<const void *>(neighbourhood_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    neighbourhood_kernel<false><<<S, NB_THREADS, lds, stream>>>(np);
+  }
   HIP_RET(hipGetLastError());
   centre_kernel<<<(3 * S + 63) / 64, 64, 0, stream>>>(s.d_nn, s.d_counts, cap, S, s.d_centers);
   HIP_RET(hipGetLastError());
@@ -1507,11 +1557,11 @@ static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, c
     int worst = 0;
     for (int i = 0; i < S; i++) worst = s.h_counts[8 * i + 3] > worst ? s.h_counts[8 * i + 3] : worst;
     if (worst <= cap) break;
-    if (cap >= 16384) {
-      set_error("search: a neighbourhood holds %d points, more than the LDS list capacity 16384", worst);
+    cap = search_next_capacity(s, worst);
+    if (!cap) {
+      set_error("search: a neighbourhood holds %d points, more than the list capacity %d", worst, kNnCapMax);
       return GPD_ERR_CAPACITY;
     }
-    cap = 16384;  // 128 KB of LDS per workgroup
     rc = search_reserve(s, S, cap, slots);
     if (rc) return rc;
   }
@@ -1562,14 +1612,15 @@ static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slo
 
 int search_next_capacity(const SearchState &s, int worst) {
   if (worst <= s.nn_cap) return s.nn_cap;
-  return worst <= 16384 ? 16384 : 0;
+  if (worst <= 16384) return 16384;  // in-place bitonic sort, 128 KB of LDS per workgroup
+  if (worst > kNnCapMax) return 0;
+  const int cap = (worst + 4095) / 4096 * 4096;  // global-memory lists
+  return cap < kNnCapMax ? cap : kNnCapMax;
 }
 int search_force_capacity(SearchState &s, int cap) {
   if (cap == s.nn_cap) return GPD_OK;
-  const int S = s.capacity_samples;
   search_free(s);
   s.nn_cap = cap;  // search_reserve allocates on the next run (capacity_samples is 0 now)
-  (void)S;
   return GPD_OK;
 }
 

@@ -315,6 +315,49 @@ def test_dense_cloud_overflow_fallbacks(oracle_mod):
         ctx.close()
 
 
+def test_neighbourhoods_beyond_every_lds_capacity(oracle_mod):
+    """An un-voxelised scan is several times denser than the 3 mm clouds the LDS capacities were sized for (the
+    reference has no limit: hand_search.cpp:178).  Four times the density: neighbourhoods of more than 16384 points
+    take the global-memory bucket sort of the search, boxes with thousands of points the large points kernel —
+    records, images and scores against the oracle."""
+    cl = synth.make_cloud(1234, 30000)
+    rng = np.random.RandomState(5)
+    parts = [cl["xyz"]] + [(cl["xyz"] + rng.uniform(-0.0012, 0.0012, cl["xyz"].shape)).astype(np.float32) for _ in range(3)]
+    xyz = np.concatenate(parts)
+    nrm = np.concatenate([cl["normals"]] * 4)
+    cam = np.ones((1, len(xyz)), np.int32)
+    obj = np.flatnonzero(cl["is_object"])
+    si = obj[np.random.RandomState(9).choice(len(obj), 48, replace=False)].astype(np.int32)
+    from scipy.spatial import cKDTree
+    t = cKDTree(xyz.astype(np.float64))
+    sizes = [len(x) for x in t.query_ball_point(xyz[si].astype(np.float64), 0.11)]
+    assert max(sizes) > 16384 + 1000, max(sizes)
+    w = _weights(15)
+    p = oracle_mod.default_params(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(xyz, nrm, cam, cl["view_points"])
+        hands, n_cand = ctx.detect(si)
+        ohands, on_cand, _ = oracle_mod.detect(p, xyz, nrm, cam, cl["view_points"], si, w)
+        assert n_cand == on_cand and n_cand > 50
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes()
+        fw = oracle_mod.filter_workspace(p, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(p, xyz, nrm, cam, cl["view_points"], fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
+        # the unfused search retries through the capacities on its own, too
+        h2 = ctx.search(si)
+        o2 = oracle_mod.search(p, xyz, nrm, si)
+        assert h2.tobytes() == o2.tobytes()
+    finally:
+        ctx.close()
+
+
 def test_two_contexts_with_different_constants_on_one_device(oracle_mod):
     """The device constant blocks (image geometry + view points, hand constants) are one per device: two
     contexts with DIFFERENT geometry and cameras on the same device must not see each other's values —
