@@ -154,7 +154,7 @@ static int reserve_scores(Lane &L, int n) {
   if (L.d_scores) (void)hipFree(L.d_scores);
   L.d_scores = nullptr;
   L.d_scores_cap = 0;
-  const int cap = n + n / 8;
+  const int cap = n + n / 4;
   HIP_TRY(hipMalloc(&L.d_scores, (size_t)cap * sizeof(float)));
   L.d_scores_cap = cap;
   return GPD_OK;
@@ -165,7 +165,7 @@ static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
     if (L.d_out) (void)hipFree(L.d_out);
     L.d_out = nullptr;
     L.d_out_cap = 0;
-    const size_t cap = records + records / 8;
+    const size_t cap = records + records / 4;
     HIP_TRY(hipMalloc(&L.d_out, cap * sizeof(gpd_hand)));
     L.d_out_cap = cap;
   }

@@ -1249,7 +1249,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
     im.d_images = nullptr;
     im.d_images_hwc = nullptr;
     im.capacity = 0;
-    const int cap = n + n / 8;  // slack: the clouds of a batch differ a little
+    const int cap = n + n / 4;  // slack: the clouds of a batch differ a little
     HIP_RET(hipMalloc(&im.d_images, (size_t)cap * kPix * C));
     HIP_RET(hipMalloc(&im.d_overflow, (size_t)(cap + 1) * sizeof(int32_t)));  // list + its counter
     HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)(cap + 1) * sizeof(int32_t)));
@@ -1259,7 +1259,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
     if (im.d_set_bits) (void)hipFree(im.d_set_bits);
     im.d_set_bits = nullptr;
     im.cap_shadow_sets = 0;
-    const int cap = im.num_shadow_sets + im.num_shadow_sets / 8;
+    const int cap = im.num_shadow_sets + im.num_shadow_sets / 4;
     HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * SETWORDS * sizeof(uint32_t)));
     im.cap_shadow_sets = cap;
   }

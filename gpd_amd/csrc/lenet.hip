@@ -548,7 +548,10 @@ __global__ __launch_bounds__(256) void fc2_score_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------
 hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   if (n <= s.capacity) return hipSuccess;
+  const int num_cus = s.num_cus;
   lenet_scratch_free(s);
+  s.num_cus = num_cus;
+  n += n / 4;  // slack: the clouds of a batch differ a little, every growth stalls the device
   hipError_t e;
   if ((e = hipMalloc(&s.pool1, (size_t)n * 20 * 784 * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
@@ -569,7 +572,7 @@ void lenet_scratch_free(LeNetScratch &s) {
 hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *d_images, int n, float *d_scores,
                          hipStream_t stream, hipEvent_t *kernel_events) {
   if (n <= 0) return hipSuccess;
-  const int kChunk = 16384;
+  const int kChunk = 65536;  // images per pass: 6.1 GB of scratch (pool1 + flat + fc1) at the full chunk — sized for 288 GB of HBM
   if (!s.num_cus) {  // persistent conv2 workgroups: one per CU (256 on MI355X)
     int dev = 0;
     hipDeviceProp_t prop;

@@ -50,8 +50,8 @@ class GraspDetector {
   ~GraspDetector();
   std::vector<std::unique_ptr<candidate::Hand>> detectGrasps(const util::Cloud &cloud);
   // CandidatesGenerator::preprocessPointCloud (candidates_generator.cpp:14-37): workspace cut (cfg
-  // workspace), voxelise (voxelize/voxel_size), normals on the GPU when the cloud has none
-  // (normals_radius; normals that came with the cloud are kept), subsample.
+  // workspace), voxelise (voxelize/voxel_size), normals recomputed on the GPU (normals_radius), subsample;
+  // cfg use_file_normals = 1 keeps the normals a PCD came with (and then does not voxelise).
   void preprocessPointCloud(util::Cloud &cloud);
   // Cloud::calculateNormals (cloud.cpp:451-476) on the device: radius PCA, flipped to the view points,
   // reverseNormals; replaces the cloud's normals.  False when the device call fails.
@@ -107,6 +107,7 @@ class GraspDetector {
   bool plugin_route_ = false;      // cfg classifier_plugin_route: score through Classifier::classifyImages
   int num_samples_ = 1000;
   bool voxelize_ = true;
+  bool use_file_normals_ = false;  // cfg use_file_normals: keep normal_x/y/z of the PCD instead of recomputing them
   double voxel_size_ = 0.003, normals_radius_ = 0.03;
   int num_selected_ = 100;
   std::vector<double> workspace_grasps_;

@@ -125,6 +125,16 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
     printf("Only ASCII and uncompressed binary .pcd files are supported (DATA %s): %s\n", kind.c_str(), filename.c_str());
     return;
   }
+  // an untrusted header: field counts must agree, sizes are 1 / 2 / 4 / 8 bytes, counts at least 1 and small
+  counts.resize(fields.size(), 1);
+  bool header_ok = !fields.empty() && fields.size() <= 64 && (sizes.empty() || sizes.size() == fields.size()) &&
+                   (types.empty() || types.size() == fields.size()) && points <= ((size_t)1 << 31);
+  for (int v : sizes) header_ok = header_ok && (v == 1 || v == 2 || v == 4 || v == 8);
+  for (int v : counts) header_ok = header_ok && v >= 1 && v <= 1024;
+  if (!header_ok) {
+    printf("PCD header is malformed (FIELDS / SIZE / TYPE / COUNT / POINTS): %s\n", filename.c_str());
+    return;
+  }
   int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1;
   for (int i = 0; i < (int)fields.size(); i++) {
     if (fields[i] == "x") ix = i;
@@ -155,8 +165,12 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
     while (std::getline(f, line)) {
       std::stringstream ss(line);
       bool good = true;
-      for (size_t i = 0; i < fields.size(); i++)
-        if (!(ss >> row[i])) good = false;
+      for (size_t i = 0; i < fields.size() && good; i++)
+        for (int c = 0; c < counts[i] && good; c++) {  // a field of COUNT n takes n columns; its first value is kept
+          double v;
+          if (!(ss >> v)) good = false;
+          if (c == 0) row[i] = v;
+        }
       if (good) keep(row.data());
     }
   } else {
@@ -165,7 +179,6 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
       printf("PCD header is incomplete (SIZE / TYPE): %s\n", filename.c_str());
       return;
     }
-    counts.resize(fields.size(), 1);
     std::vector<size_t> offset(fields.size());
     size_t stride = 0;
     for (size_t i = 0; i < fields.size(); i++) {
@@ -260,7 +273,15 @@ void Cloud::setNormalsFromFile(const std::string &filename) {
     std::string cell;
     size_t j = 0;
     while (std::getline(ls, cell, ',')) {
-      if (j < size()) normals[3 * j + i] = (float)std::stod(cell);
+      if (j < size()) {
+        char *end = nullptr;
+        const double v = std::strtod(cell.c_str(), &end);
+        if (end == cell.c_str()) {  // not a number: the file is refused as a whole (std::stod would throw)
+          printf("ERROR: cannot parse the normals file %s\n", filename.c_str());
+          return;
+        }
+        normals[3 * j + i] = (float)v;
+      }
       j++;
     }
     i++;
@@ -297,19 +318,45 @@ void Cloud::voxelizeCloud(float cell_size) {
   printf("Voxelized cloud: %zu\n", size());
 }
 
+// Cloud::subsample (cloud.cpp:350-405): samples given by coordinates are thinned to num_samples of them without
+// repetition (subsampleSamples), sample indices are redrawn num_samples times WITH repetition
+// (subsampleSampleIndices: sample_indices_[rand() % size]), otherwise num_samples points are drawn uniformly
+// (subsampleUniformly).  The reference's generators are time-seeded; here one seeded xorshift.
 void Cloud::subsample(int num_samples, unsigned seed) {
-  const int n = (int)size();
-  if (num_samples <= 0 || n == 0) return;
-  std::vector<int> idx(n);
-  std::iota(idx.begin(), idx.end(), 0);
+  if (num_samples <= 0) return;
   uint64_t s = 0x9E3779B97F4A7C15ull ^ seed;
-  const int m = std::min(num_samples, n);
-  for (int i = 0; i < m; i++) {
+  auto next = [&s]() {
     s ^= s << 13;
     s ^= s >> 7;
     s ^= s << 17;
-    std::swap(idx[i], idx[i + (int)(s % (uint64_t)(n - i))]);
+    return s;
+  };
+  if (samples_.size() >= 3) {
+    const int have = (int)(samples_.size() / 3);
+    if (num_samples >= have) return;
+    printf("Using %d out of %d available samples.\n", num_samples, have);
+    std::vector<int> seq(have);
+    std::iota(seq.begin(), seq.end(), 0);
+    for (int i = 0; i < num_samples; i++) std::swap(seq[i], seq[i + (int)(next() % (uint64_t)(have - i))]);
+    std::vector<double> sub((size_t)num_samples * 3);
+    for (int i = 0; i < num_samples; i++)
+      for (int r = 0; r < 3; r++) sub[3 * (size_t)i + r] = samples_[3 * (size_t)seq[i] + r];
+    samples_ = sub;
+    return;
   }
+  if (!sample_indices_.empty()) {
+    if (num_samples >= (int)sample_indices_.size()) return;
+    std::vector<int> indices(num_samples);
+    for (int i = 0; i < num_samples; i++) indices[i] = sample_indices_[next() % sample_indices_.size()];
+    sample_indices_ = indices;
+    return;
+  }
+  const int n = (int)size();
+  if (n == 0) return;
+  std::vector<int> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  const int m = std::min(num_samples, n);
+  for (int i = 0; i < m; i++) std::swap(idx[i], idx[i + (int)(next() % (uint64_t)(n - i))]);
   idx.resize(m);
   sample_indices_ = idx;
 }
@@ -482,6 +529,7 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   clustering_ = std::make_unique<Clustering>(min_inliers);
   cluster_grasps_ = min_inliers > 0;
   num_selected_ = config_file.getValueOfKey<int>("num_selected", 100);
+  use_file_normals_ = config_file.getValueOfKey<int>("use_file_normals", 0) != 0;
   printf("============ CANDIDATE GENERATION ============\n");
   printf("num_samples: %d\nnn_radius: %3.2f\nnum_orientations: %d\nnum_finger_placements: %d\ndeepen_hand: %s\n", num_samples_,
          params_.nn_radius_frames, params_.num_orientations, params_.num_finger_placements, params_.deepen_hand ? "true" : "false");
@@ -593,15 +641,18 @@ bool GraspDetector::calculateNormals(util::Cloud &cloud, double radius) {
   return true;
 }
 
+// CandidatesGenerator::preprocessPointCloud (candidates_generator.cpp:14-37): workspace cut, voxelise when enabled,
+// normals ALWAYS recomputed, subsample.  The reference never reads normals from a PCD; normals that came with the
+// file are used only when the cfg says so (use_file_normals = 1: no voxelisation then either, the normals belong to
+// the points as loaded) — the synthetic benchmark clouds ship their analytic normals this way.
 void GraspDetector::preprocessPointCloud(util::Cloud &cloud) {
   printf("Processing cloud with %zu points.\n", cloud.size());
   cloud.filterWorkspace(workspace_);  // candidates_generator.cpp:19 (NaN rows are dropped at load time)
-  if (!cloud.hasNormals()) {
-    // the reference's order: voxelise, then estimate normals on the voxelised cloud
+  if (!(use_file_normals_ && cloud.hasNormals())) {
     if (voxelize_) cloud.voxelizeCloud((float)voxel_size_);
     if (ctx_ && cloud.size() > 0 && !calculateNormals(cloud, normals_radius_)) return;
   }
-  if (cloud.getSampleIndices().empty()) cloud.subsample(num_samples_);
+  cloud.subsample(num_samples_);
 }
 
 bool GraspDetector::upload(const util::Cloud &cloud) {

@@ -244,7 +244,7 @@ int gpd_hip_replay(gpd_hip_ctx *ctx, int stages);
 int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *scores);
 
 /* HIP-event durations of the four LeNet kernels (conv1+pool1, conv2+pool2, ip1, ip2+score; first
- * 16384-image chunk) summed over the replays covered by the last gpd_hip_replay_times call —
+ * 65536-image chunk) summed over the replays covered by the last gpd_hip_replay_times call —
  * the per-kernel roofline input of bench.py. */
 int gpd_hip_replay_kernel_ms(gpd_hip_ctx *ctx, float ms[4]);
 

@@ -31,8 +31,8 @@ def main():
     print("# rocprofv3 summary of %s" % d)
     st = os.path.join(d, "stats", "bench_results.db")
     if os.path.exists(st):
-        print("\n## kernel-trace --stats  (bench.py --steps 10 --warmup 2: the 12 replays of the 5000-candidate list plus the")
-        print("##   first pass and two gpd_hip_detect calls on the 6077 candidates of the whole sample set; `timed_us` = average")
+        print("\n## kernel-trace --stats  (bench.py --steps 10 --warmup 2 --batch-clouds 0: the 12 replays of the 5000-candidate list plus")
+        print("##   the first passes and the gpd_hip_detect calls on the 6077 candidates of the whole sample set; `timed_us` = average")
         print("##   over the LAST 10 launches, i.e. the timed steps, which is what bench.py's HIP events measure)")
         print("%-70s %6s %12s %12s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "timed_us"))
         c = sqlite3.connect(st)
@@ -76,7 +76,11 @@ def traffic_json(d, out):
         v["read_bytes_corrected"] = 2.0 * f * 1024.0
         v["write_bytes"] = w * 1024.0
         v["hbm_bytes_per_launch"] = v["read_bytes_corrected"] + v["write_bytes"]
-    json.dump({"source": d, "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+    import os as _os
+    import sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    import bench  # the SHA-1 of the kernel sources this was measured on: bench.py drops the numbers when they change
+    json.dump({"source": d, "source_hashes": bench.source_hashes(), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@ def _write_case(tmp, cl, w, num_samples, num_selected, channels=15, min_inliers=
     cfg = tmp / "params.cfg"
     cfg.write_text("# test config in the format of cfg/eigen_params.cfg\n"
                    "hand_geometry_filename = hand_geometry.cfg\nimage_geometry_filename = image_geometry.cfg\n"
-                   "weights_file = params/\ndevice = 1\ncamera_position = 0 0 0\n"
+                   "weights_file = params/\ndevice = 1\ncamera_position = 0 0 0\nuse_file_normals = 1\n"
                    "num_samples = %d\nnum_threads = 4\nnn_radius = 0.01\nnum_orientations = 8\nnum_finger_placements = 10\n"
                    "hand_axes = 2\ndeepen_hand = 1\nfriction_coeff = 20\nmin_viable = 6\nmin_aperture = 0.0\nmax_aperture = 0.085\n"
                    "workspace_grasps = -1 1 -1 1 -1 1\nmin_inliers = %d\nnum_selected = %d\nplot_normals = 0\n%s"

@@ -93,3 +93,28 @@ def test_cli_argument_errors_without_a_gpu(tmp_path):
     for name in ("detect_grasps", "generate_candidates", "label_grasps", "cem_detect_grasps"):
         out = subprocess.run([os.path.join(host, name)], capture_output=True, text=True, timeout=60)
         assert out.returncode == 255 and "Not enough input arguments" in out.stdout, name
+
+
+def test_pcd_reader_refuses_malformed_headers(tmp_path):
+    """An untrusted PCD header (negative / huge SIZE, COUNT 0, absurd POINTS, mismatched field lists) yields an empty
+    cloud and a message, never a crash or a giant allocation."""
+    from gpd_amd import hostlib
+    base = "VERSION 0.7\nFIELDS x y z\n%s\nTYPE F F F\n%s\nWIDTH 2\nHEIGHT 1\nPOINTS %s\nDATA %s\n"
+    bad = [
+        base % ("SIZE -4 4 4", "COUNT 1 1 1", "2", "binary"),
+        base % ("SIZE 4 4 400000000", "COUNT 1 1 1", "2", "binary"),
+        base % ("SIZE 4 4 4", "COUNT 0 1 1", "2", "binary"),
+        base % ("SIZE 4 4 4", "COUNT 1 1 1", "99999999999999", "binary"),
+        base % ("SIZE 4 4", "COUNT 1 1 1", "2", "binary"),
+    ]
+    for i, head in enumerate(bad):
+        path = tmp_path / ("bad%d.pcd" % i)
+        path.write_bytes(head.encode() + b"\x00" * 24)
+        xyz, nrm = hostlib.load_pcd(str(path))
+        assert len(xyz) == 0, i
+    # an ASCII field with COUNT 2 takes two columns
+    path = tmp_path / "count2.pcd"
+    path.write_text("VERSION 0.7\nFIELDS x y z extra\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 2\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n"
+                    "1 2 3 9 9\n4 5 6 8 8\n")
+    xyz, nrm = hostlib.load_pcd(str(path))
+    assert xyz.tolist() == [[1, 2, 3], [4, 5, 6]] and nrm is None
