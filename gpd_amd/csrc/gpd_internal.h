@@ -110,6 +110,10 @@ struct SearchState {
   gpd_hand *d_hands = nullptr;        // [S][slots]
   uint8_t *d_fvalid = nullptr;        // [S][slots] is_valid after filterGraspsWorkspace (hand_eval_kernel writes it; the
                                       // unfused gpd_hip_images overwrites it with the caller's flags)
+  // centre_kernel (serial fp64 chains: a hundred-odd waves, latency-bound) runs on a side stream beside
+  // hand_eval_kernel and is joined before anything reads d_centers
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<int32_t> h_counts;      // host copy of d_counts (unfused entry points only)
   std::vector<int32_t> h_set_sample;  // set -> sample slot
   std::vector<double> h_samples;      // [S][3] sample coordinates (to validate hands passed to images)

@@ -1329,11 +1329,30 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   L.ct1 = nullptr;
   L.ce = nullptr;
   L.kc = 0;
+  // (the three coordinates of the NEXT 256 points are requested before this round's are used: one global round
+  //  trip per round otherwise, and a round is little more than that)
+  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f;
+  if (tid < N) {
+    nx0 = L.nn[0 * L.cap + tid];
+    nx1 = L.nn[1 * L.cap + tid];
+    nx2 = L.nn[2 * L.cap + tid];
+  }
   for (int e0 = 0; e0 < N; e0 += 256) {
     const int e = e0 + tid;
-    double t[3] = {0, 0, 0}, tn[3];
-    int mult;
-    const bool in = e < N && list_entry(L, e, t, tn, mult);
+    const float w0 = nx0, w1 = nx1, w2 = nx2;
+    if (e + 256 < N) {
+      nx0 = L.nn[0 * L.cap + e + 256];
+      nx1 = L.nn[1 * L.cap + e + 256];
+      nx2 = L.nn[2 * L.cap + e + 256];
+    }
+    double t[3] = {0, 0, 0};
+    bool in = false;
+    if (e < N) {  // list_entry() on the prefetched coordinates: transformToHandFrame + the height test
+      const double c0 = (double)w0 - L.sample[0], c1 = (double)w1 - L.sample[1], c2 = (double)w2 - L.sample[2];
+#pragma unroll
+      for (int r = 0; r < 3; r++) t[r] = L.FR[0 + r] * c0 + L.FR[3 + r] * c1 + L.FR[6 + r] * c2;
+      in = t[2] > -1.0 * L.hand_height && t[2] < L.hand_height;
+    }
     const unsigned long long ballot = __ballot(in);
     if (ballot) {
       int base = 0;
@@ -1467,7 +1486,10 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
 void search_free(SearchState &s) {
   void *ptrs[] = {s.d_sample_idx, s.d_sample_xyz, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands, s.d_fvalid};
   for (void *p : ptrs)
-    if (p) (void)hipFree(p);
+    if (p) (void)hipFree(p);  // hipFree waits for the device: the side stream is idle as well
+  if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
+  if (s.ev_join) (void)hipEventDestroy(s.ev_join);
+  if (s.aux) (void)hipStreamDestroy(s.aux);
   s = SearchState();
 }
 
@@ -1529,14 +1551,29 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
     neighbourhood_kernel<false><<<S, NB_THREADS, lds, stream>>>(np);
   }
   HIP_RET(hipGetLastError());
-  centre_kernel<<<(3 * S + 63) / 64, 64, 0, stream>>>(s.d_nn, s.d_counts, cap, S, s.d_centers);
+  // the centre sums fork off to the side stream; search_join() brings them back
+  if (!s.aux) {
+    HIP_RET(hipStreamCreate(&s.aux));
+    HIP_RET(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+    HIP_RET(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
+  }
+  HIP_RET(hipEventRecord(s.ev_fork, stream));
+  HIP_RET(hipStreamWaitEvent(s.aux, s.ev_fork, 0));
+  centre_kernel<<<(3 * S + 63) / 64, 64, 0, s.aux>>>(s.d_nn, s.d_counts, cap, S, s.d_centers);
   HIP_RET(hipGetLastError());
+  HIP_RET(hipEventRecord(s.ev_join, s.aux));
   s.h_counts.clear();
   if (sync_counts) {
     s.h_counts.resize((size_t)S * 8);
     HIP_RET(hipMemcpyAsync(s.h_counts.data(), s.d_counts, (size_t)S * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIP_RET(hipStreamSynchronize(stream));
   }
+  return GPD_OK;
+}
+
+// the main stream waits for the centre sums of the last run_neighbourhoods
+static int search_join(SearchState &s, hipStream_t stream) {
+  if (s.ev_join) HIP_RET(hipStreamWaitEvent(stream, s.ev_join, 0));
   return GPD_OK;
 }
 
@@ -1646,6 +1683,8 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   hp.num_samples = S;
   hand_eval_kernel<<<((S + 7) / 8) * 8 * slots, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
+  rc = search_join(s, stream);
+  if (rc) return rc;
   s.num_samples = S;
   s.cloud_generation = c.generation;
   return GPD_OK;
@@ -1679,6 +1718,8 @@ int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand
   hp.num_samples = n;
   reeval_kernel<<<n, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
+  rc = search_join(s, stream);
+  if (rc) return rc;
   HIP_RET(hipMemcpyAsync(hands, s.d_hands, (size_t)n * sizeof(gpd_hand), hipMemcpyDeviceToHost, stream));
   HIP_RET(hipMemcpyAsync(s.h_counts.data(), s.d_counts, (size_t)n * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   HIP_RET(hipStreamSynchronize(stream));
