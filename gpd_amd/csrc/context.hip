@@ -105,6 +105,7 @@ struct Job {
 
 struct gpd_hip_ctx {
   int device = 0;
+  bool in_batch = false;  // gpd_hip_detect_batch is driving the lanes
   gpd_params params;
   LeNetWeights lenet;
   Lane lane[kLanes];
@@ -234,6 +235,7 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   }
   (void)hipEventElapsedTime(&L.stage_ms[0], L.ev[0], L.ev[1]);  // here: the next job on this lane records them again
   HIP_TRY(hipEventRecord(L.ev[4], L.stream));
+  L.images.side_stream = !ctx->in_batch;
   int rc = images_run(ctx->params, L.cloud, L.search, L.plan, L.images, L.stream);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(L.ev[2], L.stream));
@@ -820,6 +822,7 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     if (rc) return rc;
   }
   std::vector<Job> J((size_t)num_jobs);
+  ctx->in_batch = true;
   int first_error = GPD_OK;
   char first_text[sizeof(g_err)] = "";
   auto fail = [&](int i, int rc) {
@@ -869,6 +872,8 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     if (i >= 1) end(i - 1);
   }
   if (num_jobs > 0) end(num_jobs - 1);
+  ctx->in_batch = false;
+  for (int l = 0; l < kLanes; l++) ctx->lane[l].images.side_stream = true;
   if (first_error) std::memcpy(g_err, first_text, sizeof(g_err));
   return first_error;
 }

@@ -229,6 +229,11 @@ struct ImageState {
   long long stat_sets = 0, stat_sum_set_ni = 0, stat_sum_cand_ni = 0;  // for the algorithmic byte count
   std::vector<unsigned char> consts;  // the constant block (image geometry) the candidate list was built with
   double view_points[3 * kMaxCams] = {0};  // of the cloud the list was built on (shadow_set_kernel argument)
+  // the normals + depth kernel does not depend on the shadow kernels: it runs on a side stream beside them (both kinds
+  // of workgroup fit a CU together) and is joined at the end of the stage
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_stream = true;  // off inside gpd_hip_detect_batch: the other cloud's kernels already fill the gaps (measured)
 };
 // Sizes the image buffers for the plan's candidate list (summary already on the host) and launches the image kernels.
 int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream);

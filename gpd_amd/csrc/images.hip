@@ -1217,6 +1217,9 @@ void images_free(ImageState &im) {
   void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_status, im.d_set_bits, im.d_overflow, im.d_pts_overflow, im.d_pts_scratch};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (im.ev_fork) (void)hipEventDestroy(im.ev_fork);
+  if (im.ev_join) (void)hipEventDestroy(im.ev_join);
+  if (im.aux) (void)hipStreamDestroy(im.aux);
   im = ImageState();
 }
 
@@ -1392,6 +1395,42 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     ip.dbg = d_dbg;
   }
   ip.set_bits = im.d_set_bits;
+  ip.cand_list = nullptr;
+  ip.cand_count = nullptr;
+  ip.num_cand = n;
+  ip.overflow_list = nullptr;
+  ip.overflow_count = nullptr;
+  // normals + depth on the side stream (15 channels: beside the shadow kernels).  Nearly every box holds fewer than
+  // PT_CAP points; the others are queued and redone by the instantiation that keeps its point arrays in a global
+  // scratch row.
+  if (!im.aux) {
+    HIP_RET(hipStreamCreate(&im.aux));
+    HIP_RET(hipEventCreateWithFlags(&im.ev_fork, hipEventDisableTiming));
+    HIP_RET(hipEventCreateWithFlags(&im.ev_join, hipEventDisableTiming));
+  }
+  hipStream_t pts_stream = (im.channels == 15 && !ip.dbg && im.side_stream) ? im.aux : stream;
+  if (pts_stream != stream) {
+    HIP_RET(hipEventRecord(im.ev_fork, stream));
+    HIP_RET(hipStreamWaitEvent(pts_stream, im.ev_fork, 0));
+  }
+  ip.pts_overflow_list = im.d_pts_overflow;
+  ip.pts_overflow_count = im.d_pts_overflow + im.capacity;
+  ip.pts_scratch = nullptr;
+  HIP_RET(hipMemsetAsync(im.d_pts_overflow + im.capacity, 0, sizeof(int32_t), pts_stream));
+  grasp_image_kernel<false><<<8 * ((n + 7) / 8), IMG_THREADS, 0, pts_stream>>>(ip);
+  HIP_RET(hipGetLastError());
+  {
+    ImgParams ib = ip;
+    ib.cand_list = im.d_pts_overflow;
+    ib.cand_count = im.d_pts_overflow + im.capacity;
+    ib.pts_overflow_list = nullptr;
+    ib.pts_overflow_count = nullptr;
+    ib.pts_scratch = im.d_pts_scratch;
+    grasp_image_kernel<true><<<LGRID, IMG_THREADS, 0, pts_stream>>>(ib);
+    HIP_RET(hipGetLastError());
+  }
+  ip.pts_overflow_list = nullptr;
+  ip.pts_overflow_count = nullptr;
   if (im.num_shadow_sets > 0) {
     SetParams sp;
     sp.nn = s.d_nn;
@@ -1423,24 +1462,8 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     shadow_image_kernel<SH_CAP_BIG><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
     HIP_RET(hipGetLastError());
   }
-  // normals + depth: nearly every box holds fewer than PT_CAP points; the others are queued and redone
-  // by the instantiation that keeps its point arrays in a global scratch row
-  ip.pts_overflow_list = im.d_pts_overflow;
-  ip.pts_overflow_count = im.d_pts_overflow + im.capacity;
-  ip.pts_scratch = nullptr;
-  HIP_RET(hipMemsetAsync(im.d_pts_overflow + im.capacity, 0, sizeof(int32_t), stream));
-  grasp_image_kernel<false><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
-  HIP_RET(hipGetLastError());
-  {
-    ImgParams ib = ip;
-    ib.cand_list = im.d_pts_overflow;
-    ib.cand_count = im.d_pts_overflow + im.capacity;
-    ib.pts_overflow_list = nullptr;
-    ib.pts_overflow_count = nullptr;
-    ib.pts_scratch = im.d_pts_scratch;
-    grasp_image_kernel<true><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
-    HIP_RET(hipGetLastError());
-  }
+  HIP_RET(hipEventRecord(im.ev_join, pts_stream));
+  if (pts_stream != stream) HIP_RET(hipStreamWaitEvent(stream, im.ev_join, 0));
   if (ip.dbg) {
     unsigned long long h[32];
     HIP_RET(hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, stream));
