@@ -36,9 +36,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # f32 vector == f32-input MFMA peak
-LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk x 2.4 GHz = 78.6 TB/s aggregate LDS bandwidth (MI355X_MICROARCH.md)
+LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk (ds_read_b32 rate; 256 B/clk for b64/b128) x 2.4 GHz (MI355X_MICROARCH.md §LDS)
 LENET_MFLOP = {15: 83.04, 12: 73.63, 3: 45.41, 1: 39.14}  # SURVEY.md §8d (+ the 1-channel strategy)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+SQ_FILE = os.path.join(ROOT, "profiles", "r02_pmc_sq.json")
 KERNEL_SOURCES = ("gpd_amd/csrc/lenet.hip", "gpd_amd/csrc/images.hip", "gpd_amd/csrc/search.hip")
 
 CONFIGS = {  # BASELINE.json configs[1..3]
@@ -271,7 +272,12 @@ def main():
             kernels[name] = {"ms": k_s * 1e3, "algorithmic_flops": fl * n_cand,
                              "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None,
                              "frac_f32": fl * n_cand / k_s / 1e12 / F32_PEAK_TFLOPS if k_s > 0 else None}
-        traffic = _pmc_traffic()
+        traffic = _pmc_traffic(n_cand)
+        sq = _pmc_sq()
+        if sq:
+            # the image kernels are latency / LDS bound, not HBM bound: their LDS roofline is the share of
+            # the chip's LDS-array cycles that moved data (peak 256 B/clk/CU, MI355X_MICROARCH.md §LDS)
+            kernels["grasp_image_kernel"]["lds_roofline"] = sq
         dom = max(kflops, key=lambda k: kernels[k]["ms"])
         if kernels[dom]["ms"] >= img_s * 1e3 / 3.0:
             # the dominant single kernel of the step (conv1 + pool1 at 15 channels): f32 MFMA bound
@@ -362,29 +368,56 @@ def _filter_workspace(hands, p):
     h["valid"] = (h["valid"].astype(bool) & ok).astype(np.uint8)
 
 
-def _pmc_traffic():
+def _fc1_tile(n):
+    """lenet.hip fc1_pick_nt: the m-tile width (in 16s) ip1 runs with for n images."""
+    r = 1
+    while True:
+        nt = -(-n // (64 * r * 16))
+        if nt <= 8:
+            return max(nt, 1)
+        r += 1
+
+
+def _pmc_traffic(n_images):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json, produced by
-    profiles/run_profile.sh + summarize.py --traffic on the default workload).  The file carries the SHA-1 of the
-    kernel sources it was measured on: when a kernel file has changed since, the numbers are stale and dropped."""
+    profiles/collect_r02.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
+    on: when a kernel file has changed since, the numbers are stale and dropped."""
     if not os.path.exists(TRAFFIC_FILE):
         return {"note": "no PMC traffic file"}
     d = json.load(open(TRAFFIC_FILE))
     if d.get("source_hashes") != source_hashes():
         return {"note": "%s was measured on other kernel sources: stale, not reported" % os.path.relpath(TRAFFIC_FILE, ROOT)}
     d = d["kernels"]
-    out = {"source": "profiles/r02_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes; reads x2 per the gfx950 note; "
-                     "same kernel sources as this run, by SHA-1)"}
-    img = [v["hbm_bytes_per_launch"] for k, v in d.items()
-           if any(s in k for s in ("grasp_image_kernel<false>", "grasp_image_kernel<0>", "shadow_image_kernel<6144>", "shadow_set_kernel"))]
-    if img:
-        out["image"] = float(sum(img))
-    net = [v["hbm_bytes_per_launch"] for k, v in d.items() if any(s in k for s in ("conv1", "conv2", "fc1_mfma", "fc2_score"))]
-    if net:
-        out["lenet"] = float(sum(net))
-    for name in ("conv1_mfma", "conv2_mfma", "fc1_mfma"):
-        one = [v["hbm_bytes_per_launch"] for k, v in d.items() if name in k]
-        if one:
-            out[name] = float(sum(one))
+    out = {"source": "profiles/r02_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; reads x2 per "
+                     "the gfx950 note; same kernel sources as this run, by SHA-1)"}
+    fc1 = "fc1_mfma_kernel<%d>" % _fc1_tile(n_images)
+
+    def total(names):
+        vals = [v["hbm_bytes_per_launch"] for k, v in d.items() if any(s in k for s in names)]
+        return float(sum(vals)) if vals else None
+
+    out["image"] = total(("grasp_image_kernel<false>", "shadow_image_kernel<6144>", "shadow_set_kernel"))
+    out["lenet"] = total(("conv1_mfma", "conv2_mfma", fc1, "fc2_score"))
+    out["conv1_mfma"] = total(("conv1_mfma",))
+    out["conv2_mfma"] = total(("conv2_mfma",))
+    out["fc1_mfma"] = total((fc1,))
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def _pmc_sq():
+    """LDS-array utilisation of the image kernels from the committed SQ-counter pass (profiles/pmc_sq.sh ->
+    profiles/r02_pmc_sq.json), dropped like the traffic numbers when the kernel sources have changed since."""
+    if not os.path.exists(SQ_FILE):
+        return None
+    d = json.load(open(SQ_FILE))
+    if d.get("source_hashes") != source_hashes():
+        return None
+    out = {"source": "profiles/r02_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
+           "peak": "256 B/clk/CU = %.1f TB/s at 2.4 GHz" % (LDS_PEAK_GBS * 2 / 1e3)}
+    for k, v in d["kernels"].items():
+        for name in ("shadow_image_kernel<6144>", "grasp_image_kernel<false>", "shadow_set_kernel"):
+            if name in k:
+                out[name] = {"frac": v["lds_util"], "conflict_share": v["lds_conflict"], "wait_any": v["wait_any"]}
     return out
 
 

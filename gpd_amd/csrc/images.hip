@@ -527,6 +527,65 @@ __device__ inline void sort_u16(uint16_t *p, int n) {
     p[j + 1] = v;
   }
 }
+// The same with at most 16 keys in registers at a time (grasp_image_kernel is held to 128 VGPRs; the 32-key network
+// alone costs it 21 spilled registers = 0.2 GB of scratch traffic per 5000 candidates).  17..32 keys: both halves
+// through the 16-key network, the cross step of the bitonic merge element by element through LDS, then each half —
+// a bitonic sequence now — through the 16-key merge network.  Same 240 compare-exchanges, five LDS round trips
+// instead of one, and only for the few pixels that hold more than 16 points.
+template <int N>
+__device__ inline void merge_regs(uint32_t (&k)[N]) {  // bitonic -> ascending
+#pragma unroll
+  for (int stride = N >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int j = i ^ stride;
+      if (j > i) {
+        const uint32_t lo = min(k[i], k[j]), hi = max(k[i], k[j]);
+        k[i] = lo;
+        k[j] = hi;
+      }
+    }
+  }
+}
+template <int N>
+__device__ inline void sort_regs(uint32_t (&k)[N]);
+__device__ inline void sort_u16_lean(uint16_t *p, int n) {
+  if (n <= 8) return sort_u16_regs<8>(p, n);
+  if (n <= 16) return sort_u16_regs<16>(p, n);
+  if (n > 32) return sort_u16(p, n);
+  uint32_t k[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) k[q] = p[q];
+  sort_regs<16>(k);
+#pragma unroll
+  for (int q = 0; q < 16; q++) p[q] = (uint16_t)k[q];
+#pragma unroll
+  for (int q = 0; q < 16; q++) k[q] = 16 + q < n ? (uint32_t)p[16 + q] : 0xffffffffu;
+  sort_regs<16>(k);
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (16 + q < n) p[16 + q] = (uint16_t)k[q];
+  // cross step: element i against element 31 - i (missing ones are +inf and stay where they are)
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if (31 - i < n) {
+      const uint16_t a = p[i], b = p[31 - i];
+      p[i] = a < b ? a : b;
+      p[31 - i] = a < b ? b : a;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; q++) k[q] = p[q];
+  merge_regs<16>(k);
+#pragma unroll
+  for (int q = 0; q < 16; q++) p[q] = (uint16_t)k[q];
+#pragma unroll
+  for (int q = 0; q < 16; q++) k[q] = 16 + q < n ? (uint32_t)p[16 + q] : 0xffffffffu;
+  merge_regs<16>(k);
+#pragma unroll
+  for (int q = 0; q < 16; q++)
+    if (16 + q < n) p[16 + q] = (uint16_t)k[q];
+}
 // N keys in registers, ascending (bitonic network, fully unrolled: 24 / 80 / 240 compare-exchanges
 // for N = 8 / 16 / 32).  The walks order their short per-pixel segments through registers: N
 // independent LDS reads, the network, N writes — one LDS round trip instead of the dependent
@@ -1024,7 +1083,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
         fc = (float)((double)fc + 1.0);
         avg = (float)((double)avg + (d - (double)avg) * recip_count<128>(S.recip, fc));
       };
-      sort_u16(&S.place[start], cn);  // neighbour order = entry order
+      sort_u16_lean(&S.place[start], cn);  // neighbour order = entry order
       for (int q = 0; q < cn; q++) visit((int)S.place[start + q]);
       S.nzv[qn] = make_float4(v0, v1, v2, (float)(1.0 - (double)avg));
     }
