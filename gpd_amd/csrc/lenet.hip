@@ -392,13 +392,18 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
 // the 64 x 64 tiles of round 1 left a 3-tile makespan on 2.47 tiles per SIMD).  128-wide u-tiles also halve
 // the operand traffic per flop from L2 (2.3 GB per launch at 64 x 64).  The four u-tiles of an m-tile run
 // on ONE XCD (workgroup L runs on XCD L % 8), so the image rows are fetched from HBM once.
-// LDS: three stages of K = 32 (W rows padded to 144 floats, X k-major with a row stride = 17 mod 32: both the
-// transposing writes and the MFMA operand reads are bank-conflict free); global loads run two stages ahead
-// through two register sets.
+// LDS: three stages of K = 32 (W rows padded to 144 floats, X k-major and swizzled: both the transposing writes and
+// the MFMA operand reads are bank-conflict free, see fc_sx); global loads run two stages ahead through two register sets.
 // ---------------------------------------------------------------------------
 constexpr int FC_BU = 128, FC_BK = 32, FC_THREADS = 512, FC_SW = FC_BU + 16, FC_STEPS = kFc1In / FC_BK;
 static_assert(kFc1In % FC_BK == 0, "K steps");
-__host__ __device__ constexpr int fc_sx(int bm) { return (bm % 32 == 16) ? bm + 1 : bm + 17; }
+// X tile in LDS: k-major rows of stride = 16 (mod 32) with the column of element (k, m) swizzled to
+// m ^ (((k >> 2) & 7) << 2).  The MFMA operand read (lanes: two k of one k-quad x 16 consecutive m) then touches
+// 32 different banks — row k + 1 sits 16 banks further, and the swizzle maps an aligned 16-block of m onto an aligned
+// 16-block — and so does the transposing write of the loader (lanes: 4 rows m x 8 k-quads, one k of each quad: the
+// swizzle spreads the 8 quads over the banks the 4 rows leave free).  (Row stride = 17 (mod 32) without the swizzle cost
+// one 2-way conflict per read: 40 % of fc1's LDS cycles, profiles/r02_pmc_sq.txt of the first collection.)
+__host__ __device__ constexpr int fc_sx(int bm) { return (bm + 31) / 32 * 32 + 16; }
 
 template <int NT>
 __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__restrict__ W, const float *__restrict__ bias,
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__res
 #pragma unroll
     for (int i = 0; i < X_PT; i++)
       if (tid + i * FC_THREADS < XV) {
-        float *d = sx + (4 * xkq[i]) * SX + xm[i];
+        float *d = sx + (4 * xkq[i]) * SX + (xm[i] ^ ((xkq[i] & 7) << 2));
         d[0] = x2[i].x;
         d[SX] = x2[i].y;
         d[2 * SX] = x2[i].z;
@@ -462,16 +467,16 @@ __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__res
   };
   auto compute = [&](int buf) {
     const float *sw = smem + buf * STAGE + g * FC_SW + wave * 16 + j;
-    const float *sx = smem + buf * STAGE + FC_BK * FC_SW + g * SX + j;
+    const float *sx = smem + buf * STAGE + FC_BK * FC_SW + g * SX;
     float a_cur = sw[0], a_nxt = 0.f, b_cur[NT], b_nxt[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) b_cur[t] = sx[16 * t];
+    for (int t = 0; t < NT; t++) b_cur[t] = sx[16 * t + j];
 #pragma unroll
     for (int ks = 0; ks < FC_BK / 4; ks++) {
       if (ks + 1 < FC_BK / 4) {  // operands of the next four k are requested before this step's MFMAs ...
         a_nxt = sw[(4 * (ks + 1)) * FC_SW];
 #pragma unroll
-        for (int t = 0; t < NT; t++) b_nxt[t] = sx[(4 * (ks + 1)) * SX + 16 * t];
+        for (int t = 0; t < NT; t++) b_nxt[t] = sx[(4 * (ks + 1)) * SX + ((16 * t + j) ^ (((ks + 1) & 7) << 2))];
       }
       __builtin_amdgcn_sched_barrier(0);  // ... and arrive while they run (the scheduler would sink the reads to their uses)
 #pragma unroll
