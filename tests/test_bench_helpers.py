@@ -1,0 +1,63 @@
+"""bench.py's host-side helpers (no GPU): the ip1 tile rule it mirrors from lenet.hip, conv1's live-pair statistic,
+the staleness check of the committed PMC numbers, the cloud -> rank assignment of the batch mode."""
+import json
+import os
+
+import numpy as np
+
+import bench
+from gpd_amd import dist as gdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fc1_tile_rule_matches_the_kernel_launcher():
+    # lenet.hip fc1_pick_nt: smallest multiple of 16 (<= 128) whose m-tiles fill 64 workgroup columns in whole rounds
+    assert [bench._fc1_tile(n) for n in (1, 37, 1024, 1025, 5000, 6077, 8192, 10000, 16384, 50000)] == [1, 1, 1, 2, 5, 6, 8, 5, 8, 7]
+    src = open(os.path.join(ROOT, "gpd_amd", "csrc", "lenet.hip")).read()
+    assert "(n + 64 * r * 16 - 1) / (64 * r * 16)" in src  # the rule restated above is the one in the launcher
+
+
+def test_conv1_live_fraction():
+    img = np.zeros((4, 60, 60, 15), np.uint8)
+    assert bench._conv1_live_fraction(img) == 0.0
+    img[:] = 1
+    assert bench._conv1_live_fraction(img) == 1.0
+    img[:] = 0
+    img[:, :, :, 3] = 7          # one live channel of fifteen
+    assert abs(bench._conv1_live_fraction(img) - 1.0 / 15.0) < 1e-12
+    img[:] = 0
+    img[0, 0, 0, 0] = 1          # one pixel: one (chunk, channel) pair of 2 x 25 x 15 (pairs of images share chunks)
+    assert abs(bench._conv1_live_fraction(img) - 1.0 / (2 * 25 * 15)) < 1e-12
+
+
+def test_pmc_numbers_are_dropped_when_a_kernel_source_changes(tmp_path, monkeypatch):
+    good = {"source_hashes": bench.source_hashes(),
+            "kernels": {"void gpd::conv1_mfma_kernel<15>(x)": {"hbm_bytes_per_launch": 8e8},
+                        "void gpd::fc1_mfma_kernel<5>(x)": {"hbm_bytes_per_launch": 2.7e8},
+                        "void gpd::fc1_mfma_kernel<6>(x)": {"hbm_bytes_per_launch": 3.0e8}}}
+    f = tmp_path / "traffic.json"
+    f.write_text(json.dumps(good))
+    monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
+    t = bench._pmc_traffic(5000)
+    assert t["conv1_mfma"] == 8e8 and t["fc1_mfma"] == 2.7e8      # the ip1 instantiation this n runs with
+    assert bench._pmc_traffic(6077)["fc1_mfma"] == 3.0e8
+    good["source_hashes"]["gpd_amd/csrc/lenet.hip"] = "0" * 40
+    f.write_text(json.dumps(good))
+    t = bench._pmc_traffic(5000)
+    assert "conv1_mfma" not in t and "stale" in t["note"]
+
+
+def test_committed_profiles_belong_to_the_committed_kernels():
+    """profiles/r02_traffic.json / r02_pmc_sq.json are only reported while the kernel sources are the ones they were
+    measured on; a commit that changes a kernel has to re-collect them (profiles/collect_r02.sh, profiles/pmc_sq.sh)."""
+    for name in ("r02_traffic.json", "r02_pmc_sq.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d["source_hashes"] == bench.source_hashes(), name + " is stale: re-collect it"
+
+
+def test_batch_mode_cloud_assignment():
+    for world in (1, 2, 4, 8):
+        seen = sorted(c for r in range(world) for c in gdist.clouds_of_rank(256, r, world))
+        assert seen == list(range(256))
+        assert all(len(gdist.clouds_of_rank(256, r, world)) == 256 // world for r in range(world))
