@@ -227,6 +227,7 @@ def main():
     n_cand = len(cand)
     ni = ctx.images_stats()
 
+    fallbacks = ctx.fallbacks()  # of the benchmark's candidate list: which slow paths its search / image stage took
     for _ in range(args.warmup):
         ctx.replay(3)
     ctx.replay_times()
@@ -304,6 +305,7 @@ def main():
                        % (points // 1000, "clutter " if clutter else "", n_cand, C), "points": points, "candidates_per_gpu": n_cand,
                        "samples": int(n_samples), "channels": C, "sharding": "one cloud per GPU, no collective"},
             "roofline": roofline, "kernels": kernels, "pmc_traffic": traffic,
+            "fallbacks": fallbacks,
             "search": {"samples": int(n_samples), "hand_sets": int(hands.shape[0]), "kernel_ms": search_ms,
                        "wall_ms_incl_download": search_wall * 1e3},
             "detect_end_to_end": {"candidates": int(n_detect), "wall_ms": detect_wall * 1e3,

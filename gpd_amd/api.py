@@ -55,7 +55,7 @@ EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_h
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
-           "gpd_hip_detect_select", "gpd_hip_detect_batch"]
+           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_last_fallbacks"]
 
 
 def build():
@@ -86,6 +86,7 @@ def lib():
         L.gpd_hip_detect_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpd_hip_detect_batch.argtypes = [C.c_void_p, C.POINTER(DetectJob), C.c_int]
+        L.gpd_hip_last_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
         L.gpd_hip_estimate_normals.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
@@ -267,6 +268,14 @@ class Context:
         out = np.zeros(4, np.int64)
         self._check(lib().gpd_hip_last_images_stats(self._h, _ptr(out)))
         return dict(candidates=int(out[0]), sets=int(out[1]), sum_set_ni=int(out[2]), sum_cand_ni=int(out[3]))
+
+    def fallbacks(self):
+        """Slow paths of the last search / image stage: list capacity, candidates redone by the large shadow / points
+        kernels, LeNet passes."""
+        out = np.zeros(4, np.int64)
+        self._check(lib().gpd_hip_last_fallbacks(self._h, _ptr(out)))
+        return dict(neighbourhood_list_capacity=int(out[0]), large_shadow_kernel_candidates=int(out[1]),
+                    large_points_kernel_candidates=int(out[2]), lenet_passes=int(out[3]))
 
     def estimate_normals(self, radius=0.03):
         """Cloud::calculateNormals on the uploaded cloud -> f32 [P,3] (also kept on the device)."""

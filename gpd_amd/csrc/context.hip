@@ -966,6 +966,27 @@ int gpd_hip_last_images_stats(gpd_hip_ctx *ctx, long long out[4]) {
   return GPD_OK;
 }
 
+int gpd_hip_last_fallbacks(gpd_hip_ctx *ctx, long long out[4]) {
+  if (!ctx || !out) return GPD_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  Lane &L = ctx->lane[0];
+  HIP_TRY(hipStreamSynchronize(L.stream));
+  out[0] = L.search.nn_cap;
+  out[1] = out[2] = 0;
+  const ImageState &im = L.images;
+  int32_t v = 0;
+  if (im.d_overflow && im.channels == 15 && im.num_candidates > 0) {
+    HIP_TRY(hipMemcpy(&v, im.d_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost));
+    out[1] = v;
+  }
+  if (im.d_pts_overflow && im.num_candidates > 0) {
+    HIP_TRY(hipMemcpy(&v, im.d_pts_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost));
+    out[2] = v;
+  }
+  out[3] = im.num_candidates > 0 ? (im.num_candidates + 65535) / 65536 : 0;
+  return GPD_OK;
+}
+
 int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]) {
   if (!ctx || !ms) return GPD_ERR_INVALID;
   for (int i = 0; i < 3; i++) ms[i] = ctx->lane[0].stage_ms[i];

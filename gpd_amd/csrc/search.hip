@@ -824,7 +824,8 @@ __global__ __launch_bounds__(64) void centre_kernel(const float *__restrict__ nn
 // component), 3x3 eigensolver, eigenvector of the smallest eigenvalue, flip towards the view
 // point of the camera that sees the point, then the reference's reversal rule.
 // ---------------------------------------------------------------------------
-constexpr int NRM_CAP = 2048;
+constexpr int NRM_CAP = 2048;      // neighbours per point on the four-per-CU instantiation (voxelised clouds: ~340)
+constexpr int NRM_CAP_BIG = 7680;  // the retry for un-voxelised scans (tutorials/table_mug.pcd as shipped: up to 3987): 150 KB of LDS, one per CU
 struct NormalsParams {
   const float *px, *py, *pz;
   int num_points;
@@ -838,9 +839,10 @@ struct NormalsParams {
   int32_t *overflow;
 };
 
+template <int CAP>
 __global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
-  __shared__ unsigned long long s_keys[NRM_CAP];
-  __shared__ float s_xyz[3][NRM_CAP];
+  __shared__ unsigned long long s_keys[CAP];
+  __shared__ float s_xyz[3][CAP];
   __shared__ int s_count;
   __shared__ double s_c[3], s_m[6];
   const int pi = blockIdx.x;
@@ -864,13 +866,13 @@ __global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
       base = __shfl(base, 0);
       if (hit) {
         const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (pos < NRM_CAP) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+        if (pos < CAP) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
       }
     }
   });
   __syncthreads();
   const int found = s_count;
-  if (found > NRM_CAP) {
+  if (found > CAP) {
     if (tid == 0) atomicMax(P.overflow, found);
     return;
   }
@@ -972,15 +974,24 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
   np.reach = (float)radius * 1.001f + 1e-5f;
   np.out = d_out;
   np.overflow = d_ovf;
-  normals_kernel<<<c.num_points, 256, 0, stream>>>(np);
+  normals_kernel<NRM_CAP><<<c.num_points, 256, 0, stream>>>(np);
   HIP_RET(hipGetLastError());
   int32_t ovf = 0;
   HIP_RET(hipMemcpyAsync(&ovf, d_ovf, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipStreamSynchronize(stream));
+  if (ovf > NRM_CAP && ovf <= NRM_CAP_BIG) {
+    // a denser cloud than the lists of the fast instantiation hold: once more, every point, with the large ones
+    HIP_RET(hipMemsetAsync(d_ovf, 0, sizeof(int32_t), stream));
+    normals_kernel<NRM_CAP_BIG><<<c.num_points, 256, 0, stream>>>(np);
+    HIP_RET(hipGetLastError());
+    HIP_RET(hipMemcpyAsync(&ovf, d_ovf, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+  }
   HIP_RET(hipMemcpyAsync(normals_out, d_out, (size_t)c.num_points * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
   HIP_RET(hipStreamSynchronize(stream));
   int rc = GPD_OK;
   if (ovf) {
-    set_error("normals: a %.3f m neighbourhood holds %d points, more than the capacity %d", radius, ovf, NRM_CAP);
+    set_error("normals: a %.3f m neighbourhood holds %d points, more than the capacity %d", radius, ovf, NRM_CAP_BIG);
     rc = GPD_ERR_CAPACITY;
   } else {
     // keep the device copy of the cloud consistent: planes nx, ny, nz

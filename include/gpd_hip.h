@@ -231,6 +231,14 @@ int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]);
  * neighbourhood size N_i, out[3] sum over candidates of N_i. */
 int gpd_hip_last_images_stats(gpd_hip_ctx *ctx, long long out[4]);
 
+/* Which slow paths the last search / image stage took (none of them changes a result):
+ * out[0] entries per neighbourhood list the search ran with (8192: bucket sort in LDS; 16384: bitonic sort in LDS;
+ * more: global-memory lists), out[1] candidates whose box held more shadow voxels than the two-per-CU shadow
+ * kernel lists (redone by the large instantiation), out[2] candidates with more in-box points than the two-per-CU
+ * normals/depth kernel holds (redone with global scratch), out[3] LeNet passes of the last scoring (65536 images
+ * each).  Waits for the context's stream. */
+int gpd_hip_last_fallbacks(gpd_hip_ctx *ctx, long long out[4]);
+
 /* Re-run stage 3 (stages == 1: grasp images), stage 4 (2: LeNet) or both (3) on the
  * candidate list that the last gpd_hip_images / gpd_hip_detect left resident on the
  * device — what calling ImageGenerator::createImages + Classifier::classifyImages
