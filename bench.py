@@ -273,7 +273,7 @@ def main():
             kernels[name] = {"ms": k_s * 1e3, "algorithmic_flops": fl * n_cand,
                              "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None,
                              "frac_f32": fl * n_cand / k_s / 1e12 / F32_PEAK_TFLOPS if k_s > 0 else None}
-        traffic = _pmc_traffic(n_cand)
+        traffic = _pmc_traffic(n_cand, C)
         sq = _pmc_sq()
         if sq:
             # the image kernels are latency / LDS bound, not HBM bound: their LDS roofline is the share of
@@ -380,12 +380,14 @@ def _fc1_tile(n):
         r += 1
 
 
-def _pmc_traffic(n_images):
+def _pmc_traffic(n_images, channels=15):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json, produced by
     profiles/collect_r02.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
     on: when a kernel file has changed since, the numbers are stale and dropped."""
     if not os.path.exists(TRAFFIC_FILE):
         return {"note": "no PMC traffic file"}
+    if channels != 15 or n_images != 5000:
+        return {"note": "the PMC passes were collected on the default workload (15 channels, 5000 candidates) only"}
     d = json.load(open(TRAFFIC_FILE))
     if d.get("source_hashes") != source_hashes():
         return {"note": "%s was measured on other kernel sources: stale, not reported" % os.path.relpath(TRAFFIC_FILE, ROOT)}

@@ -41,7 +41,7 @@ def test_pmc_numbers_are_dropped_when_a_kernel_source_changes(tmp_path, monkeypa
     monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
     t = bench._pmc_traffic(5000)
     assert t["conv1_mfma"] == 8e8 and t["fc1_mfma"] == 2.7e8      # the ip1 instantiation this n runs with
-    assert bench._pmc_traffic(6077)["fc1_mfma"] == 3.0e8
+    assert "default workload" in bench._pmc_traffic(6077)["note"] and "default workload" in bench._pmc_traffic(5000, 12)["note"]
     good["source_hashes"]["gpd_amd/csrc/lenet.hip"] = "0" * 40
     f.write_text(json.dumps(good))
     t = bench._pmc_traffic(5000)
