@@ -65,16 +65,16 @@ struct Cloud {
   int g_cells_cap = 0;
   int32_t *g_start = nullptr;         // [cells + 1]
   int32_t *g_cursor = nullptr;        // [cells] scatter cursors
-  int32_t *g_idx = nullptr;           // [P] original index of the sorted points
-  float *g_x = nullptr, *g_y = nullptr, *g_z = nullptr;  // [P] coordinates in cell order
+  float4 *g_p = nullptr;              // [P] the points in cell order: x, y, z and, as bits in w, the original index (one
+                                      // 16-byte load per visited point instead of four dword loads)
+  float4 *pxyz = nullptr, *pnrm = nullptr;  // [P] AoS copies (x, y, z, 0) / (nx, ny, nz, 0): one load per random access
 };
 struct GridView {
   float lo[3];
   float cell;
   int dim[3];
   const int32_t *start;
-  const int32_t *idx;
-  const float *x, *y, *z;
+  const float4 *p;  // x, y, z, index bits
 };
 inline GridView grid_view(const Cloud &c) {
   GridView g;
@@ -84,10 +84,7 @@ inline GridView grid_view(const Cloud &c) {
   }
   g.cell = c.g_cell;
   g.start = c.g_start;
-  g.idx = c.g_idx;
-  g.x = c.g_x;
-  g.y = c.g_y;
-  g.z = c.g_z;
+  g.p = c.g_p;
   return g;
 }
 int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,

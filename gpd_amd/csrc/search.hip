@@ -30,6 +30,8 @@
 // exactly as oracle/gpd_oracle.cpp defines them.
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <type_traits>
@@ -53,15 +55,19 @@ namespace gpd {
 // Cloud upload: AoS (caller layout) -> SoA planes.
 // ---------------------------------------------------------------------------
 __global__ void split_soa_kernel(const float *__restrict__ xyz, const float *__restrict__ nrm, int n, float *px, float *py,
-                                 float *pz, float *nx, float *ny, float *nz) {
+                                 float *pz, float *nx, float *ny, float *nz, float4 *pxyz, float4 *pnrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  px[i] = xyz[3 * i];
-  py[i] = xyz[3 * i + 1];
-  pz[i] = xyz[3 * i + 2];
-  nx[i] = nrm[3 * i];
-  ny[i] = nrm[3 * i + 1];
-  nz[i] = nrm[3 * i + 2];
+  const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  const float a = nrm[3 * i], b = nrm[3 * i + 1], c = nrm[3 * i + 2];
+  px[i] = x;
+  py[i] = y;
+  pz[i] = z;
+  nx[i] = a;
+  ny[i] = b;
+  nz[i] = c;
+  pxyz[i] = make_float4(x, y, z, 0.f);
+  pnrm[i] = make_float4(a, b, c, 0.f);
 }
 
 // ---- uniform grid ----------------------------------------------------------------------
@@ -106,15 +112,12 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const int32_t *counts, 
   if (tid == 0) start[n] = s_carry;
 }
 __global__ void grid_scatter_kernel(GridView g, const float *px, const float *py, const float *pz, int n, int32_t *cursor,
-                                    int32_t *idx, float *sx, float *sy, float *sz) {
+                                    float4 *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = (grid_coord(g, 0, px[i]) * g.dim[1] + grid_coord(g, 1, py[i])) * g.dim[2] + grid_coord(g, 2, pz[i]);
   const int pos = atomicAdd(&cursor[c], 1);
-  idx[pos] = i;
-  sx[pos] = px[i];
-  sy[pos] = py[i];
-  sz[pos] = pz[i];
+  out[pos] = make_float4(px[i], py[i], pz[i], __int_as_float(i));
 }
 
 // Visits every point of the cells overlapping the cube of half-edge `reach` around q: calls
@@ -137,13 +140,14 @@ __device__ inline void grid_visit(const GridView &g, float qx, float qy, float q
       const int t = t0 + lane;
       const bool in = t < e;
       const int tt = in ? t : b;
-      visit(in, g.idx[tt], g.x[tt], g.y[tt], g.z[tt]);
+      const float4 p = g.p[tt];
+      visit(in, __float_as_int(p.w), p.x, p.y, p.z);
     }
   }
 }
 
 void cloud_free(Cloud &c) {
-  void *ptrs[] = {c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.cam_source, c.staging, c.g_start, c.g_cursor, c.g_idx, c.g_x, c.g_y, c.g_z};
+  void *ptrs[] = {c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.cam_source, c.staging, c.g_start, c.g_cursor, c.g_p, c.pxyz, c.pnrm};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c.h_pin) (void)hipHostFree(c.h_pin);
@@ -166,11 +170,12 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
     const int cams = num_cams > c.cap_cams ? num_cams : c.cap_cams;
     cloud_free(c);  // hipFree waits for the device: kernels of an earlier cloud on this stream are done
     c.generation = gen;
-    float **planes[] = {&c.px, &c.py, &c.pz, &c.nx, &c.ny, &c.nz, &c.g_x, &c.g_y, &c.g_z};
+    float **planes[] = {&c.px, &c.py, &c.pz, &c.nx, &c.ny, &c.nz};
     for (float **p : planes) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float)));
+    float4 **quads[] = {&c.g_p, &c.pxyz, &c.pnrm};
+    for (float4 **p : quads) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float4)));
     HIP_RET(hipMalloc(&c.cam_source, (size_t)cap * cams * sizeof(int32_t)));
     HIP_RET(hipMalloc(&c.staging, (size_t)cap * 6 * sizeof(float)));
-    HIP_RET(hipMalloc(&c.g_idx, (size_t)cap * sizeof(int32_t)));
     HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&c.h_pin), (size_t)cap * (6 * sizeof(float) + cams * sizeof(int32_t)), 0));
     c.capacity = cap;
     c.cap_cams = cams;
@@ -201,7 +206,7 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
   HIP_RET(hipMemcpyAsync(c.staging, hx, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_RET(hipMemcpyAsync(c.cam_source, hc, (size_t)n * num_cams * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   split_soa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c.staging, c.staging + (size_t)n * 3, n, c.px, c.py, c.pz, c.nx, c.ny,
-                                                         c.nz);
+                                                         c.nz, c.pxyz, c.pnrm);
   HIP_RET(hipGetLastError());
   // uniform grid: bounds from the pass above, counting sort on the device
   c.g_cell = 0.02f;
@@ -231,7 +236,7 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
   HIP_RET(hipMemsetAsync(c.g_cursor, 0, (size_t)cells * sizeof(int32_t), stream));
   grid_count_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor);
   grid_scan_kernel<<<1, 1024, 0, stream>>>(c.g_cursor, c.g_start, c.g_cursor, cells);
-  grid_scatter_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor, c.g_idx, c.g_x, c.g_y, c.g_z);
+  grid_scatter_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor, c.g_p);
   HIP_RET(hipGetLastError());
   if (sync) HIP_RET(hipStreamSynchronize(stream));
   return GPD_OK;
@@ -380,6 +385,7 @@ __device__ void eigen3(double m00, double m10, double m11, double m20, double m2
 // ---------------------------------------------------------------------------
 struct NbParams {
   const float *px, *py, *pz, *nx, *ny, *nz;
+  const float4 *pxyz, *pnrm;  // AoS copies: one 16-byte load per random access
   int num_points;
   const int32_t *sample_idx;
   const double *sample_xyz;  // non-null: samples by coordinates; the query is their float cast (eigenVectorToPcl)
@@ -395,6 +401,7 @@ struct NbParams {
   int num_cams;
   GridView grid;
   float reach;  // half-edge of the cube of cells to visit (radius + margin)
+  unsigned long long *dbg;  // profiling aid (GPD_NB_TIMING=1): per-phase cycle sums of wave 0
 };
 
 // ---- bucket sort of the (d2, index) keys -------------------------------------------------
@@ -449,6 +456,15 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  unsigned long long t_last = __builtin_readcyclecounter();
+#define NTICK(k_)                                                    \
+  do {                                                              \
+    if (P.dbg && tid == 0) {                                        \
+      const unsigned long long now_ = __builtin_readcyclecounter(); \
+      atomicAdd(&P.dbg[k_], now_ - t_last);                         \
+      t_last = now_;                                                \
+    }                                                               \
+  } while (0)
   float qx, qy, qz;
   double sx, sy, sz;  // the sample the hand frame keeps (frame_estimator.cpp:20-22, 53-54)
   if (P.sample_xyz) {
@@ -489,12 +505,13 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   }
   int *s_start = s_hist + NBK;  // NBK + 1 entries
   auto d2_of = [&](int i) {  // FLANN L2_Simple<float>, the same operation order as in the visit
-    float d = qx - P.px[i];
+    const float4 p = P.pxyz[i];
+    float d = qx - p.x;
     float d2 = 0.f;
     d2 += d * d;
-    d = qy - P.py[i];
+    d = qy - p.y;
     d2 += d * d;
-    d = qz - P.pz[i];
+    d = qz - p.z;
     d2 += d * d;
     return d2;
   };
@@ -536,6 +553,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     }
   });
   hand_over();
+  NTICK(0);
   const int found = s_count;
   const int n = found < P.cap ? found : P.cap;
   if (P.bucket) {
@@ -565,6 +583,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     }
     if (tid == NB_THREADS - 1) s_start[NBK] = run;
     __syncthreads();
+    NTICK(1);
     // ... indices grouped bucket by bucket ...
     for (int t = tid; t < n; t += NB_THREADS) {
       const uint32_t i = s_a[t];
@@ -572,6 +591,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       if (pos < n) s_b[pos] = i;  // always true (the counters come from the same d2 values); keeps a corrupted table out of LDS
     }
     hand_over();
+    NTICK(2);
     // ... and every bucket ordered by (d2 bits, index); non-negative floats order as unsigned.
     // s_a (dead) receives the sorted d2 bits.
     for (int b = tid; b < NBK; b += NB_THREADS) {
@@ -607,6 +627,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       }
     }
     __syncthreads();
+    NTICK(3);
     const int ncrowd = s_ncrowd < NBK ? s_ncrowd : NBK;
     for (int c = tid >> 6; c < ncrowd; c += NB_WAVES) {
       const int b = s_hist[c];
@@ -671,6 +692,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       }
     }
     hand_over();
+    NTICK(4);
   } else {
     int m = 1;
     while (m < n) m <<= 1;
@@ -706,31 +728,66 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     if (d < rh && dn >= rh) s_bounds[2] = t + 1;
   }
   __syncthreads();
+  NTICK(5);
   // 4. sorted index list + gathered SoA neighbourhood.  Each key slot is then reused
   //    for (px, py) of its entry so that the centre sum below reads LDS.
   int32_t *oi = P.nn_idx + (size_t)s * P.cap;
   float *on = P.nn + (size_t)s * 6 * P.cap;
   const int n_img = s_bounds[0];
   int seen = 0;
-  for (int t = tid; t < n; t += NB_THREADS) {
-    const int i = index_at(t);
-    oi[t] = i;
-    const float x = P.px[i], y = P.py[i];
-    on[0 * P.cap + t] = x;
-    on[1 * P.cap + t] = y;
-    on[2 * P.cap + t] = P.pz[i];
-    on[3 * P.cap + t] = P.nx[i];
-    on[4 * P.cap + t] = P.ny[i];
-    on[5 * P.cap + t] = P.nz[i];
-    if (t < n_img)
-      for (int cam = 0; cam < P.num_cams; cam++) seen |= (P.cam_source[(size_t)cam * P.num_points + i] != 0) << cam;
+  for (int t0 = tid; t0 < n; t0 += 2 * NB_THREADS) {  // two entries per round: their loads are in flight together
+    const int t1 = t0 + NB_THREADS;
+    const bool two = t1 < n;
+    const int i0 = index_at(t0), i1 = two ? index_at(t1) : i0;
+    const float4 a0 = P.pxyz[i0], b0 = P.pnrm[i0], a1 = P.pxyz[i1], b1 = P.pnrm[i1];
+    oi[t0] = i0;
+    on[0 * P.cap + t0] = a0.x;
+    on[1 * P.cap + t0] = a0.y;
+    on[2 * P.cap + t0] = a0.z;
+    on[3 * P.cap + t0] = b0.x;
+    on[4 * P.cap + t0] = b0.y;
+    on[5 * P.cap + t0] = b0.z;
+    if (two) {
+      oi[t1] = i1;
+      on[0 * P.cap + t1] = a1.x;
+      on[1 * P.cap + t1] = a1.y;
+      on[2 * P.cap + t1] = a1.z;
+      on[3 * P.cap + t1] = b1.x;
+      on[4 * P.cap + t1] = b1.y;
+      on[5 * P.cap + t1] = b1.z;
+    }
+    for (int cam = 0; cam < P.num_cams; cam++) {
+      if (t0 < n_img) seen |= (P.cam_source[(size_t)cam * P.num_points + i0] != 0) << cam;
+      if (two && t1 < n_img) seen |= (P.cam_source[(size_t)cam * P.num_points + i1] != 0) << cam;
+    }
   }
   if (seen) atomicOr(&s_seen, seen);
   __threadfence_block();  // lane 0 reads the gathered normals back below
   __syncthreads();
-  // 5. local frame (local_frame.cpp:14-41), sequential sums in neighbour order
-  if (tid == 0) {
+  NTICK(6);
+  // 5. local frame (local_frame.cpp:14-41).  M = sum n n^T and sum n are nine sequential fp64 chains in neighbour
+  //    order: nine lanes of wave 0 walk one chain each (the same adds in the same order per chain), lane 0 collects them
+  //    and runs the eigensolver.
+  if (tid < 64) {
     const int kf = s_bounds[1];
+    // chain c accumulates n[p] * n[q] (c < 6: m00 m10 m11 m20 m21 m22) or n[p] * 1.0 == n[p] (a0 a1 a2)
+    const int cp = lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? 1 : lane == 3 ? 2 : lane == 4 ? 2 : lane == 5 ? 2 : lane == 6 ? 0 : lane == 7 ? 1 : 2;
+    const int cq = lane == 0 ? 0 : lane == 1 ? 0 : lane == 2 ? 1 : lane == 3 ? 0 : lane == 4 ? 1 : lane == 5 ? 2 : -1;
+    double acc = 0.0;
+    if (lane < 9)
+      for (int t = 0; t < kf; t++) {
+        const double x = (double)on[(3 + cp) * P.cap + t];
+        const double y = cq >= 0 ? (double)on[(3 + cq) * P.cap + t] : 1.0;
+        acc += x * y;
+      }
+    auto chain = [&](int c) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(acc);
+      const unsigned lo = __shfl((unsigned)b, c), hi = __shfl((unsigned)(b >> 32), c);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    double m00 = chain(0), m10 = chain(1), m11 = chain(2), m20 = chain(3), m21 = chain(4), m22 = chain(5);
+    double a0 = chain(6), a1 = chain(7), a2 = chain(8);
+    if (tid == 0) {
     P.counts[8 * s + 0] = s_bounds[2];
     P.counts[8 * s + 1] = s_bounds[0];
     P.counts[8 * s + 2] = kf;
@@ -740,19 +797,6 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     f[1] = sy;
     f[2] = sz;
     if (kf > 0) {
-      double m00 = 0, m10 = 0, m11 = 0, m20 = 0, m21 = 0, m22 = 0, a0 = 0, a1 = 0, a2 = 0;
-      for (int t = 0; t < kf; t++) {
-        const double n0 = (double)on[3 * P.cap + t], n1 = (double)on[4 * P.cap + t], n2 = (double)on[5 * P.cap + t];
-        m00 += n0 * n0;
-        m10 += n1 * n0;
-        m11 += n1 * n1;
-        m20 += n2 * n0;
-        m21 += n2 * n1;
-        m22 += n2 * n2;
-        a0 += n0;
-        a1 += n1;
-        a2 += n2;
-      }
       double ev[3], Q[9];
       eigen3(m00, m10, m11, m20, m21, m22, ev, Q);
       int mn = 0, mx = 0;
@@ -782,9 +826,12 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       f[10] = curv[1];
       f[11] = curv[2];
     }
+    }
   }
   __syncthreads();
+  NTICK(7);
   if (tid == 0) P.counts[8 * s + 4] = s_seen;
+#undef NTICK
 }
 
 // centre of the image neighbourhood (HandSet::calculateShadow, hand_set.cpp:131-133): sequential
@@ -996,7 +1043,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
   } else {
     // keep the device copy of the cloud consistent: planes nx, ny, nz
     split_soa_kernel<<<(c.num_points + 255) / 256, 256, 0, stream>>>(c.staging, d_out, c.num_points, c.px, c.py, c.pz, c.nx, c.ny,
-                                                                       c.nz);
+                                                                       c.nz, c.pxyz, c.pnrm);
     HIP_RET(hipGetLastError());
     HIP_RET(hipStreamSynchronize(stream));
     c.generation++;
@@ -1526,6 +1573,8 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
                               hipStream_t stream, bool sync_counts) {
   NbParams np;
   np.px = c.px; np.py = c.py; np.pz = c.pz; np.nx = c.nx; np.ny = c.ny; np.nz = c.nz;
+  np.pxyz = c.pxyz;
+  np.pnrm = c.pnrm;
   np.num_points = c.num_points;
   np.sample_idx = s.d_sample_idx;
   np.sample_xyz = by_xyz ? s.d_sample_xyz : nullptr;
@@ -1545,6 +1594,13 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.num_cams = c.num_cams;
   np.grid = grid_view(c);
   np.reach = (float)r_all * 1.001f + 1e-5f;
+  static unsigned long long *d_nbdbg = nullptr;
+  np.dbg = nullptr;
+  if (getenv("GPD_NB_TIMING")) {
+    if (!d_nbdbg) HIP_RET(hipMalloc(&d_nbdbg, 8 * sizeof(unsigned long long)));
+    HIP_RET(hipMemsetAsync(d_nbdbg, 0, 8 * sizeof(unsigned long long), stream));
+    np.dbg = d_nbdbg;
+  }
   // 8192-entry lists are bucket-sorted (64 + 8 KB of LDS: two workgroups per CU); the 16384-entry
   // retry of an overfull neighbourhood sorts in place (bitonic, 128 KB); anything larger (up to kNnCapMax) is
   // bucket-sorted in global memory
@@ -1562,6 +1618,13 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
     neighbourhood_kernel<false><<<S, NB_THREADS, lds, stream>>>(np);
   }
   HIP_RET(hipGetLastError());
+  if (np.dbg) {
+    unsigned long long h[8];
+    HIP_RET(hipMemcpyAsync(h, d_nbdbg, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+    static const char *names[8] = {"visit", "scan", "scatter", "bucket sort", "crowded buckets", "prefix lengths", "gather", "frame"};
+    for (int i = 0; i < 8; i++) fprintf(stderr, "[nb-timing] %-16s %8.1f kcycles/sample\n", names[i], (double)h[i] / S / 1e3);
+  }
   // the centre sums fork off to the side stream; search_join() brings them back
   if (!s.aux) {
     HIP_RET(hipStreamCreate(&s.aux));
