@@ -523,9 +523,10 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   if (P.bucket)
     for (int i = tid; i < NBK; i += NB_THREADS) s_hist[i] = 0;
   __syncthreads();
-  // 1. visit the grid cells around the sample; FLANN L2_Simple<float>: d2 accumulated over
-  //    x,y,z, strict <
-  grid_visit(P.grid, qx, qy, qz, P.reach, tid >> 6, NB_WAVES, lane, [&](bool in, int i, float x, float y, float z) {
+  // 1. visit the grid cells around the sample; FLANN L2_Simple<float>: d2 accumulated over x,y,z, strict <.
+  //    The point ranges of the (x, y) cell columns are fetched up front, one column per lane, into LDS (a column holds
+  //    ~45 points: one dependent global round trip less per column and wave).
+  auto visit = [&](bool in, int i, float x, float y, float z) {
     float d = qx - x;
     float d2 = 0.f;
     d2 += d * d;
@@ -543,7 +544,12 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
         const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
         if (pos < P.cap) {
           if (P.bucket) {
-            s_a[pos] = (uint32_t)i;
+            if constexpr (GLOBAL) {
+              s_a[pos] = (uint32_t)i;  // d2 is recomputed by the scatter (a thread's entries do not fit its registers)
+            } else {
+              s_a[pos] = __float_as_uint(d2);  // visit order; the scatter below re-orders both arrays in place
+              s_b[pos] = (uint32_t)i;
+            }
             atomicAdd(&s_hist[bucket_of(d2)], 1);
           } else {
             s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
@@ -551,7 +557,36 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
         }
       }
     }
-  });
+  };
+  {
+    const GridView &g = P.grid;
+    const int x0 = grid_coord(g, 0, qx - P.reach), x1 = grid_coord(g, 0, qx + P.reach);
+    const int y0 = grid_coord(g, 1, qy - P.reach), y1 = grid_coord(g, 1, qy + P.reach);
+    const int z0 = grid_coord(g, 2, qz - P.reach), z1 = grid_coord(g, 2, qz + P.reach);
+    const int ny = y1 - y0 + 1;
+    const int ncol = (x1 - x0 + 1) * ny;
+    __shared__ int s_cb[NB_THREADS], s_ce[NB_THREADS];
+    if (ncol <= NB_THREADS) {
+      if (tid < ncol) {
+        const int cx = x0 + tid / ny, cy = y0 + tid % ny;
+        const int cbase = (cx * g.dim[1] + cy) * g.dim[2];
+        s_cb[tid] = g.start[cbase + z0];
+        s_ce[tid] = g.start[cbase + z1 + 1];
+      }
+      __syncthreads();
+      for (int col = tid >> 6; col < ncol; col += NB_WAVES) {
+        const int cb = s_cb[col], ce = s_ce[col];
+        for (int t0 = cb; t0 < ce; t0 += 64) {
+          const int t = t0 + lane;
+          const bool in = t < ce;
+          const float4 p = g.p[in ? t : cb];
+          visit(in, __float_as_int(p.w), p.x, p.y, p.z);
+        }
+      }
+    } else {
+      grid_visit(g, qx, qy, qz, P.reach, tid >> 6, NB_WAVES, lane, visit);
+    }
+  }
   hand_over();
   NTICK(0);
   const int found = s_count;
@@ -584,16 +619,45 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     if (tid == NB_THREADS - 1) s_start[NBK] = run;
     __syncthreads();
     NTICK(1);
-    // ... indices grouped bucket by bucket ...
-    for (int t = tid; t < n; t += NB_THREADS) {
-      const uint32_t i = s_a[t];
-      const int pos = atomicAdd(&s_hist[bucket_of(d2_of((int)i))], 1);
-      if (pos < n) s_b[pos] = i;  // always true (the counters come from the same d2 values); keeps a corrupted table out of LDS
+    // ... entries grouped bucket by bucket ...
+    if constexpr (GLOBAL) {
+      for (int t = tid; t < n; t += NB_THREADS) {
+        const uint32_t i = s_a[t];
+        const int pos = atomicAdd(&s_hist[bucket_of(d2_of((int)i))], 1);
+        if (pos < n) s_b[pos] = i;  // always true (the counters come from the same d2 values); keeps a corrupted table out of memory
+      }
+    } else {
+      // in place: a thread takes its (at most 16) entries into registers, everybody waits, then they go to their bucket
+      // positions in the same two arrays — no second look at the coordinates
+      constexpr int EPT = 8192 / NB_THREADS;
+      uint32_t rd[EPT], ri[EPT];
+#pragma unroll
+      for (int q = 0; q < EPT; q++) {
+        const int t = tid + q * NB_THREADS;
+        rd[q] = t < n ? s_a[t] : 0u;
+        ri[q] = t < n ? s_b[t] : 0u;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < EPT; q++) {
+        const int t = tid + q * NB_THREADS;
+        if (t < n) {
+          const int pos = atomicAdd(&s_hist[bucket_of(__uint_as_float(rd[q]))], 1);
+          if (pos < n) {
+            s_a[pos] = rd[q];
+            s_b[pos] = ri[q];
+          }
+        }
+      }
     }
     hand_over();
     NTICK(2);
-    // ... and every bucket ordered by (d2 bits, index); non-negative floats order as unsigned.
-    // s_a (dead) receives the sorted d2 bits.
+    // ... and every bucket ordered by (d2 bits, index); non-negative floats order as unsigned.  The d2 bits are
+    // in s_a already (LDS mode) or recomputed into it (GLOBAL).
+    auto d2bits_of_entry = [&](int x) {
+      if constexpr (GLOBAL) return __float_as_uint(d2_of((int)s_b[x]));
+      else return s_a[x];
+    };
     for (int b = tid; b < NBK; b += NB_THREADS) {
       const int st = s_start[b], nb = s_start[b + 1] - st;
       if (nb <= 0) continue;
@@ -602,8 +666,8 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
         unsigned long long k[N];
 #pragma unroll
         for (int q = 0; q < N; q++) {
-          const uint32_t i = s_b[st + (q < nb ? q : 0)];
-          k[q] = q < nb ? ((unsigned long long)__float_as_uint(d2_of((int)i)) << 32) | i : ~0ull;
+          const int x = st + (q < nb ? q : 0);
+          k[q] = q < nb ? ((unsigned long long)d2bits_of_entry(x) << 32) | s_b[x] : ~0ull;
         }
         sort_regs64<N>(k);
 #pragma unroll
@@ -634,8 +698,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       const int st = s_start[b], nb = s_start[b + 1] - st;
       if (nb <= 64) {
         // one key per lane, bitonic network across the wave
-        const uint32_t i = lane < nb ? s_b[st + lane] : 0u;
-        unsigned long long k = lane < nb ? ((unsigned long long)__float_as_uint(d2_of((int)i)) << 32) | i : ~0ull;
+        unsigned long long k = lane < nb ? ((unsigned long long)d2bits_of_entry(st + lane) << 32) | s_b[st + lane] : ~0ull;
 #pragma unroll
         for (int size = 2; size <= 64; size <<= 1) {
 #pragma unroll
@@ -655,7 +718,8 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
         // the d2 column first, then a bitonic network over the two arrays by the whole wave.  Every comparison
         // sorts upwards (the first step of each merge pairs x with its mirror image), so positions past the end
         // would hold +inf and never move: those comparisons are simply left out.
-        for (int x = lane; x < nb; x += 64) s_a[st + x] = __float_as_uint(d2_of((int)s_b[st + x]));
+        if constexpr (GLOBAL)
+          for (int x = lane; x < nb; x += 64) s_a[st + x] = __float_as_uint(d2_of((int)s_b[st + x]));
         int m = 1;
         while (m < nb) m <<= 1;
         auto exchange = [&](int lo, int hi) {
@@ -735,8 +799,12 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   float *on = P.nn + (size_t)s * 6 * P.cap;
   const int n_img = s_bounds[0];
   int seen = 0;
-  for (int t0 = tid; t0 < n; t0 += 2 * NB_THREADS) {  // two entries per round: their loads are in flight together
-    const int t1 = t0 + NB_THREADS;
+  // The last wave computes the local frame (a serial fp64 chain + the eigensolver on one lane: ~20 k cycles) while the
+  // other seven gather; it reads its ~40 normals through the sorted indices, not through the rows being written.
+  constexpr int GW = NB_WAVES - 1, GT = 64 * GW;  // gathering waves / threads
+  if (tid < GT)
+  for (int t0 = tid; t0 < n; t0 += 2 * GT) {  // two entries per round: their loads are in flight together
+    const int t1 = t0 + GT;
     const bool two = t1 < n;
     const int i0 = index_at(t0), i1 = two ? index_at(t1) : i0;
     const float4 a0 = P.pxyz[i0], b0 = P.pnrm[i0], a1 = P.pxyz[i1], b1 = P.pnrm[i1];
@@ -762,13 +830,11 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     }
   }
   if (seen) atomicOr(&s_seen, seen);
-  __threadfence_block();  // lane 0 reads the gathered normals back below
-  __syncthreads();
   NTICK(6);
   // 5. local frame (local_frame.cpp:14-41).  M = sum n n^T and sum n are nine sequential fp64 chains in neighbour
-  //    order: nine lanes of wave 0 walk one chain each (the same adds in the same order per chain), lane 0 collects them
-  //    and runs the eigensolver.
-  if (tid < 64) {
+  //    order: nine lanes walk one chain each (the same adds in the same order per chain), the wave's first lane collects
+  //    them and runs the eigensolver.
+  if (tid >= GT) {
     const int kf = s_bounds[1];
     // chain c accumulates n[p] * n[q] (c < 6: m00 m10 m11 m20 m21 m22) or n[p] * 1.0 == n[p] (a0 a1 a2)
     const int cp = lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? 1 : lane == 3 ? 2 : lane == 4 ? 2 : lane == 5 ? 2 : lane == 6 ? 0 : lane == 7 ? 1 : 2;
@@ -776,8 +842,11 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     double acc = 0.0;
     if (lane < 9)
       for (int t = 0; t < kf; t++) {
-        const double x = (double)on[(3 + cp) * P.cap + t];
-        const double y = cq >= 0 ? (double)on[(3 + cq) * P.cap + t] : 1.0;
+        const float4 nv = P.pnrm[index_at(t)];
+        const float xs = cp == 0 ? nv.x : (cp == 1 ? nv.y : nv.z);
+        const float ys = cq == 0 ? nv.x : (cq == 1 ? nv.y : nv.z);
+        const double x = (double)xs;
+        const double y = cq >= 0 ? (double)ys : 1.0;
         acc += x * y;
       }
     auto chain = [&](int c) {
@@ -787,7 +856,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     };
     double m00 = chain(0), m10 = chain(1), m11 = chain(2), m20 = chain(3), m21 = chain(4), m22 = chain(5);
     double a0 = chain(6), a1 = chain(7), a2 = chain(8);
-    if (tid == 0) {
+    if (lane == 0) {
     P.counts[8 * s + 0] = s_bounds[2];
     P.counts[8 * s + 1] = s_bounds[0];
     P.counts[8 * s + 2] = kf;
