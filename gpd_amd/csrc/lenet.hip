@@ -22,6 +22,7 @@
 //                                                               -> fc1t  [500][n]
 //   fc2_score    2 x 500 chains per image, score = y1 - y0       -> scores[n]
 #include "gpd_internal.h"
+#include <type_traits>
 
 namespace gpd {
 
@@ -392,11 +393,12 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
 // the 64 x 64 tiles of round 1 left a 3-tile makespan on 2.47 tiles per SIMD).  128-wide u-tiles also halve
 // the operand traffic per flop from L2 (2.3 GB per launch at 64 x 64).  The four u-tiles of an m-tile run
 // on ONE XCD (workgroup L runs on XCD L % 8), so the image rows are fetched from HBM once.
-// LDS: three stages of K = 32 (W rows padded to 144 floats, X k-major and swizzled: both the transposing writes and
-// the MFMA operand reads are bank-conflict free, see fc_sx); global loads run two stages ahead through two register sets.
+// LDS: two buffers of K = 64 (W rows padded to 144 floats, X k-major and swizzled: both the transposing writes and
+// the MFMA operand reads are bank-conflict free, see fc_sx); global loads run two steps ahead through two register sets.
 // ---------------------------------------------------------------------------
-constexpr int FC_BU = 128, FC_BK = 32, FC_THREADS = 512, FC_SW = FC_BU + 16, FC_STEPS = kFc1In / FC_BK;
-static_assert(kFc1In % FC_BK == 0, "K steps");
+constexpr int FC_BU = 128, FC_BK = 64, FC_THREADS = 512, FC_SW = FC_BU + 16;
+constexpr int FC_STEPS = (kFc1In + FC_BK - 1) / FC_BK, FC_TAIL_KS = (kFc1In - (FC_STEPS - 1) * FC_BK) / 4;  // 113 steps, the last one 8 k-quads
+static_assert(kFc1In % 4 == 0 && FC_TAIL_KS >= 1 && FC_TAIL_KS <= FC_BK / 4, "K steps");
 // X tile in LDS: k-major rows of stride = 16 (mod 32) with the column of element (k, m) swizzled to
 // m ^ (((k >> 2) & 7) << 2).  The MFMA operand read (lanes: two k of one k-quad x 16 consecutive m) then touches
 // 32 different banks — row k + 1 sits 16 banks further, and the swizzle maps an aligned 16-block of m onto an aligned
@@ -410,7 +412,8 @@ __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__res
                                                               const float *__restrict__ X, float *__restrict__ out_t, int n, int ld_out) {
   constexpr int BM = 16 * NT, SX = fc_sx(BM);
   constexpr int STAGE = FC_BK * FC_SW + FC_BK * SX;  // floats per stage: W tile, then X tile
-  __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  static_assert(2 * STAGE * 4 <= 160 * 1024, "LDS");
   const int tid = threadIdx.x;
   const int L = blockIdx.x;
   const int xcd = L & 7, slot = L >> 3;
@@ -424,36 +427,36 @@ __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__res
   for (int t = 0; t < NT; t++)
 #pragma unroll
     for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
-  // loader roles.  W tile: 32 rows x 32 float4 -> two per thread.  X tile: BM rows x 8 float4 (eight lanes
-  // per image row: 128-byte segments), ceil(BM * 8 / 512) per thread.
-  constexpr int XV = BM * 8, X_PT = (XV + FC_THREADS - 1) / FC_THREADS;
-  const int wk = tid >> 5, wuq = tid & 31;  // + 16 rows for the second float4
-  // every load is unconditional (out-of-range lanes read a clamped address and their value is dropped at the
-  // LDS store): straight-line loads let the compiler count them, so the wait before a stage's LDS stores
-  // covers only ITS loads, not the ones issued for the stage after it
+  // loader roles.  W tile: 64 rows x 32 float4 -> four per thread.  X tile: BM rows x 16 float4 (sixteen lanes
+  // per image row: 256-byte segments), ceil(BM * 16 / 512) per thread.
+  constexpr int W_PT = FC_BK * 32 / FC_THREADS, XV = BM * (FC_BK / 4), X_PT = (XV + FC_THREADS - 1) / FC_THREADS;
+  const int wk = tid >> 5, wuq = tid & 31;  // + 16 rows per further float4
+  // every load is unconditional (out-of-range lanes and the k past 7200 of the last step read a clamped address and
+  // their value is dropped or never multiplied): straight-line loads let the compiler count them, so the wait
+  // before a stage's LDS stores covers only ITS loads, not the ones issued for the stage after it
   const bool w_ok = u0 + 4 * wuq < kFc1Out;
-  const float *wsrc = W + (size_t)wk * kFc1Out + min(u0 + 4 * wuq, kFc1Out - 4);
+  const float *wsrc = W + min(u0 + 4 * wuq, kFc1Out - 4);
   const float *xsrc[X_PT];
   int xm[X_PT], xkq[X_PT];
 #pragma unroll
   for (int i = 0; i < X_PT; i++) {
     const int v = min(tid + i * FC_THREADS, XV - 1);
-    xm[i] = v >> 3;
-    xkq[i] = v & 7;
-    xsrc[i] = X + (size_t)min(m0 + xm[i], n - 1) * kFc1In + 4 * xkq[i];
+    xm[i] = v / (FC_BK / 4);
+    xkq[i] = v % (FC_BK / 4);
+    xsrc[i] = X + (size_t)min(m0 + xm[i], n - 1) * kFc1In;
   }
-  float4 rw[2][2], rx[2][X_PT];
-  auto fetch = [&](int step, float4(&w2)[2], float4(&x2)[X_PT]) {
-    const size_t k0 = (size_t)step * FC_BK;
+  float4 rw[2][W_PT], rx[2][X_PT];
+  auto fetch = [&](int step, float4(&w2)[W_PT], float4(&x2)[X_PT]) {
+    const int k0 = step * FC_BK;
 #pragma unroll
-    for (int i = 0; i < 2; i++) w2[i] = *reinterpret_cast<const float4 *>(wsrc + (k0 + 16 * i) * kFc1Out);
+    for (int i = 0; i < W_PT; i++) w2[i] = *reinterpret_cast<const float4 *>(wsrc + (size_t)min(k0 + wk + 16 * i, kFc1In - 1) * kFc1Out);
 #pragma unroll
-    for (int i = 0; i < X_PT; i++) x2[i] = *reinterpret_cast<const float4 *>(xsrc[i] + k0);
+    for (int i = 0; i < X_PT; i++) x2[i] = *reinterpret_cast<const float4 *>(xsrc[i] + min(k0 + 4 * xkq[i], kFc1In - 4));
   };
-  auto stage = [&](int buf, const float4(&w2)[2], const float4(&x2)[X_PT]) {
+  auto stage = [&](int buf, const float4(&w2)[W_PT], const float4(&x2)[X_PT]) {
     float *sw = smem + buf * STAGE, *sx = sw + FC_BK * FC_SW;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < W_PT; i++)
       *reinterpret_cast<float4 *>(sw + (wk + 16 * i) * FC_SW + 4 * wuq) = w_ok ? w2[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < X_PT; i++)
@@ -465,15 +468,19 @@ __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__res
         d[3 * SX] = x2[i].w;
       }
   };
-  auto compute = [&](int buf) {
+  // (Requesting the operands of four k-quads in one run of LDS reads ahead of 4 NT back-to-back MFMAs — pure MFMA
+  // runs as in conv1 — measured 0.362 ms against 0.336 ms for this per-quad interleave; storing the next tile in the
+  // middle of the MFMAs instead of at the end 0.339.)
+  auto compute = [&](int buf, auto nks_tag) {
+    constexpr int NKS = decltype(nks_tag)::value;
     const float *sw = smem + buf * STAGE + g * FC_SW + wave * 16 + j;
     const float *sx = smem + buf * STAGE + FC_BK * FC_SW + g * SX;
     float a_cur = sw[0], a_nxt = 0.f, b_cur[NT], b_nxt[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) b_cur[t] = sx[16 * t + j];
 #pragma unroll
-    for (int ks = 0; ks < FC_BK / 4; ks++) {
-      if (ks + 1 < FC_BK / 4) {  // operands of the next four k are requested before this step's MFMAs ...
+    for (int ks = 0; ks < NKS; ks++) {
+      if (ks + 1 < NKS) {  // operands of the next four k are requested before this step's MFMAs ...
         a_nxt = sw[(4 * (ks + 1)) * FC_SW];
 #pragma unroll
         for (int t = 0; t < NT; t++) b_nxt[t] = sx[(4 * (ks + 1)) * SX + ((16 * t + j) ^ (((ks + 1) & 7) << 2))];
@@ -487,26 +494,33 @@ __global__ __launch_bounds__(FC_THREADS) void fc1_mfma_kernel(const float *__res
       for (int t = 0; t < NT; t++) b_cur[t] = b_nxt[t];
     }
   };
+  using FullStep = std::integral_constant<int, FC_BK / 4>;
+  using TailStep = std::integral_constant<int, FC_TAIL_KS>;
   // prologue: stage 0 in LDS, stage 1 in register set 1
   fetch(0, rw[0], rx[0]);
   stage(0, rw[0], rx[0]);
   fetch(1, rw[1], rx[1]);
   __syncthreads();
-  // step t: loads of step t + 2 go out first (register set t % 2), the MFMAs of stage t % 3 run, the loads of
-  // step t + 1 (issued a whole step ago) are written to stage (t + 1) % 3, whose readers finished before the
-  // last barrier
-  auto step = [&](int t, float4(&w_far)[2], float4(&x_far)[X_PT], const float4(&w_near)[2], const float4(&x_near)[X_PT]) {
-    if (t + 2 < FC_STEPS) fetch(t + 2, w_far, x_far);
-    compute(t % 3);
-    if (t + 1 < FC_STEPS) stage((t + 1) % 3, w_near, x_near);
+  // step t: loads of step t + 2 go out first (register set t % 2), the MFMAs of buffer t % 2 run (K = 64: one
+  // barrier per 16 k-quads — with K = 32 stages the eight waves met twice as often and MfmaUtil stood at 64 %),
+  // the loads of step t + 1 (issued a whole step ago) are written to the other buffer, whose readers finished
+  // before the last barrier.
+  // No conditions on the step number: the tail refetches the last step and stages a tile nobody reads, and in
+  // exchange the compiler counts the outstanding loads exactly (with `if (t + 2 < FC_STEPS)` around the fetch the two
+  // paths merged to vmcnt(0) at the loop head and before the LDS stores).
+  auto step = [&](int t, auto nks_tag, float4(&w_far)[W_PT], float4(&x_far)[X_PT], const float4(&w_near)[W_PT], const float4(&x_near)[X_PT]) {
+    fetch(min(t + 2, FC_STEPS - 1), w_far, x_far);
+    compute(t & 1, nks_tag);
+    stage((t + 1) & 1, w_near, x_near);
     __syncthreads();
   };
+  static_assert(FC_STEPS % 2 == 1, "the loop below ends on an even step");
   int t = 0;
   for (; t + 1 < FC_STEPS; t += 2) {
-    step(t, rw[0], rx[0], rw[1], rx[1]);
-    step(t + 1, rw[1], rx[1], rw[0], rx[0]);
+    step(t, FullStep{}, rw[0], rx[0], rw[1], rx[1]);
+    step(t + 1, FullStep{}, rw[1], rx[1], rw[0], rx[0]);
   }
-  if (t < FC_STEPS) step(t, rw[0], rx[0], rw[1], rx[1]);
+  compute(t & 1, TailStep{});  // k = 7168 .. 7199
   // bias, ReLU (eigen_classifier.cpp:113), transposed store for ip2
 #pragma unroll
   for (int tt = 0; tt < NT; tt++) {

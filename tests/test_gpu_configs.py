@@ -104,6 +104,27 @@ def test_replay_is_idempotent_and_matches_detect(cloud30k):
         ctx.close()
 
 
+def test_fc1_tile_shapes_agree_with_the_oracle_checked_one(oracle_mod):
+    """ip1 runs 128 x (16 .. 128)-wide tiles picked per launch (lenet.hip fc1_pick_nt): every tile width, the
+    two-round case and the ragged last tile must give each image the score it gets in a small batch (the 16-wide
+    shape, which is the one compared with the oracle image by image here and in test_lenet_scores_match_oracle)."""
+    w = _weights(15)
+    rng = np.random.RandomState(5)
+    base = (rng.randint(0, 256, (640, 60, 60, 15)) * (rng.rand(640, 60, 60, 15) < 0.3)).astype(np.uint8)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ref = ctx.score(base)  # n = 640 -> the 16-wide tile
+        assert np.array_equal(ref[:48], oracle_mod.lenet(base[:48], w))
+        assert len(np.unique(ref)) > 600
+        for n in (1025, 2100, 3100, 4200, 5000, 5200, 6200, 7200, 8192, 10000):
+            idx = rng.randint(0, len(base), n)
+            got = ctx.score(base[idx])
+            assert np.array_equal(got, ref[idx]), n
+    finally:
+        ctx.close()
+
+
 def test_edge_cases_and_errors(oracle_mod, cloud30k):
     w = _weights(15)
     ctx = api.Context(api.default_params(15))
