@@ -55,7 +55,7 @@ EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_h
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
-           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_last_fallbacks"]
+           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud"]
 
 
 def build():
@@ -90,6 +90,8 @@ def lib():
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
         L.gpd_hip_estimate_normals.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+        L.gpd_hip_preprocess_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.gpd_hip_last_images_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
@@ -276,6 +278,24 @@ class Context:
         self._check(lib().gpd_hip_last_fallbacks(self._h, _ptr(out)))
         return dict(neighbourhood_list_capacity=int(out[0]), large_shadow_kernel_candidates=int(out[1]),
                     large_points_kernel_candidates=int(out[2]), lenet_passes=int(out[3]))
+
+    def preprocess_cloud(self, xyz, cam_source=None, workspace=None, voxel_size=0.003):
+        """Cloud::filterWorkspace (points) + Cloud::voxelizeCloud on the device ->
+        (xyz f32 [M,3], cam_source i32 [cams,M], input index per output point i32 [M], kernel ms)."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        P = len(xyz)
+        cam = np.zeros((0, P), np.int32) if cam_source is None else np.ascontiguousarray(cam_source, np.int32).reshape(-1, P)
+        ws = None if workspace is None else np.ascontiguousarray(workspace, np.float64)
+        assert ws is None or ws.shape == (6,)
+        out = np.zeros((P, 3), np.float32)
+        cam_out = np.zeros((cam.shape[0], P), np.int32).reshape(-1)
+        src = np.zeros(P, np.int32)
+        n, ms = C.c_int(0), C.c_float(0)
+        self._check(lib().gpd_hip_preprocess_cloud(self._h, _ptr(xyz) if P else None, _ptr(cam) if cam.size else None, P, cam.shape[0],
+                                                   _ptr(ws) if ws is not None else None, float(voxel_size), _ptr(out) if P else None,
+                                                   _ptr(cam_out) if cam.size else None, _ptr(src) if P else None, C.byref(n), C.byref(ms)))
+        M = n.value
+        return out[:M].copy(), cam_out[: cam.shape[0] * M].reshape(cam.shape[0], M).copy(), src[:M].copy(), ms.value
 
     def estimate_normals(self, radius=0.03):
         """Cloud::calculateNormals on the uploaded cloud -> f32 [P,3] (also kept on the device)."""

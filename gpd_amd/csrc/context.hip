@@ -109,6 +109,7 @@ struct gpd_hip_ctx {
   gpd_params params;
   LeNetWeights lenet;
   Lane lane[kLanes];
+  PreState pre;
   std::vector<hipEvent_t> replay_events;  // 6 per gpd_hip_replay call: start, images done, conv1, conv2, fc1, end
   float replay_kernel_ms[4] = {0, 0, 0, 0};  // conv1, conv2, fc1, fc2 sums of the replays of the last gpd_hip_replay_times
   size_t replay_used = 0;
@@ -444,6 +445,9 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (int l = kLanes - 1; l >= 0; l--) lane_free(ctx->lane[l]);
+  preprocess_free(ctx->pre);
+  for (auto &e : ctx->pre.ev)
+    if (e) (void)hipEventDestroy(e);
   float **ws[] = {&ctx->lenet.c1w, &ctx->lenet.c1b, &ctx->lenet.c2w, &ctx->lenet.c2b,
                   &ctx->lenet.f1w, &ctx->lenet.f1b, &ctx->lenet.f2w, &ctx->lenet.f2b, &ctx->lenet.c1wp, &ctx->lenet.c2wt};
   for (float **p : ws)
@@ -567,6 +571,25 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
   HIP_TRY(hipSetDevice(ctx->device));
   Lane &L = ctx->lane[0];
   return cloud_upload(L.cloud, xyz, normals, num_points, cam_source, num_cams, view_points, L.stream, /*sync=*/true);
+}
+
+int gpd_hip_preprocess_cloud(gpd_hip_ctx *ctx, const float *xyz, const int32_t *cam_source, int num_points, int num_cams,
+                             const double *workspace, float voxel_size, float *xyz_out, int32_t *cam_out, int32_t *src_out,
+                             int *num_out, float *kernel_ms) {
+  if (!ctx || !num_out || num_points < 0 || num_cams < 0 || (num_points > 0 && (!xyz || !xyz_out)) ||
+      (num_points > 0 && num_cams > 0 && (!cam_source || !cam_out)) || !(voxel_size == voxel_size)) {
+    set_error("gpd_hip_preprocess_cloud: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  if (workspace)
+    for (int a = 0; a < 6; a++)
+      if (workspace[a] != workspace[a]) {
+        set_error("gpd_hip_preprocess_cloud: the workspace holds a NaN");
+        return GPD_ERR_INVALID;
+      }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return preprocess_run(ctx->pre, xyz, cam_source, num_points, num_cams, workspace, voxel_size, xyz_out, cam_out, src_out, num_out,
+                        kernel_ms, ctx->lane[0].stream);
 }
 
 int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals) {

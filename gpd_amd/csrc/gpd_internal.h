@@ -41,6 +41,22 @@ void lenet_scratch_free(LeNetScratch &s);
 
 void set_error(const char *fmt, ...);
 
+// ---- point-cloud preparation (preprocess.hip): workspace cut + the reference's voxeliser ------------------------
+struct PreState {
+  int capacity = 0, cap_cams = 0;
+  float *d_xyz = nullptr, *d_block_lo = nullptr, *d_out_xyz = nullptr;
+  int32_t *d_cam = nullptr, *d_block_count = nullptr, *d_block_off = nullptr, *d_src = nullptr, *d_rank = nullptr, *d_out_cam = nullptr,
+          *d_out_src = nullptr;
+  int4 *d_keys = nullptr;
+  void *d_meta = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+void preprocess_free(PreState &s);
+// workspace: 6 doubles or nullptr; cell <= 0: no voxeliser.  src_out (may be nullptr): input index of every output point.
+// ms (may be nullptr): device time of the kernels.
+int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
+                   float *xyz_out, int32_t *cam_out, int32_t *src_out, int *num_out, float *ms, hipStream_t stream);
+
 // ---- Cloud (search.hip) -----------------------------------------------------
 // Device copy of what the path reads from util::Cloud, as SoA for coalesced streaming.
 constexpr int kMaxCams = 8;

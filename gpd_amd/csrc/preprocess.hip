@@ -1,0 +1,358 @@
+// Point-cloud preparation on the device: the point-cloud part of Cloud::filterWorkspace
+// (util/cloud.cpp:243-266) followed by Cloud::voxelizeCloud (util/cloud.cpp:286-348), in the order
+// CandidatesGenerator::preprocessPointCloud runs them (candidates_generator.cpp:19-26).
+//
+// The workspace cut is a predicate + an order-preserving compaction.  The voxeliser is not a de-duplication:
+// the reference keys a std::set with UniqueVector4First3Comparator (cloud.h:105-122), comp(a, b) = "a and b differ",
+// which is not an ordering.  Under libstdc++ the descent of _M_get_insert_unique_pos goes LEFT at every node whose
+// voxel differs from the new point's and right at an equal one; so
+//   * a point is dropped exactly when its voxel equals the voxel of a node on the tree's LEFT SPINE at that moment
+//     (the descent turns right there and ends under that node, whose key then "equals" the new one);
+//   * every point that is kept becomes the new leftmost node, so the set's iteration order is the reverse of the
+//     order of insertion, and the red-black tree is the one that m leftmost insertions build: its left spine after
+//     the rebalancing (_Rb_tree_insert_and_rebalance) is a function of (key, colour, colour of the right child) of
+//     the spine nodes alone — recolouring walks up the spine, the only rotation is a right rotation at the
+//     grandparent, which takes the grandparent off the spine and makes it the parent's (red) right child.
+// (krylon.pcd: 4467 points in 2373 voxels -> 3366 points kept; checked against std::set itself in
+// tests/test_gpu_preprocess.py through oracle/gpd_oracle.cpp.)
+// That chain of decisions is sequential — which spine a point meets depends on how many points before it were kept —
+// so ONE wavefront walks the points in order with the spine spread over its lanes: a point's voxel is compared
+// with all spine nodes at once (one ballot), the spine is edited with v_readlane / v_writelane at uniform lane
+// numbers.  ~2 log2(m) <= 64 lanes hold the spine of any cloud that fits the device.  Everything around it (keys,
+// minimum, gather of the kept voxels) is data parallel.
+#include "gpd_internal.h"
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#define HIP_RET(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return GPD_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+namespace gpd {
+
+namespace {
+
+constexpr int PP_THREADS = 256;
+
+struct Workspace {
+  double w[6];
+  int active;
+};
+struct PreMeta {      // device-side results the host reads once
+  float lo[3];        // minimum of the points inside the workspace (pcl::getMinMax3D, cloud.cpp:290)
+  int32_t kept;       // points inside the workspace
+  int32_t voxels;     // points the voxeliser keeps
+  int32_t bad;        // bit 0: non-finite coordinate, bit 1: voxel index out of the int32 range, bit 2: spine overflow
+};
+
+__device__ inline bool inside_ws(const Workspace &W, float x, float y, float z) {
+  // float coordinates against double bounds, strict on both sides (cloud.cpp:246-247)
+  return !W.active || ((double)x > W.w[0] && (double)x < W.w[1] && (double)y > W.w[2] && (double)y < W.w[3] && (double)z > W.w[4] &&
+                       (double)z < W.w[5]);
+}
+
+// pass 1: per block, the number of points inside the workspace and their minimum
+__global__ __launch_bounds__(PP_THREADS) void ws_count_kernel(const float *__restrict__ xyz, int n, Workspace W, int32_t *__restrict__ block_count,
+                                                              float *__restrict__ block_lo, PreMeta *meta) {
+  __shared__ int s_cnt[PP_THREADS / 64];
+  __shared__ float s_lo[PP_THREADS / 64][3];
+  const int i = blockIdx.x * PP_THREADS + threadIdx.x;
+  float x = FLT_MAX, y = FLT_MAX, z = FLT_MAX;
+  bool keep = false;
+  if (i < n) {
+    const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
+    if (!(isfinite(px) && isfinite(py) && isfinite(pz))) atomicOr(&meta->bad, 1);
+    keep = inside_ws(W, px, py, pz);
+    if (keep) {
+      x = px;
+      y = py;
+      z = pz;
+    }
+  }
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    x = fminf(x, __shfl_xor(x, o));
+    y = fminf(y, __shfl_xor(y, o));
+    z = fminf(z, __shfl_xor(z, o));
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_cnt[wave] = __popcll(b);
+    s_lo[wave][0] = x;
+    s_lo[wave][1] = y;
+    s_lo[wave][2] = z;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    for (int w = 0; w < PP_THREADS / 64; w++) {
+      c += s_cnt[w];
+      for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], s_lo[w][a]);
+    }
+    block_count[blockIdx.x] = c;
+    for (int a = 0; a < 3; a++) block_lo[3 * blockIdx.x + a] = lo[a];
+  }
+}
+
+// pass 2 (one workgroup): exclusive scan of the block counts, global minimum
+__global__ __launch_bounds__(1024) void ws_scan_kernel(const int32_t *__restrict__ block_count, const float *__restrict__ block_lo, int nblocks,
+                                                       int32_t *__restrict__ block_off, PreMeta *meta) {
+  __shared__ int s_part[16];
+  __shared__ int s_carry;
+  __shared__ float s_lo[16][3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + tid;
+    const int v = i < nblocks ? block_count[i] : 0;
+    if (i < nblocks)
+      for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], block_lo[3 * i + a]);
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int before = s_carry;
+    for (int w = 0; w < wave; w++) before += s_part[w];
+    if (i < nblocks) block_off[i] = before + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = before + incl;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+  if (lane == 0)
+    for (int a = 0; a < 3; a++) s_lo[wave][a] = lo[a];
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; w++)
+      for (int a = 0; a < 3; a++) lo[a] = fminf(lo[a], s_lo[w][a]);
+    for (int a = 0; a < 3; a++) meta->lo[a] = lo[a];
+    meta->kept = s_carry;
+    meta->voxels = s_carry;  // without a voxeliser pass every point inside the workspace is kept
+  }
+}
+
+// pass 3: the compaction.  src[pos] = index of the pos-th point inside the workspace; with a cell size its voxel
+// (cloud.cpp:298-301: floor((pt - min_pt) / cell_size) in float) goes to keys[pos] = (ix, iy, iz, index).
+__global__ __launch_bounds__(PP_THREADS) void ws_scatter_kernel(const float *__restrict__ xyz, int n, Workspace W, const int32_t *__restrict__ block_off,
+                                                                float cell, PreMeta *meta, int32_t *__restrict__ src, int4 *__restrict__ keys) {
+  __shared__ int s_cnt[PP_THREADS / 64];
+  const int i = blockIdx.x * PP_THREADS + threadIdx.x;
+  float px = 0.f, py = 0.f, pz = 0.f;
+  bool keep = false;
+  if (i < n) {
+    px = xyz[3 * (size_t)i];
+    py = xyz[3 * (size_t)i + 1];
+    pz = xyz[3 * (size_t)i + 2];
+    keep = inside_ws(W, px, py, pz);
+  }
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_cnt[wave] = __popcll(b);
+  __syncthreads();
+  if (!keep) return;
+  int pos = block_off[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; w++) pos += s_cnt[w];
+  src[pos] = i;
+  if (cell > 0.f) {
+    const float q[3] = {floorf((px - meta->lo[0]) / cell), floorf((py - meta->lo[1]) / cell), floorf((pz - meta->lo[2]) / cell)};
+    if (!(q[0] < 2147483520.f && q[1] < 2147483520.f && q[2] < 2147483520.f)) atomicOr(&meta->bad, 2);
+    keys[pos] = make_int4((int)q[0], (int)q[1], (int)q[2], i);
+  }
+}
+
+// The sequential part of voxelizeCloud: which points the std::set keeps (see the head of the file).  One wavefront;
+// lane s holds one node of the tree's left spine in free-slot order: voxel, colour bits (1 = red, 2 = red right
+// child), slot of the parent on the spine (-1 = root).  rank[pos] = how many points were kept before this one, -1 for
+// a dropped point.
+__global__ __launch_bounds__(64) void voxel_accept_kernel(const int4 *__restrict__ keys, PreMeta *meta, int32_t *__restrict__ rank) {
+  const int lane = threadIdx.x;
+  const int n = meta->kept;
+  int kx = 0, ky = 0, kz = 0, col = 0, par = -1;
+  unsigned long long used = 0ull;  // slots that hold a spine node (uniform)
+  int leaf = -1, root = -1, m = 0; // uniform: slot of the leftmost node, of the root; points kept so far
+  auto rd = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const int4 k = i < n ? keys[i] : make_int4(0, 0, 0, 0);
+    int my_rank = -1;
+    const int cnt = n - base < 64 ? n - base : 64;
+    for (int j = 0; j < cnt; j++) {
+      const int qx = rd(k.x, j), qy = rd(k.y, j), qz = rd(k.z, j);
+      const bool hit = ((used >> lane) & 1ull) && kx == qx && ky == qy && kz == qz;
+      if (__builtin_amdgcn_ballot_w64(hit) != 0ull) continue;  // an equal voxel on the spine: the set rejects the point
+      if (~used == 0ull) {                                     // 64 spine nodes: more than 2^31 points
+        if (lane == 0) atomicOr(&meta->bad, 4);
+        break;
+      }
+      if (lane == j) my_rank = m;
+      m++;
+      // the new leftmost node: red, no children
+      const int s = __builtin_ctzll(~used);
+      used |= 1ull << s;
+      if (lane == s) {
+        kx = qx;
+        ky = qy;
+        kz = qz;
+        col = 1;
+        par = leaf;
+      }
+      if (root < 0) root = s;
+      leaf = s;
+      // _Rb_tree_insert_and_rebalance, left-hand cases only (every node here is a left child)
+      int x = s;
+      for (;;) {
+        const int p = rd(par, x);
+        if (p < 0 || !(rd(col, p) & 1)) break;  // x is the root, or its parent is black
+        const int g = rd(par, p);               // a red parent is not the root
+        const int cg = rd(col, g);
+        if (cg & 2) {                            // red uncle: recolour, continue from the grandparent
+          if (lane == p) col &= ~1;
+          if (lane == g) col = (col & ~2) | 1;
+          x = g;
+        } else {                                 // black uncle: right rotation at the grandparent, which leaves the spine
+          const int gp = rd(par, g);             // and becomes the parent's red right child
+          if (lane == p) {
+            col = 2;
+            par = gp;
+          }
+          used &= ~(1ull << g);
+          if (root == g) root = p;
+          break;
+        }
+      }
+      if (lane == root) col &= ~1;
+    }
+    if (i < n) rank[i] = my_rank;
+  }
+  if (lane == 0) meta->voxels = m;
+}
+
+// pass 5: the kept voxels in the set's iteration order (reverse order of insertion): voxel -> point
+// (cloud.cpp:322: min_pt + cell_size * voxel), camera source of the point that opened the voxel (:325-327: == 1 ? 1 : 0)
+__global__ __launch_bounds__(PP_THREADS) void voxel_emit_kernel(const int4 *__restrict__ keys, const int32_t *__restrict__ rank, const PreMeta *meta,
+                                                                float cell, const int32_t *__restrict__ cam, int n, int num_cams,
+                                                                float *__restrict__ out_xyz, int32_t *__restrict__ out_cam, int32_t *__restrict__ out_src) {
+  const int pos = blockIdx.x * PP_THREADS + threadIdx.x;
+  if (pos >= meta->kept) return;
+  const int r = rank[pos];
+  if (r < 0) return;
+  const int M = meta->voxels, o = M - 1 - r;
+  const int4 k = keys[pos];
+  out_xyz[3 * (size_t)o] = meta->lo[0] + cell * (float)k.x;
+  out_xyz[3 * (size_t)o + 1] = meta->lo[1] + cell * (float)k.y;
+  out_xyz[3 * (size_t)o + 2] = meta->lo[2] + cell * (float)k.z;
+  out_src[o] = k.w;
+  for (int c = 0; c < num_cams; c++) out_cam[(size_t)c * M + o] = cam[(size_t)c * n + k.w] == 1 ? 1 : 0;
+}
+
+// without a voxeliser: the points inside the workspace as they are, camera source columns copied (cloud.cpp:252-259)
+__global__ __launch_bounds__(PP_THREADS) void ws_emit_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ src, const PreMeta *meta,
+                                                             const int32_t *__restrict__ cam, int n, int num_cams, float *__restrict__ out_xyz,
+                                                             int32_t *__restrict__ out_cam) {
+  const int pos = blockIdx.x * PP_THREADS + threadIdx.x;
+  const int K = meta->kept;
+  if (pos >= K) return;
+  const int i = src[pos];
+  for (int a = 0; a < 3; a++) out_xyz[3 * (size_t)pos + a] = xyz[3 * (size_t)i + a];
+  for (int c = 0; c < num_cams; c++) out_cam[(size_t)c * K + pos] = cam[(size_t)c * n + i];
+}
+
+}  // namespace
+
+void preprocess_free(PreState &s) {
+  void *dev[] = {s.d_xyz, s.d_cam, s.d_block_count, s.d_block_off, s.d_block_lo, s.d_src, s.d_keys, s.d_rank, s.d_out_xyz, s.d_out_cam, s.d_out_src, s.d_meta};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  hipEvent_t e0 = s.ev[0], e1 = s.ev[1];  // the events outlive a re-allocation
+  s = PreState();
+  s.ev[0] = e0;
+  s.ev[1] = e1;
+}
+
+int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
+                   float *xyz_out, int32_t *cam_out, int32_t *src_out, int *num_out, float *ms, hipStream_t stream) {
+  *num_out = 0;
+  if (ms) *ms = 0.f;
+  if (n == 0) return GPD_OK;
+  if (n > s.capacity || num_cams > s.cap_cams) {
+    const int cap = n > s.capacity ? n + n / 4 : s.capacity, cams = num_cams > s.cap_cams ? num_cams : s.cap_cams;
+    preprocess_free(s);
+    const int blocks = (cap + PP_THREADS - 1) / PP_THREADS;
+    HIP_RET(hipMalloc(&s.d_xyz, (size_t)cap * 3 * sizeof(float)));
+    HIP_RET(hipMalloc(&s.d_cam, (size_t)cap * (cams > 0 ? cams : 1) * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_block_count, (size_t)blocks * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_block_off, (size_t)blocks * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_block_lo, (size_t)blocks * 3 * sizeof(float)));
+    HIP_RET(hipMalloc(&s.d_src, (size_t)cap * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_keys, (size_t)cap * sizeof(int4)));
+    HIP_RET(hipMalloc(&s.d_rank, (size_t)cap * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_out_xyz, (size_t)cap * 3 * sizeof(float)));
+    HIP_RET(hipMalloc(&s.d_out_cam, (size_t)cap * (cams > 0 ? cams : 1) * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_out_src, (size_t)cap * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_meta, sizeof(PreMeta)));
+    s.capacity = cap;
+    s.cap_cams = cams;
+  }
+  if (!s.ev[0])
+    for (auto &e : s.ev) HIP_RET(hipEventCreate(&e));
+  Workspace W;
+  W.active = workspace != nullptr;
+  for (int a = 0; a < 6; a++) W.w[a] = workspace ? workspace[a] : 0.0;
+  PreMeta *meta = static_cast<PreMeta *>(s.d_meta);
+  const int blocks = (n + PP_THREADS - 1) / PP_THREADS;
+  HIP_RET(hipMemcpyAsync(s.d_xyz, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, stream));
+  if (num_cams > 0) HIP_RET(hipMemcpyAsync(s.d_cam, cam_source, (size_t)n * num_cams * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  HIP_RET(hipEventRecord(s.ev[0], stream));
+  HIP_RET(hipMemsetAsync(s.d_meta, 0, sizeof(PreMeta), stream));
+  ws_count_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, n, W, s.d_block_count, s.d_block_lo, meta);
+  ws_scan_kernel<<<1, 1024, 0, stream>>>(s.d_block_count, s.d_block_lo, blocks, s.d_block_off, meta);
+  ws_scatter_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, n, W, s.d_block_off, cell, meta, s.d_src, s.d_keys);
+  if (cell > 0.f) {
+    voxel_accept_kernel<<<1, 64, 0, stream>>>(s.d_keys, meta, s.d_rank);
+    voxel_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_keys, s.d_rank, meta, cell, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam, s.d_out_src);
+  } else {
+    ws_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, s.d_src, meta, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam);
+  }
+  HIP_RET(hipGetLastError());
+  HIP_RET(hipEventRecord(s.ev[1], stream));
+  PreMeta h;
+  HIP_RET(hipMemcpyAsync(&h, s.d_meta, sizeof(h), hipMemcpyDeviceToHost, stream));
+  HIP_RET(hipStreamSynchronize(stream));
+  if (h.bad & 1) {
+    set_error("preprocess_cloud: the cloud holds non-finite coordinates (remove NaN/Inf points first)");
+    return GPD_ERR_INVALID;
+  }
+  if (h.bad & 6) {
+    set_error("preprocess_cloud: %s", (h.bad & 2) ? "a voxel index does not fit 32 bits (voxel size too small for the cloud's extent)"
+                                                  : "more points than the voxeliser's tree walk supports");
+    return GPD_ERR_CAPACITY;
+  }
+  const int M = cell > 0.f ? h.voxels : h.kept;
+  if (M > 0) {
+    HIP_RET(hipMemcpyAsync(xyz_out, s.d_out_xyz, (size_t)M * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (num_cams > 0) HIP_RET(hipMemcpyAsync(cam_out, s.d_out_cam, (size_t)M * num_cams * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    if (src_out) HIP_RET(hipMemcpyAsync(src_out, cell > 0.f ? s.d_out_src : s.d_src, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+  }
+  if (ms) HIP_RET(hipEventElapsedTime(ms, s.ev[0], s.ev[1]));
+  *num_out = M;
+  return GPD_OK;
+}
+
+}  // namespace gpd

@@ -40,6 +40,11 @@ class Cloud {
   // INDICES are replaced by the positions of the surviving entries (:215) and not remapped to the
   // filtered cloud — call it before sampling, as preprocessPointCloud does.
   void filterWorkspace(const std::vector<double> &workspace);
+  // its first two blocks alone (cloud.cpp:208-241): sample indices and samples by coordinate; the detector runs the
+  // third one — the points — on the device (gpd_hip_preprocess_cloud) and hands the result back through setProcessed
+  void filterWorkspaceSamples(const std::vector<double> &workspace);
+  // replaces points and camera source (rows of xyz.size() / 3); normals may be empty; sample indices are kept
+  void setProcessed(const std::vector<float> &xyz, const std::vector<int> &camera_source, const std::vector<float> &normals);
   // Cloud::voxelizeCloud (cloud.cpp:286-348), including what its std::set comparator (cloud.h:105-122,
   // not an ordering) keeps under libstdc++; drops normals like the reference's preprocessing order does.
   void voxelizeCloud(float cell_size);

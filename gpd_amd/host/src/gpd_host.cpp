@@ -224,7 +224,13 @@ struct VoxelDiffers {  // UniqueVector4First3Comparator (cloud.h:105-122)
 };
 }  // namespace
 
-void Cloud::filterWorkspace(const std::vector<double> &ws) {
+void Cloud::setProcessed(const std::vector<float> &xyz, const std::vector<int> &camera_source, const std::vector<float> &normals) {
+  xyz_ = xyz;
+  camera_source_ = camera_source;
+  normals_ = normals;
+}
+
+void Cloud::filterWorkspaceSamples(const std::vector<double> &ws) {
   if (ws.size() < 6) return;
   auto inside = [&](double x, double y, double z) { return x > ws[0] && x < ws[1] && y > ws[2] && y < ws[3] && z > ws[4] && z < ws[5]; };
   if (!sample_indices_.empty()) {
@@ -243,6 +249,12 @@ void Cloud::filterWorkspace(const std::vector<double> &ws) {
     samples_ = keep;
     std::cout << samples_.size() / 3 << " samples left after workspace filtering \n";
   }
+}
+
+void Cloud::filterWorkspace(const std::vector<double> &ws) {
+  if (ws.size() < 6) return;
+  auto inside = [&](double x, double y, double z) { return x > ws[0] && x < ws[1] && y > ws[2] && y < ws[3] && z > ws[4] && z < ws[5]; };
+  filterWorkspaceSamples(ws);
   const size_t n = size();
   const int cams = numCameras();
   const bool with_normals = hasNormals();
@@ -645,13 +657,40 @@ bool GraspDetector::calculateNormals(util::Cloud &cloud, double radius) {
 // normals ALWAYS recomputed, subsample.  The reference never reads normals from a PCD; normals that came with the
 // file are used only when the cfg says so (use_file_normals = 1: no voxelisation then either, the normals belong to
 // the points as loaded) — the synthetic benchmark clouds ship their analytic normals this way.
+// The workspace cut and the voxeliser run on the device (gpd_hip_preprocess_cloud); util::Cloud's own
+// filterWorkspace / voxelizeCloud are the host-side API mirror for callers that hold a Cloud and no detector.
 void GraspDetector::preprocessPointCloud(util::Cloud &cloud) {
   printf("Processing cloud with %zu points.\n", cloud.size());
-  cloud.filterWorkspace(workspace_);  // candidates_generator.cpp:19 (NaN rows are dropped at load time)
-  if (!(use_file_normals_ && cloud.hasNormals())) {
-    if (voxelize_) cloud.voxelizeCloud((float)voxel_size_);
-    if (ctx_ && cloud.size() > 0 && !calculateNormals(cloud, normals_radius_)) return;
+  const bool keep_normals = use_file_normals_ && cloud.hasNormals();
+  if (!ctx_) {
+    printf("ERROR: no device context\n");
+    return;
   }
+  cloud.filterWorkspaceSamples(workspace_);  // candidates_generator.cpp:19 (NaN rows are dropped at load time)
+  const int n = (int)cloud.size(), cams = cloud.numCameras();
+  if (n > 0) {
+    std::vector<float> xyz((size_t)n * 3);
+    std::vector<int> cam((size_t)n * cams), src(n);
+    int m = 0;
+    const bool voxelise = voxelize_ && !keep_normals;
+    if (gpd_hip_preprocess_cloud(ctx_, cloud.getCloudProcessed().data(), cloud.getCameraSource().data(), n, cams,
+                                 workspace_.size() >= 6 ? workspace_.data() : nullptr, voxelise ? (float)voxel_size_ : 0.f, xyz.data(),
+                                 cam.data(), src.data(), &m, nullptr) != GPD_OK) {
+      printf("ERROR: %s\n", gpd_hip_last_error());
+      return;
+    }
+    xyz.resize((size_t)m * 3);
+    cam.resize((size_t)m * cams);
+    std::vector<float> normals;
+    if (keep_normals) {
+      normals.resize((size_t)m * 3);
+      for (int k = 0; k < m; k++)
+        for (int r = 0; r < 3; r++) normals[3 * (size_t)k + r] = cloud.getNormals()[3 * (size_t)src[k] + r];
+    }
+    cloud.setProcessed(xyz, cam, normals);
+    if (voxelise) printf("Voxelized cloud: %zu\n", cloud.size());
+  }
+  if (!keep_normals && cloud.size() > 0 && !calculateNormals(cloud, normals_radius_)) return;
   cloud.subsample(num_samples_);
 }
 

@@ -125,6 +125,23 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
                          int num_points, const int32_t *cam_source, int num_cams,
                          const double *view_points);
 
+/* SURVEY §8f rank 2 (the step before the normals): replaces the point-cloud part of Cloud::filterWorkspace
+ * (util/cloud.cpp:243-266) followed by Cloud::voxelizeCloud (util/cloud.cpp:286-348) as
+ * CandidatesGenerator::preprocessPointCloud runs them on a cloud without normals (candidates_generator.cpp:19-26).
+ * xyz: num_points x 3 float32 without NaN/Inf (pcl::removeNaNFromPointCloud ran at load time, cloud.cpp:154-164);
+ * cam_source: num_cams rows of num_points (may be NULL with num_cams = 0).
+ * workspace: 6 doubles (min/max x, y, z; strict comparisons) or NULL = no cut.  voxel_size <= 0: no voxeliser, the
+ * points inside the workspace come back in input order with their camera-source columns.  voxel_size > 0: the points
+ * the reference's std::set keeps under its "differs" comparator (cloud.h:105-122) — not one per voxel, see
+ * gpd_amd/csrc/preprocess.hip — replaced by their voxel corner min + voxel_size * index, in the set's iteration order,
+ * camera source reduced to (== 1 ? 1 : 0) as cloud.cpp:325-327.
+ * xyz_out / cam_out (num_cams rows of *num_out) / src_out (input index per output point, may be NULL) must hold
+ * num_points entries.  kernel_ms (may be NULL) receives the device time of the kernels.  The context's uploaded cloud
+ * is not touched: gpd_hip_upload_cloud + gpd_hip_estimate_normals follow with the result. */
+int gpd_hip_preprocess_cloud(gpd_hip_ctx *ctx, const float *xyz, const int32_t *cam_source, int num_points, int num_cams,
+                             const double *workspace, float voxel_size, float *xyz_out, int32_t *cam_out, int32_t *src_out,
+                             int *num_out, float *kernel_ms);
+
 /* SURVEY §8f rank 1 (the step that feeds the path its normals): replaces Cloud::calculateNormals
  * (util/cloud.cpp:451-476) = calculateNormalsOMP (:497-535, radius search, PCA, flip towards the
  * view point) + reverseNormals (:573-604), on the cloud uploaded last (its normals argument may

@@ -1,0 +1,146 @@
+"""SURVEY §8f rank 2 on the device: Cloud::filterWorkspace (cloud.cpp:243-266) + Cloud::voxelizeCloud
+(cloud.cpp:286-348) through gpd_hip_preprocess_cloud, against the oracle's restatement — which IS libstdc++'s
+std::set under the reference's "differs" comparator — and numpy for the workspace cut."""
+import os
+
+import numpy as np
+import pytest
+
+from gpd_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(api.default_params(15))
+    yield c
+    c.close()
+
+
+def _inside(xyz, ws):
+    x = xyz.astype(np.float64)
+    return (x[:, 0] > ws[0]) & (x[:, 0] < ws[1]) & (x[:, 1] > ws[2]) & (x[:, 1] < ws[3]) & (x[:, 2] > ws[4]) & (x[:, 2] < ws[5])
+
+
+def _check(ctx, oracle_mod, xyz, cam, ws, cell):
+    got_xyz, got_cam, got_src, ms = ctx.preprocess_cloud(xyz, cam, ws, cell)
+    keep = np.flatnonzero(_inside(xyz, ws)) if ws is not None else np.arange(len(xyz))
+    if cell > 0:
+        want_xyz, src = oracle_mod.voxelize(xyz[keep], cell) if len(keep) else (np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
+        want_src = keep[src]
+        want_cam = (cam[:, want_src] == 1).astype(np.int32)
+    else:
+        want_xyz, want_src = xyz[keep], keep
+        want_cam = cam[:, keep]
+    assert got_xyz.shape == want_xyz.shape
+    assert np.array_equal(got_src, want_src)
+    assert got_xyz.tobytes() == want_xyz.tobytes()
+    assert np.array_equal(got_cam, want_cam)
+    return len(got_xyz), ms
+
+
+def test_krylon_known_answer(ctx, oracle_mod):
+    """4467 points in 2373 voxels -> the std::set keeps 3366, first from input 4466, 4464, 4459."""
+    xyz = np.load(os.path.join(GOLD, "krylon_xyz.npz"))["xyz"]
+    cam = np.ones((1, len(xyz)), np.int32)
+    n, _ = _check(ctx, oracle_mod, xyz, cam, None, 0.003)
+    assert n == 3366
+    _, _, src, _ = ctx.preprocess_cloud(xyz, cam, None, 0.003)
+    assert src[:5].tolist() == [4466, 4464, 4459, 4458, 4457]
+    # the reference's default workspace ([-1, 1]^3) keeps every point of this scan; a tight one cuts before the voxeliser
+    assert _check(ctx, oracle_mod, xyz, cam, np.array([-1.0, 1.0, -1.0, 1.0, -1.0, 1.0]), 0.003)[0] == 3366
+    lo, hi = xyz.min(0).astype(np.float64), xyz.max(0).astype(np.float64)
+    mid = 0.5 * (lo + hi)
+    n_cut, _ = _check(ctx, oracle_mod, xyz, cam, np.array([lo[0], mid[0], lo[1] - 1, hi[1] + 1, lo[2] - 1, hi[2] + 1]), 0.003)
+    assert 0 < n_cut < 3366
+
+
+def test_table_mug_scan(ctx, oracle_mod):
+    """tutorials/table_mug.pcd as shipped: 104 444 points -> 35 788, two cameras' worth of source flags."""
+    xyz = np.load(os.path.join(GOLD, "table_mug_xyz.npz"))["xyz"]
+    rng = np.random.RandomState(3)
+    cam = rng.randint(0, 3, (2, len(xyz))).astype(np.int32)  # values other than 0 / 1 exercise the == 1 rule
+    n, ms = _check(ctx, oracle_mod, xyz, cam, None, 0.003)
+    assert n == 35788
+    print("table_mug voxelise: %.2f ms of kernels" % ms)
+    # no voxeliser: the workspace cut alone, order and camera columns preserved
+    ws = np.array([-0.2, 0.15, -0.3, 0.1, 0.0, 1.2])
+    n_ws, _ = _check(ctx, oracle_mod, xyz, cam, ws, 0.0)
+    assert 0 < n_ws < len(xyz)
+    _check(ctx, oracle_mod, xyz, cam, ws, 0.003)
+    _check(ctx, oracle_mod, xyz, cam, ws, 0.01)
+
+
+def test_fuzz_against_std_set(ctx, oracle_mod):
+    """Point orders of every kind — scan lines, shuffled, heavy repetition, all in one voxel, sizes around the 64-point
+    batches of the tree walk and the 256-point blocks of the compaction."""
+    rng = np.random.RandomState(17)
+    for trial, n in enumerate((1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097, 30000, 131072, 300000)):
+        kind = trial % 4
+        if kind == 0:      # a raster scan with noise: neighbours in the sequence are neighbours in space
+            t = np.arange(n)
+            xyz = np.stack([(t % 517) * 0.0011, (t // 517) * 0.0013, 0.4 + 0.01 * np.sin(t * 0.01)], 1) + rng.randn(n, 3) * 2e-4
+        elif kind == 1:    # uniformly random in a small box: many revisits of the same voxels, far apart in the sequence
+            xyz = rng.rand(n, 3) * [0.05, 0.04, 0.03]
+        elif kind == 2:    # a handful of distinct voxels
+            xyz = rng.randint(0, 3, (n, 3)) * 0.003 + 1e-4
+        else:              # a synthetic scene
+            xyz = synth.make_cloud(40 + trial, max(n, 1000))["xyz"][:n]
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        cam = rng.randint(0, 2, (1 + trial % 3, n)).astype(np.int32)
+        cell = (0.003, 0.005, 0.0007)[trial % 3]
+        got = _check(ctx, oracle_mod, xyz, cam, None, cell)[0]
+        assert 1 <= got <= n
+        if n >= 1000:
+            lo, hi = xyz.min(0).astype(np.float64), xyz.max(0).astype(np.float64)
+            ws = np.array([lo[0] + 0.1 * (hi[0] - lo[0]), hi[0], lo[1], hi[1] - 0.2 * (hi[1] - lo[1]), lo[2] - 1, hi[2] + 1])
+            _check(ctx, oracle_mod, xyz, cam, ws, cell)
+            _check(ctx, oracle_mod, xyz, cam, ws, 0.0)
+
+
+def test_edges_and_errors(ctx, oracle_mod):
+    xyz = np.array([[0.1, 0.2, 0.3], [0.1, 0.2, 0.3], [0.5, 0.5, 0.5]], np.float32)
+    cam = np.array([[1, 0, 2]], np.int32)
+    # nothing inside the workspace -> an empty cloud, with or without the voxeliser
+    far = np.array([5.0, 6.0, 5.0, 6.0, 5.0, 6.0])
+    for cell in (0.003, 0.0):
+        out, c, s, _ = ctx.preprocess_cloud(xyz, cam, far, cell)
+        assert out.shape == (0, 3) and c.shape == (1, 0) and len(s) == 0
+    # the bounds are strict (cloud.cpp:246): a point on the face is outside
+    ws = np.array([float(np.float32(0.1)), 1.0, 0.0, 1.0, 0.0, 1.0])
+    out, _, s, _ = ctx.preprocess_cloud(xyz, cam, ws, 0.0)
+    assert s.tolist() == [2]
+    # an empty input, and no camera rows at all
+    out, c, s, _ = ctx.preprocess_cloud(np.zeros((0, 3), np.float32), None, None, 0.003)
+    assert out.shape == (0, 3)
+    out, c, s, _ = ctx.preprocess_cloud(xyz, None, None, 0.003)
+    assert len(out) == 2 and c.shape == (0, 2) and s.tolist() == [2, 0]
+    # NaN / Inf coordinates are the loader's job (cloud.cpp:154-164): refused here, as by gpd_hip_upload_cloud
+    bad = xyz.copy()
+    bad[1, 2] = np.nan
+    with pytest.raises(api.GpdHipError, match="non-finite"):
+        ctx.preprocess_cloud(bad, cam, None, 0.003)
+    # a voxel size far too small for the extent: the voxel index would leave the int32 range
+    wide = np.array([[0, 0, 0], [3000.0, 0, 0]], np.float32)
+    with pytest.raises(api.GpdHipError, match="32 bits"):
+        ctx.preprocess_cloud(wide, None, None, 1e-7)
+    # the context's own cloud is untouched by all of this
+    cl = synth.make_cloud(7, 12000)
+    ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+    before = ctx.search(synth.sample_indices(cl, 20)).tobytes()
+    ctx.preprocess_cloud(cl["xyz"], cl["cam_source"], None, 0.003)
+    assert ctx.search(synth.sample_indices(cl, 20)).tobytes() == before
+
+
+def test_config1_preprocessing_on_the_device(ctx, oracle_mod):
+    """candidates_generator.cpp:19-31 for configs[0] without a host pass: cut + voxelise + normals on the device
+    equal the oracle's voxelise + normals."""
+    xyz = np.load(os.path.join(GOLD, "krylon_xyz.npz"))["xyz"]
+    cam = np.ones((1, len(xyz)), np.int32)
+    v, c, _, _ = ctx.preprocess_cloud(xyz, cam, np.array([-1.0, 1.0, -1.0, 1.0, -1.0, 1.0]), 0.003)
+    ctx.upload_cloud(v, np.zeros_like(v), c, np.zeros((1, 3)))
+    n = ctx.estimate_normals(0.03)
+    ov, _ = oracle_mod.voxelize(xyz, 0.003)
+    assert np.array_equal(n, oracle_mod.estimate_normals(ov))
