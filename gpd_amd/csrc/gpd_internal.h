@@ -121,6 +121,7 @@ struct SearchState {
   double *d_frames = nullptr;         // [S][12] sample, normal, binormal, curvature
   double *d_centers = nullptr;        // [S][3] mean of the image neighbourhood
   gpd_hand *d_hands = nullptr;        // [S][slots]
+  float4 *d_hl = nullptr;             // [S][cap] points that can be in-height for some orientation: x, y, z, rank bits (height_list_kernel)
   uint8_t *d_fvalid = nullptr;        // [S][slots] is_valid after filterGraspsWorkspace (hand_eval_kernel writes it; the
                                       // unfused gpd_hip_images overwrites it with the caller's flags)
   // centre_kernel (serial fp64 chains: a hundred-odd waves, latency-bound) runs on a side stream beside

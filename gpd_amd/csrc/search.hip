@@ -1129,6 +1129,12 @@ struct HandConsts {
   double rot[GPD_MAX_SLOTS][9];
   double rot_binormal[9];
   double spacing[32];
+  double spfw[32];  // spacing[i] + finger width, as isGapFree adds them (finger_hand.cpp:173-184)
+  // finger slots a lateral coordinate can fall into: cell q = (t1 - lut_base) * lut_inv of 256 cells over the slots'
+  // extent (the outer cells reach to infinity) -> bit mask of the slots whose open interval touches the cell widened
+  // by 1 % — a superset; the exact comparisons decide
+  uint32_t slot_lut[256];
+  double lut_base, lut_inv;
   double depths[32];
   int num_deepen;
   int nfp;  // num_finger_placements
@@ -1147,8 +1153,11 @@ struct HandParams {
   int cap;
   gpd_hand *hands;
   uint8_t *fvalid;  // hand_eval_kernel: [S][slots] is_valid after filterGraspsWorkspace
+  float4 *hl;       // [S][cap] height_list_kernel -> hand_eval_kernel; its length per sample in counts[8 s + 6]
+  double radius;    // of the hand-search neighbourhood (bounds |p - sample|)
   int num_samples;
   int32_t *labels;  // reeval_kernel only: [n][8] rows of the counts table, column 5
+  unsigned long long *dbg;  // profiling aid (GPD_HE_TIMING=1): per-phase cycle sums of thread 0, [8] = sum of N, [9] = sum of k
 };
 
 __device__ inline void mat3mul(const double *a, const double *b, double *c) {
@@ -1394,6 +1403,71 @@ __global__ __launch_bounds__(256) void reeval_kernel(HandParams P) {
   }
 }
 
+// The height crop shared by the orientations of a sample.  cropByHandHeight (point_list.cpp:35-55) keeps the points
+// whose coordinate along the hand frame's third axis lies in (-h, h); that axis is the one the orientations rotate
+// about, so the eight frames of a sample have the same third column up to rounding ((1 - c) + c instead of 1) — every
+// orientation transformed all N neighbours to keep the same third of them.  One workgroup per sample lists the points
+// with |z| < h + margin for the axis of slot 0, margin = (largest deviation of any slot's axis from it) x radius +
+// 1e-12: a superset of every orientation's exact crop, which hand_eval_kernel then decides with its own frame.  When
+// the slots' axes differ (hand_axes other than the rotation axis) the margin is large and the list is everything.
+__global__ __launch_bounds__(256) void height_list_kernel(HandParams P, int32_t *counts) {
+  const HandConsts &K = c_hand;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int N = P.counts[8 * s + 0], kf = P.counts[8 * s + 2];
+  __shared__ int s_n;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  if (kf == 0 || N == 0) {
+    if (tid == 0) counts[8 * s + 6] = 0;
+    return;
+  }
+  const double *fr = P.frames + 12 * (size_t)s;
+  double F[9], FRB[9], FR[9], sample[3], axis[3] = {0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    sample[r] = fr[r];
+    F[3 * r + 0] = fr[3 + r];
+    F[3 * r + 1] = fr[6 + r];
+    F[3 * r + 2] = fr[9 + r];
+  }
+  mat3mul(F, K.rot_binormal, FRB);
+  double dev = 0.0;
+  for (int slot = 0; slot < K.slots; slot++) {
+    mat3mul(FRB, K.rot[slot], FR);
+    if (slot == 0) {
+      axis[0] = FR[2];
+      axis[1] = FR[5];
+      axis[2] = FR[8];
+    }
+    dev = fmax(dev, fabs(FR[2] - axis[0]) + fabs(FR[5] - axis[1]) + fabs(FR[8] - axis[2]));
+  }
+  const double margin = dev * P.radius + 1e-12;
+  const double lim = K.hand_height + margin;
+  const float *nn = P.nn + (size_t)s * 6 * P.cap;
+  float4 *out = P.hl + (size_t)s * P.cap;
+  for (int e0 = 0; e0 < N; e0 += 256) {
+    const int e = e0 + tid;
+    bool in = false;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (e < N) {
+      x = nn[0 * P.cap + e];
+      y = nn[1 * P.cap + e];
+      z = nn[2 * P.cap + e];
+      const double z0 = axis[0] * ((double)x - sample[0]) + axis[1] * ((double)y - sample[1]) + axis[2] * ((double)z - sample[2]);
+      in = z0 > -lim && z0 < lim;
+    }
+    const unsigned long long ballot = __ballot(in);
+    if (ballot) {
+      int base = 0;
+      if ((tid & 63) == 0) base = atomicAdd(&s_n, __popcll(ballot));
+      base = __shfl(base, 0);
+      if (in) out[base + __popcll(ballot & ((1ull << (tid & 63)) - 1ull))] = make_float4(x, y, z, __int_as_float(e));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) counts[8 * s + 6] = s_n;
+}
+
 __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   __shared__ unsigned s_u[4];
   __shared__ double s_d[4];
@@ -1411,16 +1485,28 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   const int kf = P.counts[8 * s + 2];
   gpd_hand *H = P.hands + (size_t)s * K.slots + slot;
   const double *fr = P.frames + 12 * (size_t)s;
+  // The 184-byte record is put together in LDS and stored by 46 lanes, one dword each: a gpd_hand on thread 0's
+  // stack lives in scratch memory (184 B/lane), and writing it there and copying it out was a tenth of the kernel.
+  constexpr int REC_DW = (int)(sizeof(gpd_hand) / 4);
+  static_assert(sizeof(gpd_hand) % 4 == 0 && REC_DW <= 64, "record store");
+  __shared__ gpd_hand s_rec;
   if (kf == 0 || N == 0) {  // no frame: the sample is dropped on the host
-    if (tid == 0) {
-      gpd_hand z;
-      memset(&z, 0, sizeof(z));
-      z.finger_placement_index = -1;
-      z.slot = slot;
-      *H = z;
-      P.fvalid[(size_t)s * K.slots + slot] = 0;
+    if (tid < REC_DW) {
+      uint32_t v = 0u;
+      if (tid == (int)(offsetof(gpd_hand, finger_placement_index) / 4)) v = 0xffffffffu;  // -1
+      if (tid == (int)(offsetof(gpd_hand, slot) / 4)) v = (uint32_t)slot;
+      reinterpret_cast<uint32_t *>(H)[tid] = v;
     }
+    if (tid == 0) P.fvalid[(size_t)s * K.slots + slot] = 0;
     return;
+  }
+  if (tid < REC_DW) reinterpret_cast<uint32_t *>(&s_rec)[tid] = 0u;  // ordered before thread 0's fields by the barriers below
+  long long t_last = P.dbg ? clock64() : 0;
+#define HTICK(k)                                  \
+  if (P.dbg && tid == 0) {                        \
+    const long long now_ = clock64();             \
+    atomicAdd(&P.dbg[k], (unsigned long long)(now_ - t_last)); \
+    t_last = now_;                                \
   }
   ListCtx L;
   L.nn = P.nn + (size_t)s * 6 * P.cap;
@@ -1450,54 +1536,76 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   __shared__ double s_t0[HE_COMPACT], s_t1[HE_COMPACT];
   __shared__ unsigned short s_e[HE_COMPACT];
   __shared__ int s_kc;
+  __shared__ uint32_t s_lut[256];
+  __shared__ double s_sp[32], s_spfw[32];
   if (tid == 0) s_kc = 0;
+  s_lut[tid] = K.slot_lut[tid];
+  if (tid < 32) {
+    s_sp[tid] = K.spacing[tid];
+    s_spfw[tid] = K.spfw[tid];
+  }
   __syncthreads();
   L.ct0 = nullptr;
   L.ct1 = nullptr;
   L.ce = nullptr;
   L.kc = 0;
-  // (the three coordinates of the NEXT 256 points are requested before this round's are used: one global round
-  //  trip per round otherwise, and a round is little more than that)
-  float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f;
-  if (tid < N) {
-    nx0 = L.nn[0 * L.cap + tid];
-    nx1 = L.nn[1 * L.cap + tid];
-    nx2 = L.nn[2 * L.cap + tid];
-  }
-  for (int e0 = 0; e0 < N; e0 += 256) {
-    const int e = e0 + tid;
-    const float w0 = nx0, w1 = nx1, w2 = nx2;
-    if (e + 256 < N) {
-      nx0 = L.nn[0 * L.cap + e + 256];
-      nx1 = L.nn[1 * L.cap + e + 256];
-      nx2 = L.nn[2 * L.cap + e + 256];
-    }
-    double t[3] = {0, 0, 0};
-    bool in = false;
-    if (e < N) {  // list_entry() on the prefetched coordinates: transformToHandFrame + the height test
-      const double c0 = (double)w0 - L.sample[0], c1 = (double)w1 - L.sample[1], c2 = (double)w2 - L.sample[2];
+  // The points come from the sample's height list (height_list_kernel: the superset of every orientation's crop, one
+  // 16-byte record per point); two rounds are in flight per thread.
+  const float4 *hl = P.hl + (size_t)s * P.cap;
+  const int NL = P.counts[8 * s + 6];
+  constexpr int HE_R = 2;
+  float4 cx[2][HE_R];
+  auto request = [&](int i0, float4(&c)[HE_R]) {
 #pragma unroll
-      for (int r = 0; r < 3; r++) t[r] = L.FR[0 + r] * c0 + L.FR[3 + r] * c1 + L.FR[6 + r] * c2;
-      in = t[2] > -1.0 * L.hand_height && t[2] < L.hand_height;
-    }
-    const unsigned long long ballot = __ballot(in);
-    if (ballot) {
-      int base = 0;
-      if ((tid & 63) == 0) base = atomicAdd(&s_kc, __popcll(ballot));
-      base = __shfl(base, 0);
-      if (in) {
-        const int c = base + __popcll(ballot & ((1ull << (tid & 63)) - 1ull));
-        if (c < HE_COMPACT) {
-          s_t0[c] = t[0];
-          s_t1[c] = t[1];
-          s_e[c] = (unsigned short)e;
+    for (int q = 0; q < HE_R; q++) c[q] = hl[min(i0 + 256 * q + tid, NL - 1)];
+  };
+  auto consume = [&](int i0, const float4(&c)[HE_R]) {
+#pragma unroll
+    for (int q = 0; q < HE_R; q++) {
+      const int i = i0 + 256 * q + tid;
+      if (i0 + 256 * q >= NL) break;  // uniform
+      double t[3] = {0, 0, 0};
+      bool in = false;
+      if (i < NL) {  // list_entry() on the listed coordinates: transformToHandFrame + the height test
+        const double c0 = (double)c[q].x - L.sample[0], c1 = (double)c[q].y - L.sample[1], c2 = (double)c[q].z - L.sample[2];
+#pragma unroll
+        for (int r = 0; r < 3; r++) t[r] = L.FR[0 + r] * c0 + L.FR[3 + r] * c1 + L.FR[6 + r] * c2;
+        in = t[2] > -1.0 * L.hand_height && t[2] < L.hand_height;
+      }
+      const unsigned long long ballot = __ballot(in);
+      if (ballot) {
+        int base = 0;
+        if ((tid & 63) == 0) base = atomicAdd(&s_kc, __popcll(ballot));
+        base = __shfl(base, 0);
+        if (in) {
+          const int cpos = base + __popcll(ballot & ((1ull << (tid & 63)) - 1ull));
+          if (cpos < HE_COMPACT) {
+            s_t0[cpos] = t[0];
+            s_t1[cpos] = t[1];
+            s_e[cpos] = (unsigned short)__float_as_int(c[q].w);
+          }
         }
       }
     }
+  };
+  if (NL > 0) {
+    request(0, cx[0]);
+    for (int i0 = 0; i0 < NL; i0 += 2 * 256 * HE_R) {
+      if (i0 + 256 * HE_R < NL) request(i0 + 256 * HE_R, cx[1]);
+      consume(i0, cx[0]);
+      if (i0 + 256 * HE_R >= NL) break;
+      if (i0 + 2 * 256 * HE_R < NL) request(i0 + 2 * 256 * HE_R, cx[0]);
+      consume(i0 + 256 * HE_R, cx[1]);
+    }
   }
   __syncthreads();
+  HTICK(0);
   const int k = s_kc;
   L.ghost_mult = N - k;
+  if (P.dbg && tid == 0) {
+    atomicAdd(&P.dbg[8], (unsigned long long)N);
+    atomicAdd(&P.dbg[9], (unsigned long long)k);
+  }
   if (k <= HE_COMPACT) {
     L.ct0 = s_t0;
     L.ct1 = s_t1;
@@ -1506,16 +1614,26 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   }
   // ---- pass 1: finger collision masks at init_bite (finger_hand.cpp:26-73)
   unsigned blocked = 0, flags = 0;  // flags bit0: some x<bite, bit1: some x<bottom
+  // isGapFree for all 2 nfp slots: the slots an entry can block come from the lookup table (none, one, rarely
+  // two), the reference's own comparisons decide — twenty pairs of comparisons per entry were 31 of the kernel's
+  // 85 kcycles per workgroup
   for_each_entry(L, [&](double t0, double t1, int, int) {
     if (t0 < bite) {
       flags |= 1u;
       if (t0 < bottom0) flags |= 2u;
-      for (int i = 0; i < 2 * nfp; i++)
-        if (t1 > K.spacing[i] && t1 < K.spacing[i] + K.fw) blocked |= 1u << i;
+      const double u = (t1 - K.lut_base) * K.lut_inv;
+      const int q = u < 0.0 ? 0 : (u >= 255.0 ? 255 : (int)u);
+      unsigned m = s_lut[q] & ~blocked;
+      while (m) {
+        const int i = __ffs(m) - 1;
+        m &= m - 1u;
+        if (t1 > s_sp[i] && t1 < s_spfw[i]) blocked |= 1u << i;
+      }
     }
   });
   blocked = block_or(blocked, s_u);
   flags = block_or(flags, s_u);
+  HTICK(1);
   unsigned fingers = 0;
   if ((flags & 1u) && !(flags & 2u)) fingers = ~blocked & ((1u << (2 * nfp)) - 1u);
   unsigned hand = fingers & (fingers >> nfp) & ((1u << nfp) - 1u);
@@ -1556,6 +1674,7 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
       m_any = block_or(m_any, s_u);
       m_back = block_or(m_back, s_u);
       m_blk = block_or(m_blk, s_u);
+      HTICK(2);
       for (int j = 0; j < K.num_deepen; j++) {
         const bool ok = (m_any >> j & 1u) && !(m_back >> j & 1u) && !(m_blk >> j & 1u);
         if (!ok) break;
@@ -1579,10 +1698,10 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
       center = 0.0;
       fidx = __ffs(fingers & (fingers >> nfp) & ((1u << nfp) - 1u)) - 1;
     }
+    HTICK(3);
   }
   if (tid == 0) {
-    gpd_hand h;
-    memset(&h, 0, sizeof(h));
+    gpd_hand &h = s_rec;
 #pragma unroll
     for (int r = 0; r < 3; r++) h.sample[r] = L.sample[r];
 #pragma unroll
@@ -1600,18 +1719,21 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
     h.valid = valid ? 1 : 0;
     h.half_antipodal = label >= 1;
     h.full_antipodal = label == 2;
-    *H = h;
     // detectGrasps step 2 (grasp_detector.cpp:238): the workspace / aperture filter only clears is_valid, the
     // record itself stays as the search produced it
     P.fvalid[(size_t)s * K.slots + slot] = (valid && workspace_ok(K.filter, h)) ? 1 : 0;
   }
+  __syncthreads();
+  if (tid < REC_DW) reinterpret_cast<uint32_t *>(H)[tid] = reinterpret_cast<const uint32_t *>(&s_rec)[tid];
+  HTICK(4);
+#undef HTICK
 }
 
 // ---------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------
 void search_free(SearchState &s) {
-  void *ptrs[] = {s.d_sample_idx, s.d_sample_xyz, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands, s.d_fvalid};
+  void *ptrs[] = {s.d_sample_idx, s.d_sample_xyz, s.d_counts, s.d_nn_idx, s.d_nn, s.d_frames, s.d_centers, s.d_hands, s.d_fvalid, s.d_hl};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);  // hipFree waits for the device: the side stream is idle as well
   if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
@@ -1633,6 +1755,7 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
   HIP_RET(hipMalloc(&s.d_centers, (size_t)newS * 3 * sizeof(double)));
   HIP_RET(hipMalloc(&s.d_hands, (size_t)newS * slots * sizeof(gpd_hand)));
   HIP_RET(hipMalloc(&s.d_fvalid, (size_t)newS * slots));
+  HIP_RET(hipMalloc(&s.d_hl, (size_t)newS * cap * sizeof(float4)));
   s.capacity_samples = newS;
   s.nn_cap = cap;
   return GPD_OK;
@@ -1764,6 +1887,26 @@ static int upload_hand_consts(const gpd_params &p, const HostConsts &hc, int slo
   std::memcpy(hk.rot_binormal, hc.rot_binormal, sizeof(hk.rot_binormal));
   std::memcpy(hk.spacing, hc.finger_spacing, sizeof(hk.spacing));
   std::memcpy(hk.depths, hc.deepen_depths, sizeof(hk.depths));
+  {
+    const int nslots = 2 * p.num_finger_placements;
+    double lo = DBL_MAX, hi = -DBL_MAX;
+    for (int i = 0; i < nslots; i++) {
+      hk.spfw[i] = hk.spacing[i] + p.finger_width;
+      lo = std::fmin(lo, hk.spacing[i]);
+      hi = std::fmax(hi, hk.spfw[i]);
+    }
+    const double w = (hi - lo) / 256.0;
+    hk.lut_base = lo;
+    hk.lut_inv = w > 0.0 ? 1.0 / w : 0.0;
+    for (int c = 0; c < 256; c++) {
+      const double c_lo = c == 0 ? -DBL_MAX : lo + (c - 0.01) * w - 1e-12;
+      const double c_hi = c == 255 ? DBL_MAX : lo + (c + 1.01) * w + 1e-12;
+      uint32_t m = 0;
+      for (int i = 0; i < nslots; i++)
+        if (hk.spacing[i] < c_hi && hk.spfw[i] > c_lo) m |= 1u << i;
+      hk.slot_lut[c] = w > 0.0 ? m : (nslots >= 32 ? 0xffffffffu : (1u << nslots) - 1u);
+    }
+  }
   hk.num_deepen = hc.num_deepen;
   hk.nfp = p.num_finger_placements;
   hk.slots = slots;
@@ -1824,8 +1967,27 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   hp.fvalid = s.d_fvalid;
   hp.labels = nullptr;
   hp.num_samples = S;
+  static unsigned long long *d_hedbg = nullptr;
+  hp.dbg = nullptr;
+  if (getenv("GPD_HE_TIMING")) {
+    if (!d_hedbg) HIP_RET(hipMalloc(&d_hedbg, 16 * sizeof(unsigned long long)));
+    HIP_RET(hipMemsetAsync(d_hedbg, 0, 16 * sizeof(unsigned long long), stream));
+    hp.dbg = d_hedbg;
+  }
+  hp.hl = s.d_hl;
+  hp.radius = hc.nn_radius_hands * 1.001 + 1e-6;
+  height_list_kernel<<<S, 256, 0, stream>>>(hp, s.d_counts);
   hand_eval_kernel<<<((S + 7) / 8) * 8 * slots, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
+  if (hp.dbg) {
+    unsigned long long h[16];
+    HIP_RET(hipMemcpyAsync(h, d_hedbg, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+    static const char *names[5] = {"transform+compact", "finger masks", "deepen", "closing region", "record"};
+    const double wg = (double)S * slots;
+    for (int i = 0; i < 5; i++) fprintf(stderr, "[he-timing] %-18s %8.2f kcycles/workgroup\n", names[i], (double)h[i] / wg / 1e3);
+    fprintf(stderr, "[he-timing] mean N %.0f, mean in-height k %.0f\n", (double)h[8] / wg, (double)h[9] / wg);
+  }
   rc = search_join(s, stream);
   if (rc) return rc;
   s.num_samples = S;
@@ -1858,6 +2020,9 @@ int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand
   hp.hands = s.d_hands;
   hp.fvalid = nullptr;
   hp.labels = s.d_counts;
+  hp.dbg = nullptr;
+  hp.hl = nullptr;
+  hp.radius = 0.0;
   hp.num_samples = n;
   reeval_kernel<<<n, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
