@@ -319,8 +319,13 @@ def main():
             batch["note"] = ("gpd_hip_detect_batch, %d clouds per rank x %d samples, two clouds in flight per context: upload + grid + "
                              "search + filter + images + LeNet + scored candidates back to the host" % (args.batch_clouds, args.batch_samples))
             out["batch_end_to_end"] = batch
+        raw = None
+        if args.config is None and C == 15 and not clutter:  # the widened row before the path, on the default line only
+            raw, out["preprocess"] = _preprocess_leg(ctx)
         if args.cpu_samples > 0 and args.gpus == 1:  # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = _cpu_baseline(cloud, w, C, args.cpu_samples)
+            if raw is not None:
+                out["cpu_baseline"]["preprocess_ms"] = _cpu_preprocess_ms(raw)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
@@ -423,6 +428,37 @@ def _pmc_sq():
             if name in k:
                 out[name] = {"frac": v["lds_util"], "conflict_share": v["lds_conflict"], "wait_any": v["wait_any"]}
     return out
+
+
+PRE_POINTS, PRE_VOXEL = 120000, 0.003
+PRE_WORKSPACE = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)  # cfg/eigen_params.cfg
+
+
+def _preprocess_leg(ctx):
+    """SURVEY §8f rank 2 (gpd_hip_preprocess_cloud): workspace cut + the reference's std::set voxeliser on a raw
+    120k-point synthetic scan; not part of `value`."""
+    import time
+    import numpy as np
+    from gpd_amd import synth
+    raw = synth.make_cloud(4321, PRE_POINTS)
+    xyz, cam = raw["xyz"], raw["cam_source"]
+    ws = np.array(PRE_WORKSPACE)
+    ctx.preprocess_cloud(xyz, cam, ws, PRE_VOXEL)
+    t0 = time.perf_counter()
+    v, _, _, ms = ctx.preprocess_cloud(xyz, cam, ws, PRE_VOXEL)
+    wall = time.perf_counter() - t0
+    return raw, {"points": int(len(xyz)), "kept": int(len(v)), "voxel_size": PRE_VOXEL, "kernel_ms": float(ms), "wall_ms_incl_pcie": wall * 1e3,
+                 "note": "Cloud::filterWorkspace + Cloud::voxelizeCloud on the device; the voxeliser's keep / drop decisions are a "
+                         "sequential chain (one wavefront), the CPU time beside it is cpu_baseline.preprocess_ms"}
+
+
+def _cpu_preprocess_ms(raw):
+    import time
+    import oracle
+    oracle.voxelize(raw["xyz"][:1000], PRE_VOXEL)
+    t0 = time.perf_counter()
+    oracle.voxelize(raw["xyz"], PRE_VOXEL)  # every point of the synthetic scan lies inside the workspace
+    return (time.perf_counter() - t0) * 1e3
 
 
 def _cpu_baseline(cloud, w, C, n_samples):

@@ -9,18 +9,18 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-python bench.py > $OUT/bench_config2.json 2> $OUT/bench_config2.err
-python bench.py --config 3a > $OUT/bench_config3a.json 2> $OUT/bench_config3a.err
-python bench.py --config 3b > $OUT/bench_config3b.json 2> $OUT/bench_config3b.err
-python bench.py --config 4 --steps 5 --warmup 1 --cpu-samples 600 > $OUT/bench_config4.json 2> $OUT/bench_config4.err
-python bench.py --mode batch --clouds 64 --steps 2 --warmup 1 > $OUT/bench_batch64.json 2> $OUT/bench_batch64.err
+timeout 400 python bench.py > $OUT/bench_config2.json 2> $OUT/bench_config2.err
+timeout 400 python bench.py --config 3a > $OUT/bench_config3a.json 2> $OUT/bench_config3a.err
+timeout 400 python bench.py --config 3b > $OUT/bench_config3b.json 2> $OUT/bench_config3b.err
+timeout 600 python bench.py --config 4 --steps 5 --warmup 1 --cpu-samples 600 > $OUT/bench_config4.json 2> $OUT/bench_config4.err
+timeout 400 python bench.py --mode batch --clouds 64 --steps 2 --warmup 1 > $OUT/bench_batch64.json 2> $OUT/bench_batch64.err
 cd /tmp && export TMPDIR=/tmp
 P=$OUT/prof
 mkdir -p $P
-rocprofv3 --kernel-trace --stats -d $P/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-samples 0 --batch-clouds 0 > $P/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $P/pmc_fetch -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $P/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $P/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --stats -d $P/batch -o batch -- python $ROOT/bench.py --mode batch --clouds 16 --steps 2 --warmup 1 > $P/batch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $P/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-samples 0 --batch-clouds 0 > $P/stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $P/pmc_fetch -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $P/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $P/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $P/batch -o batch -- python $ROOT/bench.py --mode batch --clouds 16 --steps 2 --warmup 1 > $P/batch.log 2>&1
 cd $ROOT
 python profiles/summarize.py $P > $OUT/rocprof_summary.txt 2>&1
 python profiles/summarize.py $P --traffic $OUT/traffic.json
