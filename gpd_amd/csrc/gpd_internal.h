@@ -49,6 +49,8 @@ struct PreState {
           *d_out_src = nullptr;
   int4 *d_keys = nullptr;
   void *d_meta = nullptr;
+  void *d_ops = nullptr;      // int8 per kept point: the voxeliser's spine table (preprocess.hip spine_ops)
+  size_t ops_on_device = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};
 };
 void preprocess_free(PreState &s);

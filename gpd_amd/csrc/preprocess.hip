@@ -17,13 +17,15 @@
 // tests/test_gpu_preprocess.py through oracle/gpd_oracle.cpp.)
 // That chain of decisions is sequential — which spine a point meets depends on how many points before it were kept —
 // so ONE wavefront walks the points in order with the spine spread over its lanes: a point's voxel is compared
-// with all spine nodes at once (one ballot), the spine is edited with v_readlane / v_writelane at uniform lane
-// numbers.  ~2 log2(m) <= 64 lanes hold the spine of any cloud that fits the device.  Everything around it (keys,
-// minimum, gather of the kept voxels) is data parallel.
+// with all spine nodes at once (one ballot); the colours are two uniform bit masks, so the rebalancing is scalar.
+// ~2 log2(m) <= 64 lanes hold the spine of any cloud that fits the device.  Everything around it (keys, minimum,
+// gather of the kept voxels) is data parallel.
 #include "gpd_internal.h"
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #define HIP_RET(expr)                                                                       \
   do {                                                                                      \
@@ -177,66 +179,55 @@ __global__ __launch_bounds__(PP_THREADS) void ws_scatter_kernel(const float *__r
 }
 
 // The sequential part of voxelizeCloud: which points the std::set keeps (see the head of the file).  One wavefront;
-// lane s holds one node of the tree's left spine in free-slot order: voxel, colour bits (1 = red, 2 = red right
-// child), slot of the parent on the spine (-1 = root).  rank[pos] = how many points were kept before this one, -1 for
-// a dropped point.
-__global__ __launch_bounds__(64) void voxel_accept_kernel(const int4 *__restrict__ keys, PreMeta *meta, int32_t *__restrict__ rank) {
+// lane d holds the voxel of the spine node at depth d (0 = root, L - 1 = the leftmost leaf).  How the spine is
+// rebuilt by the m-th kept point does not depend on the data — recolouring and the one rotation are a function of m
+// alone — so the host tabulates it once (spine_ops: the depth that leaves the spine at the m-th insertion, or -1) and
+// the kernel's step is: compare with the spine (one ballot), append the voxel, close the gap the table names.
+// rank[pos] = how many points were kept before this one, -1 for a dropped point.
+__global__ __launch_bounds__(64) void voxel_accept_kernel(const int4 *__restrict__ keys, const int8_t *__restrict__ ops, PreMeta *meta,
+                                                          int32_t *__restrict__ rank) {
   const int lane = threadIdx.x;
   const int n = meta->kept;
-  int kx = 0, ky = 0, kz = 0, col = 0, par = -1;
-  unsigned long long used = 0ull;  // slots that hold a spine node (uniform)
-  int leaf = -1, root = -1, m = 0; // uniform: slot of the leftmost node, of the root; points kept so far
+  int kx = 0, ky = 0, kz = 0;
+  int L = 0, m = 0, m_base = 0;
   auto rd = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+  int4 k_next = lane < n ? keys[lane] : make_int4(0, 0, 0, 0);
+  int op_cur = lane < n ? (int)ops[lane] : -1, op_next = 64 + lane < n ? (int)ops[64 + lane] : -1;  // lane t: ops[m_base + t]
   for (int base = 0; base < n; base += 64) {
     const int i = base + lane;
-    const int4 k = i < n ? keys[i] : make_int4(0, 0, 0, 0);
+    const int4 k = k_next;
+    if (i + 64 < n) k_next = keys[i + 64];  // the next 64 voxels travel while these are walked
     int my_rank = -1;
     const int cnt = n - base < 64 ? n - base : 64;
     for (int j = 0; j < cnt; j++) {
       const int qx = rd(k.x, j), qy = rd(k.y, j), qz = rd(k.z, j);
-      const bool hit = ((used >> lane) & 1ull) && kx == qx && ky == qy && kz == qz;
+      const bool hit = lane < L && kx == qx && ky == qy && kz == qz;
       if (__builtin_amdgcn_ballot_w64(hit) != 0ull) continue;  // an equal voxel on the spine: the set rejects the point
-      if (~used == 0ull) {                                     // 64 spine nodes: more than 2^31 points
-        if (lane == 0) atomicOr(&meta->bad, 4);
-        break;
-      }
       if (lane == j) my_rank = m;
-      m++;
-      // the new leftmost node: red, no children
-      const int s = __builtin_ctzll(~used);
-      used |= 1ull << s;
-      if (lane == s) {
+      if (lane == L) {  // the new leftmost node
         kx = qx;
         ky = qy;
         kz = qz;
-        col = 1;
-        par = leaf;
       }
-      if (root < 0) root = s;
-      leaf = s;
-      // _Rb_tree_insert_and_rebalance, left-hand cases only (every node here is a left child)
-      int x = s;
-      for (;;) {
-        const int p = rd(par, x);
-        if (p < 0 || !(rd(col, p) & 1)) break;  // x is the root, or its parent is black
-        const int g = rd(par, p);               // a red parent is not the root
-        const int cg = rd(col, g);
-        if (cg & 2) {                            // red uncle: recolour, continue from the grandparent
-          if (lane == p) col &= ~1;
-          if (lane == g) col = (col & ~2) | 1;
-          x = g;
-        } else {                                 // black uncle: right rotation at the grandparent, which leaves the spine
-          const int gp = rd(par, g);             // and becomes the parent's red right child
-          if (lane == p) {
-            col = 2;
-            par = gp;
-          }
-          used &= ~(1ull << g);
-          if (root == g) root = p;
-          break;
+      const int g = rd(op_cur, m - m_base);
+      m++;
+      L++;
+      if (g >= 0) {  // the node at depth g leaves the spine, the ones below move up
+        // wave_shl:1 — lane l reads lane l + 1 over the whole wavefront (a DPP move: no LDS round trip as ds_bpermute)
+        const int sx = __builtin_amdgcn_update_dpp(kx, kx, 0x130, 0xf, 0xf, false), sy = __builtin_amdgcn_update_dpp(ky, ky, 0x130, 0xf, 0xf, false),
+                  sz = __builtin_amdgcn_update_dpp(kz, kz, 0x130, 0xf, 0xf, false);
+        if (lane >= g) {
+          kx = sx;
+          ky = sy;
+          kz = sz;
         }
+        L--;
       }
-      if (lane == root) col &= ~1;
+      if (m - m_base == 64) {
+        m_base = m;
+        op_cur = op_next;
+        op_next = m_base + 64 + lane < n ? (int)ops[m_base + 64 + lane] : -1;
+      }
     }
     if (i < n) rank[i] = my_rank;
   }
@@ -275,8 +266,41 @@ __global__ __launch_bounds__(PP_THREADS) void ws_emit_kernel(const float *__rest
 
 }  // namespace
 
+// The structural half of the voxeliser's tree walk, which is the same for every cloud: ops[m] = depth of the node that
+// the m-th leftmost insertion rotates off the left spine (-1: recolouring only).  Colours as two bit masks over the
+// spine depths (node red / its right child red); _Rb_tree_insert_and_rebalance restricted to left children: a red
+// uncle recolours and moves two levels up, a black one ends with a right rotation at the grandparent.
+static bool spine_ops(std::vector<int8_t> &ops, size_t n, unsigned long long &C, unsigned long long &R, int &L) {
+  while (ops.size() < n) {
+    if (L == 64) return false;
+    C |= 1ull << L;
+    R &= ~(1ull << L);
+    int x = L++, gone = -1;
+    while (x > 0 && (C >> (x - 1) & 1ull)) {
+      const int g = x - 2;  // a red parent is not the root
+      if (R >> g & 1ull) {
+        C = (C & ~(1ull << (x - 1))) | (1ull << g);
+        R &= ~(1ull << g);
+        x = g;
+      } else {
+        C &= ~(1ull << (x - 1));
+        R |= 1ull << (x - 1);
+        const unsigned long long low = (1ull << g) - 1ull;
+        C = (C & low) | ((C >> 1) & ~low);
+        R = (R & low) | ((R >> 1) & ~low);
+        L--;
+        gone = g;
+        break;
+      }
+    }
+    C &= ~1ull;
+    ops.push_back((int8_t)gone);
+  }
+  return true;
+}
+
 void preprocess_free(PreState &s) {
-  void *dev[] = {s.d_xyz, s.d_cam, s.d_block_count, s.d_block_off, s.d_block_lo, s.d_src, s.d_keys, s.d_rank, s.d_out_xyz, s.d_out_cam, s.d_out_src, s.d_meta};
+  void *dev[] = {s.d_xyz, s.d_cam, s.d_block_count, s.d_block_off, s.d_block_lo, s.d_src, s.d_keys, s.d_rank, s.d_out_xyz, s.d_out_cam, s.d_out_src, s.d_meta, s.d_ops};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   hipEvent_t e0 = s.ev[0], e1 = s.ev[1];  // the events outlive a re-allocation
@@ -306,6 +330,7 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
     HIP_RET(hipMalloc(&s.d_out_cam, (size_t)cap * (cams > 0 ? cams : 1) * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_out_src, (size_t)cap * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_meta, sizeof(PreMeta)));
+    HIP_RET(hipMalloc(&s.d_ops, (size_t)cap));
     s.capacity = cap;
     s.cap_cams = cams;
   }
@@ -324,7 +349,24 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
   ws_scan_kernel<<<1, 1024, 0, stream>>>(s.d_block_count, s.d_block_lo, blocks, s.d_block_off, meta);
   ws_scatter_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, n, W, s.d_block_off, cell, meta, s.d_src, s.d_keys);
   if (cell > 0.f) {
-    voxel_accept_kernel<<<1, 64, 0, stream>>>(s.d_keys, meta, s.d_rank);
+    // the spine table up to n kept points (it only ever grows; the device copy is refreshed when it did or was re-allocated)
+    static std::vector<int8_t> ops;
+    static unsigned long long ops_C = 0ull, ops_R = 0ull;
+    static int ops_L = 0;
+    static std::mutex ops_mutex;
+    {
+      std::lock_guard<std::mutex> lock(ops_mutex);
+      if (!spine_ops(ops, (size_t)n, ops_C, ops_R, ops_L)) {
+        set_error("preprocess_cloud: more points than the voxeliser's tree walk supports");
+        return GPD_ERR_CAPACITY;
+      }
+      if (s.ops_on_device < (size_t)n) {
+        HIP_RET(hipMemcpyAsync(s.d_ops, ops.data(), (size_t)n, hipMemcpyHostToDevice, stream));
+        HIP_RET(hipStreamSynchronize(stream));  // `ops` may grow (re-allocate) under another context's call
+        s.ops_on_device = (size_t)n;
+      }
+    }
+    voxel_accept_kernel<<<1, 64, 0, stream>>>(s.d_keys, static_cast<const int8_t *>(s.d_ops), meta, s.d_rank);
     voxel_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_keys, s.d_rank, meta, cell, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam, s.d_out_src);
   } else {
     ws_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, s.d_src, meta, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam);
