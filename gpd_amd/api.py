@@ -55,7 +55,7 @@ EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_h
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
-           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud"]
+           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters"]
 
 
 def build():
@@ -90,6 +90,8 @@ def lib():
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
         L.gpd_hip_estimate_normals.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+        L.gpd_hip_find_clusters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_int)]
         L.gpd_hip_preprocess_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.gpd_hip_last_images_stats.argtypes = [C.c_void_p, C.c_void_p]
@@ -278,6 +280,20 @@ class Context:
         self._check(lib().gpd_hip_last_fallbacks(self._h, _ptr(out)))
         return dict(neighbourhood_list_capacity=int(out[0]), large_shadow_kernel_candidates=int(out[1]),
                     large_points_kernel_candidates=int(out[2]), lenet_passes=int(out[3]))
+
+    def find_clusters(self, hands, scores, min_inliers=1, remove_inliers=False):
+        """Clustering::findClusters on the device -> (cluster records, scores f64, seed index)."""
+        hands = np.ascontiguousarray(hands, HAND_DTYPE).reshape(-1)
+        scores = np.ascontiguousarray(scores, np.float64)
+        assert len(scores) == len(hands)
+        n = len(hands)
+        out = np.zeros(max(n, 1), HAND_DTYPE)
+        osc = np.zeros(max(n, 1), np.float64)
+        src = np.zeros(max(n, 1), np.int32)
+        k = C.c_int(0)
+        self._check(lib().gpd_hip_find_clusters(self._h, _ptr(hands), _ptr(scores), n, int(min_inliers), int(bool(remove_inliers)), _ptr(out),
+                                                _ptr(osc), _ptr(src), C.byref(k)))
+        return out[: k.value].copy(), osc[: k.value].copy(), src[: k.value].copy()
 
     def preprocess_cloud(self, xyz, cam_source=None, workspace=None, voxel_size=0.003):
         """Cloud::filterWorkspace (points) + Cloud::voxelizeCloud on the device ->

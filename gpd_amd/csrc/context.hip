@@ -110,6 +110,7 @@ struct gpd_hip_ctx {
   LeNetWeights lenet;
   Lane lane[kLanes];
   PreState pre;
+  ClusterState cluster;
   std::vector<hipEvent_t> replay_events;  // 6 per gpd_hip_replay call: start, images done, conv1, conv2, fc1, end
   float replay_kernel_ms[4] = {0, 0, 0, 0};  // conv1, conv2, fc1, fc2 sums of the replays of the last gpd_hip_replay_times
   size_t replay_used = 0;
@@ -446,6 +447,7 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   for (int l = kLanes - 1; l >= 0; l--) lane_free(ctx->lane[l]);
   preprocess_free(ctx->pre);
+  cluster_free(ctx->cluster);
   for (auto &e : ctx->pre.ev)
     if (e) (void)hipEventDestroy(e);
   float **ws[] = {&ctx->lenet.c1w, &ctx->lenet.c1b, &ctx->lenet.c2w, &ctx->lenet.c2b,
@@ -571,6 +573,16 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
   HIP_TRY(hipSetDevice(ctx->device));
   Lane &L = ctx->lane[0];
   return cloud_upload(L.cloud, xyz, normals, num_points, cam_source, num_cams, view_points, L.stream, /*sync=*/true);
+}
+
+int gpd_hip_find_clusters(gpd_hip_ctx *ctx, const gpd_hand *hands, const double *scores, int n, int min_inliers, int remove_inliers,
+                          gpd_hand *out, double *out_scores, int32_t *out_src, int *num_out) {
+  if (!ctx || !num_out || n < 0 || (n > 0 && (!hands || !scores || !out || !out_scores || !out_src))) {
+    set_error("gpd_hip_find_clusters: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  return cluster_run(ctx->cluster, hands, scores, n, min_inliers, remove_inliers, out, out_scores, out_src, num_out, ctx->lane[0].stream);
 }
 
 int gpd_hip_preprocess_cloud(gpd_hip_ctx *ctx, const float *xyz, const int32_t *cam_source, int num_points, int num_cams,

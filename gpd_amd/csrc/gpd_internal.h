@@ -59,6 +59,18 @@ void preprocess_free(PreState &s);
 int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
                    float *xyz_out, int32_t *cam_out, int32_t *src_out, int *num_out, float *ms, hipStream_t stream);
 
+// ---- Clustering::findClusters on the device (cluster.hip) ---------------------------------------------------------
+struct ClusterState {
+  int capacity = 0;
+  gpd_hand *d_hands = nullptr, *d_out = nullptr;
+  double *d_scores = nullptr, *d_res = nullptr, *d_out_scores = nullptr;
+  uint8_t *d_used = nullptr;
+  int32_t *d_keep = nullptr, *d_out_src = nullptr, *d_num = nullptr;
+};
+void cluster_free(ClusterState &s);
+int cluster_run(ClusterState &s, const gpd_hand *hands, const double *scores, int n, int min_inliers, int remove_inliers, gpd_hand *out,
+                double *out_scores, int32_t *out_src, int *num_out, hipStream_t stream);
+
 // ---- Cloud (search.hip) -----------------------------------------------------
 // Device copy of what the path reads from util::Cloud, as SoA for coalesced streaming.
 constexpr int kMaxCams = 8;

@@ -538,7 +538,7 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   direction_ = {approach[0], approach[1], approach[2]};
   thresh_rad_ = config_file.getValueOfKey<double>("thresh_rad", 2.3);
   const int min_inliers = config_file.getValueOfKey<int>("min_inliers", 1);
-  clustering_ = std::make_unique<Clustering>(min_inliers);
+  clustering_ = std::make_unique<Clustering>(min_inliers);  // runs on ctx_ once that exists (below)
   cluster_grasps_ = min_inliers > 0;
   num_selected_ = config_file.getValueOfKey<int>("num_selected", 100);
   use_file_normals_ = config_file.getValueOfKey<int>("use_file_normals", 0) != 0;
@@ -551,6 +551,7 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
     ctx_ = nullptr;
     return;
   }
+  if (ctx_) clustering_->setContext(ctx_);
   // classifier (grasp_detector.cpp:129-145): created through the plugin factory, as the reference does.  For the
   // Eigen-layout parameters weights_file is the parameter directory.
   std::string model_file = config_file.getValueOfKeyAsString("model_file", "");
@@ -617,6 +618,7 @@ GraspDetector::GraspDetector(const candidate::HandSearch::Parameters &hs, const 
     printf("ERROR: %s\n", gpd_hip_last_error());
     ctx_ = nullptr;
   }
+  if (ctx_) clustering_->setContext(ctx_);
 }
 
 candidate::HandSearch::Parameters GraspDetector::getHandSearchParameters() const {
@@ -1284,63 +1286,47 @@ std::vector<std::unique_ptr<candidate::Hand>> SequentialImportanceSampling::dete
 }
 
 // ---------------------------------------------------------------------------
-// Clustering::findClusters — clustering.cpp:5-105.  fp64 throughout; the thresholds are the
-// reference's constants (:9-13).  `inliers.push_back(i)` (:62) feeds nothing and is dropped.
+// Clustering::findClusters — clustering.cpp:5-105, on the device (gpd_hip_find_clusters); the per-cluster lines the
+// reference prints (:88-91) are printed from the results.
 // ---------------------------------------------------------------------------
+Clustering::~Clustering() {
+  if (own_ctx_) gpd_hip_destroy(own_ctx_);
+}
+
 std::vector<std::unique_ptr<candidate::Hand>> Clustering::findClusters(const std::vector<std::unique_ptr<candidate::Hand>> &hand_list,
                                                                         bool remove_inliers) {
-  const double AXIS_ALIGN_ANGLE_THRESH = 12.0 * M_PI / 180.0;
-  const double AXIS_ALIGN_DIST_THRESH = 0.005;
-  const double MAX_DIST_THRESH = 0.05;
-  const double cos_thresh = cos(AXIS_ALIGN_ANGLE_THRESH);
-  const int n = (int)hand_list.size();
   std::vector<std::unique_ptr<candidate::Hand>> hands_out;
-  std::vector<bool> has_used(remove_inliers ? n : 0, false);
+  const int n = (int)hand_list.size();
+  if (n == 0) return hands_out;
+  if (!ctx_) {
+    gpd_params p;
+    gpd_hip_default_params(&p);
+    if (gpd_hip_create(0, &p, &own_ctx_) != GPD_OK) {
+      printf("ERROR: %s\n", gpd_hip_last_error());
+      return hands_out;
+    }
+    ctx_ = own_ctx_;
+  }
+  std::vector<gpd_hand> in(n), out(n);
+  std::vector<double> scores(n), out_scores(n);
+  std::vector<int32_t> src(n);
   for (int i = 0; i < n; i++) {
-    int num_inliers = 0;
-    const std::array<double, 3> ai = hand_list[i]->getAxis(), pi = hand_list[i]->getPosition();
-    double proj[3][3];  // I - a a^T
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) proj[r][c] = (r == c ? 1.0 : 0.0) - ai[r] * ai[c];
-    double position_delta[3] = {0, 0, 0};
-    double mean = 0.0, standard_deviation = 0.0;
-    for (int j = 0; j < n; j++) {
-      if (i == j || (remove_inliers && has_used[j])) continue;
-      const std::array<double, 3> aj = hand_list[j]->getAxis(), pj = hand_list[j]->getPosition();
-      const double axis_aligned = ai[0] * aj[0] + ai[1] * aj[1] + ai[2] * aj[2];
-      const bool axis_aligned_binary = fabs(axis_aligned) > cos_thresh;
-      const double d[3] = {pi[0] - pj[0], pi[1] - pj[1], pi[2] - pj[2]};
-      const bool delta_pos_mag_binary = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) <= MAX_DIST_THRESH;
-      double q[3];
-      for (int r = 0; r < 3; r++) q[r] = proj[r][0] * d[0] + proj[r][1] * d[1] + proj[r][2] * d[2];
-      const bool delta_pos_proj_mag_binary = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) <= AXIS_ALIGN_DIST_THRESH;
-      if (axis_aligned_binary && delta_pos_mag_binary && delta_pos_proj_mag_binary) {
-        num_inliers++;
-        for (int r = 0; r < 3; r++) position_delta[r] += pj[r];
-        const double sj = hand_list[j]->getScore();
-        const double old_mean = mean;
-        mean += (sj - mean) / static_cast<double>(num_inliers);
-        standard_deviation += (sj - mean) * (sj - old_mean);
-        if (remove_inliers) has_used[j] = true;
-      }
-    }
-    if (num_inliers >= min_inliers_) {
-      const double dn = static_cast<double>(num_inliers);
-      for (int r = 0; r < 3; r++) position_delta[r] = position_delta[r] / dn - pi[r];
-      standard_deviation /= dn;
-      if (standard_deviation != 0) standard_deviation = sqrt(standard_deviation);
-      const double sqrt_n = sqrt((double)num_inliers);
-      const double conf_lb = mean - 2.576 * standard_deviation / sqrt_n;
-      const double conf_ub = mean + 2.576 * standard_deviation / sqrt_n;
-      printf("grasp %d, inliers: %d, ||position_delta||: %3.4f, ", i, num_inliers,
-             sqrt(position_delta[0] * position_delta[0] + position_delta[1] * position_delta[1] + position_delta[2] * position_delta[2]));
-      printf("mean: %3.4f, STD: %3.4f, conf_int: (%3.4f, %3.4f)\n", mean, standard_deviation, conf_lb, conf_ub);
-      auto hand = std::make_unique<candidate::Hand>(*hand_list[i]);
-      hand->setPosition({pi[0] + position_delta[0], pi[1] + position_delta[1], pi[2] + position_delta[2]});
-      hand->setScore(conf_lb);
-      hand->setFullAntipodal(hand_list[i]->isFullAntipodal());
-      hands_out.push_back(std::move(hand));
-    }
+    in[i] = hand_list[i]->record();
+    scores[i] = hand_list[i]->getScore();
+  }
+  int k = 0;
+  if (gpd_hip_find_clusters(ctx_, in.data(), scores.data(), n, min_inliers_, remove_inliers ? 1 : 0, out.data(), out_scores.data(), src.data(),
+                            &k) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return hands_out;
+  }
+  for (int c = 0; c < k; c++) {
+    const gpd_hand &seed = in[src[c]];
+    const double d[3] = {out[c].position[0] - seed.position[0], out[c].position[1] - seed.position[1], out[c].position[2] - seed.position[2]};
+    printf("grasp %d, ||position_delta||: %3.4f, conf_lb: %3.4f\n", (int)src[c], sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), out_scores[c]);
+    auto hand = std::make_unique<candidate::Hand>(out[c]);
+    hand->setScore(out_scores[c]);
+    hands_out.push_back(std::move(hand));
   }
   return hands_out;
 }

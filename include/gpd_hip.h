@@ -125,6 +125,17 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
                          int num_points, const int32_t *cam_source, int num_cams,
                          const double *view_points);
 
+/* SURVEY §8f rank 3, the step after selectGrasps: replaces Clustering::findClusters (clustering.cpp:5-105).
+ * hands: n records (axis = third column of `frame`, `position`); scores: their scores as doubles (Hand keeps a double,
+ * hand.h:253; the record's float is not read).  A seed hand with at least min_inliers inliers (axis within 12 degrees,
+ * position within 0.05 m and within 0.005 m of the seed's axis line, clustering.cpp:9-13) yields a cluster: the seed's
+ * record with position = mean inlier position, out_scores = lower bound of the 99 % confidence interval of the inlier
+ * scores (the record's float score is its rounding), out_src = index of the seed; clusters come in seed order.
+ * remove_inliers != 0: a hand that was an inlier of an earlier seed is skipped by the later ones (:36, :70-72).
+ * out / out_scores / out_src must hold n entries. */
+int gpd_hip_find_clusters(gpd_hip_ctx *ctx, const gpd_hand *hands, const double *scores, int n, int min_inliers, int remove_inliers,
+                          gpd_hand *out, double *out_scores, int32_t *out_src, int *num_out);
+
 /* SURVEY §8f rank 2 (the step before the normals): replaces the point-cloud part of Cloud::filterWorkspace
  * (util/cloud.cpp:243-266) followed by Cloud::voxelizeCloud (util/cloud.cpp:286-348) as
  * CandidatesGenerator::preprocessPointCloud runs them on a cloud without normals (candidates_generator.cpp:19-26).

@@ -1,8 +1,11 @@
-"""Clustering::findClusters (clustering.cpp:5-105): host mirror vs oracle vs an independent numpy form."""
+"""Clustering::findClusters (clustering.cpp:5-105): the device kernel (gpd_hip_find_clusters), reached through the C-ABI
+and through the host mirror's Clustering class, vs the oracle vs an independent numpy form."""
 import numpy as np
 import pytest
 
-from gpd_amd import hostlib, synth
+from gpd_amd import api, hostlib, synth
+
+pytestmark = pytest.mark.gpu
 
 
 def _numpy_clusters(hands, scores, min_inliers, remove_inliers):
@@ -51,12 +54,19 @@ def scored_hands(oracle_mod):
 def test_host_clusters_match_oracle(oracle_mod, scored_hands, min_inliers, remove):
     hands, scores = scored_hands
     want, wsc, wsrc = oracle_mod.find_clusters(hands, scores, min_inliers, remove)
-    got, gsc, gsrc = hostlib.find_clusters(hands, scores, min_inliers, remove)
     assert len(want) > 3
-    assert np.array_equal(gsrc, wsrc)
-    assert gsc.tobytes() == wsc.tobytes()
-    assert got["position"].tobytes() == want["position"].tobytes()
-    assert np.array_equal(got["frame"], hands["frame"][wsrc])
+    ctx = api.Context(api.default_params(15))
+    try:
+        routes = [hostlib.find_clusters(hands, scores, min_inliers, remove),  # Clustering class of the host mirror -> C-ABI
+                  ctx.find_clusters(hands, scores, min_inliers, remove)]      # the C-ABI directly
+    finally:
+        ctx.close()
+    for got, gsc, gsrc in routes:
+        assert np.array_equal(gsrc, wsrc)
+        assert gsc.tobytes() == wsc.tobytes()
+        assert got["position"].tobytes() == want["position"].tobytes()
+        assert np.array_equal(got["frame"], hands["frame"][wsrc])
+        assert np.array_equal(got["score"], wsc.astype(np.float32))
     ref = _numpy_clusters(hands, scores, min_inliers, remove)
     assert [r[0] for r in ref] == list(wsrc)
     assert np.allclose(np.array([r[1] for r in ref]), want["position"], atol=1e-12)
@@ -74,3 +84,28 @@ def test_cluster_edge_cases(oracle_mod, scored_hands):
     got, gsc, gsrc = hostlib.find_clusters(two, np.array([1.5, -2.0]), 1)
     assert list(gsrc) == [0, 1] and list(gsc) == [-2.0, 1.5]
     assert np.array_equal(got["position"], two["position"])
+
+
+def test_clusters_of_many_hands(oracle_mod):
+    """More hands than one 256-lane chunk and more than one 1024-entry round of the output scan (pruneGraspCandidates
+    hands every valid grasp to the clustering: sequential_importance_sampling.cpp:178)."""
+    rng = np.random.RandomState(9)
+    cl = synth.make_cloud(12, 12000)
+    p = oracle_mod.default_params(15)
+    hands = oracle_mod.search(p, cl["xyz"], cl["normals"], synth.sample_indices(cl, 400)).reshape(-1)
+    hands = hands[hands["valid"].astype(bool)]
+    assert len(hands) > 1100
+    extra = hands[rng.randint(0, len(hands), 600)].copy()
+    ax = extra["frame"].reshape(-1, 3, 3)[:, :, 2]
+    extra["position"] += ax * rng.uniform(-0.03, 0.03, (len(extra), 1)) + rng.normal(0, 0.001, (len(extra), 3))
+    hands = np.concatenate([hands, extra])[rng.permutation(len(hands) + len(extra))]
+    scores = rng.normal(0, 3, len(hands))
+    ctx = api.Context(api.default_params(15))
+    try:
+        for min_inliers, remove in ((1, False), (2, True)):
+            want, wsc, wsrc = oracle_mod.find_clusters(hands, scores, min_inliers, remove)
+            got, gsc, gsrc = ctx.find_clusters(hands, scores, min_inliers, remove)
+            assert len(want) > 200 and np.array_equal(gsrc, wsrc)
+            assert gsc.tobytes() == wsc.tobytes() and got["position"].tobytes() == want["position"].tobytes()
+    finally:
+        ctx.close()
