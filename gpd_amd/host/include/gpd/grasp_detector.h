@@ -91,6 +91,7 @@ class GraspDetector {
   }
   const std::vector<double> &getWorkspaceGrasps() const { return workspace_grasps_; }
   bool ok() const { return ctx_ != nullptr; }
+  gpd_hip_ctx *context() const { return ctx_; }  // for the objects that run on the same device context (Clustering)
   // stage runtimes of the last detectGrasps, seconds: candidates, images, classification, total
   const double *lastRuntimes() const { return runtimes_; }
 

@@ -1147,6 +1147,7 @@ SequentialImportanceSampling::SequentialImportanceSampling(const std::string &co
   rng_state_ = 0x9E3779B97F4A7C15ull ^ (unsigned long long)config_file.getValueOfKey<int>("random_seed", 0);
   grasp_detector_ = std::make_unique<GraspDetector>(config_filename);
   clustering_ = std::make_unique<Clustering>(config_file.getValueOfKey<int>("min_inliers", 1));
+  if (grasp_detector_->context()) clustering_->setContext(grasp_detector_->context());
 }
 
 unsigned long long SequentialImportanceSampling::nextRandom() {
