@@ -326,6 +326,7 @@ def main():
             out["cpu_baseline"] = _cpu_baseline(cloud, w, C, args.cpu_samples)
             if raw is not None:
                 out["cpu_baseline"]["preprocess_ms"] = _cpu_preprocess_ms(raw)
+                out["cpu_baseline"]["normals_ms"] = _cpu_normals_ms()
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ctx.close()
@@ -430,7 +431,7 @@ def _pmc_sq():
     return out
 
 
-PRE_POINTS, PRE_VOXEL = 120000, 0.003
+PRE_POINTS, PRE_VOXEL, PRE_NORMALS_POINTS = 120000, 0.003, 30000
 PRE_WORKSPACE = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)  # cfg/eigen_params.cfg
 
 
@@ -447,9 +448,18 @@ def _preprocess_leg(ctx):
     t0 = time.perf_counter()
     v, _, _, ms = ctx.preprocess_cloud(xyz, cam, ws, PRE_VOXEL)
     wall = time.perf_counter() - t0
+    # SURVEY §8f rank 1 on the same scan, voxelised to the grid the reference uses: Cloud::calculateNormals (radius 0.03)
+    grid = synth.make_cloud(4321, PRE_NORMALS_POINTS)
+    ctx.upload_cloud(grid["xyz"], np.zeros_like(grid["xyz"]), grid["cam_source"], grid["view_points"])
+    ctx.estimate_normals(0.03)
+    t0 = time.perf_counter()
+    ctx.estimate_normals(0.03)
+    n_wall = time.perf_counter() - t0
     return raw, {"points": int(len(xyz)), "kept": int(len(v)), "voxel_size": PRE_VOXEL, "kernel_ms": float(ms), "wall_ms_incl_pcie": wall * 1e3,
+                 "normals": {"points": PRE_NORMALS_POINTS, "radius": 0.03, "wall_ms_incl_download": n_wall * 1e3},
                  "note": "Cloud::filterWorkspace + Cloud::voxelizeCloud on the device; the voxeliser's keep / drop decisions are a "
-                         "sequential chain (one wavefront), the CPU time beside it is cpu_baseline.preprocess_ms"}
+                         "sequential chain (one wavefront), the CPU time beside it is cpu_baseline.preprocess_ms.  normals: "
+                         "gpd_hip_estimate_normals on a 30k-point cloud of the benchmark's density"}
 
 
 def _cpu_preprocess_ms(raw):
@@ -458,6 +468,16 @@ def _cpu_preprocess_ms(raw):
     oracle.voxelize(raw["xyz"][:1000], PRE_VOXEL)
     t0 = time.perf_counter()
     oracle.voxelize(raw["xyz"], PRE_VOXEL)  # every point of the synthetic scan lies inside the workspace
+    return (time.perf_counter() - t0) * 1e3
+
+
+def _cpu_normals_ms():
+    import time
+    import oracle
+    from gpd_amd import synth
+    grid = synth.make_cloud(4321, PRE_NORMALS_POINTS)
+    t0 = time.perf_counter()
+    oracle.estimate_normals(grid["xyz"], grid["cam_source"], grid["view_points"], 0.03)  # OpenMP over the points, all host cores
     return (time.perf_counter() - t0) * 1e3
 
 
