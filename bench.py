@@ -287,9 +287,10 @@ def main():
                         "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": frac,
                         "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
                         "flops_per_launch": kernels[dom]["algorithmic_flops"], "launch_ms": kernels[dom]["ms"],
-                        "note": "frac = algorithmic (dense) FLOPs / measured time / peak.  conv1 drops the (64-pixel chunk, channel) pairs "
-                                "whose input patches are all zero (exact): frac_executed = frac x live pair fraction is the rate "
-                                "the matrix pipe actually sustains"}
+                        "note": "frac = algorithmic (dense) FLOPs / measured time / peak, as SURVEY 8d counts them.  conv1 drops the "
+                                "(64-pixel chunk, channel) pairs whose input patches are all zero (exact), so this dense-equivalent "
+                                "figure can reach or pass 1.0 without the matrix pipe doing so: frac_executed = frac x live pair "
+                                "fraction is the rate the pipe actually sustains, and the number to compare with MfmaUtil"}
             if dom == "conv1_mfma_kernel" and live_frac is not None:
                 roofline["live_pair_fraction"] = live_frac
                 roofline["frac_executed"] = frac * live_frac
