@@ -117,7 +117,9 @@ def test_fc1_tile_shapes_agree_with_the_oracle_checked_one(oracle_mod):
         ref = ctx.score(base)  # n = 640 -> the 16-wide tile
         assert np.array_equal(ref[:48], oracle_mod.lenet(base[:48], w))
         assert len(np.unique(ref)) > 600
-        for n in (1025, 2100, 3100, 4200, 5000, 5200, 6200, 7200, 8192, 10000):
+        # (the small and odd counts walk conv1's persistent grid: one workgroup with 1-3 images, 256 workgroups with 2 / 3
+        #  images each, image counts that do not divide by the grid)
+        for n in (1, 2, 3, 5, 17, 255, 256, 257, 511, 512, 513, 767, 1000, 1025, 2100, 3100, 4200, 5000, 5200, 6200, 7200, 8192, 10000):
             idx = rng.randint(0, len(base), n)
             got = ctx.score(base[idx])
             assert np.array_equal(got, ref[idx]), n
