@@ -30,7 +30,6 @@ struct LeNetScratch {
   float *pool1 = nullptr;  // [cap][20][28][28]
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
-  int32_t *c1_next = nullptr;  // conv1's image counter (its persistent workgroups draw their images from it)
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)
 };
 

@@ -46,51 +46,44 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ahead anyway.  Pooled pixels are numbered strip-major (four strips of 7 columns), so a chunk is
 // a compact ~9 x 7 block: 28 % of the (chunk, channel) pairs drop out (14 % with row-major chunks;
 // profiles/r01m_conv1_skip_stats.txt).
-// Persistent workgroups (one per CU: 142 KB of LDS) over a two-slot image ring.  A workgroup draws its images one
-// at a time from a counter of the launch (the first two together), numbers the pooled pixels of ITS sequence of images
-// through (784 per image) and cuts them into chunks of 64, whatever the image boundaries.  The s-th image of the
-// workgroup sits in slot s & 1; the wave that completes the last chunk touching image s draws the next image and loads
-// it into that slot while the other waves work on image s + 1 (a chunk takes ~45 us of wave time, the load ~10), so
-// the task stream never runs dry inside a workgroup, and a workgroup whose images are dense simply draws fewer of
-// them: with a fixed deal (image b, b + G, ...) the slowest workgroup ran 13 % longer than the average.
-// The two-images-per-workgroup version before that spent, per workgroup of 350 kcycles: 17 in the prologue (images +
-// weights), 34 with the average wave waiting for the last one at the end of the 25-task queue, and another 10 % of the
-// kernel between workgroups (dispatch, 9.77 rounds on 256 CUs): 1.69 ms for 1.30 ms of tasks.
+// Persistent workgroups (one per CU: 142 KB of LDS) over a two-slot image ring.  Workgroup b of G takes the images
+// b, b + G, b + 2 G, ... (neighbouring candidates have similar images: dealing them out keeps the workgroups' loads
+// alike, contiguous ranges differed by 12 %), numbers their pooled pixels through (784 per image) and cuts them into
+// chunks of 64 — 245 chunks for 20 images, whatever the image boundaries.  The s-th image of the workgroup sits in
+// slot s & 1; the wave that completes the last chunk touching image s loads image s + 2 into its slot while the other
+// waves work on image s + 1 (a chunk takes ~45 us of wave time, the load ~10), so the task stream never runs dry
+// inside a workgroup.  The two-images-per-workgroup version this replaces spent, per workgroup of 350 kcycles: 17 in the
+// prologue (images + weights), 34 with the average wave waiting for the last one at the end of the 25-task queue, and
+// another 10 % of the kernel between workgroups (dispatch, 9.77 rounds on 256 CUs): 1.69 ms for 1.30 ms of tasks.
 constexpr int C1_WAVES = 8, C1_THREADS = 64 * C1_WAVES, C1_STRIP = 7, C1_PIX = 784;
 
-// chunks of a workgroup's pixel stream that touch its s-th image (the number of releases the image's slot waits for)
-__device__ inline int c1_chunks_of_image(int s) { return (C1_PIX * s + C1_PIX - 1) / 64 - (C1_PIX * s) / 64 + 1; }
+// chunks of [c0, c1) that touch image j (the number of releases its slot waits for)
+__device__ inline int c1_chunks_of_image(int j, int c0, int c1) {
+  const int lo = max(c0, (C1_PIX * j) / 64), hi = min(c1 - 1, (C1_PIX * j + C1_PIX - 1) / 64);
+  return hi >= lo ? hi - lo + 1 : 0;
+}
 
 template <int C>
 __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wp,
-                                                               const float *__restrict__ bias, float *__restrict__ out, int n,
-                                                               int32_t *__restrict__ next_image) {
+                                                               const float *__restrict__ bias, float *__restrict__ out, int n) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
   __shared__ __attribute__((aligned(16))) float s_wa[16 * C * 28];  // filters 0..15: [f][c][25 taps + 3 pad]
   __shared__ __attribute__((aligned(16))) float s_wb[4 * C * 28];   // filters 16..19
   __shared__ int s_next;
-  __shared__ int s_slot_seq[2];  // sequence number of the image the slot holds (published after its bytes), -1: none
-  __shared__ int s_slot_img[2];  // ... and which image of the batch that is
-  __shared__ int s_refs[2];      // chunks that still have to release the slot's image
-  __shared__ int s_end;          // images in this workgroup's sequence, once the counter has run out (INT_MAX before)
+  __shared__ int s_slot_img[2];  // image held by the slot (published after its bytes), -1: none
+  __shared__ int s_refs[2];      // chunks of this workgroup that still have to release the slot's image
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  if (tid == 0) {
-    const int g0 = atomicAdd(next_image, 2);
-    s_next = 0;
-    s_end = g0 >= n ? 0 : (g0 + 1 >= n ? 1 : 0x7fffffff);
-    for (int q = 0; q < 2; q++) {
-      s_slot_seq[q] = g0 + q < n ? q : -1;
-      s_slot_img[q] = g0 + q;
-      s_refs[q] = c1_chunks_of_image(q);
-    }
-  }
-  __syncthreads();
-  if (s_end == 0) return;
+  const int first = blockIdx.x, stride = gridDim.x;  // the workgroup's s-th image is first + s * stride
+  if (first >= n) return;
+  const int nimg = (n - first + stride - 1) / stride;
+  const int c0 = 0, c1 = (nimg * C1_PIX + 63) / 64;  // its chunks
+  const int img_first = 0, img_last = nimg - 1;      // (sequence numbers)
   for (int q = 0; q < 2; q++) {  // the first two images, by everybody
-    if (s_slot_seq[q] < 0) break;
-    const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)s_slot_img[q] * kPix * C);
-    uint4 *dst = reinterpret_cast<uint4 *>(s_img[q]);
+    const int img = img_first + q;
+    if (img > img_last) break;
+    const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)(first + img * stride) * kPix * C);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_img[img & 1]);
     for (int i = tid; i < kPix * C / 16; i += C1_THREADS) dst[i] = src[i];
   }
   {  // padded weight table [20][C][28] (built once on the host side of the C-ABI): filters 0..15, then 16..19
@@ -99,6 +92,15 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     for (int i = tid; i < 16 * C * 7; i += C1_THREADS) da[i] = src[i];
     for (int i = tid; i < 4 * C * 7; i += C1_THREADS) db[i] = src[16 * C * 7 + i];
   }
+  if (tid == 0) {
+    s_next = c0;
+    s_slot_img[0] = s_slot_img[1] = -1;
+    for (int q = 0; q < 2; q++)
+      if (img_first + q <= img_last) {
+        s_slot_img[(img_first + q) & 1] = img_first + q;
+        s_refs[(img_first + q) & 1] = c1_chunks_of_image(img_first + q, c0, c1);
+      }
+  }
   __syncthreads();
   const float *wa_row = s_wa + (lane & 15) * C * 28;
   const float *wb_row = s_wb + (lane & 3) * C * 28;
@@ -106,26 +108,20 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     int task = 0;
     if (lane == 0) task = atomicAdd(&s_next, 1);
     task = __builtin_amdgcn_readfirstlane(task);
-    // the images this chunk reads (the second one only when the chunk straddles an image boundary): wait until each is
-    // in its slot or known not to exist
-    const int ia = (64 * task) / C1_PIX, ib = (64 * task + 63) / C1_PIX;
-    while ((*(volatile int *)&s_slot_seq[ia & 1] != ia && *(volatile int *)&s_end > ia) ||
-           (*(volatile int *)&s_slot_seq[ib & 1] != ib && *(volatile int *)&s_end > ib))
-      __builtin_amdgcn_s_sleep(4);
+    if (task >= c1) break;
+    // the images this chunk reads (the second one only when the chunk straddles an image boundary)
+    const int ia = (64 * task) / C1_PIX, ib = min((64 * task + 63) / C1_PIX, img_last);
+    while (*(volatile int *)&s_slot_img[ia & 1] != ia || *(volatile int *)&s_slot_img[ib & 1] != ib) __builtin_amdgcn_s_sleep(4);
     __threadfence_block();  // the image bytes are read after the slot numbers
-    const int nimg = *(volatile int *)&s_end;  // images of the sequence as far as this chunk can tell (> ib, or final)
-    if (ia >= nimg) break;                     // the sequence ended before this chunk
-    const bool has_b = ib < nimg;
     // pooled pixel of the lane: image, then strip-major pixel number -> (row, column).  Lanes past the last pixel of
-    // the sequence redo it and store nothing.
+    // the workgroup redo it and store nothing.
     const int g = task * 64 + lane;
-    const int q = (g >= C1_PIX * (ia + 1) && has_b) ? ib : ia;
-    const bool live = g < C1_PIX * (ia + 1) || has_b;
-    const int pc = live ? g - q * C1_PIX : C1_PIX - 1;
+    const int gc = g < nimg * C1_PIX ? g : nimg * C1_PIX - 1;
+    const int q = gc >= C1_PIX * (ia + 1) ? ia + 1 : ia, pc = gc - q * C1_PIX;
     const int strip = pc / (28 * C1_STRIP), within = pc - strip * (28 * C1_STRIP);
     const int py = within / C1_STRIP, px = strip * C1_STRIP + (within - py * C1_STRIP);
     // where the lane's pixel goes in pool1; -1: nothing to store
-    const int ooff = live ? s_slot_img[q & 1] * 20 * C1_PIX + py * 28 + px : -1;
+    const int ooff = g < nimg * C1_PIX ? (first + q * stride) * 20 * C1_PIX + py * 28 + px : -1;
     const uint8_t *base = s_img[q & 1] + (2 * py) * kImg + 2 * px;
     f32x16 acc16[4];
     f32x4 acc4[4];
@@ -223,25 +219,18 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
           o[(16 + f) * 784 + ooff] = fmaxf(fmaxf(acc4[0][f], acc4[1][f]), fmaxf(acc4[2][f], acc4[3][f])) + bias[16 + f];
       }
     }
-    // release the chunk's image(s); the wave that releases an image last draws the next image of the batch and loads it
-    // into the freed slot as image s + 2 of this workgroup
+    // release the chunk's image(s); the wave that releases an image last refills its slot with the image two ahead
     int refill = 0;  // bit 0: slot of ia, bit 1: slot of ib
     if (lane == 0) {
       if (atomicSub(&s_refs[ia & 1], 1) == 1) refill |= 1;
-      if (has_b && ib != ia && atomicSub(&s_refs[ib & 1], 1) == 1) refill |= 2;
+      if (ib != ia && atomicSub(&s_refs[ib & 1], 1) == 1) refill |= 2;
     }
     refill = __builtin_amdgcn_readfirstlane(refill);
     for (int r = 0; r < 2; r++) {
       if (!(refill >> r & 1)) continue;
       const int nxt = (r ? ib : ia) + 2;
-      int gi = 0;
-      if (lane == 0) gi = atomicAdd(next_image, 1);
-      gi = __builtin_amdgcn_readfirstlane(gi);
-      if (gi >= n) {  // the batch is dealt out: this workgroup's sequence has nxt images (or fewer, if the other slot said so first)
-        if (lane == 0) atomicMin(&s_end, nxt);
-        continue;
-      }
-      const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)gi * kPix * C);
+      if (nxt > img_last) continue;
+      const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)(first + nxt * stride) * kPix * C);
       uint4 *dst = reinterpret_cast<uint4 *>(s_img[nxt & 1]);
       constexpr int NV = kPix * C / 16;
       for (int i0 = 0; i0 < NV; i0 += 64 * 8) {  // eight loads in flight per lane
@@ -257,12 +246,9 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
           if (i < NV) dst[i] = v[u];
         }
       }
-      if (lane == 0) {
-        s_refs[nxt & 1] = c1_chunks_of_image(nxt);
-        s_slot_img[nxt & 1] = gi;
-      }
-      __threadfence_block();  // the bytes, the release count and the image number are in LDS before the slot is published
-      if (lane == 0) *(volatile int *)&s_slot_seq[nxt & 1] = nxt;
+      if (lane == 0) s_refs[nxt & 1] = c1_chunks_of_image(nxt, c0, c1);
+      __threadfence_block();  // the bytes and the release count are in LDS before the slot is published
+      if (lane == 0) *(volatile int *)&s_slot_img[nxt & 1] = nxt;
     }
   }
 }
@@ -653,7 +639,6 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   if ((e = hipMalloc(&s.pool1, (size_t)n * 20 * 784 * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
-  if ((e = hipMalloc(&s.c1_next, sizeof(int32_t))) != hipSuccess) return e;
   s.capacity = n;
   return hipSuccess;
 }
@@ -662,7 +647,6 @@ void lenet_scratch_free(LeNetScratch &s) {
   if (s.pool1) (void)hipFree(s.pool1);
   if (s.flat) (void)hipFree(s.flat);
   if (s.fc1t) (void)hipFree(s.fc1t);
-  if (s.c1_next) (void)hipFree(s.c1_next);
   s = LeNetScratch();
 }
 
@@ -686,12 +670,11 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
     // persistent conv1: one workgroup per CU, at least two images each
     const int c1_grid = m / 2 < 1 ? 1 : (m / 2 < num_cus ? m / 2 : num_cus);
-    if ((e = hipMemsetAsync(s.c1_next, 0, sizeof(int32_t), stream)) != hipSuccess) return e;  // the launch's image counter
     switch (w.channels) {
-      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_next); break;
-      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_next); break;
-      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_next); break;
-      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_next); break;
+      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
+      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
+      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
+      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
