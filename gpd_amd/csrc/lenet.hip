@@ -111,7 +111,12 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     if (task >= c1) break;
     // the images this chunk reads (the second one only when the chunk straddles an image boundary)
     const int ia = (64 * task) / C1_PIX, ib = min((64 * task + 63) / C1_PIX, img_last);
-    while (*(volatile int *)&s_slot_img[ia & 1] != ia || *(volatile int *)&s_slot_img[ib & 1] != ib) __builtin_amdgcn_s_sleep(4);
+    // (a slot is refilled within ~10 us of its release; a wait of ~0.5 s can only be a broken protocol: abort the
+    //  launch — the host sees a failed kernel — rather than hang the device)
+    for (int spins = 0; *(volatile int *)&s_slot_img[ia & 1] != ia || *(volatile int *)&s_slot_img[ib & 1] != ib; spins++) {
+      __builtin_amdgcn_s_sleep(4);
+      if (spins > (1 << 22)) __builtin_trap();
+    }
     __threadfence_block();  // the image bytes are read after the slot numbers
     // pooled pixel of the lane: image, then strip-major pixel number -> (row, column).  Lanes past the last pixel of
     // the workgroup redo it and store nothing.
