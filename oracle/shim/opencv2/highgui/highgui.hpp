@@ -1,0 +1,2 @@
+// oracle/shim/opencv2/highgui/highgui.hpp — test-only stand-in, see shim_all.hpp
+#include "../shim_all.hpp"
