@@ -1042,15 +1042,16 @@ __global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
       if (ev[q] < ev[mn]) mn = q;
     const double nx = Q[mn], ny = Q[3 + mn], nz = Q[6 + mn];
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    for (int cam = 0; cam < P.num_cams; cam++) {  // the last seeing camera wins (cloud.cpp:525-533)
-      if (!P.cam_source[(size_t)cam * P.num_points + pi]) continue;
+    // estimated once, with the view point of the FIRST camera that sees the point (convertCameraSourceMatrixToLists,
+    // cloud.cpp:606-620: `== 1` and a break); NormalEstimation::setViewPoint takes floats (cloud.cpp:513)
+    for (int cam = 0; cam < P.num_cams; cam++) {
+      if (P.cam_source[(size_t)cam * P.num_points + pi] != 1) continue;
       const double *vp = P.view_points + 3 * cam;
-      const double dot = (vp[0] - (double)qx) * nx + (vp[1] - (double)qy) * ny + (vp[2] - (double)qz) * nz;
-      const double sgn = dot < 0 ? -1.0 : 1.0;
+      const double dot = ((double)(float)vp[0] - (double)qx) * nx + ((double)(float)vp[1] - (double)qy) * ny + ((double)(float)vp[2] - (double)qz) * nz;
       o0 = (float)(dot < 0 ? -nx : nx);
       o1 = (float)(dot < 0 ? -ny : ny);
       o2 = (float)(dot < 0 ? -nz : nz);
-      (void)sgn;
+      break;
     }
     bool needs_reverse = true;  // reverseNormals (cloud.cpp:573-604)
     for (int cam = 0; cam < P.num_cams && needs_reverse; cam++) {

@@ -48,7 +48,8 @@ tier_a() {
   done
   for p in $pids; do wait $p || fail=1; done
   [ $fail = 0 ] || { echo "oracle/build_ref.sh: tier A FAILED to compile a reference translation unit"; exit 1; }
-  g++ $CXXFLAGS -shared -o "$OUT/libgpd_ref.so" "$HERE/ref_glue.cpp" "$HERE/ref_plot_stub.cpp" $objs -lgomp \
+  g++ $CXXFLAGS -fno-access-control -c "$HERE/ref_glue.cpp" -o "$OUT/obj/ref_glue.o" \
+    && g++ $CXXFLAGS -shared -o "$OUT/libgpd_ref.so" "$OUT/obj/ref_glue.o" "$HERE/ref_plot_stub.cpp" $objs -lgomp \
     || { echo "oracle/build_ref.sh: tier A FAILED to link"; exit 1; }
   echo "oracle/build_ref.sh: tier A built $OUT/libgpd_ref.so (reference sources through oracle/shim)"
 }

@@ -4,11 +4,16 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this library.  The product (libgpd_hip.so) never links or calls it.
  *
- * PARITY UNPINNED: the reference (atenpas/gpd) cannot be built here (PCL, Eigen,
- * OpenCV, Boost absent) and ships no golden vectors, so this
- * restatement is checked against the known-answer constants of SURVEY.md §9-K and
- * independent numpy/scipy/torch re-derivations (tests/test_oracle_*.py), not
- * against outputs of the reference binary.
+ * PARITY STATUS: the IN-TREE logic of the reference is pinned — the reference's own translation units
+ * (candidate/, descriptor/, net/, util/cloud, clustering, grasp_detector) are compiled UNMODIFIED through
+ * test-only interface subsets of Eigen / PCL / OpenCV / Boost (oracle/shim, oracle/build_ref.sh tier A ->
+ * oracle/_ref/libgpd_ref.so); what they return is committed as tests/golden/ref_pin_*.npz and this file must
+ * reproduce it bit for bit (tests/test_ref_pin.py).  THIRD-PARTY NUMERICS STAY UNPINNED: the real PCL / FLANN,
+ * Eigen, OpenCV and Boost are absent here, the shim restates their semantics from memory, and so does this
+ * file (FLANN result order, Eigen's eigensolver and product summation order, OpenCV's rounding); the
+ * reference BINARY never ran here (tier B of build_ref.sh needs the real libraries), and the reference
+ * ships no golden vectors.  Also checked: the known-answer constants of SURVEY.md §9-K and
+ * independent numpy/scipy/torch re-derivations (tests/test_oracle_*.py).
  *
  * Every function cites the reference file:line it follows (paths relative to the
  * reference tree).  Third-party semantics (FLANN radiusSearch, Eigen
@@ -1406,15 +1411,18 @@ void gpd_oracle_normals(const float *xyz, int P, const int32_t *cam_source, int 
     for (int q = 1; q < 3; q++)
       if (ev[q] < ev[mn]) mn = q;
     double nrm[3] = {V[mn], V[3 + mn], V[6 + mn]};
-    // the last camera that sees the point wins (cloud.cpp:525-533 overwrites per camera)
+    // every point is estimated once, with the view point of the FIRST camera that sees it
+    // (convertCameraSourceMatrixToLists, cloud.cpp:606-620: `== 1` and a break); setViewPoint takes floats (cloud.cpp:513)
     for (int cam = 0; cam < n_cams; cam++) {
-      if (!cam_source[(size_t)cam * P + i]) continue;
+      if (cam_source[(size_t)cam * P + i] != 1) continue;
       double t[3] = {nrm[0], nrm[1], nrm[2]};
       const double *vp = view_points + 3 * cam;
-      const double dot = (vp[0] - (double)xyz[3 * i]) * t[0] + (vp[1] - (double)xyz[3 * i + 1]) * t[1] + (vp[2] - (double)xyz[3 * i + 2]) * t[2];
+      const double dot = ((double)(float)vp[0] - (double)xyz[3 * i]) * t[0] + ((double)(float)vp[1] - (double)xyz[3 * i + 1]) * t[1] +
+                         ((double)(float)vp[2] - (double)xyz[3 * i + 2]) * t[2];
       if (dot < 0)
         for (int r = 0; r < 3; r++) t[r] = -t[r];
       for (int r = 0; r < 3; r++) normals_out[3 * i + r] = (float)t[r];
+      break;
     }
     // reverseNormals: reverse unless some seeing camera has normal . (p - vp) < 0
     bool needs_reverse = true;

@@ -70,6 +70,11 @@ def set_product_mode(mode):
         lib().gpd_ref_set_product_mode(int(mode))
 
 
+def reset_shadow_seed():
+    """HandSet::seed_ = 0: the state of a fresh process (the oracle restarts the shadow LCG for every cloud)."""
+    lib().gpd_ref_reset_shadow_seed()
+
+
 def _fmt(v):
     return repr(float(v))
 
@@ -220,12 +225,19 @@ class Detector:
             self.h = None
         self._tmp.cleanup()
 
+    def load_weights(self, weights, name="params2"):
+        """Classifier::create on another parameter directory (the detector's own classifier is not touched)."""
+        wdir = write_weights_dir(os.path.join(self._tmp.name, name), weights)
+        with _Quiet():
+            assert lib().gpd_ref_classifier_load(self.h, wdir.encode()) == 0
+
     def preprocess(self, cloud):
         with _Quiet():
             lib().gpd_ref_preprocess(self.h, cloud.h)
 
     def generate(self, cloud, cap_sets):
         """generateGraspCandidates -> records [n_sets, n_slots]."""
+        reset_shadow_seed()
         hands = np.zeros((cap_sets, self.n_slots), HAND_DTYPE)
         n = C.c_int(0)
         with _Quiet():

@@ -118,6 +118,11 @@ int gpd_ref_abi() { return (int)sizeof(gpd_hand); }
 
 void gpd_ref_set_product_mode(int mode) { Eigen::shim::product_mode() = mode; }
 
+// HandSet::seed_ (hand_set.cpp:14, 263-266) is a private static that keeps counting across detectGrasps calls of one
+// process; the oracle and the product restart the shadow LCG at 0 for every cloud.  This file — and
+// only this file — is compiled with -fno-access-control so that a test can put the reference into the same state.
+void gpd_ref_reset_shadow_seed() { candidate::HandSet::seed_ = 0; }
+
 // ---- detector (GraspDetector::GraspDetector, grasp_detector.cpp:5-190) ----------------------------------------
 void *gpd_ref_create(const char *cfg_path) {
   Ref *r = new Ref;
