@@ -71,9 +71,16 @@ def main():
     ap.add_argument("--clutter", action="store_true")
     ap.add_argument("--clouds", type=int, default=256, help="--mode batch: clouds of the whole job (cloud i -> rank i mod N)")
     ap.add_argument("--batch-samples", type=int, default=2564, help="samples per cloud of the batch legs")
-    ap.add_argument("--batch-clouds", type=int, default=12, help="replay mode: clouds per rank of the batch_end_to_end leg (0 disables)")
+    ap.add_argument("--batch-clouds", type=int, default=None,
+                    help="replay mode: clouds per rank of the batch_end_to_end leg (default 12 on one GPU, 64 on several; 0 disables)")
     ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: one process per GPU under torch.distributed.run (RCCL / gloo rendezvous on
+        # 127.0.0.1), same arguments; rank 0 of the children prints the ONE line
+        sys.exit(_self_launch(args.gpus))
+    if args.batch_clouds is None:
+        args.batch_clouds = 12 if args.gpus == 1 else 64
     if args.steps is None:
         args.steps = 20 if args.mode == "replay" else 2
     if args.warmup is None:
@@ -93,12 +100,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE = %d (run `python bench.py --gpus %d`, or torch.distributed.run with "
+                 "--nproc-per-node %d)" % (args.gpus, world, args.gpus, args.gpus))
+    if os.environ.get("GPD_BENCH_DRYRUN"):
+        # the launch / rendezvous / reduction plumbing without a GPU (tests/test_bench_helpers.py, gloo): everything up to the
+        # point where a context would be created
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([1.0 + rank, 10.0 * (rank + 1)], dtype=torch.float64)
+        tmax, tsum = t.clone(), t.clone()
+        dist.all_reduce(tmax[0:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum[1:2], op=dist.ReduceOp.SUM)
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"dryrun": True, "n_gpus": args.gpus, "world": world, "max": float(tmax[0]), "sum": float(tsum[1]),
+                                           "batch_clouds": args.batch_clouds}) + "\n").encode())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dist = None
     if world > 1 or os.environ.get("GPD_BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from gpd_amd import api, synth
     from gpd_amd import dist as gdist
@@ -121,6 +146,15 @@ def main():
         dist.all_reduce(tmax[0:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
         return float(tmax[0]), float(t[1])
+
+    def minmax(x):
+        if dist is None:
+            return float(x), float(x)
+        lo = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return float(lo[0]), float(hi[0])
 
     ctx = api.Context(api.default_params(C), device=local_rank)
     ctx.set_lenet_weights(w)                       # weights copied once per device at init
@@ -145,9 +179,12 @@ def main():
             dist.barrier()
         el, tot = reduce(elapsed, n_cand)
         _, ncl = reduce(elapsed, len(clouds) * passes)
-        return dict(clouds=int(ncl), candidates=int(tot), wall_s=el, clouds_per_s=ncl / el, cand_per_s=tot / el,
-                    kernel_ms_rank0={"search": float(stage[0]), "images": float(stage[1]), "lenet": float(stage[2])},
-                    kernel_bound_cand_per_s_rank0=n_cand / (stage.sum() / 1e3) if stage.sum() > 0 else None)
+        mine = len(clouds) * passes / elapsed  # this rank's own rate: a host-side limiter shows as a spread
+        rmin, rmax = minmax(mine)
+        return dict(clouds=int(ncl), clouds_per_rank=len(clouds) * passes, candidates=int(tot), wall_s=el, clouds_per_s=ncl / el,
+                    cand_per_s=tot / el, rank_clouds_per_s={"min": rmin, "max": rmax},
+                    kernel_ms_rank0={"search": float(stage[0]), "images": float(stage[1]), "lenet": float(stage[2]),
+                                     "note": "summed per cloud; two clouds are in flight, so the sum exceeds the wall time"})
 
     if args.mode == "batch":
         mine = gdist.clouds_of_rank(args.clouds, rank, world)
@@ -212,17 +249,6 @@ def main():
     mid = int(np.argsort(walls)[len(walls) // 2])
     detect_wall, detect_kernel_ms = walls[mid], kms[mid]
 
-    # a sample of the images for conv1's zero-skip statistics (the executed-FLOP fraction of the roofline line)
-    live_frac = None
-    if C in (12, 15):
-        sub = hands_f.copy()
-        sflat = sub.reshape(-1)
-        keep = np.flatnonzero(sflat["valid"])[::max(1, len(vidx) // 256)][:256]
-        sflat["valid"] = 0
-        sflat["valid"][keep] = 1
-        imgs, _ = ctx.images(sub, download=True)
-        live_frac = _conv1_live_fraction(imgs)
-
     _, cand = ctx.images(hands_f, download=False)   # the benchmark's candidate list, first pass
     n_cand = len(cand)
     ni = ctx.images_stats()
@@ -231,6 +257,7 @@ def main():
     for _ in range(args.warmup):
         ctx.replay(3)
     ctx.replay_times()
+    ctx.conv1_stats(reset=True)  # conv1 counts the (chunk, channel) pairs it executes: from here on, the timed launches only
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -243,6 +270,9 @@ def main():
         dist.barrier()
     elapsed, total_cand = reduce(elapsed, n_cand)
     assert launches == args.steps
+    pairs_done, pairs_seen = ctx.conv1_stats(reset=True)
+    live_frac = pairs_done / pairs_seen if pairs_seen else None
+    trained = _trained_magnitude_leg(ctx, hands_f, C, real) if (rank == 0 and args.gpus == 1 and C == 15 and args.cpu_samples > 0) else None
 
     batch = None
     if args.batch_clouds > 0 and C == 15 and not clutter:
@@ -281,22 +311,33 @@ def main():
             kernels["grasp_image_kernel"]["lds_roofline"] = sq
         dom = max(kflops, key=lambda k: kernels[k]["ms"])
         if kernels[dom]["ms"] >= img_s * 1e3 / 3.0:
-            # the dominant single kernel of the step (conv1 + pool1 at 15 channels): f32 MFMA bound
-            frac = kernels[dom]["achieved_TFLOPs"] / F32_PEAK_TFLOPS
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": kernels[dom]["achieved_TFLOPs"],
-                        "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": frac,
+            # the dominant single kernel of the step (conv1 + pool1 at 15 channels): f32 MFMA bound.  conv1 drops the
+            # (64-pixel chunk, channel) pairs whose input patches are all zero (exact: the products are zeros), so the
+            # FLOPs it EXECUTES are the dense count x the live-pair fraction the kernel counts itself (gpd_hip_conv1_stats,
+            # over exactly the timed launches).  `frac` is that executed rate over the peak — a utilisation, <= 1, the
+            # number to hold against MfmaUtil; the dense-equivalent figure (SURVEY 8d's algorithmic FLOPs / time) rides along.
+            dense = kernels[dom]["achieved_TFLOPs"]
+            lf = live_frac if (dom == "conv1_mfma_kernel" and live_frac is not None) else 1.0
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": dense * lf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": dense * lf / F32_PEAK_TFLOPS,
                         "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
                         "flops_per_launch": kernels[dom]["algorithmic_flops"], "launch_ms": kernels[dom]["ms"],
-                        "note": "frac = algorithmic (dense) FLOPs / measured time / peak, as SURVEY 8d counts them.  conv1 drops the "
-                                "(64-pixel chunk, channel) pairs whose input patches are all zero (exact), so this dense-equivalent "
-                                "figure can reach or pass 1.0 without the matrix pipe doing so: frac_executed = frac x live pair "
-                                "fraction is the rate the pipe actually sustains, and the number to compare with MfmaUtil"}
-            if dom == "conv1_mfma_kernel" and live_frac is not None:
-                roofline["live_pair_fraction"] = live_frac
-                roofline["frac_executed"] = frac * live_frac
+                        "live_pair_fraction": lf, "executed_flops_per_launch": kernels[dom]["algorithmic_flops"] * lf,
+                        "achieved_dense_equivalent": dense, "frac_dense_equivalent": dense / F32_PEAK_TFLOPS,
+                        "note": "achieved = executed FLOPs (dense 2*20*25*C*56*56 per image x live (chunk, channel) pair fraction, counted "
+                                "by the kernel over the timed launches) / HIP-event time of the kernel; *_dense_equivalent = all algorithmic "
+                                "FLOPs / the same time (can pass 1.0 of peak: skipped work is not work)"}
+            kernels[dom]["frac_executed"] = roofline["frac"]
         else:
             roofline = {"kernel": "image stage (shadow_set + shadow_image + grasp_image kernels)", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}
+        # the stage before the timed one, per call of gpd_hip_search (B_search = sum_samples [12 k_f + 24 N_h + 12] + S n_orient 184)
+        sum_kf, sum_nh = _neighbour_counts(cloud, si, ctx.params)
+        b_search = 12.0 * sum_kf + 24.0 * sum_nh + 12.0 * n_samples + float(hands.size) * 184.0
+        kernels["search"] = {"ms": search_ms, "samples": int(n_samples), "algorithmic_bytes": b_search,
+                             "achieved_GBps": b_search / (search_ms / 1e3) / 1e9, "frac_hbm": b_search / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                             "pmc_traffic_bytes": traffic.get("search"),
+                             "note": "neighbourhood + height_list + hand_eval + plan (+ centre on a side stream); not part of `value`"}
         out = {
             "metric": "15-ch grasp candidates scored/sec (imagegen+LeNet) at 1/2/4/8 MI355X" if C == 15 else "%d-ch grasp candidates scored/sec (imagegen+LeNet)" % C,
             "value": value, "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -316,6 +357,8 @@ def main():
                                   "note": "gpd_hip_detect: all candidates of the sample set, host buffers in, scored hands out; "
                                           "filter / compaction / score scatter on the device"},
         }
+        if trained is not None:
+            out["scores_trained_magnitude"] = trained
         if batch is not None:
             batch["note"] = ("gpd_hip_detect_batch, %d clouds per rank x %d samples, two clouds in flight per context: upload + grid + "
                              "search + filter + images + LeNet + scored candidates back to the host" % (args.batch_clouds, args.batch_samples))
@@ -336,28 +379,6 @@ def main():
         dist.destroy_process_group()
 
 
-def _conv1_live_fraction(imgs):
-    """Fraction of the (64-pooled-pixel chunk, channel) pairs conv1_mfma_kernel executes: a pair is dropped when the
-    6x6 input patches of all 64 pooled pixels of the chunk are zero in that channel.  Chunks as the kernel numbers
-    them: image pairs, 2 x 784 pooled pixels, strips of 7 columns (lenet.hip: C1_STRIP)."""
-    imgs = np.asarray(imgs)
-    n, Cc = imgs.shape[0] & ~1, imgs.shape[3]
-    if n < 2:
-        return None
-    nz = imgs[:n] != 0
-    win = np.zeros((n, 28, 28, Cc), bool)
-    for dy in range(6):
-        for dx in range(6):
-            win |= nz[:, dy:dy + 56:2, dx:dx + 56:2, :]
-    order = np.array([r * 28 + c for s in range(0, 28, 7) for r in range(28) for c in range(s, s + 7)])
-    seq = win[:, order // 28, order % 28, :].reshape(n // 2, 2 * 784, Cc)   # the pair's pixels, numbered through
-    live = tot = 0
-    for s in range(0, 2 * 784, 64):
-        live += seq[:, s:s + 64].any(axis=1).sum()
-        tot += (n // 2) * Cc
-    return float(live) / float(tot)
-
-
 def _filter_workspace(hands, p):
     """GraspDetector::filterGraspsWorkspace (grasp_detector.cpp:334-398) in numpy, Q6 typo kept."""
     h = hands.reshape(-1)
@@ -375,6 +396,77 @@ def _filter_workspace(hands, p):
     for r in range(3):
         ok &= (mn[:, r] >= ws[2 * r]) & (mx[:, r] <= ws[2 * r + 1])
     h["valid"] = (h["valid"].astype(bool) & ok).astype(np.uint8)
+
+
+def _neighbour_counts(cloud, si, p):
+    """sum over the samples of k_f (frame radius) and N_h (hand radius) — the sizes SURVEY 8d's B_search is made of
+    (bookkeeping for the byte count, by scipy's k-d tree)."""
+    from scipy.spatial import cKDTree
+    tree = cKDTree(cloud["xyz"].astype(np.float64))
+    q = cloud["xyz"][si].astype(np.float64)
+    r_hand = max(p.hand_outer_diameter - p.finger_width, p.hand_depth, p.hand_height / 2.0)  # hand_search.cpp:10-22
+    kf = tree.query_ball_point(q, p.nn_radius_frames, return_length=True)
+    nh = tree.query_ball_point(q, r_hand, return_length=True)
+    return float(kf.sum()), float(nh.sum())
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _lenet_f64(images, w):
+    """The LeNet in float64 (torch CPU): an order-free yardstick for the float32 scores."""
+    import torch
+    import torch.nn.functional as Fn
+    C = images.shape[3]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+    with torch.no_grad():
+        x = d(images.transpose(0, 3, 1, 2).astype(np.float64))
+        h = Fn.max_pool2d(Fn.conv2d(x, d(w["c1w"].reshape(20, C, 5, 5)), d(w["c1b"])), 2)
+        h = Fn.max_pool2d(Fn.conv2d(h, d(w["c2w"].reshape(50, 20, 5, 5)), d(w["c2b"])), 2)
+        flat = h.permute(0, 2, 3, 1).reshape(len(h), 7200)  # pixel-major, channel-minor (eigen_classifier.cpp:103-107)
+        y = torch.relu(Fn.linear(flat, d(w["f1w"].reshape(7200, 500).T.copy()), d(w["f1b"])))
+        z = Fn.linear(y, d(w["f2w"].reshape(500, 2).T.copy()), d(w["f2b"]))
+        return (z[:, 1] - z[:, 0]).numpy()
+
+
+def _trained_magnitude_leg(ctx, hands_f, C, real, n=256):
+    """BASELINE's "scores within 1e-4 of the Eigen path" decided where it can be: the benchmark's synthetic ip1 drives the
+    logits to |score| ~ 1000 (one float32 ulp = 6e-5: no two float32 summation orders agree to 1e-4 there), so a second
+    weight set — the same ip1 / 128, logits of the size a trained LeNet produces — scores a sample of the benchmark's own
+    images: HIP against the oracle's k-ascending fma chains (bit-identical by construction) and both against float64."""
+    import oracle
+    from gpd_amd import synth
+    sub = hands_f.copy()
+    flat = sub.reshape(-1)
+    keep = np.flatnonzero(flat["valid"])
+    keep = keep[:: max(1, len(keep) // n)][:n]
+    flat["valid"] = 0
+    flat["valid"][keep] = 1
+    imgs, _ = ctx.images(sub, download=True)
+    out = {}
+    for tag, tm in (("trained_magnitude", True), ("benchmark_weights", False)):
+        w = synth.lenet_weights(C, real=real, trained_magnitude=tm)
+        ctx.set_lenet_weights(w)
+        hip = ctx.score(imgs)
+        orc = oracle.lenet(imgs, w)
+        f64 = _lenet_f64(imgs, w)
+        out[tag] = {"images": int(len(imgs)), "max_abs_score": float(np.abs(f64).max()), "max_abs_hip_minus_oracle": float(np.abs(hip - orc).max()),
+                    "max_abs_oracle_minus_float64": float(np.abs(orc - f64).max()), "max_abs_hip_minus_float64": float(np.abs(hip - f64).max())}
+    out["note"] = ("the absolute 1e-4 bar of BASELINE.json is met at trained-net magnitudes; at the benchmark's synthetic magnitudes it is "
+                   "a relative 8e-6 (tests/test_lenet_reorder.py)")
+    return out
 
 
 def _fc1_tile(n):

@@ -55,7 +55,7 @@ EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_h
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
-           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters"]
+           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters"]
 
 
 def build():
@@ -86,6 +86,7 @@ def lib():
         L.gpd_hip_detect_select.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpd_hip_detect_batch.argtypes = [C.c_void_p, C.POINTER(DetectJob), C.c_int]
+        L.gpd_hip_detect_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(DetectJob), C.c_int]
         L.gpd_hip_last_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
@@ -96,6 +97,7 @@ def lib():
                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.gpd_hip_last_images_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpd_hip_conv1_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         _LIB = L
     return _LIB
@@ -221,10 +223,7 @@ class Context:
                                                 C.byref(ns), C.byref(nc), C.byref(nh)))
         return hands[: nh.value], ns.value, nc.value
 
-    def detect_batch(self, clouds, samples, num_selected=0):
-        """detect_grasps over independent clouds (two in flight per context).  clouds: dicts with xyz, normals,
-        cam_source, view_points; samples: one int32 index array per cloud.
-        -> list of (hands[k], n_sets, n_candidates, stage_ms[3]) in cloud order."""
+    def _jobs(self, clouds, samples, num_selected):
         jobs = (DetectJob * len(clouds))()
         keep = []
         for j, cl, si in zip(jobs, clouds, samples):
@@ -241,7 +240,24 @@ class Context:
             j.sample_indices, j.hands = _ptr(si), _ptr(hands)
             j.num_points, j.num_cams, j.num_samples = P, cam.shape[0], len(si)
             j.num_selected, j.hands_capacity = int(num_selected), cap
+        return jobs, keep
+
+    def detect_batch(self, clouds, samples, num_selected=0):
+        """detect_grasps over independent clouds (two in flight per context).  clouds: dicts with xyz, normals,
+        cam_source, view_points; samples: one int32 index array per cloud.
+        -> list of (hands[k], n_sets, n_candidates, stage_ms[3]) in cloud order."""
+        jobs, keep = self._jobs(clouds, samples, num_selected)
         self._check(lib().gpd_hip_detect_batch(self._h, jobs, len(clouds)))
+        return [(k[5][: j.num_hands], j.num_sets, j.num_candidates, [float(x) for x in j.stage_ms])
+                for j, k in zip(jobs, keep)]
+
+    def detect_batch_multi(self, others, clouds, samples, num_selected=0):
+        """gpd_hip_detect_batch_multi over this context and `others` (one host thread per context, cloud i ->
+        context i mod G).  Same return value as detect_batch."""
+        ctxs = [self] + list(others)
+        jobs, keep = self._jobs(clouds, samples, num_selected)
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        self._check(lib().gpd_hip_detect_batch_multi(arr, len(ctxs), jobs, len(clouds)))
         return [(k[5][: j.num_hands], j.num_sets, j.num_candidates, [float(x) for x in j.stage_ms])
                 for j, k in zip(jobs, keep)]
 
@@ -267,6 +283,12 @@ class Context:
         ms = np.zeros(4, np.float32)
         self._check(lib().gpd_hip_replay_kernel_ms(self._h, _ptr(ms)))
         return [float(x) for x in ms]
+
+    def conv1_stats(self, reset=True):
+        """(executed, looked-at) (chunk, channel) pairs of conv1's launches since the last reset."""
+        out = np.zeros(2, np.uint64)
+        self._check(lib().gpd_hip_conv1_stats(self._h, _ptr(out), int(bool(reset))))
+        return int(out[0]), int(out[1])
 
     def images_stats(self):
         out = np.zeros(4, np.int64)

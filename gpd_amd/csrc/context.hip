@@ -23,6 +23,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "gpd_internal.h"
@@ -81,6 +83,8 @@ struct Lane {
   HostFlags *h_flags = nullptr;  // pinned
   int32_t *d_sel = nullptr;      // [SEL capacity] candidate ordinals of the selection, then the tie flag
   int d_sel_cap = 0;
+  gpd_hand *d_all = nullptr;     // selections (num_selected > 0): every candidate record of the job, scored — what a selection
+  size_t d_all_cap = 0;          // gathers from, also after the lane's search / plan buffers belong to the next cloud
   // staging for gpd_hip_score with host images
   uint8_t *d_img_in = nullptr;      // HWC images handed to gpd_hip_score
   uint8_t *d_img_planar = nullptr;  // their planar copy
@@ -139,7 +143,7 @@ static void lane_free(Lane &L) {
   search_free(L.search);
   plan_free(L.plan);
   images_free(L.images);
-  void *dev[] = {L.d_scores, L.d_out, L.d_sel, L.d_img_in, L.d_img_planar};
+  void *dev[] = {L.d_scores, L.d_out, L.d_sel, L.d_all, L.d_img_in, L.d_img_planar};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   if (L.h_out) (void)hipHostFree(L.h_out);
@@ -260,11 +264,28 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
       HIP_TRY(hipMalloc(&L.d_sel, (size_t)(k + 1) * sizeof(int32_t)));
       L.d_sel_cap = k + 1;
     }
-    rc = select_topk(L.d_scores, n, k, L.d_sel, L.d_sel + k, L.stream);
+    if ((size_t)n > L.d_all_cap) {
+      if (L.d_all) (void)hipFree(L.d_all);
+      L.d_all = nullptr;
+      L.d_all_cap = 0;
+      const size_t cap = (size_t)n + (size_t)n / 4;
+      HIP_TRY(hipMalloc(&L.d_all, cap * sizeof(gpd_hand)));
+      L.d_all_cap = cap;
+    }
+    // every candidate record, scored, in a list of this job's own: the selection gathers from it, and so does the
+    // std::partial_sort rerun of job_end — by then, in a batch, the lane's search / plan buffers already hold the
+    // cloud after next (begin(i + 1) is enqueued before end(i - 1))
+    rc = plan_emit_hands(ctx->params, L.search, L.plan, L.d_scores, L.d_all, true, L.stream);
     if (rc) return rc;
-    rc = gather_hands(ctx->params, L.search, L.plan, L.d_scores, L.d_sel, k, L.d_out, L.stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(&L.h_flags->tie, L.d_sel + k, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+    if (k <= select_topk_capacity()) {
+      rc = select_topk(L.d_scores, n, k, L.d_sel, L.d_sel + k, L.stream);
+      if (rc) return rc;
+      rc = gather_records(L.d_all, L.d_sel, k, L.d_out, L.stream);
+      if (rc) return rc;
+      HIP_TRY(hipMemcpyAsync(&L.h_flags->tie, L.d_sel + k, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+    } else {
+      L.h_flags->tie = 2;  // more winners than the device selection sorts: std::partial_sort on the host (job_end), no limit
+    }
     // the scores (4 bytes per candidate) ride along: equal scores are settled with std::partial_sort on the host
     HIP_TRY(hipMemcpyAsync(L.h_out + L.d_out_cap * sizeof(gpd_hand), L.d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost,
                            L.stream));
@@ -305,7 +326,7 @@ static int job_end(gpd_hip_ctx *ctx, Lane &L, Job &J) {
     std::vector<int32_t> sel((size_t)k);
     for (int i = 0; i < k; i++) sel[i] = v[i].second;
     HIP_TRY(hipMemcpyAsync(L.d_sel, sel.data(), (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, L.stream));
-    int rc = gather_hands(ctx->params, L.search, L.plan, L.d_scores, L.d_sel, k, L.d_out, L.stream);
+    int rc = gather_records(L.d_all, L.d_sel, k, L.d_out, L.stream);  // not from L.search / L.plan: see job_middle
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(L.h_out, L.d_out, (size_t)k * sizeof(gpd_hand), hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipStreamSynchronize(L.stream));
@@ -863,6 +884,9 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
   auto fail = [&](int i, int rc) {
     jobs[i].status = rc;
     J[i].live = false;
+    // a job that fails after its uploads were enqueued leaves async copies out of the lane's pinned staging in flight;
+    // the next job of the lane rewrites (or frees) that staging, so they have to land first
+    (void)hipStreamSynchronize(ctx->lane[i % kLanes].stream);
     if (!first_error) {
       first_error = rc;
       std::memcpy(first_text, g_err, sizeof(g_err));
@@ -911,6 +935,45 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
   for (int l = 0; l < kLanes; l++) ctx->lane[l].images.side_stream = true;
   if (first_error) std::memcpy(g_err, first_text, sizeof(g_err));
   return first_error;
+}
+
+// One host thread per context (one context per GPU; more than one on a device is allowed), job i -> context i mod
+// num_ctx: the in-process form of "independent clouds shard over the GPUs of a node" (the reference's unit
+// of work is one detect_grasps run per cloud, src/detect_grasps.cpp:20-86).  No device talks to another.
+int gpd_hip_detect_batch_multi(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect_job *jobs, int num_jobs) {
+  if (!ctxs || num_ctx < 1 || num_jobs < 0 || (num_jobs > 0 && !jobs)) {
+    set_error("gpd_hip_detect_batch_multi: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  for (int c = 0; c < num_ctx; c++) {
+    if (!ctxs[c]) {
+      set_error("gpd_hip_detect_batch_multi: context %d is null", c);
+      return GPD_ERR_INVALID;
+    }
+    for (int d = 0; d < c; d++)
+      if (ctxs[d] == ctxs[c]) {
+        set_error("gpd_hip_detect_batch_multi: context %d is listed twice (a context serves one thread)", c);
+        return GPD_ERR_INVALID;
+      }
+  }
+  std::vector<std::vector<gpd_detect_job>> mine((size_t)num_ctx);
+  for (int i = 0; i < num_jobs; i++) mine[(size_t)(i % num_ctx)].push_back(jobs[i]);
+  std::vector<int> rcs((size_t)num_ctx, GPD_OK);
+  std::vector<std::string> texts((size_t)num_ctx);
+  std::vector<std::thread> threads;
+  for (int c = 0; c < num_ctx; c++)
+    threads.emplace_back([&, c]() {
+      rcs[(size_t)c] = gpd_hip_detect_batch(ctxs[c], mine[(size_t)c].data(), (int)mine[(size_t)c].size());
+      if (rcs[(size_t)c]) texts[(size_t)c] = g_err;  // the error text is per thread
+    });
+  for (auto &t : threads) t.join();
+  for (int i = 0; i < num_jobs; i++) jobs[i] = mine[(size_t)(i % num_ctx)][(size_t)(i / num_ctx)];
+  for (int c = 0; c < num_ctx; c++)
+    if (rcs[(size_t)c]) {
+      set_error("context %d: %s", c, texts[(size_t)c].c_str());
+      return rcs[(size_t)c];
+    }
+  return GPD_OK;
 }
 
 int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
@@ -982,6 +1045,21 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
     images_status_text(status, g_err, sizeof(g_err));
     return GPD_ERR_CAPACITY;
   }
+  return GPD_OK;
+}
+
+int gpd_hip_conv1_stats(gpd_hip_ctx *ctx, unsigned long long pairs[2], int reset) {
+  if (!ctx || !pairs) {
+    set_error("gpd_hip_conv1_stats: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  LeNetScratch &s = ctx->lane[0].lenet_scratch;
+  pairs[0] = pairs[1] = 0;
+  if (!s.c1_stats) return GPD_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->lane[0].stream));
+  HIP_TRY(hipMemcpy(pairs, s.c1_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(s.c1_stats, 0, 2 * sizeof(unsigned long long)));
   return GPD_OK;
 }
 

@@ -31,6 +31,8 @@ struct LeNetScratch {
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)
+  unsigned long long *c1_stats = nullptr;  // device: [0] (chunk, channel) pairs conv1 executed, [1] pairs it looked at — summed
+                                           // over its launches since the last gpd_hip_conv1_stats(reset)
 };
 
 // Scores n images (device pointer, planar u8 [n][C][3600]) into d_scores (device). Async on stream.
@@ -240,6 +242,10 @@ int select_topk(const float *d_scores, int n, int k, int32_t *d_sel /* [k] candi
                 hipStream_t stream);
 int gather_hands(const gpd_params &p, const SearchState &s, const Plan &pl, const float *d_scores, const int32_t *d_sel, int k,
                  gpd_hand *d_out, hipStream_t stream);
+// records sel[0..k) of a flat candidate list emitted earlier (plan_emit_hands, candidates only)
+int gather_records(const gpd_hand *d_all, const int32_t *d_sel, int k, gpd_hand *d_out, hipStream_t stream);
+// the largest k select_topk takes; beyond it the fused entries select with std::partial_sort on the downloaded scores
+int select_topk_capacity();
 
 // ---- Grasp images (images.hip) ---------------------------------------------------
 struct ImageState {

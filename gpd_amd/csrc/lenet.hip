@@ -65,7 +65,8 @@ __device__ inline int c1_chunks_of_image(int j, int c0, int c1) {
 
 template <int C>
 __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wp,
-                                                               const float *__restrict__ bias, float *__restrict__ out, int n) {
+                                                               const float *__restrict__ bias, float *__restrict__ out, int n,
+                                                               unsigned long long *__restrict__ stats) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
   __shared__ __attribute__((aligned(16))) float s_wa[16 * C * 28];  // filters 0..15: [f][c][25 taps + 3 pad]
   __shared__ __attribute__((aligned(16))) float s_wb[4 * C * 28];   // filters 16..19
@@ -104,11 +105,13 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
   __syncthreads();
   const float *wa_row = s_wa + (lane & 15) * C * 28;
   const float *wb_row = s_wb + (lane & 3) * C * 28;
+  unsigned n_live = 0, n_tasks = 0;  // (chunk, channel) pairs this wave executed / chunks it took: the executed-FLOP count
   for (;;) {
     int task = 0;
     if (lane == 0) task = atomicAdd(&s_next, 1);
     task = __builtin_amdgcn_readfirstlane(task);
     if (task >= c1) break;
+    n_tasks++;
     // the images this chunk reads (the second one only when the chunk straddles an image boundary)
     const int ia = (64 * task) / C1_PIX, ib = min((64 * task + 63) / C1_PIX, img_last);
     // (a slot is refilled within ~10 us of its release; a wait of ~0.5 s can only be a broken protocol: abort the
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
           for (int e = 0; e < 3; e++) raw[r][e] = *reinterpret_cast<const uint16_t *>(base + c * kPix + r * kImg + 2 * e);
       }
       if (!live) break;
+      n_live++;
       const uint8_t *nb = base + (c + 1 < C ? c + 1 : c) * kPix;
       float4 ta[7], tb[7];
 #pragma unroll
@@ -255,6 +259,10 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
       __threadfence_block();  // the bytes and the release count are in LDS before the slot is published
       if (lane == 0) *(volatile int *)&s_slot_img[nxt & 1] = nxt;
     }
+  }
+  if (stats && lane == 0) {  // two atomics per wave and launch: what bench.py's roofline divides by
+    atomicAdd(&stats[0], (unsigned long long)n_live);
+    atomicAdd(&stats[1], (unsigned long long)n_tasks * C);
   }
 }
 
@@ -644,6 +652,8 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   if ((e = hipMalloc(&s.pool1, (size_t)n * 20 * 784 * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
+  if ((e = hipMalloc(&s.c1_stats, 2 * sizeof(unsigned long long))) != hipSuccess) return e;
+  if ((e = hipMemset(s.c1_stats, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return e;
   s.capacity = n;
   return hipSuccess;
 }
@@ -652,6 +662,7 @@ void lenet_scratch_free(LeNetScratch &s) {
   if (s.pool1) (void)hipFree(s.pool1);
   if (s.flat) (void)hipFree(s.flat);
   if (s.fc1t) (void)hipFree(s.fc1t);
+  if (s.c1_stats) (void)hipFree(s.c1_stats);
   s = LeNetScratch();
 }
 
@@ -676,10 +687,10 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     // persistent conv1: one workgroup per CU, at least two images each
     const int c1_grid = m / 2 < 1 ? 1 : (m / 2 < num_cus ? m / 2 : num_cus);
     switch (w.channels) {
-      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
-      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
-      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
-      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m); break;
+      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
+      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
+      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
+      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);

@@ -390,6 +390,26 @@ int gather_hands(const gpd_params &p, const SearchState &s, const Plan &pl, cons
   return GPD_OK;
 }
 
+// the selected records out of a flat candidate list that was emitted earlier (the fused entries with num_selected > 0
+// keep such a list per lane, so that a selection can be redone after the lane's search / plan buffers have moved on to
+// the next cloud of a batch)
+__global__ __launch_bounds__(256) void gather_records_kernel(const gpd_hand *__restrict__ all, const int32_t *__restrict__ sel, int k,
+                                                             gpd_hand *__restrict__ out) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int rec = g / 11, piece = g % 11;  // 176 bytes = 11 x 16
+  if (rec >= k) return;
+  const uint4 *src = reinterpret_cast<const uint4 *>(all + sel[rec]);
+  reinterpret_cast<uint4 *>(out + rec)[piece] = src[piece];
+}
+
+int gather_records(const gpd_hand *d_all, const int32_t *d_sel, int k, gpd_hand *d_out, hipStream_t stream) {
+  if (k <= 0) return GPD_OK;
+  static_assert(sizeof(gpd_hand) == 176, "gather_records_kernel copies 11 x 16 bytes per record");
+  gather_records_kernel<<<(unsigned)(((size_t)k * 11 + 255) / 256), 256, 0, stream>>>(d_all, d_sel, k, d_out);
+  HIP_RET(hipGetLastError());
+  return GPD_OK;
+}
+
 // ---------------------------------------------------------------------------
 // selectGrasps (grasp_detector.cpp:405-420): std::partial_sort of the hands by score, descending, first
 // num_selected kept.  One workgroup: radix select of the k-th largest score (four 8-bit passes over the
@@ -402,9 +422,9 @@ int gather_hands(const gpd_params &p, const SearchState &s, const Plan &pl, cons
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAX_K = 8192;  // keys sorted in LDS (64 KB)
 
-__device__ inline uint32_t score_key(float f) {  // larger float <-> larger key; -0 and +0 stay distinct (as they compare equal,
-                                                 // they count as a tie below via the float comparison)
-  const uint32_t u = __float_as_uint(f);
+__device__ inline uint32_t score_key(float f) {  // larger float <-> larger key; -0 is mapped onto +0 (they compare equal under
+                                                 // isScoreGreater, so they must share a key for the tie test at the cut)
+  const uint32_t u = __float_as_uint(f + 0.0f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
@@ -517,13 +537,16 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(const float *_
 int select_topk(const float *d_scores, int n, int k, int32_t *d_sel, int32_t *d_tie, hipStream_t stream) {
   if (k <= 0 || n <= 0) return GPD_OK;
   if (k > n) k = n;
-  if (k > SEL_MAX_K) {
+  if (k > SEL_MAX_K) {  // the callers route such selections through std::partial_sort on the host (select_topk_capacity)
     set_error("select_topk: k = %d exceeds the device selection capacity %d", k, SEL_MAX_K);
     return GPD_ERR_CAPACITY;
   }
+  static_assert(sizeof(unsigned long long) * SEL_MAX_K == 64 * 1024, "s_keys alone is 64 KB of LDS: a gfx950-class (160 KB) workgroup");
   select_topk_kernel<<<1, SEL_THREADS, 0, stream>>>(d_scores, n, k, d_sel, d_tie);
   HIP_RET(hipGetLastError());
   return GPD_OK;
 }
+
+int select_topk_capacity() { return SEL_MAX_K; }
 
 }  // namespace gpd

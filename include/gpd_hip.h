@@ -245,6 +245,13 @@ typedef struct gpd_detect_job {
  * is replaced. */
 int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs);
 
+/* The same over several contexts — one per GPU of a node, one host thread per context, job i -> context
+ * i mod num_ctx, no device talks to another ("one host thread + one gpd_hip_ctx + 2-3 streams per
+ * GPU"; the reference's unit of work is one detect_grasps process per cloud, src/detect_grasps.cpp:20-86).
+ * Every context must carry the LeNet weights.  Results are those of gpd_hip_detect_batch on any one context
+ * (the shadow LCG restarts per cloud, so they do not depend on the sharding).  Returns the first error. */
+int gpd_hip_detect_batch_multi(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect_job *jobs, int num_jobs);
+
 /* gpd_hip_detect for samples given by coordinates (see gpd_hip_search_samples). */
 int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples,
                            gpd_hand *hands, int *num_sets, int *num_candidates);
@@ -283,6 +290,12 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
  * 65536-image chunk) summed over the replays covered by the last gpd_hip_replay_times call —
  * the per-kernel roofline input of bench.py. */
 int gpd_hip_replay_kernel_ms(gpd_hip_ctx *ctx, float ms[4]);
+
+/* conv1's zero skipping, counted by the kernel itself: pairs[0] = (64-pixel chunk, channel) pairs it executed,
+ * pairs[1] = pairs it looked at, summed over the launches on the context's first lane since the last reset.
+ * executed / looked-at x the dense FLOP count = the FLOPs the matrix pipe really ran (bench.py's roofline.frac).
+ * Measurement only: no reference counterpart. */
+int gpd_hip_conv1_stats(gpd_hip_ctx *ctx, unsigned long long pairs[2], int reset);
 
 #ifdef __cplusplus
 }

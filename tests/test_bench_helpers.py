@@ -20,17 +20,26 @@ def test_fc1_tile_rule_matches_the_kernel_launcher():
     assert "(n + 64 * r * 16 - 1) / (64 * r * 16)" in src  # the rule restated above is the one in the launcher
 
 
-def test_conv1_live_fraction():
-    img = np.zeros((4, 60, 60, 15), np.uint8)
-    assert bench._conv1_live_fraction(img) == 0.0
-    img[:] = 1
-    assert bench._conv1_live_fraction(img) == 1.0
-    img[:] = 0
-    img[:, :, :, 3] = 7          # one live channel of fifteen
-    assert abs(bench._conv1_live_fraction(img) - 1.0 / 15.0) < 1e-12
-    img[:] = 0
-    img[0, 0, 0, 0] = 1          # one pixel: one (chunk, channel) pair of 2 x 25 x 15 (pairs of images share chunks)
-    assert abs(bench._conv1_live_fraction(img) - 1.0 / (2 * 25 * 15)) < 1e-12
+def test_bench_launches_itself_for_several_gpus(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command): bench.py re-runs itself
+    under torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1, and prints ONE line.  GPD_BENCH_DRYRUN stops
+    each rank where it would create its context (gloo instead of RCCL): launch, rendezvous, barrier, max / sum over ranks."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GPD_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d == {"dryrun": True, "n_gpus": 2, "world": 2, "max": 2.0, "sum": 30.0, "batch_clouds": 64}
+    # a launcher that disagrees with --gpus is refused with a message, not an AssertionError
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
 
 
 def test_pmc_numbers_are_dropped_when_a_kernel_source_changes(tmp_path, monkeypatch):

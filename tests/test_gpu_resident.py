@@ -161,6 +161,71 @@ def test_detect_batch_equals_separate_calls(ctx, oracle_mod, lenet15_real):
         assert a[cid][0].tobytes() == want.tobytes()
 
 
+def test_detect_batch_with_tied_scores_and_repeated_samples(oracle_mod, lenet15_real):
+    """Four clouds, selectGrasps inside the batch, equal scores among the winners (all scores equal; and sample indices
+    drawn WITH repetition, as the reference's subsampleSampleIndices does — duplicated hand sets, duplicated scores).
+    The std::partial_sort rerun of a job happens after the lane's search / plan buffers already hold the cloud after
+    next: it must still return THIS cloud's records (it gathered from the wrong job's buffers)."""
+    clouds, samples = [], []
+    rng = np.random.RandomState(11)
+    for cid in range(4):
+        cl = synth.make_cloud(500 + cid, 12000 + 2000 * cid)
+        si = synth.sample_indices(cl, 60)
+        clouds.append(cl)
+        samples.append(si[rng.randint(0, len(si), 90)].astype(np.int32))  # with repetition
+    for variant in ("repeated_samples", "all_equal"):
+        w = {k: v.copy() for k, v in lenet15_real.items()}
+        if variant == "all_equal":
+            w["f2w"][:] = 0.0
+        c = api.Context(api.default_params(15))
+        try:
+            c.set_lenet_weights(w)
+            res = c.detect_batch(clouds, samples, 40)
+            for cid, (cl, si) in enumerate(zip(clouds, samples)):
+                _, ocand, on = _oracle_candidates(oracle_mod, cl, si, w)
+                assert res[cid][2] == on and on > 60
+                if variant == "all_equal":  # (repeated samples repeat the hand sets, but each set draws its own shadow points)
+                    assert len(np.unique(ocand["score"])) == 1
+                _same_records(res[cid][0], ocand[oracle_mod.select(ocand["score"], 40)])
+        finally:
+            c.close()
+
+
+def test_detect_select_beyond_the_device_selection_capacity(ctx, oracle_mod, cloud30k, lenet15_real):
+    """num_selected larger than what select_topk_kernel sorts in LDS (8192): std::partial_sort on the downloaded scores,
+    no limit — "all candidates, sorted" is a legitimate request (grasp_detector.cpp:405-420 has none)."""
+    cl = cloud30k
+    si = synth.sample_indices(cl, 4200)
+    ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+    allc, _, nc = ctx.detect_select(si, 0)
+    assert nc > 8192 + 500
+    for k in (8193, nc, nc + 1000):
+        sel, _, _ = ctx.detect_select(si, k)
+        want = oracle_mod.select(allc["score"], k)
+        assert len(sel) == min(k, nc) and sel.tobytes() == allc[want].tobytes()
+
+
+def test_detect_batch_multi_two_contexts_on_one_device(ctx, lenet15_real):
+    """gpd_hip_detect_batch_multi: one host thread per context, cloud i -> context i mod G.  Two contexts on the one
+    GPU of the test box stand in for two GPUs; results are those of the single-context batch, cloud by cloud."""
+    clouds = [synth.make_cloud(700 + cid, 10000 + 1000 * cid) for cid in range(7)]
+    samples = [synth.sample_indices(cl, 50 + 5 * cid) for cid, cl in enumerate(clouds)]
+    want = ctx.detect_batch(clouds, samples, 0)
+    other = api.Context(api.default_params(15))
+    try:
+        other.set_lenet_weights(lenet15_real)
+        for nsel in (0, 30):
+            got = ctx.detect_batch_multi([other], clouds, samples, nsel)
+            ref = want if nsel == 0 else ctx.detect_batch(clouds, samples, nsel)
+            assert len(got) == len(clouds)
+            for g, r in zip(got, ref):
+                assert g[1:3] == r[1:3] and g[0].tobytes() == r[0].tobytes()
+        with pytest.raises(api.GpdHipError, match="listed twice"):
+            ctx.detect_batch_multi([ctx], clouds, samples, 0)
+    finally:
+        other.close()
+
+
 def test_detect_batch_reports_a_bad_cloud(ctx, cloud30k):
     cl = cloud30k
     si = synth.sample_indices(cl, 40)
