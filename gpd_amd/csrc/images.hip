@@ -132,7 +132,8 @@ struct __attribute__((aligned(16))) SmemPts {
   typename std::conditional<BIG, NoPointArrays, PointArrays>::type p;
   uint32_t cells[kPix];   // (segment start << 16) | count of a pixel; after the walks: the f32 plane being finished
   uint16_t place[BIG ? PT_CAP_BIG : PT_CAP];  // segment table: entry numbers (entries are numbered in neighbour order)
-  float4 nzv[BIG ? kPix : PT_CAP];            // per non-empty pixel: the three normal values and the depth value
+  float4 nzv[(BIG ? kPix : PT_CAP) + 1];      // slot 0: the empty pixel (zeros); slot q + 1: the three normal values and the
+                                              // depth value of the q-th non-empty pixel
   uint16_t nzlist[BIG ? kPix : PT_CAP];       // the non-empty pixels, longest segment first
   double thr[3][kImg + 1];
   double recip[128];  // 1.0 / k
@@ -976,6 +977,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
   if (tid == 0) {
     S.flag = 0;
     S.counter = 0;
+    S.nzv[0] = make_float4(0.f, 0.f, 0.f, 0.f);  // the empty pixel of the index raster (the walks write slots >= 1)
   }
   __syncthreads();
   // The in-box points are numbered IN NEIGHBOUR ORDER (an ordered compaction: per 512 neighbours one ballot per wave
@@ -1085,47 +1087,130 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       };
       sort_u16_lean(&S.place[start], cn);  // neighbour order = entry order
       for (int q = 0; q < cn; q++) visit((int)S.place[start + q]);
-      S.nzv[qn] = make_float4(v0, v1, v2, (float)(1.0 - (double)avg));
+      S.nzv[qn + 1] = make_float4(v0, v1, v2, (float)(1.0 - (double)avg));
+      S.cells[c] = 0x80000000u | (uint32_t)(qn + 1);  // the pixel's own word, read above: from here on the index raster
     }
     TICK(13);
     __syncthreads();
     TICK(7);
-    // ---- the planes, one after the other in the storage of the (dead) segment counters: empty pixels are 0 in all of
-    //      them, the non-empty pixels of a projection are the same for its normal and depth planes
-    float *raster = reinterpret_cast<float *>(S.cells);
-    for (int c = tid; c < kPix; c += IMG_THREADS) raster[c] = 0.f;
-    __syncthreads();
-    TICK(12);
+    // ---- the four planes of the projection at once.  `cells` is now an index raster: bit 31 set <-> the pixel holds
+    //      points, low bits = its slot in nzv (float4: the three normal values and the depth value); every other word has
+    //      bit 31 clear (segment starts are < 2^15) and stands for the empty pixel, slot 0 = zeros.  A thread dilates its
+    //      groups of four pixels for all four planes from one set of index reads + float4 gathers (a dense float raster
+    //      per plane cost four scatter / dilate / barrier rounds); empty pixels take part with the value 0 exactly as in
+    //      the reference's zero-initialised cv::Mat (the running normal "average" can go negative, so 0 matters).
     const bool with_normals = K.C != 1, with_depth = K.C == 1 || K.C >= 12;
-    if (with_normals) {
-      // createNormalsImage: the three planes are dilated and normalised as ONE 3-channel image (image_strategy.cpp:144-153)
-      float d[3][GPT][4];
-      float mn = FLT_MAX, mx = -FLT_MAX;
+    float d[GPT][4][4];  // [group][plane][pixel]
+    float mn0 = FLT_MAX, mx0 = -FLT_MAX, mn1 = FLT_MAX, mx1 = -FLT_MAX;
+    TICK(12);
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++) {
-        for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
-          const float4 v = S.nzv[qn];
-          raster[nz[qn]] = pl == 0 ? v.x : (pl == 1 ? v.y : v.z);
+    for (int k = 0; k < GPT; k++) {
+      const int g = tid + k * IMG_THREADS;
+      if (g < 900) {
+        const int r = g / 15, c0 = (g - r * 15) * 4;
+        const int rows[3] = {r > 0 ? r - 1 : 0, r, r < kImg - 1 ? r + 1 : kImg - 1};
+        const int cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + 4 < kImg ? c0 + 4 : kImg - 1;
+        uint32_t ix[3][6];
+        uint32_t any = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const uint4 m = *reinterpret_cast<const uint4 *>(&S.cells[rows[q] * kImg + c0]);
+          ix[q][0] = S.cells[rows[q] * kImg + cl];
+          ix[q][1] = m.x;
+          ix[q][2] = m.y;
+          ix[q][3] = m.z;
+          ix[q][4] = m.w;
+          ix[q][5] = S.cells[rows[q] * kImg + cr];
+#pragma unroll
+          for (int e = 0; e < 6; e++) any |= ix[q][e];
         }
-        __syncthreads();
-        dilate_plane(raster, d[pl], mn, mx);
-        __syncthreads();
-      }
-      float fs, fb;
-      minmax_scale(S, mn, mx, fs, fb);
+        float col[4][6];  // per plane: column maxima over the three rows
 #pragma unroll
-      for (int pl = 0; pl < 3; pl++) store_plane(d[pl], fs, fb, out + (size_t)(pr * K.per + pl) * kPix);
+        for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+          for (int e = 0; e < 6; e++) col[pl][e] = 0.f;
+        if (any >> 31) {  // some pixel of the 3 x 6 window holds points
+#pragma unroll
+          for (int e = 0; e < 6; e++) {
+            const float4 a = S.nzv[(ix[0][e] >> 31) ? (ix[0][e] & 0xffffu) : 0u];
+            const float4 b = S.nzv[(ix[1][e] >> 31) ? (ix[1][e] & 0xffffu) : 0u];
+            const float4 c = S.nzv[(ix[2][e] >> 31) ? (ix[2][e] & 0xffffu) : 0u];
+            col[0][e] = fmaxf(fmaxf(a.x, b.x), c.x);
+            col[1][e] = fmaxf(fmaxf(a.y, b.y), c.y);
+            col[2][e] = fmaxf(fmaxf(a.z, b.z), c.z);
+            col[3][e] = fmaxf(fmaxf(a.w, b.w), c.w);
+          }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) d[k][pl][j] = fmaxf(fmaxf(col[pl][j], col[pl][j + 1]), col[pl][j + 2]);
+          const float lo = fminf(fminf(d[k][pl][0], d[k][pl][1]), fminf(d[k][pl][2], d[k][pl][3]));
+          const float hi = fmaxf(fmaxf(d[k][pl][0], d[k][pl][1]), fmaxf(d[k][pl][2], d[k][pl][3]));
+          if (pl < 3) {
+            mn0 = fminf(mn0, lo);
+            mx0 = fmaxf(mx0, hi);
+          } else {
+            mn1 = fminf(mn1, lo);
+            mx1 = fmaxf(mx1, hi);
+          }
+        }
+      }
     }
-    if (with_depth) {
-      // createDepthImage (image_strategy.cpp:178-187); Image1ChannelsStrategy is this plane alone
-      float d[GPT][4];
-      float mn = FLT_MAX, mx = -FLT_MAX;
-      for (int qn = tid; qn < n_nz; qn += IMG_THREADS) raster[nz[qn]] = S.nzv[qn].w;
-      __syncthreads();
-      dilate_plane(raster, d, mn, mx);
-      float fs, fb;
-      minmax_scale(S, mn, mx, fs, fb);
-      store_plane(d, fs, fb, out + (size_t)(K.C == 1 ? 0 : pr * K.per + 3) * kPix);
+    // createNormalsImage: the three planes are normalised as ONE 3-channel image; createDepthImage on its own
+    // (image_strategy.cpp:144-153, 178-187; Image1ChannelsStrategy is the depth plane alone)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn0 = fminf(mn0, __shfl_xor(mn0, o));
+      mx0 = fmaxf(mx0, __shfl_xor(mx0, o));
+      mn1 = fminf(mn1, __shfl_xor(mn1, o));
+      mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+    }
+    if (lane == 0) {
+      S.red_f[4 * (tid >> 6) + 0] = mn0;
+      S.red_f[4 * (tid >> 6) + 1] = mx0;
+      S.red_f[4 * (tid >> 6) + 2] = mn1;
+      S.red_f[4 * (tid >> 6) + 3] = mx1;
+    }
+    __syncthreads();
+    float fs[2], fb[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      float a = S.red_f[2 * q], b = S.red_f[2 * q + 1];
+#pragma unroll
+      for (int w = 1; w < IMG_WAVES; w++) {
+        a = fminf(a, S.red_f[4 * w + 2 * q]);
+        b = fmaxf(b, S.red_f[4 * w + 2 * q + 1]);
+      }
+      const double smin = (double)a, smax = (double)b;
+      const double scale = 1.0 * ((smax - smin) > DBL_EPSILON ? 1.0 / (smax - smin) : 0.0);
+      const double shift = 0.0 - smin * scale;
+      fs[q] = (float)scale;
+      fb[q] = (float)shift;
+    }
+#pragma unroll
+    for (int k = 0; k < GPT; k++) {
+      const int g = tid + k * IMG_THREADS;
+      if (g < 900) {
+        const int r = g / 15, c0 = (g - r * 15) * 4;
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++) {
+          if (pl < 3 ? !with_normals : !with_depth) continue;
+          const int q = pl < 3 ? 0 : 1;
+          uint32_t packed = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const float v = d[k][pl][j] * fs[q] + fb[q];
+            const float u = v * 255.0f + 0.0f;
+            float t = rintf(u);
+            t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+            packed |= (uint32_t)(int)t << (8 * j);
+          }
+          // image row = 59 - cell row (image_strategy.cpp:128-129)
+          const int ch = K.C == 1 ? 0 : pr * K.per + pl;
+          *reinterpret_cast<uint32_t *>(out + (size_t)ch * kPix + (kImg - 1 - r) * kImg + c0) = packed;
+        }
+      }
     }
     __syncthreads();
     TICK(8);
@@ -1467,7 +1552,8 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     HIP_RET(hipEventCreateWithFlags(&im.ev_fork, hipEventDisableTiming));
     HIP_RET(hipEventCreateWithFlags(&im.ev_join, hipEventDisableTiming));
   }
-  hipStream_t pts_stream = (im.channels == 15 && !ip.dbg && im.side_stream) ? im.aux : stream;
+  static const bool serial = getenv("GPD_IMG_SERIAL") != nullptr;  // profiling aid: each image kernel alone on the chip
+  hipStream_t pts_stream = (im.channels == 15 && !ip.dbg && im.side_stream && !serial) ? im.aux : stream;
   if (pts_stream != stream) {
     HIP_RET(hipEventRecord(im.ev_fork, stream));
     HIP_RET(hipStreamWaitEvent(pts_stream, im.ev_fork, 0));
