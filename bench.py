@@ -550,9 +550,12 @@ def _preprocess_leg(ctx):
     n_wall = time.perf_counter() - t0
     return raw, {"points": int(len(xyz)), "kept": int(len(v)), "voxel_size": PRE_VOXEL, "kernel_ms": float(ms), "wall_ms_incl_pcie": wall * 1e3,
                  "normals": {"points": PRE_NORMALS_POINTS, "radius": 0.03, "wall_ms_incl_download": n_wall * 1e3},
-                 "note": "Cloud::filterWorkspace + Cloud::voxelizeCloud on the device; the voxeliser's keep / drop decisions are a "
-                         "sequential chain (one wavefront), the CPU time beside it is cpu_baseline.preprocess_ms.  normals: "
-                         "gpd_hip_estimate_normals on a 30k-point cloud of the benchmark's density"}
+                 "note": "Cloud::filterWorkspace + Cloud::voxelizeCloud: cut, voxel keys and the gather of the kept voxels on the device; the "
+                         "voxeliser's keep / drop decisions are a strictly sequential chain and run as a table-driven spine walk on ONE host "
+                         "core between two small copies (kernel_ms = first to last device operation, the walk included; "
+                         "voxel_accept_kernel, the same walk on one wavefront, took 20 ms and stays as GPD_VOXEL_DEVICE=1 for the parity "
+                         "tests).  cpu_baseline.preprocess_ms is the reference's std::set on one core.  normals: gpd_hip_estimate_normals on a "
+                         "30k-point cloud of the benchmark's density"}
 
 
 def _cpu_preprocess_ms(raw):

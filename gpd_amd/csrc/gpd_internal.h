@@ -53,6 +53,8 @@ struct PreState {
   void *d_meta = nullptr;
   void *d_ops = nullptr;      // int8 per kept point: the voxeliser's spine table (preprocess.hip spine_ops)
   size_t ops_on_device = 0;
+  std::vector<char> h_keys;     // host route of the voxeliser's chain: the voxel keys of the points inside the workspace ...
+  std::vector<int32_t> h_rank;  // ... and what the walk decided (rank among the kept points, -1: dropped)
   hipEvent_t ev[2] = {nullptr, nullptr};
 };
 void preprocess_free(PreState &s);

@@ -625,20 +625,24 @@ static int fc1_pick_nt(int n) {
   }
 }
 
-// FC2 + score.  One thread per image; reads of fc1t are coalesced over images.
-__global__ __launch_bounds__(256) void fc2_score_kernel(const float *__restrict__ fc1t, const float *__restrict__ w,
-                                                        const float *__restrict__ b, float *__restrict__ scores, int n, int ld) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= n) return;
-  float y0 = 0.f, y1 = 0.f;
-  for (int j = 0; j < kFc1Out; j++) {
-    const float x = fc1t[(size_t)j * ld + m];
-    y0 = __builtin_fmaf(w[2 * j], x, y0);
-    y1 = __builtin_fmaf(w[2 * j + 1], x, y1);
-  }
-  y0 += b[0];
-  y1 += b[1];
-  scores[m] = y1 - y0;
+// FC2 + score (dense_layer.cpp:6-15 with 2 units; eigen_classifier.cpp:74: score = y1 - y0).  Each logit is ONE fmaf
+// chain over the 500 ip1 units in ascending order — the definition the oracle and the reference pins share — so it
+// cannot be folded into ip1's epilogue as partial sums over ip1's four u-tiles (that changes the rounding).  What can be
+// spread is everything else: the two logits of an image are two lanes (a lane pair), the images of a workgroup are only
+// 32, so that n = 5000 fills 157 CUs instead of 20; reads of fc1t stay coalesced over the images.
+constexpr int FC2_THREADS = 64;
+__global__ __launch_bounds__(FC2_THREADS) void fc2_score_kernel(const float *__restrict__ fc1t, const float *__restrict__ w,
+                                                               const float *__restrict__ b, float *__restrict__ scores, int n, int ld) {
+  const int lane = threadIdx.x;
+  const int which = lane >> 5;                      // logit 0 in lanes 0..31, logit 1 in lanes 32..63
+  const int m = blockIdx.x * 32 + (lane & 31);
+  const int mc = m < n ? m : n - 1;
+  float y = 0.f;
+#pragma unroll 10
+  for (int j = 0; j < kFc1Out; j++) y = __builtin_fmaf(w[2 * j + which], fc1t[(size_t)j * ld + mc], y);
+  y += b[which];
+  const float other = __shfl_xor(y, 32);
+  if (which == 1 && m < n) scores[m] = y - other;  // y1 - y0
 }
 
 // ---------------------------------------------------------------------------
@@ -707,7 +711,7 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
       default: fc1_launch<8>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[2], stream);
-    fc2_score_kernel<<<(m + 255) / 256, 256, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
+    fc2_score_kernel<<<(m + 31) / 32, FC2_THREADS, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
   }
   return hipGetLastError();
 }

@@ -23,6 +23,8 @@
 #include "gpd_internal.h"
 #include <cfloat>
 #include <cmath>
+#include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -299,6 +301,45 @@ static bool spine_ops(std::vector<int8_t> &ops, size_t n, unsigned long long &C,
   return true;
 }
 
+// The same walk on the host: the chain is strictly sequential (which spine a point meets depends on how many points
+// before it were kept), a job for one scalar core rather than for one wavefront — ~400 cycles per point in
+// voxel_accept_kernel against a few dozen here (and ~150 for the std::set the reference itself uses, which allocates a
+// node per kept point).  Default route of gpd_hip_preprocess_cloud; the kernel stays as GPD_VOXEL_DEVICE=1 and the tests
+// hold the two against each other and against std::set.
+static int voxel_accept_host(const int4 *keys, int n, const int8_t *ops, int32_t *rank) {
+  int sx[64], sy[64], sz[64];
+  int L = 0, m = 0;
+  for (int i = 0; i < n; i++) {
+    const int qx = keys[i].x, qy = keys[i].y, qz = keys[i].z;
+    bool hit = false;
+    for (int d = L - 1; d >= 0; d--)  // the recent nodes sit at the bottom of the spine: most drops end here at once
+      if (sx[d] == qx && sy[d] == qy && sz[d] == qz) {
+        hit = true;
+        break;
+      }
+    if (hit) {
+      rank[i] = -1;
+      continue;
+    }
+    rank[i] = m;
+    sx[L] = qx;
+    sy[L] = qy;
+    sz[L] = qz;
+    const int g = ops[m];
+    m++;
+    L++;
+    if (g >= 0) {  // the node at depth g leaves the spine, the ones below move up
+      for (int d = g; d + 1 < L; d++) {
+        sx[d] = sx[d + 1];
+        sy[d] = sy[d + 1];
+        sz[d] = sz[d + 1];
+      }
+      L--;
+    }
+  }
+  return m;
+}
+
 void preprocess_free(PreState &s) {
   void *dev[] = {s.d_xyz, s.d_cam, s.d_block_count, s.d_block_off, s.d_block_lo, s.d_src, s.d_keys, s.d_rank, s.d_out_xyz, s.d_out_cam, s.d_out_src, s.d_meta, s.d_ops};
   for (void *p : dev)
@@ -366,7 +407,30 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
         s.ops_on_device = (size_t)n;
       }
     }
-    voxel_accept_kernel<<<1, 64, 0, stream>>>(s.d_keys, static_cast<const int8_t *>(s.d_ops), meta, s.d_rank);
+    const bool on_device = getenv("GPD_VOXEL_DEVICE") != nullptr;  // read per call: the tests switch routes inside one process
+    if (on_device) {
+      voxel_accept_kernel<<<1, 64, 0, stream>>>(s.d_keys, static_cast<const int8_t *>(s.d_ops), meta, s.d_rank);
+    } else {
+      // keys to the host (16 bytes per point inside the workspace), the walk, the ranks back (4 bytes per point)
+      PreMeta hm;
+      HIP_RET(hipMemcpyAsync(&hm, s.d_meta, sizeof(hm), hipMemcpyDeviceToHost, stream));
+      HIP_RET(hipStreamSynchronize(stream));
+      const int kept = hm.kept;
+      if (kept > 0 && !(hm.bad & 3)) {
+        s.h_keys.resize((size_t)kept * sizeof(int4));
+        s.h_rank.resize((size_t)kept);
+        HIP_RET(hipMemcpyAsync(s.h_keys.data(), s.d_keys, (size_t)kept * sizeof(int4), hipMemcpyDeviceToHost, stream));
+        HIP_RET(hipStreamSynchronize(stream));
+        int m;
+        {
+          std::lock_guard<std::mutex> lock(ops_mutex);  // `ops` may grow under another context's call
+          m = voxel_accept_host(reinterpret_cast<const int4 *>(s.h_keys.data()), kept, ops.data(), s.h_rank.data());
+        }
+        HIP_RET(hipMemcpyAsync(s.d_rank, s.h_rank.data(), (size_t)kept * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_RET(hipMemcpyAsync(reinterpret_cast<char *>(s.d_meta) + offsetof(PreMeta, voxels), &m, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_RET(hipStreamSynchronize(stream));  // m and h_rank are read by the copies
+      }
+    }
     voxel_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_keys, s.d_rank, meta, cell, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam, s.d_out_src);
   } else {
     ws_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, s.d_src, meta, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam);
