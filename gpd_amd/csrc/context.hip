@@ -60,7 +60,8 @@ constexpr int kLanes = 2;
 struct HostFlags {  // pinned; written by the last copies of a job
   int32_t status;   // capacity flags of the image kernels
   int32_t tie;      // select_topk: equal scores among the winners or at the cut
-  int32_t pad_[2];
+  int32_t lenet;    // != 0: a conv1 launch of this job gave up on its slot protocol (lenet.hip)
+  int32_t pad_;
 };
 
 struct Lane {
@@ -249,6 +250,9 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
     rc = reserve_scores(L, n);
     if (rc) return rc;
     HIP_TRY(lenet_forward(ctx->lenet, L.lenet_scratch, L.images.d_images, n, L.d_scores, L.stream));
+    HIP_TRY(hipMemcpyAsync(&L.h_flags->lenet, L.lenet_scratch.c1_stats + 2, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+  } else {
+    L.h_flags->lenet = 0;
   }
   HIP_TRY(hipEventRecord(L.ev[3], L.stream));
   rc = reserve_out(L, (size_t)J.out_records, k ? (size_t)n * sizeof(float) : 0);
@@ -312,6 +316,10 @@ static int job_end(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   if (L.h_flags->status) {
     images_status_text(L.h_flags->status, g_err, sizeof(g_err));
     return GPD_ERR_CAPACITY;
+  }
+  if (L.h_flags->lenet) {
+    const int rc = lenet_check(L.lenet_scratch);  // clears the device word, sets the error text
+    return rc ? rc : GPD_ERR_HIP;
   }
   const int n = J.num_candidates;
   if (J.mode == 1 && J.num_selected > 0 && J.out_records > 0 && L.h_flags->tie) {
@@ -582,7 +590,7 @@ int gpd_hip_score(gpd_hip_ctx *ctx, const uint8_t *images, int n, float *scores)
   HIP_TRY(hipMemcpyAsync(scores, L.d_scores, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, L.stream));
   HIP_TRY(hipStreamSynchronize(L.stream));
   HIP_TRY(hipEventElapsedTime(&L.stage_ms[2], L.ev[2], L.ev[3]));
-  return GPD_OK;
+  return lenet_check(L.lenet_scratch);
 }
 
 int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normals, int num_points, const int32_t *cam_source,
@@ -1045,7 +1053,7 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
     images_status_text(status, g_err, sizeof(g_err));
     return GPD_ERR_CAPACITY;
   }
-  return GPD_OK;
+  return lenet_check(L.lenet_scratch);
 }
 
 int gpd_hip_conv1_stats(gpd_hip_ctx *ctx, unsigned long long pairs[2], int reset) {

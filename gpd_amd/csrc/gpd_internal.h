@@ -32,13 +32,16 @@ struct LeNetScratch {
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)
   unsigned long long *c1_stats = nullptr;  // device: [0] (chunk, channel) pairs conv1 executed, [1] pairs it looked at — summed
-                                           // over its launches since the last gpd_hip_conv1_stats(reset)
+                                           // over its launches since the last gpd_hip_conv1_stats(reset); [2] != 0: a launch gave up
+                                           // waiting for an image slot (its scores are invalid: lenet_check)
 };
 
 // Scores n images (device pointer, planar u8 [n][C][3600]) into d_scores (device). Async on stream.
 hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *d_images, int n, float *d_scores,
                          hipStream_t stream, hipEvent_t *kernel_events = nullptr);
 hipError_t lenet_scratch_reserve(LeNetScratch &s, int n);
+// after the stream was synchronised: GPD_ERR_HIP (and the error word cleared) when a conv1 launch gave up on its slot protocol
+int lenet_check(LeNetScratch &s);
 void lenet_scratch_free(LeNetScratch &s);
 
 void set_error(const char *fmt, ...);

@@ -21,6 +21,8 @@
 //   fc1_mfma     [500 x 7200] x [7200 x n] on v_mfma_f32_16x16x4_f32, 128 x 16..128 tiles picked per launch, + bias, ReLU
 //                                                               -> fc1t  [500][n]
 //   fc2_score    2 x 500 chains per image, score = y1 - y0       -> scores[n]
+#include <cstdlib>
+
 #include "gpd_internal.h"
 #include <type_traits>
 
@@ -66,13 +68,14 @@ __device__ inline int c1_chunks_of_image(int j, int c0, int c1) {
 template <int C>
 __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wp,
                                                                const float *__restrict__ bias, float *__restrict__ out, int n,
-                                                               unsigned long long *__restrict__ stats) {
+                                                               unsigned long long *__restrict__ stats, int fault) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
   __shared__ __attribute__((aligned(16))) float s_wa[16 * C * 28];  // filters 0..15: [f][c][25 taps + 3 pad]
   __shared__ __attribute__((aligned(16))) float s_wb[4 * C * 28];   // filters 16..19
   __shared__ int s_next;
   __shared__ int s_slot_img[2];  // image held by the slot (published after its bytes), -1: none
   __shared__ int s_refs[2];      // chunks of this workgroup that still have to release the slot's image
+  __shared__ int s_abort;        // a wave gave up waiting for a slot: the others of the workgroup leave too
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int first = blockIdx.x, stride = gridDim.x;  // the workgroup's s-th image is first + s * stride
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
   }
   if (tid == 0) {
     s_next = c0;
+    s_abort = 0;
     s_slot_img[0] = s_slot_img[1] = -1;
     for (int q = 0; q < 2; q++)
       if (img_first + q <= img_last) {
@@ -114,11 +118,24 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     n_tasks++;
     // the images this chunk reads (the second one only when the chunk straddles an image boundary)
     const int ia = (64 * task) / C1_PIX, ib = min((64 * task + 63) / C1_PIX, img_last);
-    // (a slot is refilled within ~10 us of its release; a wait of ~0.5 s can only be a broken protocol: abort the
-    //  launch — the host sees a failed kernel — rather than hang the device)
+    // (a slot is refilled within ~10 us of its release; a wait of ~0.5 s can only be a broken protocol.  The wave then
+    //  raises the launch's error word — stats[2], which the host turns into GPD_ERR_HIP at its next synchronisation — and
+    //  the workgroup's abort flag, and every wave of the workgroup leaves: the kernel ends, the context stays usable,
+    //  the scores of this launch are not handed out.  It used to be a __builtin_trap(), which killed the HIP context.)
+    bool give_up = false;
     for (int spins = 0; *(volatile int *)&s_slot_img[ia & 1] != ia || *(volatile int *)&s_slot_img[ib & 1] != ib; spins++) {
       __builtin_amdgcn_s_sleep(4);
-      if (spins > (1 << 22)) __builtin_trap();
+      if (*(volatile int *)&s_abort || spins > (1 << 22)) {
+        give_up = true;
+        break;
+      }
+    }
+    if (give_up) {
+      if (lane == 0) {
+        *(volatile int *)&s_abort = 1;
+        if (stats) atomicMax(&stats[2], 1ull);
+      }
+      break;
     }
     __threadfence_block();  // the image bytes are read after the slot numbers
     // pooled pixel of the lane: image, then strip-major pixel number -> (row, column).  Lanes past the last pixel of
@@ -257,7 +274,8 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
       }
       if (lane == 0) s_refs[nxt & 1] = c1_chunks_of_image(nxt, c0, c1);
       __threadfence_block();  // the bytes and the release count are in LDS before the slot is published
-      if (lane == 0) *(volatile int *)&s_slot_img[nxt & 1] = nxt;
+      // (fault: the test hook GPD_C1_FAULT=1 makes workgroup 0 "forget" to publish — the protocol bug the watchdog is for)
+      if (lane == 0 && !(fault && blockIdx.x == 0)) *(volatile int *)&s_slot_img[nxt & 1] = nxt;
     }
   }
   if (stats && lane == 0) {  // two atomics per wave and launch: what bench.py's roofline divides by
@@ -656,10 +674,23 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   if ((e = hipMalloc(&s.pool1, (size_t)n * 20 * 784 * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
-  if ((e = hipMalloc(&s.c1_stats, 2 * sizeof(unsigned long long))) != hipSuccess) return e;
-  if ((e = hipMemset(s.c1_stats, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return e;
+  if ((e = hipMalloc(&s.c1_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
+  if ((e = hipMemset(s.c1_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
   s.capacity = n;
   return hipSuccess;
+}
+
+int lenet_check(LeNetScratch &s) {
+  if (!s.c1_stats) return GPD_OK;
+  unsigned long long flag = 0;
+  if (hipMemcpy(&flag, s.c1_stats + 2, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess) {
+    set_error("lenet: reading the launch error word failed");
+    return GPD_ERR_HIP;
+  }
+  if (!flag) return GPD_OK;
+  (void)hipMemset(s.c1_stats + 2, 0, sizeof(flag));
+  set_error("lenet: conv1 gave up waiting for an image slot (slot protocol timeout); the scores of that launch are invalid");
+  return GPD_ERR_HIP;
 }
 
 void lenet_scratch_free(LeNetScratch &s) {
@@ -689,12 +720,13 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     const int m = (n - off < kChunk) ? (n - off) : kChunk;
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
     // persistent conv1: one workgroup per CU, at least two images each
+    const int fault = getenv("GPD_C1_FAULT") != nullptr;  // test hook of the slot watchdog (tests/test_gpu_lenet_stress.py)
     const int c1_grid = m / 2 < 1 ? 1 : (m / 2 < num_cus ? m / 2 : num_cus);
     switch (w.channels) {
-      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
-      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
-      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
-      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats); break;
+      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
+      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
+      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
+      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
