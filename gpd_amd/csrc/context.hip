@@ -195,10 +195,17 @@ static int job_begin(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   J.num_sets = J.num_candidates = J.num_hands = 0;
   if (J.S == 0) return GPD_OK;
   HIP_TRY(hipEventRecord(L.ev[0], L.stream));
-  int rc = search_run(ctx->params, L.cloud, L.search, J.sample_idx, J.sample_xyz, J.S, L.stream, /*sync_counts=*/false);
+  int rc;
+  {
+    StageRange r("gpd:search (neighbourhoods, frames, hand evaluation, workspace filter)");
+    rc = search_run(ctx->params, L.cloud, L.search, J.sample_idx, J.sample_xyz, J.S, L.stream, /*sync_counts=*/false);
+  }
   if (rc) return rc;
   HIP_TRY(hipEventRecord(L.ev[1], L.stream));
-  rc = plan_build(ctx->params, L.cloud, L.search, L.plan, L.stream);
+  {
+    StageRange r("gpd:plan (hand sets, candidate list, shadow LCG offsets)");
+    rc = plan_build(ctx->params, L.cloud, L.search, L.plan, L.stream);
+  }
   if (rc) return rc;
   HIP_TRY(hipEventRecord(L.ev_plan, L.stream));
   J.live = true;
@@ -243,13 +250,20 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   (void)hipEventElapsedTime(&L.stage_ms[0], L.ev[0], L.ev[1]);  // here: the next job on this lane records them again
   HIP_TRY(hipEventRecord(L.ev[4], L.stream));
   L.images.side_stream = !ctx->in_batch;
-  int rc = images_run(ctx->params, L.cloud, L.search, L.plan, L.images, L.stream);
+  int rc;
+  {
+    StageRange r("gpd:images (shadow sets, shadow channels, normals + depth channels)");
+    rc = images_run(ctx->params, L.cloud, L.search, L.plan, L.images, L.stream);
+  }
   if (rc) return rc;
   HIP_TRY(hipEventRecord(L.ev[2], L.stream));
   if (n > 0) {
     rc = reserve_scores(L, n);
     if (rc) return rc;
-    HIP_TRY(lenet_forward(ctx->lenet, L.lenet_scratch, L.images.d_images, n, L.d_scores, L.stream));
+    {
+      StageRange r("gpd:lenet (conv1, conv2, ip1, ip2)");
+      HIP_TRY(lenet_forward(ctx->lenet, L.lenet_scratch, L.images.d_images, n, L.d_scores, L.stream));
+    }
     HIP_TRY(hipMemcpyAsync(&L.h_flags->lenet, L.lenet_scratch.c1_stats + 2, sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
   } else {
     L.h_flags->lenet = 0;
@@ -548,6 +562,7 @@ int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1
 }
 
 int gpd_hip_score(gpd_hip_ctx *ctx, const uint8_t *images, int n, float *scores) {
+  StageRange range_("gpd:score (classifyImages)");
   if (!ctx || !scores || n < 0) {
     set_error("gpd_hip_score: bad argument");
     return GPD_ERR_INVALID;
@@ -595,6 +610,7 @@ int gpd_hip_score(gpd_hip_ctx *ctx, const uint8_t *images, int n, float *scores)
 
 int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normals, int num_points, const int32_t *cam_source,
                          int num_cams, const double *view_points) {
+  StageRange range_("gpd:upload_cloud (+ uniform grid)");
   if (!ctx || !xyz || !normals || num_points <= 0 || !cam_source || num_cams < 1 || !view_points) {
     set_error("gpd_hip_upload_cloud: bad argument");
     return GPD_ERR_INVALID;
@@ -606,6 +622,7 @@ int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normal
 
 int gpd_hip_find_clusters(gpd_hip_ctx *ctx, const gpd_hand *hands, const double *scores, int n, int min_inliers, int remove_inliers,
                           gpd_hand *out, double *out_scores, int32_t *out_src, int *num_out) {
+  StageRange range_("gpd:find_clusters");
   if (!ctx || !num_out || n < 0 || (n > 0 && (!hands || !scores || !out || !out_scores || !out_src))) {
     set_error("gpd_hip_find_clusters: bad argument");
     return GPD_ERR_INVALID;
@@ -617,6 +634,7 @@ int gpd_hip_find_clusters(gpd_hip_ctx *ctx, const gpd_hand *hands, const double 
 int gpd_hip_preprocess_cloud(gpd_hip_ctx *ctx, const float *xyz, const int32_t *cam_source, int num_points, int num_cams,
                              const double *workspace, float voxel_size, float *xyz_out, int32_t *cam_out, int32_t *src_out,
                              int *num_out, float *kernel_ms) {
+  StageRange range_("gpd:preprocess_cloud (workspace cut, voxeliser)");
   if (!ctx || !num_out || num_points < 0 || num_cams < 0 || (num_points > 0 && (!xyz || !xyz_out)) ||
       (num_points > 0 && num_cams > 0 && (!cam_source || !cam_out)) || !(voxel_size == voxel_size)) {
     set_error("gpd_hip_preprocess_cloud: bad argument");
@@ -634,6 +652,7 @@ int gpd_hip_preprocess_cloud(gpd_hip_ctx *ctx, const float *xyz, const int32_t *
 }
 
 int gpd_hip_estimate_normals(gpd_hip_ctx *ctx, double radius, float *normals) {
+  StageRange range_("gpd:estimate_normals");
   if (!ctx || !normals || !(radius > 0.0)) {
     set_error("gpd_hip_estimate_normals: bad argument");
     return GPD_ERR_INVALID;
@@ -675,6 +694,7 @@ static int search_any(gpd_hip_ctx *ctx, const char *who, const int32_t *sample_i
 }
 
 int gpd_hip_search(gpd_hip_ctx *ctx, const int32_t *sample_indices, int num_samples, gpd_hand *hands, int *num_sets) {
+  StageRange range_("gpd:search (unfused entry)");
   if (!sample_indices) {
     set_error("gpd_hip_search: bad argument");
     return GPD_ERR_INVALID;
@@ -691,6 +711,7 @@ int gpd_hip_search_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_
 }
 
 int gpd_hip_reevaluate(gpd_hip_ctx *ctx, gpd_hand *hands, int num_hands, int32_t *labels) {
+  StageRange range_("gpd:reevaluate");
   if (!ctx || num_hands < 0 || (num_hands > 0 && (!hands || !labels))) {
     set_error("gpd_hip_reevaluate: bad argument");
     return GPD_ERR_INVALID;
@@ -714,6 +735,7 @@ int gpd_hip_reevaluate(gpd_hip_ctx *ctx, gpd_hand *hands, int num_hands, int32_t
 
 int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets, uint8_t *images, int32_t *cand_index,
                    int *num_candidates) {
+  StageRange range_("gpd:images (unfused entry)");
   if (!ctx || !hands || num_sets < 0 || !num_candidates) {
     set_error("gpd_hip_images: bad argument");
     return GPD_ERR_INVALID;
@@ -861,6 +883,7 @@ int gpd_hip_detect_select(gpd_hip_ctx *ctx, const int32_t *sample_indices, int n
 }
 
 int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
+  StageRange range_("gpd:detect_batch");
   if (!ctx || num_jobs < 0 || (num_jobs > 0 && !jobs)) {
     set_error("gpd_hip_detect_batch: bad argument");
     return GPD_ERR_INVALID;
@@ -985,6 +1008,7 @@ int gpd_hip_detect_batch_multi(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect
 }
 
 int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
+  StageRange range_("gpd:replay (images + lenet on the resident list)");
   if (!ctx || !(stages & 3) || (stages & ~3)) {
     set_error("gpd_hip_replay: bad argument");
     return GPD_ERR_INVALID;

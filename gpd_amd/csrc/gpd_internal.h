@@ -7,6 +7,8 @@
 
 #include <vector>
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include "../../include/gpd_hip.h"
 
 namespace gpd {
@@ -45,6 +47,15 @@ int lenet_check(LeNetScratch &s);
 void lenet_scratch_free(LeNetScratch &s);
 
 void set_error(const char *fmt, ...);
+
+// roctx range around a stage of the path (host side: what the stage enqueues); `rocprofv3 --marker-trace --kernel-trace`
+// shows them over the kernel timeline (the reference times its stages with omp_get_wtime, grasp_detector.cpp:223-273)
+struct StageRange {
+  explicit StageRange(const char *name) { roctxRangePushA(name); }
+  ~StageRange() { roctxRangePop(); }
+  StageRange(const StageRange &) = delete;
+  StageRange &operator=(const StageRange &) = delete;
+};
 
 // ---- point-cloud preparation (preprocess.hip): workspace cut + the reference's voxeliser ------------------------
 struct PreState {

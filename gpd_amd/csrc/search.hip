@@ -402,6 +402,12 @@ struct NbParams {
   GridView grid;
   float reach;  // half-edge of the cube of cells to visit (radius + margin)
   unsigned long long *dbg;  // profiling aid (GPD_NB_TIMING=1): per-phase cycle sums of wave 0
+  // the height list of the hand search (the crop shared by a sample's orientations, see hl_note below), built by the
+  // frame wave once the frame is known; hl == nullptr: not wanted (re-evaluation)
+  float4 *hl;                       // [S][cap]: x, y, z, rank bits of the points that can be in-height for some orientation
+  int hl_slots;
+  double hl_col[GPD_MAX_SLOTS][3];  // third column of rot_binormal * rot[slot]: the slot's hand axis in the local frame
+  double hl_height, hl_radius;
 };
 
 // ---- bucket sort of the (d2, index) keys -------------------------------------------------
@@ -895,6 +901,64 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       f[10] = curv[1];
       f[11] = curv[2];
     }
+    }
+    // hl_note.  The height crop shared by the orientations of a sample: cropByHandHeight (point_list.cpp:35-55) keeps the
+    // points whose coordinate along the hand frame's third axis lies in (-h, h); that axis is the one the orientations
+    // rotate about, so the frames of a sample's slots have the same third column up to rounding.  The points with
+    // |z| < h + margin for the axis of slot 0 — margin = (largest deviation of any slot's axis from it) x radius + 1e-12,
+    // a superset of every orientation's exact crop, which hand_eval_kernel then decides with its own frame — are listed
+    // here, in neighbour order, by the wave that has just finished the frame while the other seven still gather (it
+    // reads the coordinates through the sorted indices: L2 hits).  This was a kernel of its own that read the gathered
+    // rows back from HBM (110 MB per 2564 samples).
+    if (P.hl) {
+      const int Nh = s_bounds[2];
+      auto bc = [&](double v) {  // lane 0's value to the wave
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      };
+      int total = 0;
+      if (kf > 0 && Nh > 0) {
+        // lane 0 holds the frame it has just stored: F = [normal | binormal | curvature] (hand_set.cpp:39-40)
+        const double *f = P.frames + 12 * (size_t)s;
+        double F[9];
+        __threadfence_block();
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          F[3 * r + 0] = bc(lane == 0 ? f[3 + r] : 0.0);
+          F[3 * r + 1] = bc(lane == 0 ? f[6 + r] : 0.0);
+          F[3 * r + 2] = bc(lane == 0 ? f[9 + r] : 0.0);
+        }
+        double axis[3] = {0.0, 0.0, 0.0}, dev = 0.0;
+        for (int slot = 0; slot < P.hl_slots; slot++) {
+          double a[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++)
+            a[r] = F[3 * r] * P.hl_col[slot][0] + F[3 * r + 1] * P.hl_col[slot][1] + F[3 * r + 2] * P.hl_col[slot][2];
+          if (slot == 0) {
+            axis[0] = a[0];
+            axis[1] = a[1];
+            axis[2] = a[2];
+          }
+          dev = fmax(dev, fabs(a[0] - axis[0]) + fabs(a[1] - axis[1]) + fabs(a[2] - axis[2]));
+        }
+        const double lim = P.hl_height + dev * P.hl_radius + 1e-12;
+        float4 *out = P.hl + (size_t)s * P.cap;
+        for (int e0 = 0; e0 < Nh; e0 += 128) {  // two entries per lane: their loads are in flight together
+          const int ea = e0 + lane, eb = e0 + 64 + lane;
+          const float4 pa = P.pxyz[index_at(ea < Nh ? ea : Nh - 1)], pb = P.pxyz[index_at(eb < Nh ? eb : Nh - 1)];
+          const double za = axis[0] * ((double)pa.x - sx) + axis[1] * ((double)pa.y - sy) + axis[2] * ((double)pa.z - sz);
+          const double zb = axis[0] * ((double)pb.x - sx) + axis[1] * ((double)pb.y - sy) + axis[2] * ((double)pb.z - sz);
+          const bool ina = ea < Nh && za > -lim && za < lim, inb = eb < Nh && zb > -lim && zb < lim;
+          const unsigned long long ba = __ballot(ina), bb = __ballot(inb);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (ina) out[total + __popcll(ba & below)] = make_float4(pa.x, pa.y, pa.z, __int_as_float(ea));
+          total += __popcll(ba);
+          if (inb) out[total + __popcll(bb & below)] = make_float4(pb.x, pb.y, pb.z, __int_as_float(eb));
+          total += __popcll(bb);
+        }
+      }
+      if (lane == 0) P.counts[8 * s + 6] = total;
     }
   }
   __syncthreads();
@@ -1763,7 +1827,7 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
 }
 
 static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, int S, int cap, bool by_xyz,
-                              hipStream_t stream, bool sync_counts) {
+                              int slots, bool want_height_list, hipStream_t stream, bool sync_counts) {
   NbParams np;
   np.px = c.px; np.py = c.py; np.pz = c.pz; np.nx = c.nx; np.ny = c.ny; np.nz = c.nz;
   np.pxyz = c.pxyz;
@@ -1787,6 +1851,14 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.num_cams = c.num_cams;
   np.grid = grid_view(c);
   np.reach = (float)r_all * 1.001f + 1e-5f;
+  np.hl = want_height_list ? s.d_hl : nullptr;
+  np.hl_slots = slots;
+  for (int slot = 0; slot < slots && slot < GPD_MAX_SLOTS; slot++)
+    for (int r = 0; r < 3; r++)  // third column of rot_binormal * rot[slot]
+      np.hl_col[slot][r] = hc.rot_binormal[3 * r] * hc.rot[slot][2] + hc.rot_binormal[3 * r + 1] * hc.rot[slot][5] +
+                           hc.rot_binormal[3 * r + 2] * hc.rot[slot][8];
+  np.hl_height = p.hand_height;
+  np.hl_radius = hc.nn_radius_hands * 1.001 + 1e-6;
   static unsigned long long *d_nbdbg = nullptr;
   np.dbg = nullptr;
   if (getenv("GPD_NB_TIMING")) {
@@ -1846,7 +1918,8 @@ static int search_join(SearchState &s, hipStream_t stream) {
 
 // neighbourhoods of S samples (by index or by coordinates), list capacity grown once if needed
 static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, const int32_t *sample_idx,
-                          const double *sample_xyz, int S, int slots, int *cap_out, hipStream_t stream, bool sync_counts = true) {
+                          const double *sample_xyz, int S, int slots, int *cap_out, hipStream_t stream, bool sync_counts = true,
+                          bool want_height_list = true) {
   int cap = s.nn_cap ? s.nn_cap : 8192;
   int rc = search_reserve(s, S, cap, slots);
   if (rc) return rc;
@@ -1855,7 +1928,7 @@ static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, c
       HIP_RET(hipMemcpyAsync(s.d_sample_xyz, sample_xyz, (size_t)S * 3 * sizeof(double), hipMemcpyHostToDevice, stream));
     else
       HIP_RET(hipMemcpyAsync(s.d_sample_idx, sample_idx, (size_t)S * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    rc = run_neighbourhoods(p, c, s, hc, S, cap, sample_xyz != nullptr, stream, sync_counts);
+    rc = run_neighbourhoods(p, c, s, hc, S, cap, sample_xyz != nullptr, slots, want_height_list, stream, sync_counts);
     if (rc) return rc;
     if (!sync_counts) break;  // the caller reads `worst found` from the plan summary and retries (search_next_capacity)
     int worst = 0;
@@ -1977,7 +2050,6 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   }
   hp.hl = s.d_hl;
   hp.radius = hc.nn_radius_hands * 1.001 + 1e-6;
-  height_list_kernel<<<S, 256, 0, stream>>>(hp, s.d_counts);
   hand_eval_kernel<<<((S + 7) / 8) * 8 * slots, 256, 0, stream>>>(hp);
   HIP_RET(hipGetLastError());
   if (hp.dbg) {
@@ -2007,7 +2079,7 @@ int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand
   for (int i = 0; i < n; i++)
     for (int r = 0; r < 3; r++) xyz[3 * (size_t)i + r] = hands[i].sample[r];
   int cap = 0;
-  int rc = neighbourhoods(p, c, s, hc, nullptr, xyz.data(), n, slots, &cap, stream);
+  int rc = neighbourhoods(p, c, s, hc, nullptr, xyz.data(), n, slots, &cap, stream, true, /*want_height_list=*/false);
   if (rc) return rc;
   std::unique_lock<std::mutex> consts_lock;  // held until the kernels that read c_hand are enqueued
   rc = upload_hand_consts(p, hc, slots, stream, consts_lock);
