@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # f32 vector == f32-input MFMA peak
 LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk (ds_read_b32 rate; 256 B/clk for b64/b128) x 2.4 GHz (MI355X_MICROARCH.md §LDS)
 LENET_MFLOP = {15: 83.04, 12: 73.63, 3: 45.41, 1: 39.14}  # SURVEY.md §8d (+ the 1-channel strategy)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
-SQ_FILE = os.path.join(ROOT, "profiles", "r02_pmc_sq.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+SQ_FILE = os.path.join(ROOT, "profiles", "r03_pmc_sq.json")
 KERNEL_SOURCES = ("gpd_amd/csrc/lenet.hip", "gpd_amd/csrc/images.hip", "gpd_amd/csrc/search.hip")
 
 CONFIGS = {  # BASELINE.json configs[1..3]
@@ -480,8 +480,8 @@ def _fc1_tile(n):
 
 
 def _pmc_traffic(n_images, channels=15):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json, produced by
-    profiles/collect_r02.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json, produced by
+    profiles/collect_r03.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
     on: when a kernel file has changed since, the numbers are stale and dropped."""
     if not os.path.exists(TRAFFIC_FILE):
         return {"note": "no PMC traffic file"}
@@ -491,7 +491,7 @@ def _pmc_traffic(n_images, channels=15):
     if d.get("source_hashes") != source_hashes():
         return {"note": "%s was measured on other kernel sources: stale, not reported" % os.path.relpath(TRAFFIC_FILE, ROOT)}
     d = d["kernels"]
-    out = {"source": "profiles/r02_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; reads x2 per "
+    out = {"source": "profiles/r03_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; reads x2 per "
                      "the gfx950 note; same kernel sources as this run, by SHA-1)"}
     fc1 = "fc1_mfma_kernel<%d>" % _fc1_tile(n_images)
 
@@ -504,18 +504,19 @@ def _pmc_traffic(n_images, channels=15):
     out["conv1_mfma"] = total(("conv1_mfma",))
     out["conv2_mfma"] = total(("conv2_mfma",))
     out["fc1_mfma"] = total((fc1,))
+    out["search"] = total(("neighbourhood_kernel<false>", "hand_eval_kernel", "plan_kernel", "centre_kernel"))
     return {k: v for k, v in out.items() if v is not None}
 
 
 def _pmc_sq():
     """LDS-array utilisation of the image kernels from the committed SQ-counter pass (profiles/pmc_sq.sh ->
-    profiles/r02_pmc_sq.json), dropped like the traffic numbers when the kernel sources have changed since."""
+    profiles/r03_pmc_sq.json), dropped like the traffic numbers when the kernel sources have changed since."""
     if not os.path.exists(SQ_FILE):
         return None
     d = json.load(open(SQ_FILE))
     if d.get("source_hashes") != source_hashes():
         return None
-    out = {"source": "profiles/r02_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
+    out = {"source": "profiles/r03_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
            "peak": "256 B/clk/CU = %.1f TB/s at 2.4 GHz" % (LDS_PEAK_GBS * 2 / 1e3)}
     for k, v in d["kernels"].items():
         for name in ("shadow_image_kernel<6144>", "grasp_image_kernel<false>", "shadow_set_kernel"):

@@ -150,8 +150,11 @@ struct __attribute__((aligned(16))) SmemShadow {
   uint32_t cells[kPix];
   uint32_t lin[SHC];  // set bits inside the box, ascending: voxel index | cell x << 17 | cell y << 23
   union {
-    uint32_t bits[VWORDS];  // candidate voxel bitset, dead once `lin` is built
-    uint16_t place[SHC];    // segment table of the counting sort
+    struct {                        // while the list is built: per row of the voxel window (a line along world z) ...
+      uint16_t rowbase[VDIM * VDIM];  // ... where its in-box voxels start in `lin`
+      uint8_t rowcnt[VDIM * VDIM];    // ... and how many they are
+    } rows;
+    uint16_t place[SHC];  // afterwards: segment table of the counting sort
   } bp;
   uint16_t nz[kPix];
   uint8_t cz[SHC];  // cell z of the list entries
@@ -677,7 +680,6 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
   load_box(P.hands[P.cand_hand[cand]], B);
   for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
   for (int i = tid; i < 128; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
-  for (int w = tid; w < VWORDS; w += IMG_THREADS) S.bp.bits[w] = 0u;
   if (tid == 0) {
     S.flag = 0;
     // voxel AABB of the image box: corners sample + F * (bx, by, bz)
@@ -711,7 +713,13 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
   __syncthreads();
   const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
   // ---- the set's shadow voxels (shadow_set_kernel) restricted to this candidate's box:
-  //      walk the AABB rows of the set bitset(s), exact f64 box test per set voxel
+  //      walk the AABB rows of the set bitset(s), exact f64 box test per set voxel.  A thread keeps the in-box voxels of
+  //      its rows (row = tid + k * 512: neighbouring rows go to neighbouring lanes) as bit masks in registers — no
+  //      candidate bitset in LDS, no atomics, nothing to zero or to count again.
+  constexpr int NROWS = VDIM * VDIM, RPT = (NROWS + IMG_THREADS - 1) / IMG_THREADS;
+  unsigned long long mask[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; k++) mask[k] = 0ull;
   if (set_ord >= 0) {
     const uint32_t *sb = P.set_bits + (size_t)set_ord * SETWORDS;
     const int ox = (int)floor(B.sample[0] * K.voxel_mult) - SR, oy = (int)floor(B.sample[1] * K.voxel_mult) - SR,
@@ -724,7 +732,10 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
       const double bz = B.F[6 + a] * K.voxel;
       invBz[a] = uniform_f64(fabs(bz) > 1e-9 ? 1.0 / bz : 0.0);
     }
-    for (int row = tid; row < VDIM * VDIM; row += IMG_THREADS) {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int row = tid + k * IMG_THREADS;
+      if (row >= NROWS) continue;
       const int ix = row / VDIM, iy = row - ix * VDIM;
       const int sx = x0 + ix - ox, sy = y0 + iy - oy;
       if ((unsigned)sx >= (unsigned)SD || (unsigned)sy >= (unsigned)SD) continue;
@@ -776,22 +787,24 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
         const int iz = za + t - zlo;
         double th[3];
         to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
-        if (in_box(B, th)) {
-          const int bit = (ix * VDIM + iy) * VDIM + iz;
-          atomicOr(&S.bp.bits[bit >> 5], 1u << (bit & 31));
-        }
+        if (in_box(B, th)) mask[k] |= 1ull << iz;
       }
     }
   }
+  // ---- ordered list of the in-box voxels (ascending voxel index = row, then z): row counts -> exclusive prefix over
+  //      the rows in row order (a thread sums RPT consecutive rows) -> every thread writes its rows' voxels
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    const int row = tid + k * IMG_THREADS;
+    if (row < NROWS) S.bp.rows.rowcnt[row] = (uint8_t)__popcll(mask[k]);
+  }
   __syncthreads();
   TICK(0);
-  // ---- ordered list of the set bits
-  constexpr int WPT = (VWORDS + IMG_THREADS - 1) / IMG_THREADS;  // words per thread, contiguous
   int cnt = 0;
 #pragma unroll
-  for (int k = 0; k < WPT; k++) {
-    const int w = tid * WPT + k;
-    if (w < VWORDS) cnt += __popc(S.bp.bits[w]);
+  for (int k = 0; k < RPT; k++) {
+    const int row = tid * RPT + k;
+    if (row < NROWS) cnt += S.bp.rows.rowcnt[row];
   }
   int n_sh;
   int pos = block_excl_scan(S, cnt, &n_sh);
@@ -806,18 +819,28 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     }
     return;
   }
-  for (int k = 0; k < WPT; k++) {
-    const int w = tid * WPT + k;
-    if (w >= VWORDS) break;
-    uint32_t bits = S.bp.bits[w];
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      if (pos < SHC) S.lin[pos] = (uint32_t)(w * 32 + b);
-      pos++;
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    const int row = tid * RPT + k;
+    if (row < NROWS) {
+      S.bp.rows.rowbase[row] = (uint16_t)pos;
+      pos += S.bp.rows.rowcnt[row];
     }
   }
-  __syncthreads();  // from here on bp.place may overwrite bp.bits
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    const int row = tid + k * IMG_THREADS;
+    if (row >= NROWS) continue;
+    unsigned long long m = mask[k];
+    int at = S.bp.rows.rowbase[row];
+    while (m) {
+      const int iz = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      S.lin[at++] = (uint32_t)(row * VDIM + iz);
+    }
+  }
+  __syncthreads();  // from here on bp.place may overwrite the row tables
   const int ns = n_sh < SHC ? n_sh : SHC;
   if (P.dbg && tid == 0) {
     atomicMax(&P.dbg[28], (unsigned long long)n_sh);
