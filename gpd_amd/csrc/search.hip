@@ -458,6 +458,8 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   __shared__ int s_count;
   __shared__ int s_bounds[3];
   __shared__ int s_seen;
+  __shared__ double s_hl_axis[4];  // height list: hand axis of slot 0 and the limit h + margin (published by the frame wave)
+  __shared__ int s_hl_n, s_hl_ready, s_hl_next, s_hl_count;
   __shared__ int s_ncrowd;
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
@@ -495,6 +497,10 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     s_bounds[1] = 0;
     s_bounds[2] = 0;
     s_seen = 0;
+    s_hl_n = 0;
+    s_hl_ready = 0;
+    s_hl_next = 0;
+    s_hl_count = 0;
     s_ncrowd = 0;
   }
   // bucket mode: two u32 arrays in the key storage, counters behind them
@@ -907,9 +913,10 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     // rotate about, so the frames of a sample's slots have the same third column up to rounding.  The points with
     // |z| < h + margin for the axis of slot 0 — margin = (largest deviation of any slot's axis from it) x radius + 1e-12,
     // a superset of every orientation's exact crop, which hand_eval_kernel then decides with its own frame — are listed
-    // here, in neighbour order, by the wave that has just finished the frame while the other seven still gather (it
-    // reads the coordinates through the sorted indices: L2 hits).  This was a kernel of its own that read the gathered
-    // rows back from HBM (110 MB per 2564 samples).
+    // in this kernel: the frame wave publishes the axis and the limit, and every wave, once it is out of the gather,
+    // takes chunks of the sorted list (coordinates through the sorted indices: L2 hits; order of the list: none, the
+    // entries carry their rank).  This was a kernel of its own that read the gathered rows back from HBM (110 MB per
+    // 2564 samples); done by the frame wave alone it made that wave the kernel's critical path (260 -> 334 us).
     if (P.hl) {
       const int Nh = s_bounds[2];
       auto bc = [&](double v) {  // lane 0's value to the wave
@@ -917,7 +924,6 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
         return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
       };
-      int total = 0;
       if (kf > 0 && Nh > 0) {
         // lane 0 holds the frame it has just stored: F = [normal | binormal | curvature] (hand_set.cpp:39-40)
         const double *f = P.frames + 12 * (size_t)s;
@@ -942,28 +948,52 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
           }
           dev = fmax(dev, fabs(a[0] - axis[0]) + fabs(a[1] - axis[1]) + fabs(a[2] - axis[2]));
         }
-        const double lim = P.hl_height + dev * P.hl_radius + 1e-12;
-        float4 *out = P.hl + (size_t)s * P.cap;
-        for (int e0 = 0; e0 < Nh; e0 += 128) {  // two entries per lane: their loads are in flight together
-          const int ea = e0 + lane, eb = e0 + 64 + lane;
-          const float4 pa = P.pxyz[index_at(ea < Nh ? ea : Nh - 1)], pb = P.pxyz[index_at(eb < Nh ? eb : Nh - 1)];
-          const double za = axis[0] * ((double)pa.x - sx) + axis[1] * ((double)pa.y - sy) + axis[2] * ((double)pa.z - sz);
-          const double zb = axis[0] * ((double)pb.x - sx) + axis[1] * ((double)pb.y - sy) + axis[2] * ((double)pb.z - sz);
-          const bool ina = ea < Nh && za > -lim && za < lim, inb = eb < Nh && zb > -lim && zb < lim;
-          const unsigned long long ba = __ballot(ina), bb = __ballot(inb);
-          const unsigned long long below = (1ull << lane) - 1ull;
-          if (ina) out[total + __popcll(ba & below)] = make_float4(pa.x, pa.y, pa.z, __int_as_float(ea));
-          total += __popcll(ba);
-          if (inb) out[total + __popcll(bb & below)] = make_float4(pb.x, pb.y, pb.z, __int_as_float(eb));
-          total += __popcll(bb);
+        if (lane == 0) {
+          s_hl_axis[0] = axis[0];
+          s_hl_axis[1] = axis[1];
+          s_hl_axis[2] = axis[2];
+          s_hl_axis[3] = P.hl_height + dev * P.hl_radius + 1e-12;
+          s_hl_n = Nh;
         }
       }
-      if (lane == 0) P.counts[8 * s + 6] = total;
+      __threadfence_block();
+      if (lane == 0) *(volatile int *)&s_hl_ready = 1;
+    }
+  }
+  // the height list itself: every wave, as it comes out of the gather (or the frame), takes chunks of 128 neighbours
+  // until none is left — the frame is long done by the time the gathering waves arrive (hl_note above)
+  if (P.hl) {
+    while (*(volatile int *)&s_hl_ready == 0) __builtin_amdgcn_s_sleep(2);
+    __threadfence_block();
+    const int Nh = *(volatile int *)&s_hl_n;
+    const double ax0 = s_hl_axis[0], ax1 = s_hl_axis[1], ax2 = s_hl_axis[2], lim = s_hl_axis[3];
+    float4 *out = P.hl + (size_t)s * P.cap;
+    for (;;) {
+      int chunk = 0;
+      if (lane == 0) chunk = atomicAdd(&s_hl_next, 1);
+      chunk = __builtin_amdgcn_readfirstlane(chunk);
+      const int e0 = chunk * 128;
+      if (e0 >= Nh) break;
+      const int ea = e0 + lane, eb = e0 + 64 + lane;  // two entries per lane: their loads are in flight together
+      const float4 pa = P.pxyz[index_at(ea < Nh ? ea : Nh - 1)], pb = P.pxyz[index_at(eb < Nh ? eb : Nh - 1)];
+      const double za = ax0 * ((double)pa.x - sx) + ax1 * ((double)pa.y - sy) + ax2 * ((double)pa.z - sz);
+      const double zb = ax0 * ((double)pb.x - sx) + ax1 * ((double)pb.y - sy) + ax2 * ((double)pb.z - sz);
+      const bool ina = ea < Nh && za > -lim && za < lim, inb = eb < Nh && zb > -lim && zb < lim;
+      const unsigned long long ba = __ballot(ina), bb = __ballot(inb);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_hl_count, __popcll(ba) + __popcll(bb));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (ina) out[base + __popcll(ba & below)] = make_float4(pa.x, pa.y, pa.z, __int_as_float(ea));
+      if (inb) out[base + __popcll(ba) + __popcll(bb & below)] = make_float4(pb.x, pb.y, pb.z, __int_as_float(eb));
     }
   }
   __syncthreads();
   NTICK(7);
-  if (tid == 0) P.counts[8 * s + 4] = s_seen;
+  if (tid == 0) {
+    P.counts[8 * s + 4] = s_seen;
+    if (P.hl) P.counts[8 * s + 6] = s_hl_count;
+  }
 #undef NTICK
 }
 
