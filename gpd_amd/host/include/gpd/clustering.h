@@ -26,10 +26,14 @@ class Clustering {
                                                               bool remove_inliers = false);
   int getMinInliers() const { return min_inliers_; }
   void setMinInliers(int m) { min_inliers_ = m; }
+  // true when the last findClusters call could not run on the device (no context, HIP error): its empty result is then
+  // a failure, not "no clusters" — callers must not mistake it for the reference's "fewer than 4 clusters" case
+  bool failed() const { return failed_; }
 
  private:
   int min_inliers_;
   gpd_hip_ctx *ctx_ = nullptr, *own_ctx_ = nullptr;
+  bool failed_ = false;
 };
 
 }  // namespace gpd

@@ -1096,6 +1096,10 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
   std::vector<std::unique_ptr<candidate::Hand>> clusters;
   if (cluster_grasps_) {
     clusters = clustering_->findClusters(hands);
+    if (clustering_->failed()) {  // a device error is not "fewer than four clusters": print-and-return-empty, as for every failure
+      printf("ERROR: the clustering step failed; no grasps returned.\n");
+      return std::vector<std::unique_ptr<candidate::Hand>>();
+    }
     printf("Found %d clusters.\n", (int)clusters.size());
     if (clusters.size() <= 3) {
       printf("Not enough clusters found! Adding all grasps from previous step.");
@@ -1280,7 +1284,10 @@ std::vector<std::unique_ptr<candidate::Hand>> SequentialImportanceSampling::dete
   std::vector<std::unique_ptr<candidate::Hand>> valid_grasps = grasp_detector_->pruneGraspCandidates(cloud, hand_set_list, min_score_);
   printf("Valid grasps: %zu\n", valid_grasps.size());
   // 4. cluster
-  if (clustering_->getMinInliers() > 0) valid_grasps = clustering_->findClusters(valid_grasps);
+  if (clustering_->getMinInliers() > 0) {
+    valid_grasps = clustering_->findClusters(valid_grasps);
+    if (clustering_->failed()) printf("ERROR: the clustering step failed; no grasps returned.\n");
+  }
   printf("Final result: found %zu grasps.\n", valid_grasps.size());
   printf("Total runtime: %3.4fs\n.\n", now_s() - t0);
   return valid_grasps;
@@ -1297,13 +1304,15 @@ Clustering::~Clustering() {
 std::vector<std::unique_ptr<candidate::Hand>> Clustering::findClusters(const std::vector<std::unique_ptr<candidate::Hand>> &hand_list,
                                                                         bool remove_inliers) {
   std::vector<std::unique_ptr<candidate::Hand>> hands_out;
+  failed_ = false;
   const int n = (int)hand_list.size();
   if (n == 0) return hands_out;
   if (!ctx_) {
     gpd_params p;
     gpd_hip_default_params(&p);
     if (gpd_hip_create(0, &p, &own_ctx_) != GPD_OK) {
-      printf("ERROR: %s\n", gpd_hip_last_error());
+      printf("ERROR: Clustering::findClusters: %s\n", gpd_hip_last_error());
+      failed_ = true;
       return hands_out;
     }
     ctx_ = own_ctx_;
@@ -1318,7 +1327,8 @@ std::vector<std::unique_ptr<candidate::Hand>> Clustering::findClusters(const std
   int k = 0;
   if (gpd_hip_find_clusters(ctx_, in.data(), scores.data(), n, min_inliers_, remove_inliers ? 1 : 0, out.data(), out_scores.data(), src.data(),
                             &k) != GPD_OK) {
-    printf("ERROR: %s\n", gpd_hip_last_error());
+    printf("ERROR: Clustering::findClusters: %s\n", gpd_hip_last_error());
+    failed_ = true;
     return hands_out;
   }
   for (int c = 0; c < k; c++) {
