@@ -61,8 +61,6 @@ constexpr int PT_CAP_BIG = 16384;  // fallback instantiation of the points kerne
 constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
 constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
 constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
-constexpr int VBITS = VDIM * VDIM * VDIM;
-constexpr int VWORDS = (VBITS + 31) / 32;
 constexpr int SR = 43;        // region reach: every image box of a set lies within 0.1233 m (41.1 voxels, so 42 whole
                               // voxels) of the sample; one more on the low side, where the box window starts
 constexpr int SD = 86;        // per-set shadow region edge in voxels: offsets -43 .. +42 from the sample's voxel.

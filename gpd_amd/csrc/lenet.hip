@@ -45,8 +45,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Zero skipping: grasp images are ~70 % zeros.  A channel in which the patches of all 64 lanes are
 // zero adds exact zeros to every chain (fmaf(w, 0, acc) == acc for finite w; acc is never -0) and
 // is skipped — decided from the patch bytes themselves (one ballot), which are fetched a channel
-// ahead anyway.  Pooled pixels are numbered strip-major (four strips of 7 columns), so a chunk is
-// a compact ~9 x 7 block: 28 % of the (chunk, channel) pairs drop out (14 % with row-major chunks;
+// ahead anyway.  Pooled pixels are numbered strip-major (strips of 8, 8, 8 and 4 columns), so a chunk is
+// a compact 8 x 8 block (strips of 7 columns, ~9 x 7 blocks, measured the same skip rate): 28 % of the (chunk, channel) pairs drop out (14 % with row-major chunks;
 // profiles/r01m_conv1_skip_stats.txt).
 // Persistent workgroups (one per CU: 142 KB of LDS) over a two-slot image ring.  Workgroup b of G takes the images
 // b, b + G, b + 2 G, ... (neighbouring candidates have similar images: dealing them out keeps the workgroups' loads
@@ -57,7 +57,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // inside a workgroup.  The two-images-per-workgroup version this replaces spent, per workgroup of 350 kcycles: 17 in the
 // prologue (images + weights), 34 with the average wave waiting for the last one at the end of the 25-task queue, and
 // another 10 % of the kernel between workgroups (dispatch, 9.77 rounds on 256 CUs): 1.69 ms for 1.30 ms of tasks.
-constexpr int C1_WAVES = 8, C1_THREADS = 64 * C1_WAVES, C1_STRIP = 7, C1_PIX = 784;
+constexpr int C1_WAVES = 8, C1_THREADS = 64 * C1_WAVES, C1_STRIP = 8, C1_PIX = 784;
+// pool1 in HBM: [n][20][28][P1_ROW] floats, rows padded from 28 to 32 — with strips of 8 columns (8, 8, 8, 4) every run of a
+// chunk's stores is one whole, aligned 32-byte sector (strips of 7 columns on 112-byte rows wrote 28-byte runs over two
+// sectors: 672 MB of write traffic for 314 MB of pool1, profiles/r02_traffic.json); 14 % more bytes, half the traffic
+constexpr int P1_ROW = 32, P1_PLANE = 28 * P1_ROW, P1_IMG = 20 * P1_PLANE;
 
 // chunks of [c0, c1) that touch image j (the number of releases its slot waits for)
 __device__ inline int c1_chunks_of_image(int j, int c0, int c1) {
@@ -143,10 +147,12 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     const int g = task * 64 + lane;
     const int gc = g < nimg * C1_PIX ? g : nimg * C1_PIX - 1;
     const int q = gc >= C1_PIX * (ia + 1) ? ia + 1 : ia, pc = gc - q * C1_PIX;
+    // strips of 8, 8, 8 and 4 columns, 28 rows each
     const int strip = pc / (28 * C1_STRIP), within = pc - strip * (28 * C1_STRIP);
-    const int py = within / C1_STRIP, px = strip * C1_STRIP + (within - py * C1_STRIP);
+    const int sw = strip < 3 ? C1_STRIP : 4;
+    const int py = within / sw, px = strip * C1_STRIP + (within - py * sw);
     // where the lane's pixel goes in pool1; -1: nothing to store
-    const int ooff = g < nimg * C1_PIX ? (first + q * stride) * 20 * C1_PIX + py * 28 + px : -1;
+    const int ooff = g < nimg * C1_PIX ? (first + q * stride) * P1_IMG + py * P1_ROW + px : -1;
     const uint8_t *base = s_img[q & 1] + (2 * py) * kImg + 2 * px;
     f32x16 acc16[4];
     f32x4 acc4[4];
@@ -235,14 +241,14 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int reg = 4 * b + r, f = 4 * (lane >> 4) + r;
-            o[f * 784 + po] = fmaxf(fmaxf(acc16[0][reg], acc16[1][reg]), fmaxf(acc16[2][reg], acc16[3][reg])) + bias[f];
+            o[f * P1_PLANE + po] = fmaxf(fmaxf(acc16[0][reg], acc16[1][reg]), fmaxf(acc16[2][reg], acc16[3][reg])) + bias[f];
           }
         }
       }
       if (ooff >= 0) {
 #pragma unroll
         for (int f = 0; f < 4; f++)
-          o[(16 + f) * 784 + ooff] = fmaxf(fmaxf(acc4[0][f], acc4[1][f]), fmaxf(acc4[2][f], acc4[3][f])) + bias[16 + f];
+          o[(16 + f) * P1_PLANE + ooff] = fmaxf(fmaxf(acc4[0][f], acc4[1][f]), fmaxf(acc4[2][f], acc4[3][f])) + bias[16 + f];
       }
     }
     // release the chunk's image(s); the wave that releases an image last refills its slot with the image two ahead
@@ -338,18 +344,22 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
   }
   // the next image's planes travel HBM -> registers while the current image is convolved (six named
   // 16-byte registers per lane: an array would live in scratch memory)
-  constexpr int IN_V = 20 * 784 / 4;
+  constexpr int IN_V = P1_IMG / 4;  // float4 of one image in HBM (rows padded to 32 floats: the eighth float4 of a row is padding)
   static_assert(IN_V <= 6 * C2_THREADS, "prefetch registers");
   float4 p0, p1, p2, p3, p4, p5;
   p0 = p1 = p2 = p3 = p4 = p5 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define C2_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #define C2_FETCH1(v) \
   if (tid + v * C2_THREADS < IN_V) p##v = fsrc[tid + v * C2_THREADS];
-#define C2_STAGE1(v) \
-  if (tid + v * C2_THREADS < IN_V) reinterpret_cast<float4 *>(s_in)[tid + v * C2_THREADS] = p##v;
+#define C2_STAGE1(v)                                                                                              \
+  {                                                                                                               \
+    const int iv = tid + v * C2_THREADS, pc_ = iv / (P1_PLANE / 4), rem_ = iv - pc_ * (P1_PLANE / 4);             \
+    const int row_ = rem_ >> 3, q_ = rem_ & 7;                                                                    \
+    if (iv < IN_V && q_ < 7) *reinterpret_cast<float4 *>(s_in + pc_ * 784 + row_ * 28 + 4 * q_) = p##v;           \
+  }
 #define C2_FETCH(IMG)                                                                              \
   {                                                                                                \
-    const float4 *fsrc = reinterpret_cast<const float4 *>(pool1 + (size_t)(IMG) * 20 * 784);       \
+    const float4 *fsrc = reinterpret_cast<const float4 *>(pool1 + (size_t)(IMG) * P1_IMG);         \
     C2_EACH(C2_FETCH1)                                                                             \
   }
   if ((int)blockIdx.x < n) C2_FETCH(blockIdx.x)
@@ -671,7 +681,7 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   s.num_cus = num_cus;
   n += n / 4;  // slack: the clouds of a batch differ a little, every growth stalls the device
   hipError_t e;
-  if ((e = hipMalloc(&s.pool1, (size_t)n * 20 * 784 * sizeof(float))) != hipSuccess) return e;
+  if ((e = hipMalloc(&s.pool1, (size_t)n * P1_IMG * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.c1_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
