@@ -1004,43 +1004,71 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
   // The in-box points are numbered IN NEIGHBOUR ORDER (an ordered compaction: per 512 neighbours one ballot per wave
   // and a prefix over the eight wave counts), so that an entry's number is its rank among the in-box points: the
   // walks order a pixel's segment by entry number alone — no rank bits to carry, whatever the neighbourhood size.
-  int n_before = 0;  // in-box points of the earlier rounds (the same in every thread)
-  for (int i0 = 0; i0 < N; i0 += IMG_THREADS) {
-    const int i = i0 + tid;
-    double t[3] = {0, 0, 0};
-    bool in = false;
-    if (i < N) {
-      to_hand(B, (double)nn[0 * P.cap + i], (double)nn[1 * P.cap + i], (double)nn[2 * P.cap + i], t);
-      in = in_box(B, t);
-    }
-    const unsigned long long ballot = __ballot(in);
-    if (lane == 0) S.red_i[tid >> 6] = __popcll(ballot);
-    __syncthreads();
-    int base = n_before, round_total = 0;
+  // Two passes over blocks of 16 rounds (8192 neighbours): first every thread tests its 16 points — straight-line
+  // loads, all in flight together, no barrier — and the waves leave their 16 x 8 ballot counts in LDS; ONE barrier; then
+  // every thread derives the entry numbers of its in-box points from those counts and writes them.  (One round per
+  // barrier pair exposed the latency of its global loads six times per candidate: 28 of the kernel's 130 kcycles.)
+  int n_before = 0;  // in-box points of the earlier blocks (the same in every thread)
+  int *cnt = reinterpret_cast<int *>(S.cells);  // [16 + 3][IMG_WAVES] ballot counts; the cell counters are not in use yet
+  constexpr int RB = 16;
+  const int wave = tid >> 6;
+  for (int b0 = 0; b0 < N; b0 += RB * IMG_THREADS) {
+    unsigned inmask = 0;
+    const int left = N - b0, nr = left >= RB * IMG_THREADS ? RB : (left + IMG_THREADS - 1) / IMG_THREADS;  // rounds of this block
+    for (int r0 = 0; r0 < nr; r0 += 4) {  // four rounds at a time: twelve loads in flight before the first use
+      float px[4], py[4], pz[4];
 #pragma unroll
-    for (int w = 0; w < IMG_WAVES; w++) {
-      const int c = S.red_i[w];
-      if (w < (tid >> 6)) base += c;
-      round_total += c;
-    }
-    if (in) {
-      const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
-      if (e < CAP) {
-        const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
-        T(0, e) = t[0];
-        T(1, e) = t[1];
-        T(2, e) = t[2];
-        AN(e) = make_float4((float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2),
-                            (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2),
-                            (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2), __uint_as_float(cells_of(S, B, t)));
+      for (int q = 0; q < 4; q++) {
+        const int i = b0 + (r0 + q) * IMG_THREADS + tid;
+        const int ic = i < N ? i : N - 1;
+        px[q] = nn[0 * P.cap + ic];
+        py[q] = nn[1 * P.cap + ic];
+        pz[q] = nn[2 * P.cap + ic];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = r0 + q;
+        const int i = b0 + r * IMG_THREADS + tid;
+        double t[3];
+        to_hand(B, (double)px[q], (double)py[q], (double)pz[q], t);
+        const bool in = i < N && in_box(B, t);
+        const unsigned long long ballot = __ballot(in);
+        if (lane == 0) cnt[r * IMG_WAVES + wave] = __popcll(ballot);  // (rounds past nr: zeros, never read)
+        inmask |= (unsigned)in << r;
       }
     }
-    n_before += round_total;
-    __syncthreads();  // red_i is rewritten by the next round
+    __syncthreads();
+    int run = n_before;
+    for (int r = 0; r < nr; r++) {
+      int base = run;
+#pragma unroll
+      for (int w = 0; w < IMG_WAVES; w++) {
+        const int c = cnt[r * IMG_WAVES + w];
+        if (w < wave) base += c;
+        run += c;
+      }
+      const bool in = (inmask >> r) & 1u;
+      const unsigned long long ballot = __ballot(in);
+      if (in) {
+        const int i = b0 + r * IMG_THREADS + tid;
+        const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
+        if (e < CAP) {
+          double t[3];
+          to_hand(B, (double)nn[0 * P.cap + i], (double)nn[1 * P.cap + i], (double)nn[2 * P.cap + i], t);
+          const double n0 = (double)nn[3 * P.cap + i], n1 = (double)nn[4 * P.cap + i], n2 = (double)nn[5 * P.cap + i];
+          T(0, e) = t[0];
+          T(1, e) = t[1];
+          T(2, e) = t[2];
+          AN(e) = make_float4((float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2),
+                              (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2),
+                              (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2), __uint_as_float(cells_of(S, B, t)));
+        }
+      }
+    }
+    n_before = run;
+    __syncthreads();  // the counts are rewritten by the next block / the cell counters start here
   }
-  if (tid == 0) S.counter = n_before;
-  __syncthreads();
-  const int n_box_all = S.counter;
+  const int n_box_all = n_before;
   if (n_box_all > CAP) {
     // more in-box points than this instantiation holds: queue the candidate for the large one
     // (nothing has been written yet), or report it when this already is the large one
