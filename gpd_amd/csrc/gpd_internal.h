@@ -29,7 +29,7 @@ struct LeNetWeights {
 
 struct LeNetScratch {
   int capacity = 0;        // images per chunk
-  float *pool1 = nullptr;  // [cap][20][28][32]: rows padded to 32 floats (whole-sector stores, lenet.hip P1_ROW)
+  float *pool1 = nullptr;  // [cap][20][784]: planes in conv1's chunk order (whole-line stores, lenet.hip P1_PLANE)
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)

@@ -57,11 +57,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // inside a workgroup.  The two-images-per-workgroup version this replaces spent, per workgroup of 350 kcycles: 17 in the
 // prologue (images + weights), 34 with the average wave waiting for the last one at the end of the 25-task queue, and
 // another 10 % of the kernel between workgroups (dispatch, 9.77 rounds on 256 CUs): 1.69 ms for 1.30 ms of tasks.
-constexpr int C1_WAVES = 8, C1_THREADS = 64 * C1_WAVES, C1_STRIP = 8, C1_PIX = 784;
-// pool1 in HBM: [n][20][28][P1_ROW] floats, rows padded from 28 to 32 — with strips of 8 columns (8, 8, 8, 4) every run of a
-// chunk's stores is one whole, aligned 32-byte sector (strips of 7 columns on 112-byte rows wrote 28-byte runs over two
-// sectors: 672 MB of write traffic for 314 MB of pool1, profiles/r02_traffic.json); 14 % more bytes, half the traffic
-constexpr int P1_ROW = 32, P1_PLANE = 28 * P1_ROW, P1_IMG = 20 * P1_PLANE;
+constexpr int C1_WAVES = 8, C1_THREADS = 64 * C1_WAVES, C1_PIX = 784;
+// pool1 in HBM: [n][20][784] floats with the 784 pooled pixels of a plane IN CHUNK ORDER (the strip-major numbering
+// below, not row-major): the 64 pixels of a chunk are then 256 consecutive bytes per filter plane and every store of a
+// wave is whole cache lines.  (Row-major planes made a chunk's stores runs of 28-32 bytes: 672 MB of write traffic for
+// 314 MB of pool1, profiles/r02_traffic.json; rows padded to whole sectors still 614 MB.)  conv2 undoes the
+// permutation when it stages a plane into LDS (c1_pixel_of).
+constexpr int P1_PLANE = 784, P1_IMG = 20 * P1_PLANE;
+// pooled pixel (row, column) of chunk-order position pc: strips of 8, 8, 8 and 4 columns, 28 rows each
+__host__ __device__ inline void c1_pixel_of(int pc, int &py, int &px) {
+  const int strip = pc / (28 * 8), within = pc - strip * (28 * 8);
+  const int sw = strip < 3 ? 8 : 4;
+  py = within / sw;
+  px = strip * 8 + (within - py * sw);
+}
 
 // chunks of [c0, c1) that touch image j (the number of releases its slot waits for)
 __device__ inline int c1_chunks_of_image(int j, int c0, int c1) {
@@ -147,12 +156,10 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     const int g = task * 64 + lane;
     const int gc = g < nimg * C1_PIX ? g : nimg * C1_PIX - 1;
     const int q = gc >= C1_PIX * (ia + 1) ? ia + 1 : ia, pc = gc - q * C1_PIX;
-    // strips of 8, 8, 8 and 4 columns, 28 rows each
-    const int strip = pc / (28 * C1_STRIP), within = pc - strip * (28 * C1_STRIP);
-    const int sw = strip < 3 ? C1_STRIP : 4;
-    const int py = within / sw, px = strip * C1_STRIP + (within - py * sw);
+    int py, px;
+    c1_pixel_of(pc, py, px);
     // where the lane's pixel goes in pool1; -1: nothing to store
-    const int ooff = g < nimg * C1_PIX ? (first + q * stride) * P1_IMG + py * P1_ROW + px : -1;
+    const int ooff = g < nimg * C1_PIX ? (first + q * stride) * P1_IMG + pc : -1;  // chunk order: see P1_PLANE
     const uint8_t *base = s_img[q & 1] + (2 * py) * kImg + 2 * px;
     f32x16 acc16[4];
     f32x4 acc4[4];
@@ -344,18 +351,22 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
   }
   // the next image's planes travel HBM -> registers while the current image is convolved (six named
   // 16-byte registers per lane: an array would live in scratch memory)
-  constexpr int IN_V = P1_IMG / 4;  // float4 of one image in HBM (rows padded to 32 floats: the eighth float4 of a row is padding)
+  constexpr int IN_V = P1_IMG / 4;  // float4 of one image in HBM (planes in conv1's chunk order)
   static_assert(IN_V <= 6 * C2_THREADS, "prefetch registers");
   float4 p0, p1, p2, p3, p4, p5;
   p0 = p1 = p2 = p3 = p4 = p5 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define C2_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #define C2_FETCH1(v) \
   if (tid + v * C2_THREADS < IN_V) p##v = fsrc[tid + v * C2_THREADS];
-#define C2_STAGE1(v)                                                                                              \
-  {                                                                                                               \
-    const int iv = tid + v * C2_THREADS, pc_ = iv / (P1_PLANE / 4), rem_ = iv - pc_ * (P1_PLANE / 4);             \
-    const int row_ = rem_ >> 3, q_ = rem_ & 7;                                                                    \
-    if (iv < IN_V && q_ < 7) *reinterpret_cast<float4 *>(s_in + pc_ * 784 + row_ * 28 + 4 * q_) = p##v;           \
+#define C2_STAGE1(v)                                                                                         \
+  {                                                                                                          \
+    const int iv = tid + v * C2_THREADS;                                                                     \
+    if (iv < IN_V) {                                                                                         \
+      const int pl_ = iv / (P1_PLANE / 4), pc_ = 4 * (iv - pl_ * (P1_PLANE / 4));                            \
+      int py_, px_;                                                                                          \
+      c1_pixel_of(pc_, py_, px_); /* four consecutive positions = four consecutive columns of one row */     \
+      *reinterpret_cast<float4 *>(s_in + pl_ * 784 + py_ * 28 + px_) = p##v;                                 \
+    }                                                                                                        \
   }
 #define C2_FETCH(IMG)                                                                              \
   {                                                                                                \
