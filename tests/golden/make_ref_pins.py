@@ -162,6 +162,22 @@ def extras():
         print(tag, len(final), "grasps, best scores", final["score"][:3])
         det.close()
         rc.close()
+    # --- detectGrasps with the approach-direction filter and clustering (grasp_detector.cpp:247-255, 283-303, 422-453)
+    cl = synth.make_cloud(99, 12000)
+    si = synth.sample_indices(cl, 300)
+    p = default_params(15)
+    det = ref.Detector(p, weights=rcs.weights(15, trained_magnitude=True), num_selected=120, min_inliers=1, filter_approach_direction=1,
+                       direction=(0.0, 0.0, -1.0), thresh_rad=1.2)
+    rc = ref.Cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+    rc.set_sample_indices(si)
+    ref.reset_shadow_seed()
+    ref.set_product_mode(1)
+    final = det.detect(rc, 4096)
+    ref.set_product_mode(0)
+    out["dirfilter_hands"] = final.view(np.uint8)
+    print("dirfilter_e2e", len(final), "grasps")
+    det.close()
+    rc.close()
     np.savez_compressed(os.path.join(HERE, "ref_pin_extras.npz"), **out)
     print("extras:", sorted(out))
 

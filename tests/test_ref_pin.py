@@ -155,6 +155,34 @@ def test_oracle_config1_end_to_end_matches_reference_detectGrasps(oracle_mod, ta
     assert key(sel, scores) == key(rh, rh["score"])
 
 
+def test_oracle_direction_filter_and_clustering_match_reference_detectGrasps(oracle_mod):
+    """detectGrasps with filter_approach_direction = 1 and min_inliers = 1 through the reference's own GraspDetector
+    (filterGraspsWorkspace -> filterGraspsDirection -> createImages -> classifyImages -> selectGrasps -> findClusters ->
+    sort) against the oracle's stages + the direction filter in numpy (acos unclamped: a NaN angle keeps the hand)."""
+    pin = _pin("extras")
+    rh = pin["dirfilter_hands"].view(_hand_dtype()).reshape(-1)
+    cl = synth.make_cloud(99, 12000)
+    si = synth.sample_indices(cl, 300)
+    p = oracle_mod.default_params(15)
+    w = rcs.weights(15, trained_magnitude=True)
+    hands = oracle_mod.filter_workspace(p, oracle_mod.search(p, cl["xyz"], cl["normals"], si))
+    app = hands["frame"].reshape(hands.shape + (3, 3))[..., :, 0]
+    with np.errstate(invalid="ignore"):
+        ang = np.arccos(app @ np.array([0.0, 0.0, -1.0]))
+    n_before = int(hands["valid"].sum())
+    hands["valid"] &= (~(ang > 1.2)).astype(np.uint8)
+    assert 0 < hands["valid"].sum() < n_before
+    img, cand = oracle_mod.images(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], hands)
+    sc = oracle_mod.lenet(img, w)
+    flat = hands.reshape(-1)[cand]
+    keep = oracle_mod.select(sc, 120)
+    sel, ssc = flat[keep], sc[keep].astype(np.float64)
+    clusters, csc, _ = oracle_mod.find_clusters(sel, ssc, 1, False)
+    assert len(clusters) > 3 and len(clusters) == len(rh)
+    key = lambda a, s_: sorted(zip(np.asarray(s_, np.float32).tolist(), map(tuple, a["position"].tolist())))
+    assert key(clusters, csc) == key(rh, rh["score"])
+
+
 # ---- GPU suite: the HIP path against the same pins --------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(rcs.VARIANTS))
@@ -250,6 +278,36 @@ def test_hip_config1_end_to_end_matches_reference_detectGrasps():
         sel = sel[order]
         assert len(sel) == len(rh)
         assert np.array_equal(sel["score"], rh["score"]) and np.array_equal(sel["position"], rh["position"]) and np.array_equal(sel["frame"], rh["frame"])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_direction_filter_and_clustering_match_reference_detectGrasps(oracle_mod):
+    """The same pipeline through the C-ABI (the unfused route the host mirror takes when filter_approach_direction is set:
+    search -> workspace filter on the device -> direction filter on the host -> images -> scores -> select -> clusters)."""
+    from gpd_amd import api
+    pin = _pin("extras")
+    rh = pin["dirfilter_hands"].view(_hand_dtype()).reshape(-1)
+    cl = synth.make_cloud(99, 12000)
+    si = synth.sample_indices(cl, 300)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(rcs.weights(15, trained_magnitude=True))
+        ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+        hands = ctx.search(si)
+        hands["valid"] = ctx.detect(si)[0]["valid"]  # the flags after filterGraspsWorkspace, from the fused entry
+        app = hands["frame"].reshape(hands.shape + (3, 3))[..., :, 0]
+        with np.errstate(invalid="ignore"):
+            ang = np.arccos(app @ np.array([0.0, 0.0, -1.0]))
+        hands["valid"] &= (~(ang > 1.2)).astype(np.uint8)
+        img, cand = ctx.images(hands)
+        sc = ctx.score(img)
+        flat = hands.reshape(-1)[cand]
+        keep = oracle_mod.select(sc, 120)  # std::partial_sort on the scores (the fused entries do this on the device)
+        clusters, csc, _ = ctx.find_clusters(flat[keep], sc[keep].astype(np.float64), 1, False)
+        key = lambda a, s_: sorted(zip(np.asarray(s_, np.float32).tolist(), map(tuple, a["position"].tolist())))
+        assert len(clusters) == len(rh) and key(clusters, csc) == key(rh, rh["score"])
     finally:
         ctx.close()
 
