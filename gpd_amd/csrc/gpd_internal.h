@@ -271,6 +271,7 @@ struct ImageState {
   uint8_t *d_images_hwc = nullptr;    // [n][60][60][C], only when the caller downloads pixels
   uint32_t *d_set_bits = nullptr;     // [sets][SETWORDS] shadow voxel bitsets
   int num_shadow_sets = 0, cap_shadow_sets = 0;
+  bool wide = false, cap_wide = false;  // the shadow kernels' wide voxel windows (images.hip Vox<WIDE>), picked from the image volume
   int channels = 0;
   int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
   int32_t *d_pts_overflow = nullptr;  // [capacity + 1]: candidates for the large points instantiation, then their count

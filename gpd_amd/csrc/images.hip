@@ -60,12 +60,20 @@ constexpr int PT_CAP = 1024;  // in-box points per candidate on the two-per-CU i
 constexpr int PT_CAP_BIG = 16384;  // fallback instantiation of the points kernel: storage in a global scratch row
 constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
 constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
-constexpr int VDIM = 46;      // voxel AABB edge (box diagonal 0.1233 m / 3 mm + margins)
-constexpr int SR = 43;        // region reach: every image box of a set lies within 0.1233 m (41.1 voxels, so 42 whole
-                              // voxels) of the sample; one more on the low side, where the box window starts
-constexpr int SD = 86;        // per-set shadow region edge in voxels: offsets -43 .. +42 from the sample's voxel.
-                              // 86^3 bits = 79.5 KB: two shadow_set workgroups per CU (88^3 = 85 KB allowed one)
-constexpr int SETWORDS = (SD * SD * SD + 31) / 32;
+// Voxel windows of the shadow kernels.  Default geometry (image box diagonal 0.1233 m, every box of a hand set within
+// 0.1233 m of the sample): a 46^3 window per candidate and an 86^3 region per set, the latter an LDS bitset.  WIDE — picked
+// on the host for image volumes that do not fit those (images_run: up to ~0.18 m of box diagonal / 0.19 m of reach, e.g.
+// volume_width 0.16): 64^3 / 128^3, the set region filled with global-memory atomics (256 KB per set and camera).  The
+// reference has no such limits (hand_set.cpp:138); beyond WIDE the kernels still report GPD_ERR_CAPACITY.
+template <bool WIDE>
+struct Vox {
+  static constexpr int VD = WIDE ? 64 : 46;   // candidate window edge (a window row = VD bits along world z, one 64-bit word)
+  static constexpr int SD = WIDE ? 128 : 86;  // set region edge: offsets -SR .. SD - SR - 1 from the sample's voxel
+  static constexpr int SR = WIDE ? 64 : 43;   // (default: 41.1 voxels of reach -> 42 whole ones, one more on the low side;
+                                              //  86^3 bits = 79.5 KB: two shadow_set workgroups per CU)
+  static constexpr int LB = WIDE ? 18 : 17;   // bits of a voxel index inside the window
+  static constexpr int SETWORDS = (SD * SD * SD + 31) / 32;
+};
 
 struct ImgConsts {
   double vol_depth, vol_width, vol_height, half_od, dbl_h;
@@ -88,7 +96,7 @@ struct ImgParams {
   const gpd_hand *hands;      // [S][slots] records of the search
   const int32_t *cand_hand;   // [n] record of a candidate (plan_kernel)
   const int32_t *meta;    // [n][4]: sample slot, N_images, first shadow bitset (< 0: no shadow), number of bitsets (cameras)
-  const uint32_t *set_bits;  // [live sets][SETWORDS] shadow voxel bitsets (shadow_set_kernel)
+  const uint32_t *set_bits;  // [live sets][Vox::SETWORDS] shadow voxel bitsets (shadow_set_kernel)
   uint8_t *images;        // planar [n][C][3600]
   int32_t *status;
   int num_cand;              // candidates of the launch (the kernels that do not take a list)
@@ -142,15 +150,15 @@ struct __attribute__((aligned(16))) SmemPts {
 };
 typedef SmemPts<false> Smem;
 // shadow kernel: kept under 80 KB (SHC = 6144) so that two workgroups share a CU
-template <int SHC>
+template <int SHC, bool WIDE>
 struct __attribute__((aligned(16))) SmemShadow {
   float raster0[kPix];
   uint32_t cells[kPix];
-  uint32_t lin[SHC];  // set bits inside the box, ascending: voxel index | cell x << 17 | cell y << 23
+  uint32_t lin[SHC];  // set bits inside the box, ascending: voxel index | cell x << LB | cell y << (LB + 6)
   union {
     struct {                        // while the list is built: per row of the voxel window (a line along world z) ...
-      uint16_t rowbase[VDIM * VDIM];  // ... where its in-box voxels start in `lin`
-      uint8_t rowcnt[VDIM * VDIM];    // ... and how many they are
+      uint16_t rowbase[Vox<WIDE>::VD * Vox<WIDE>::VD];  // ... where its in-box voxels start in `lin`
+      uint8_t rowcnt[Vox<WIDE>::VD * Vox<WIDE>::VD];    // ... and how many they are
     } rows;
     uint16_t place[SHC];  // afterwards: segment table of the counting sort
   } bp;
@@ -665,8 +673,9 @@ __device__ __forceinline__ int xcd_candidate(int n) {
   return cand < n ? cand : -1;
 }
 
-template <int SHC>
-__device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow<SHC> &S, const int cand) {
+template <int SHC, bool WIDE>
+__device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow<SHC, WIDE> &S, const int cand) {
+  constexpr int VDIM = Vox<WIDE>::VD, SD = Vox<WIDE>::SD, SR = Vox<WIDE>::SR, LB = Vox<WIDE>::LB, SETWORDS = Vox<WIDE>::SETWORDS;
   unsigned long long t_last = __builtin_readcyclecounter();
   const ImgConsts &K = c_img;
   const int tid = threadIdx.x;
@@ -851,14 +860,14 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     double th[3];
     to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
     const uint32_t c3 = cells_of(S, B, th);
-    S.lin[k] = (uint32_t)lin | ((c3 & 0xfffu) << 17);
+    S.lin[k] = (uint32_t)lin | ((c3 & 0xfffu) << LB);
     S.cz[k] = (uint8_t)(c3 >> 12);
   }
   __syncthreads();
   TICK(1);
   auto cell_of_entry = [&](int k, int pr) {
     const uint32_t v = S.lin[k];
-    return cell_of_key(((v >> 17) & 0xfffu) | ((uint32_t)S.cz[k] << 12), pr);
+    return cell_of_key(((v >> LB) & 0xfffu) | ((uint32_t)S.cz[k] << 12), pr);
   };
   for (int pr = 0; pr < 3; pr++) {
     for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
@@ -890,7 +899,7 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
       const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
       float v = 0.f, fc = 0.f;
       auto visit = [&](int k) {  // one set voxel, in ascending voxel order (the std::set order of the oracle)
-        const int lin = (int)(S.lin[k] & 0x1ffffu);
+        const int lin = (int)(S.lin[k] & ((1u << LB) - 1u));
         const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
         const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
                      c2 = (double)(iz + z0) * K.voxel - B.sample[2];
@@ -944,19 +953,19 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
 // on the device, so the host enqueues them without waiting for it (an empty queue costs an empty launch)
 constexpr int LGRID = 256;
 
-template <int SHC>
+template <int SHC, bool WIDE>
 __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_image_kernel(ImgParams P) {
-  __shared__ SmemShadow<SHC> S;
+  __shared__ SmemShadow<SHC, WIDE> S;
   if constexpr (SHC > SH_CAP) {
     const int count = *P.cand_count;
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
       __syncthreads();  // the previous candidate's LDS is dead
-      shadow_image_body<SHC>(P, S, P.cand_list[q]);
+      shadow_image_body<SHC, WIDE>(P, S, P.cand_list[q]);
     }
   } else {
     const int cand = xcd_candidate(P.num_cand);
     if (cand < 0) return;
-    shadow_image_body<SHC>(P, S, cand);
+    shadow_image_body<SHC, WIDE>(P, S, cand);
   }
 }
 
@@ -1296,13 +1305,17 @@ struct SetParams {
   const double *centers;
   const double *frames;     // [S][12], sample first
   const int32_t *set_meta;  // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera, -
-  uint32_t *set_bits;       // [sets][SETWORDS]
+  uint32_t *set_bits;       // [sets][Vox::SETWORDS]
   double view_point[3 * kMaxCams];  // of the cloud (a kernel argument, not a device constant: clouds of a batch
                                     // with different cameras run side by side)
 };
 
+template <bool WIDE>
 __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
-  __shared__ uint32_t bits[SETWORDS];
+  constexpr int SD = Vox<WIDE>::SD, SR = Vox<WIDE>::SR, SETWORDS = Vox<WIDE>::SETWORDS;
+  // default: the region's bitset is built in LDS and written out once; WIDE (128^3 bits = 256 KB): straight into the
+  // set's global row, which the host has cleared
+  __shared__ uint32_t lds_bits[WIDE ? 1 : SETWORDS];
   const ImgConsts &K = c_img;
   const int set = blockIdx.x;
   const int tid = threadIdx.x;
@@ -1312,8 +1325,12 @@ __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
       ((unsigned long long)(uint32_t)P.set_meta[8 * set + 3] << 32) | (uint32_t)P.set_meta[8 * set + 2];
   const int cam = P.set_meta[8 * set + 4];
   const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
-  for (int w = tid; w < SETWORDS; w += SET_THREADS) bits[w] = 0u;
-  __syncthreads();
+  uint32_t *out = P.set_bits + (size_t)set * SETWORDS;
+  uint32_t *bits = WIDE ? out : lds_bits;
+  if (!WIDE) {
+    for (int w = tid; w < SETWORDS; w += SET_THREADS) lds_bits[w] = 0u;
+    __syncthreads();
+  }
   const double *smp = P.frames + 12 * (size_t)slot_s;
   const int ox = (int)floor(smp[0] * K.voxel_mult) - SR, oy = (int)floor(smp[1] * K.voxel_mult) - SR,
             oz = (int)floor(smp[2] * K.voxel_mult) - SR;
@@ -1339,9 +1356,10 @@ __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
     }
     state = K.stride_a * state + K.stride_c;  // advance by SET_THREADS * num_shadow draws
   }
-  __syncthreads();
-  uint32_t *out = P.set_bits + (size_t)set * SETWORDS;
-  for (int w = tid; w < SETWORDS; w += SET_THREADS) out[w] = bits[w];
+  if (!WIDE) {
+    __syncthreads();
+    for (int w = tid; w < SETWORDS; w += SET_THREADS) out[w] = lds_bits[w];
+  }
 }
 
 // planar [n][C][3600] <-> HWC [n][3600][C] (cv::Mat CV_8UC(C), the reference's image layout)
@@ -1451,13 +1469,26 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
     HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)(cap + 1) * sizeof(int32_t)));
     im.capacity = cap;
   }
-  if (im.num_shadow_sets > im.cap_shadow_sets) {
+  {
+    // which voxel windows the shadow kernels need (Vox<WIDE>): the window of a candidate must hold the diagonal of the
+    // image box (+ 3 voxels of margins), the region of a set every box of the set.  A box spans x in [bottom, bottom + depth]
+    // with init_bite - hand_depth <= bottom <= 0, y in center -+ width / 2 with |center| <= (outer_diameter - finger_width) / 2,
+    // |z| <= height (finger_hand.cpp:155-168, image_strategy.cpp:53-70).
+    const double vox = 0.003;
+    const double diag = std::sqrt(p.volume_depth * p.volume_depth + p.volume_width * p.volume_width + 4.0 * p.volume_height * p.volume_height);
+    const double rx = std::fmax(p.hand_depth - p.init_bite, p.volume_depth);
+    const double ry = 0.5 * (p.hand_outer_diameter - p.finger_width) + 0.5 * p.volume_width;
+    const double reach = std::sqrt(rx * rx + ry * ry + p.volume_height * p.volume_height);
+    im.wide = std::ceil(diag / vox) + 3.0 > (double)Vox<false>::VD || std::ceil(reach / vox) + 1.0 > (double)(Vox<false>::SR - 1);
+  }
+  if (im.num_shadow_sets > im.cap_shadow_sets || (im.wide && !im.cap_wide)) {
     if (im.d_set_bits) (void)hipFree(im.d_set_bits);
     im.d_set_bits = nullptr;
     im.cap_shadow_sets = 0;
     const int cap = im.num_shadow_sets + im.num_shadow_sets / 4;
-    HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * SETWORDS * sizeof(uint32_t)));
+    HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * (im.wide ? Vox<true>::SETWORDS : Vox<false>::SETWORDS) * sizeof(uint32_t)));
     im.cap_shadow_sets = cap;
+    im.cap_wide = im.wide;  // (a wide allocation also serves the default windows)
   }
   ImgConsts k;
   std::memset(&k, 0, sizeof(k));
@@ -1634,7 +1665,12 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     sp.set_meta = pl.d_set_meta;
     sp.set_bits = im.d_set_bits;
     std::memcpy(sp.view_point, im.view_points, sizeof(sp.view_point));
-    shadow_set_kernel<<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
+    if (im.wide) {
+      HIP_RET(hipMemsetAsync(im.d_set_bits, 0, (size_t)im.num_shadow_sets * Vox<true>::SETWORDS * sizeof(uint32_t), stream));
+      shadow_set_kernel<true><<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
+    } else {
+      shadow_set_kernel<false><<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
+    }
     HIP_RET(hipGetLastError());
   }
   ip.cand_list = nullptr;
@@ -1646,14 +1682,20 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     // most boxes fit the two-per-CU instantiation; the few that do not are queued by it and
     // redone by the large one
     HIP_RET(hipMemsetAsync(im.d_overflow + im.capacity, 0, sizeof(int32_t), stream));
-    shadow_image_kernel<SH_CAP><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
-    HIP_RET(hipGetLastError());
     ImgParams ib = ip;
     ib.cand_list = im.d_overflow;
     ib.cand_count = im.d_overflow + im.capacity;
     ib.overflow_list = nullptr;
     ib.overflow_count = nullptr;
-    shadow_image_kernel<SH_CAP_BIG><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
+    if (im.wide) {
+      shadow_image_kernel<SH_CAP, true><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
+      HIP_RET(hipGetLastError());
+      shadow_image_kernel<SH_CAP_BIG, true><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
+    } else {
+      shadow_image_kernel<SH_CAP, false><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
+      HIP_RET(hipGetLastError());
+      shadow_image_kernel<SH_CAP_BIG, false><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
+    }
     HIP_RET(hipGetLastError());
   }
   HIP_RET(hipEventRecord(im.ev_join, pts_stream));

@@ -34,6 +34,7 @@ VARIANTS = {
     "six_placements_wide_fingers": dict(num_finger_placements=6, finger_width=0.015),
     "small_hand": dict(hand_outer_diameter=0.09, hand_depth=0.045, hand_height=0.015, init_bite=0.008),
     "other_image_volume": dict(volume_width=0.08, volume_depth=0.05, volume_height=0.03),
+    "wide_image_volume": dict(volume_width=0.16),  # box diagonal 0.176 m: the 64^3 / 128^3 voxel windows (images.hip Vox<WIDE>)
     "friction_viable_aperture": dict(friction_coeff=35.0, min_viable=2, min_aperture=0.02, max_aperture=0.07),
     "tight_workspace": dict(workspace_grasps=[-0.1, 0.1, -0.1, 0.12, -1.0, 1.0]),
     "frame_radius": dict(nn_radius_frames=0.02),
@@ -73,9 +74,10 @@ def test_detect_matches_oracle_under_parameter_variant(oracle_mod, name):
 
 @pytest.mark.gpu
 def test_oversized_image_volume_is_refused_not_truncated(oracle_mod):
-    """An image volume whose box does not fit the shadow kernel's voxel window (46^3 voxels of 3 mm) must come
-    back as GPD_ERR_CAPACITY — the kernel would otherwise lose shadow voxels without a trace.  A volume that
-    still fits is computed and matches the oracle (covered by `other_image_volume` above)."""
+    """An image volume whose box does not fit even the wide voxel window of the shadow kernel (64^3 voxels of 3 mm: box
+    diagonals up to ~0.18 m) must come back as GPD_ERR_CAPACITY — the kernel would otherwise lose shadow voxels without
+    a trace.  Volumes that fit the default (46^3) or the wide windows are computed and match the oracle
+    (`other_image_volume`, `wide_image_volume` above)."""
     cl = synth.make_cloud(4242, 20000)
     si = synth.sample_indices(cl, 40)
     gp = _set(api.default_params(15), volume_width=0.16, volume_depth=0.10)
