@@ -1713,6 +1713,8 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     HIP_RET(hipEventCreateWithFlags(&im.ev_join, hipEventDisableTiming));
   }
   static const bool serial = getenv("GPD_IMG_SERIAL") != nullptr;  // profiling aid: each image kernel alone on the chip
+  // profiling aid: unused dynamic LDS per workgroup of the two per-candidate kernels (8192: one workgroup per CU instead of two)
+  static const size_t lds_pad = getenv("GPD_IMG_LDS_PAD") ? (size_t)atoi(getenv("GPD_IMG_LDS_PAD")) : 0;
   hipStream_t pts_stream = (im.channels == 15 && !ip.dbg && im.side_stream && !serial) ? im.aux : stream;
   if (pts_stream != stream) {
     HIP_RET(hipEventRecord(im.ev_fork, stream));
@@ -1722,7 +1724,7 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
   ip.pts_overflow_count = im.d_pts_overflow + im.capacity;
   ip.pts_scratch = nullptr;
   HIP_RET(hipMemsetAsync(im.d_pts_overflow + im.capacity, 0, sizeof(int32_t), pts_stream));
-  grasp_image_kernel<false><<<8 * ((n + 7) / 8), IMG_THREADS, 0, pts_stream>>>(ip);
+  grasp_image_kernel<false><<<8 * ((n + 7) / 8), IMG_THREADS, lds_pad, pts_stream>>>(ip);
   HIP_RET(hipGetLastError());
   {
     ImgParams ib = ip;
@@ -1772,7 +1774,7 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
       HIP_RET(hipGetLastError());
       shadow_image_kernel<SH_CAP_BIG, true><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
     } else {
-      shadow_image_kernel<SH_CAP, false><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
+      shadow_image_kernel<SH_CAP, false><<<8 * ((n + 7) / 8), IMG_THREADS, lds_pad, stream>>>(ip);
       HIP_RET(hipGetLastError());
       shadow_image_kernel<SH_CAP_BIG, false><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
     }
