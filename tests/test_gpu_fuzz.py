@@ -90,3 +90,59 @@ def test_fuzz_normals_match_oracle(oracle_mod, seed):
         assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
     finally:
         ctx.close()
+
+
+def _geometry(seed):
+    """Every knob of the hand / image geometry and of the search at once, drawn as arbitrary doubles (the shipped cfg files
+    hold round decimals): threshold tables, the correctly-rounded division by the box extents, the finger lookup table, the
+    deepen steps and the voxel windows all depend on them."""
+    rng = np.random.RandomState(77000 + seed)
+    fw = rng.uniform(0.005, 0.02)
+    od = rng.uniform(0.08, 0.14)
+    kw = dict(finger_width=fw, hand_outer_diameter=od, hand_depth=rng.uniform(0.04, 0.08), hand_height=rng.uniform(0.01, 0.03),
+              init_bite=rng.uniform(0.005, 0.015), volume_width=rng.uniform(0.06, 0.125), volume_depth=rng.uniform(0.04, 0.08),
+              volume_height=rng.uniform(0.01, 0.03), nn_radius_frames=rng.uniform(0.008, 0.02),
+              friction_coeff=rng.uniform(5.0, 40.0), min_viable=int(rng.randint(1, 12)), num_orientations=int(rng.randint(1, 9)),
+              num_finger_placements=int(rng.randint(4, 13)), deepen_hand=int(rng.rand() < 0.8))
+    if rng.rand() < 0.3:
+        kw["min_aperture"], kw["max_aperture"] = rng.uniform(0.0, 0.03), rng.uniform(0.05, 0.1)
+    axes = [int(a) for a in rng.permutation(3)[: rng.randint(1, 4)]]
+    return kw, axes, rng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_FUZZ_GEOMETRY", "6"))))
+def test_fuzz_geometry_matches_oracle(oracle_mod, seed):
+    """Random hand / image geometry on random clouds: records and images byte for byte, scores to 1e-4.
+    GPD_FUZZ_GEOMETRY=N widens the draw (soak runs; `profiles/README.md`)."""
+    kw, axes, rng = _geometry(seed)
+    c = _case(seed + 3)
+    C = c["C"]
+    w = _weights(C)
+    gp, op = api.default_params(C), oracle_mod.default_params(C)
+    for p in (gp, op):
+        for k, v in kw.items():
+            setattr(p, k, v)
+        p.num_hand_axes = len(axes)
+        for i, a in enumerate(axes):
+            p.hand_axes[i] = a
+    obj = np.flatnonzero(c["obj"])
+    si = rng.choice(obj, size=min(100, len(obj)), replace=False).astype(np.int32)
+    ctx = api.Context(gp)
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(c["xyz"], c["normals"], c["cam"], c["vp"])
+        hands, n_cand = ctx.detect(si)
+        ohands, on_cand, _ = oracle_mod.detect(op, c["xyz"], c["normals"], c["cam"], c["vp"], si, w)
+        assert hands.shape == ohands.shape and n_cand == on_cand, (kw, axes)
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4, (kw, axes)
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes(), (kw, axes)
+        fw = oracle_mod.filter_workspace(op, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(op, c["xyz"], c["normals"], c["cam"], c["vp"], fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg), (kw, axes)
+    finally:
+        ctx.close()
