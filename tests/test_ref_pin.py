@@ -370,3 +370,48 @@ def test_pins_are_what_the_live_reference_returns():
     finally:
         det.close()
         rc.close()
+
+
+def _random_geometry(seed):
+    """Every hand / image geometry knob as an arbitrary double (the same draw as tests/test_gpu_fuzz.py::_geometry)."""
+    rng = np.random.RandomState(77000 + seed)
+    kw = dict(finger_width=rng.uniform(0.005, 0.02), hand_outer_diameter=rng.uniform(0.08, 0.14), hand_depth=rng.uniform(0.04, 0.08),
+              hand_height=rng.uniform(0.01, 0.03), init_bite=rng.uniform(0.005, 0.015), volume_width=rng.uniform(0.06, 0.125),
+              volume_depth=rng.uniform(0.04, 0.08), volume_height=rng.uniform(0.01, 0.03), nn_radius_frames=rng.uniform(0.008, 0.02),
+              friction_coeff=rng.uniform(5.0, 40.0), min_viable=int(rng.randint(1, 12)), num_orientations=int(rng.randint(1, 9)),
+              num_finger_placements=int(rng.randint(4, 13)), deepen_hand=int(rng.rand() < 0.8))
+    if rng.rand() < 0.3:
+        kw["min_aperture"], kw["max_aperture"] = rng.uniform(0.0, 0.03), rng.uniform(0.05, 0.1)
+    kw["hand_axes"] = [int(a) for a in rng.permutation(3)[: rng.randint(1, 4)]]
+    return kw, rng
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_GEOMETRY", "4"))))
+def test_oracle_matches_live_reference_on_random_geometry(oracle_mod, seed):
+    """The reference's own code under arbitrary-double geometry (finger table, deepen steps, box extents, cell thresholds):
+    hands, filter, images of 1 / 3 / 12 / 15 channels.  GPD_REF_FUZZ_GEOMETRY=N widens the draw."""
+    ref = _live()
+    kw, rng = _random_geometry(seed)
+    C = int(rng.choice([15, 15, 12, 3, 1]))
+    cl = synth.make_cloud(3000 + seed, int(rng.randint(4000, 10000)), clutter=bool(rng.randint(2)))
+    si = synth.sample_indices(cl, 24, seed=seed)
+    p = rcs.set_params(oracle_mod.default_params(C), **kw)
+    ncam = 1 + seed % 3
+    cam, vp = (cl["cam_source"], cl["view_points"]) if ncam == 1 else rcs._cams(ncam, len(cl["xyz"]), seed)
+    det = ref.Detector(p)
+    rc = ref.Cloud(cl["xyz"], cl["normals"], cam, vp)
+    try:
+        rc.set_sample_indices(si)
+        rh = det.generate(rc, len(si))
+        oh = oracle_mod.search(p, cl["xyz"], cl["normals"], si)
+        assert oh.shape == rh.shape and np.array_equal(oh["valid"], rh["valid"]), kw
+        assert rcs.records_equal(oh, rh, rh["valid"].astype(bool)) == [], kw
+        rv = det.filter_workspace()
+        ohf = oracle_mod.filter_workspace(p, oh.copy())
+        assert np.array_equal(rv, ohf["valid"]), kw
+        rimg, rcand = det.images(rc, int(rv.sum()) + 1)
+        oimg, ocand = oracle_mod.images(p, cl["xyz"], cl["normals"], cam, vp, ohf)
+        assert np.array_equal(rcand, ocand) and np.array_equal(rimg, oimg), kw
+    finally:
+        det.close()
+        rc.close()
