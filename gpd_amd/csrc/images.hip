@@ -785,21 +785,31 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
       unsigned long long field = fld[k];
       field &= (nbits >= 64) ? ~0ull : ((1ull << (nbits > 0 ? nbits : 0)) - 1ull);
       if (field) {
-        // The row is a line along world z: its hand-frame coordinates are affine in z, so the part that can lie in
-        // the box is an interval, found from the three slabs and widened by 1.5 voxels.  It only spares work — the
-        // exact f64 box test below decides for every voxel that is left (the set voxels of the rows around a box
-        // are ~3x those inside it, and a lane's trip count is what its whole wave waits for).
+        // The row is a line along world z: its hand-frame coordinates are affine in z, t_a(z) = tb_a + z * bz_a, so per slab
+        // lo_a < t_a < hi_a the voxels inside form an interval of z.  Voxels at least EPS steps inside all three intervals
+        // are in the box (sure), voxels at least EPS outside one are not; only a voxel within EPS of a slab face goes
+        // through the exact f64 test of the oracle below.  EPS = 1e-3 steps is >= 1e-12 m of hand coordinate (|bz| > 1e-9)
+        // against ~1e-15 m of rounding in either evaluation, and ~1e-7 steps of error in the quotient.  (Every voxel of
+        // the interval used to be tested exactly: ~35 VALU instructions per voxel and wave trip, a sixth of the kernel's
+        // instructions — profiles/pmc_mix.sh: the kernel keeps the VALU pipe 56 % busy, it is instruction bound.)
+        constexpr double EPS = 1e-3;
         double tb[3];
         to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(za - zlo + z0) * K.voxel, tb);
-        double dmin = 0.0, dmax = (double)(nbits - 1);
+        double dmin = 0.0, dmax = (double)(nbits - 1);  // may be inside
+        double smin = 0.0, smax = (double)(nbits - 1);  // surely inside
 #pragma unroll
         for (int a = 0; a < 3; a++) {
           if (invBz[a] != 0.0) {
             const double d0 = (B.lo[a] - tb[a]) * invBz[a], d1 = (B.hi[a] - tb[a]) * invBz[a];
-            dmin = fmax(dmin, fmin(d0, d1) - 1.5);
-            dmax = fmin(dmax, fmax(d0, d1) + 1.5);
+            const double dl = fmin(d0, d1), dh = fmax(d0, d1);
+            dmin = fmax(dmin, dl - EPS);
+            dmax = fmin(dmax, dh + EPS);
+            smin = fmax(smin, dl + EPS);
+            smax = fmin(smax, dh - EPS);
           } else if (tb[a] < B.lo[a] - 1e-6 || tb[a] > B.hi[a] + 1e-6) {
-            dmax = -1.0;  // the row runs parallel to this slab, outside it
+            dmax = -1.0;  // the row runs parallel to this slab (it moves < 1e-7 m over its 64 voxels), outside it
+          } else if (!(tb[a] > B.lo[a] + 1e-6 && tb[a] < B.hi[a] - 1e-6)) {
+            smax = -1.0;  // parallel and within a micrometre of a face: every voxel of the row is tested
           }
         }
         if (dmax < dmin) {
@@ -808,6 +818,16 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
           const int t0 = (int)ceil(dmin), t1 = (int)floor(dmax);
           if (t0 > 0) field &= ~((1ull << t0) - 1ull);
           if (t1 < 63) field &= (2ull << t1) - 1ull;
+          if (smax >= smin) {
+            const int u0 = (int)ceil(smin), u1 = (int)floor(smax);
+            if (u1 >= u0) {
+              unsigned long long sure = field;
+              if (u0 > 0) sure &= ~((1ull << u0) - 1ull);
+              if (u1 < 63) sure &= (2ull << u1) - 1ull;
+              mask[k] |= sure << (za - zlo);
+              field &= ~sure;
+            }
+          }
         }
       }
       while (field) {
