@@ -71,7 +71,7 @@ struct Vox {
   static constexpr int SD = WIDE ? 128 : 86;  // set region edge: offsets -SR .. SD - SR - 1 from the sample's voxel
   static constexpr int SR = WIDE ? 64 : 43;   // (default: 41.1 voxels of reach -> 42 whole ones, one more on the low side;
                                               //  86^3 bits = 79.5 KB: two shadow_set workgroups per CU)
-  static constexpr int LB = WIDE ? 18 : 17;   // bits of a voxel index inside the window
+  static constexpr int LB = 18;               // bits of a voxel position inside the window: iz | iy << 6 | ix << 12 (ascending = lexicographic)
   static constexpr int SETWORDS = (SD * SD * SD + 31) / 32;
 };
 
@@ -108,6 +108,7 @@ struct ImgParams {
   int32_t *pts_overflow_list;   // points kernel: candidates with more than PT_CAP in-box points
   int32_t *pts_overflow_count;
   char *pts_scratch;            // fallback instantiation: PTS_SCRATCH_BYTES per listed candidate
+  int exit_after;               // profiling aid (GPD_IMG_EXIT=k): leave the kernel after phase k (0: run to the end)
 };
 
 struct Box {
@@ -136,7 +137,7 @@ struct NoPointArrays {};
 template <bool BIG>
 struct __attribute__((aligned(16))) SmemPts {
   typename std::conditional<BIG, NoPointArrays, PointArrays>::type p;
-  uint32_t cells[kPix];   // (segment start << 16) | count of a pixel; after the walks: the f32 plane being finished
+  __attribute__((aligned(16))) uint32_t cells[kPix];   // (segment start << 16) | count of a pixel; after the walks: the index raster, then the staged bytes
   uint16_t place[BIG ? PT_CAP_BIG : PT_CAP];  // segment table: entry numbers (entries are numbered in neighbour order)
   float4 nzv[(BIG ? kPix : PT_CAP) + 1];      // slot 0: the empty pixel (zeros); slot q + 1: the three normal values and the
                                               // depth value of the q-th non-empty pixel
@@ -152,9 +153,9 @@ typedef SmemPts<false> Smem;
 // shadow kernel: kept under 80 KB (SHC = 6144) so that two workgroups share a CU
 template <int SHC, bool WIDE>
 struct __attribute__((aligned(16))) SmemShadow {
-  float raster0[kPix];
-  uint32_t cells[kPix];
-  uint32_t lin[SHC];  // set bits inside the box, ascending: voxel index | cell x << LB | cell y << (LB + 6)
+  __attribute__((aligned(16))) float raster0[kPix];
+  __attribute__((aligned(16))) uint32_t cells[kPix];
+  uint32_t lin[SHC];  // set bits inside the box, ascending: voxel position (iz | iy << 6 | ix << 12) | cell x << LB | cell y << (LB + 6)
   union {
     struct {                        // while the list is built: per row of the voxel window (a line along world z) ...
       uint16_t rowbase[Vox<WIDE>::VD * Vox<WIDE>::VD];  // ... where its in-box voxels start in `lin`
@@ -197,8 +198,15 @@ template <class SM>
 __device__ inline int cell_coord(const SM &S, int axis, double x) {
   int k = (int)(x * c_img.inv_cell[axis]);
   k = k < 0 ? 0 : (k > kImg - 1 ? kImg - 1 : k);
-  while (k > 0 && x < S.thr[axis][k]) k--;
-  while (k < kImg - 1 && x >= S.thr[axis][k + 1]) k++;
+  // both neighbours of the guess at once (one LDS round trip; the guess is off by one at most, the loops are for the proof)
+  const double t0 = S.thr[axis][k], t1 = S.thr[axis][k + 1];
+  if (k > 0 && x < t0) {
+    k--;
+    while (k > 0 && x < S.thr[axis][k]) k--;
+  } else if (k < kImg - 1 && x >= t1) {
+    k++;
+    while (k < kImg - 1 && x >= S.thr[axis][k + 1]) k++;
+  }
   return k;
 }
 template <class SM>
@@ -282,22 +290,30 @@ __device__ inline int block_excl_scan(SM &S, int v, int *total) {
 template <class SM>
 __device__ int scan_cells(SM &S) {
   const int tid = threadIdx.x;
-  constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;  // 4
-  int c[PER];
+  constexpr int PER = 8;  // consecutive cells per thread: two 16-byte LDS accesses each way (450 threads hold the 3600 cells)
+  static_assert(kPix % PER == 0 && kPix / PER <= IMG_THREADS, "scan_cells: cells per thread");
+  uint4 *c4 = reinterpret_cast<uint4 *>(S.cells);
+  uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
+  if (tid < kPix / PER) {
+    a = c4[2 * tid];
+    b = c4[2 * tid + 1];
+  }
+  const int c[PER] = {(int)(a.x & 0xffffu), (int)(a.y & 0xffffu), (int)(a.z & 0xffffu), (int)(a.w & 0xffffu),
+                      (int)(b.x & 0xffffu), (int)(b.y & 0xffffu), (int)(b.z & 0xffffu), (int)(b.w & 0xffffu)};
   int sum = 0;
 #pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const int i = tid * PER + k;
-    c[k] = i < kPix ? (int)(S.cells[i] & 0xffffu) : 0;
-    sum += c[k];
-  }
+  for (int k = 0; k < PER; k++) sum += c[k];
   int total;
   int run = block_excl_scan(S, sum, &total);
+  uint32_t o[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    const int i = tid * PER + k;
-    if (i < kPix) S.cells[i] = (uint32_t)(run < 0xffff ? run : 0xffff) << 16;
+    o[k] = (uint32_t)(run < 0xffff ? run : 0xffff) << 16;
     run += c[k];
+  }
+  if (tid < kPix / PER) {
+    c4[2 * tid] = make_uint4(o[0], o[1], o[2], o[3]);
+    c4[2 * tid + 1] = make_uint4(o[4], o[5], o[6], o[7]);
   }
   __syncthreads();
   return total;
@@ -629,6 +645,14 @@ __device__ inline void sort_u16_regs(uint16_t *p, int n) {
   for (int q = 0; q < N; q++)
     if (q < n) p[q] = (uint16_t)k[q];
 }
+// profiling build only (make EXTRA=-DGPD_IMG_EXITS, profiles/img_phases.sh): the early returns cost the shipped kernels
+// 11-24 spilled registers
+#ifdef GPD_IMG_EXITS
+#define EXIT_AT(k) \
+  if (P.exit_after == (k)) return
+#else
+#define EXIT_AT(k)
+#endif
 #define TICK(k)                                                     \
   do {                                                              \
     if (P.dbg && tid == 0) {                                        \
@@ -849,6 +873,7 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
   }
   __syncthreads();
   TICK(0);
+  EXIT_AT(1);
   int cnt = 0;
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
@@ -883,10 +908,12 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     if (row >= NROWS) continue;
     unsigned long long m = mask[k];
     int at = S.bp.rows.rowbase[row];
+    const int rx = row / VDIM, ry = row - rx * VDIM;
+    const uint32_t rowpos = ((uint32_t)rx << 12) | ((uint32_t)ry << 6);  // shifts instead of divisions wherever it is read
     while (m) {
       const int iz = __ffsll((long long)m) - 1;
       m &= m - 1;
-      S.lin[at++] = (uint32_t)(row * VDIM + iz);
+      S.lin[at++] = rowpos | (uint32_t)iz;
     }
   }
   __syncthreads();  // from here on bp.place may overwrite the row tables
@@ -898,7 +925,7 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
   // the three cell coordinates of every entry, once: voxel -> hand frame -> exact threshold lookup
   for (int k = tid; k < ns; k += IMG_THREADS) {
     const int lin = (int)S.lin[k];
-    const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
+    const int ix = lin >> 12, iy = (lin >> 6) & 63, iz = lin & 63;
     double th[3];
     to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
     const uint32_t c3 = cells_of(S, B, th);
@@ -907,12 +934,13 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
   }
   __syncthreads();
   TICK(1);
+  EXIT_AT(2);
   auto cell_of_entry = [&](int k, int pr) {
     const uint32_t v = S.lin[k];
     return cell_of_key(((v >> LB) & 0xfffu) | ((uint32_t)S.cz[k] << 12), pr);
   };
   for (int pr = 0; pr < 3; pr++) {
-    for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
+    for (int c = tid; c < kPix / 4; c += IMG_THREADS) reinterpret_cast<uint4 *>(S.cells)[c] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     for (int k = tid; k < ns; k += IMG_THREADS) atomicAdd(&S.cells[cell_of_entry(k, pr)], 1u);
     __syncthreads();
@@ -923,6 +951,7 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     }
     __syncthreads();
     TICK(2);
+    if (pr == 0) EXIT_AT(3);
     const int da = depth_axis(pr);
     // column `da` of F and the matching offset, selected without indexing the register-resident box
     const double Fd0 = da == 0 ? B.F[0] : (da == 1 ? B.F[1] : B.F[2]);
@@ -932,9 +961,10 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     float lmax = -FLT_MAX;
     int lany = 0;
     const int n_nz = list_nonempty_cells(S, S.nz);
-    for (int c = tid; c < kPix; c += IMG_THREADS) S.raster0[c] = 0.f;
+    for (int c = tid; c < kPix / 4; c += IMG_THREADS) reinterpret_cast<float4 *>(S.raster0)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     TICK(9);
+    if (pr == 0) EXIT_AT(4);
     for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
       const int c = S.nz[qn];
       const uint32_t w = S.cells[c];
@@ -942,7 +972,7 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
       float v = 0.f, fc = 0.f;
       auto visit = [&](int k) {  // one set voxel, in ascending voxel order (the std::set order of the oracle)
         const int lin = (int)(S.lin[k] & ((1u << LB) - 1u));
-        const int ix = lin / (VDIM * VDIM), iy = (lin / VDIM) % VDIM, iz = lin % VDIM;
+        const int ix = lin >> 12, iy = (lin >> 6) & 63, iz = lin & 63;
         const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
                      c2 = (double)(iz + z0) * K.voxel - B.sample[2];
         const double td = Fd0 * c0 + Fd1 * c1 + Fd2 * c2;
@@ -958,6 +988,7 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     }
     __syncthreads();
     TICK(10);
+    if (pr == 0) EXIT_AT(5);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       lmax = fmaxf(lmax, __shfl_xor(lmax, o));
@@ -987,6 +1018,8 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     TICK(3);
     finalize_planes<1>(S, &S.raster0[0], nullptr, out + (size_t)(pr * K.per + 4) * kPix);
     TICK(4);
+    if (pr == 0) EXIT_AT(6);
+    if (pr == 1) EXIT_AT(7);
   }
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
@@ -1090,46 +1123,19 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     }
     __syncthreads();
     int run = n_before;
-    for (int r0 = 0; r0 < nr; r0 += 4) {  // four rounds at a time: the entry numbers, then 24 loads in flight, then the entries
-      int ent[4];                         // (one round per iteration was a dependent global round trip per round)
+    for (int r = 0; r < nr; r++) {  // entry numbers of the thread's in-box points: their neighbour indices go to the list
+      int base = run;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int r = r0 + q;
-        int base = run;
-        if (r < nr) {
-#pragma unroll
-          for (int w = 0; w < IMG_WAVES; w++) {
-            const int c = cnt[r * IMG_WAVES + w];
-            if (w < wave) base += c;
-            run += c;
-          }
-        }
-        const bool in = r < nr && ((inmask >> r) & 1u);
-        const unsigned long long ballot = __ballot(in);
+      for (int w = 0; w < IMG_WAVES; w++) {
+        const int c = cnt[r * IMG_WAVES + w];
+        if (w < wave) base += c;
+        run += c;
+      }
+      const bool in = (inmask >> r) & 1u;
+      const unsigned long long ballot = __ballot(in);
+      if (in) {
         const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        ent[q] = in && e < CAP ? e : -1;
-      }
-      float v[4][6];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int i = ent[q] >= 0 ? b0 + (r0 + q) * IMG_THREADS + tid : 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) v[q][a] = nn[a * P.cap + i];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int e = ent[q];
-        if (e >= 0) {
-          double t[3];
-          to_hand(B, (double)v[q][0], (double)v[q][1], (double)v[q][2], t);
-          const double n0 = (double)v[q][3], n1 = (double)v[q][4], n2 = (double)v[q][5];
-          T(0, e) = t[0];
-          T(1, e) = t[1];
-          T(2, e) = t[2];
-          AN(e) = make_float4((float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2),
-                              (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2),
-                              (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2), __uint_as_float(cells_of(S, B, t)));
-        }
+        if (e < CAP) S.place[e] = (uint16_t)(b0 + r * IMG_THREADS + tid);
       }
     }
     n_before = run;
@@ -1147,6 +1153,35 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     }
     return;
   }
+  // The entries themselves, densely: one in-box point per lane (hand-frame coordinates, |normal| in the hand frame, the
+  // three cell coordinates: ~150 instructions) — inside the rounds above a wave paid them per round for the one lane
+  // in seven that was in the box (a sixth of the kernel's instructions; it is instruction bound, profiles/pmc_mix.sh).
+  for (int e0 = 0; e0 < n_box_all; e0 += 2 * IMG_THREADS) {
+    float v[2][6];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int e = e0 + q * IMG_THREADS + tid;
+      const int i = e < n_box_all ? (int)S.place[e] : 0;
+#pragma unroll
+      for (int a = 0; a < 6; a++) v[q][a] = nn[a * P.cap + i];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int e = e0 + q * IMG_THREADS + tid;
+      if (e < n_box_all) {
+        double t[3];
+        to_hand(B, (double)v[q][0], (double)v[q][1], (double)v[q][2], t);
+        const double n0 = (double)v[q][3], n1 = (double)v[q][4], n2 = (double)v[q][5];
+        T(0, e) = t[0];
+        T(1, e) = t[1];
+        T(2, e) = t[2];
+        AN(e) = make_float4((float)fabs(B.F[0] * n0 + B.F[3] * n1 + B.F[6] * n2),
+                            (float)fabs(B.F[1] * n0 + B.F[4] * n1 + B.F[7] * n2),
+                            (float)fabs(B.F[2] * n0 + B.F[5] * n1 + B.F[8] * n2), __uint_as_float(cells_of(S, B, t)));
+      }
+    }
+  }
+  // (the index list lives in the segment table; the first projection rewrites it two barriers from here)
   if constexpr (BIG) {
     __threadfence_block();  // the point arrays are global memory here: written above, read by other lanes below
     __syncthreads();
@@ -1157,8 +1192,9 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     atomicAdd(&P.dbg[31], (unsigned long long)n_box_all);
   }
   TICK(5);
+  EXIT_AT(11);
   for (int pr = 0; pr < K.nproj; pr++) {
-    for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
+    for (int c = tid; c < kPix / 4; c += IMG_THREADS) reinterpret_cast<uint4 *>(S.cells)[c] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(__float_as_uint(AN(e).w), pr)], 1u);
     __syncthreads();
@@ -1170,12 +1206,14 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     }
     __syncthreads();
     TICK(6);
+    if (pr == 0) EXIT_AT(12);
     // the pixel owner walks its segment in neighbour order
     const int da = depth_axis(pr);
     const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
     uint16_t *nz = S.nzlist;
     const int n_nz = list_nonempty_cells(S, nz);
     TICK(11);
+    if (pr == 0) EXIT_AT(13);
     for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
       const int c = nz[qn];
       const uint32_t w = S.cells[c];
@@ -1209,6 +1247,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     TICK(13);
     __syncthreads();
     TICK(7);
+    if (pr == 0) EXIT_AT(14);
     // ---- the four planes of the projection at once.  `cells` is now an index raster: bit 31 set <-> the pixel holds
     //      points, low bits = its slot in nzv (float4: the three normal values and the depth value); every other word has
     //      bit 31 clear (segment starts are < 2^15) and stands for the empty pixel, slot 0 = zeros.  A group of four pixels
@@ -1259,6 +1298,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       }
     }
     __syncthreads();
+    if (pr == 0) EXIT_AT(21);
     const int n_live = S.counter;
     float d[GPT][4][4];  // the thread's live groups alist[tid + k * IMG_THREADS]: [plane][pixel]
     float mn0 = FLT_MAX, mx0 = -FLT_MAX, mn1 = FLT_MAX, mx1 = -FLT_MAX;
@@ -1299,6 +1339,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
         }
       }
     }
+    if (pr == 0) EXIT_AT(22);
     // createNormalsImage: the three planes are normalised as ONE 3-channel image; createDepthImage on its own
     // (image_strategy.cpp:144-153, 178-187; Image1ChannelsStrategy is the depth plane alone)
 #pragma unroll
@@ -1339,19 +1380,21 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       fb[q] = (float)shift;
       bg[q] = to_byte(0.f, fs[q], fb[q]) * 0x01010101u;  // four background pixels: the value 0 through the same arithmetic
     }
-    // image row = 59 - cell row (image_strategy.cpp:128-129)
-    auto store_group = [&](int g, int pl, uint32_t packed) {
-      const int r = g / 15, c0 = (g - r * 15) * 4;
-      const int ch = K.C == 1 ? 0 : pr * K.per + pl;
-      *reinterpret_cast<uint32_t *>(out + (size_t)ch * kPix + (kImg - 1 - r) * kImg + c0) = packed;
+    if (pr == 0) EXIT_AT(23);
+    // The bytes are staged in LDS — the index raster is dead after the barrier above: 4 planes x 900 dwords in MEMORY order
+    // (image row = 59 - cell row, image_strategy.cpp:128-129) — and leave as 16-byte stores, 15 per wave instead of 56
+    // four-byte ones (the store phase was issue bound: 36 of the 158 us a projection costs, profiles/img_phases.sh).
+    uint32_t *stage = S.cells;
+    auto stage_group = [&](int g, int pl, uint32_t packed) {
+      const int r = g / 15, cg = g - r * 15;
+      stage[pl * 900 + (kImg - 1 - r) * 15 + cg] = packed;
     };
 #pragma unroll
     for (int k = 0; k < GPT; k++) {
       const int g = tid + k * IMG_THREADS;
       if (g < 900 && !live[k]) {
 #pragma unroll
-        for (int pl = 0; pl < 4; pl++)
-          if (pl < 3 ? with_normals : with_depth) store_group(g, pl, bg[pl < 3 ? 0 : 1]);
+        for (int pl = 0; pl < 4; pl++) stage_group(g, pl, bg[pl < 3 ? 0 : 1]);
       }
     }
 #pragma unroll
@@ -1361,17 +1404,26 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
         const int g = (int)alist[a];
 #pragma unroll
         for (int pl = 0; pl < 4; pl++) {
-          if (pl < 3 ? !with_normals : !with_depth) continue;
           const int q = pl < 3 ? 0 : 1;
           uint32_t packed = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) packed |= to_byte(d[k][pl][j], fs[q], fb[q]) << (8 * j);
-          store_group(g, pl, packed);
+          stage_group(g, pl, packed);
         }
       }
     }
     __syncthreads();
+    for (int a = tid; a < 900; a += IMG_THREADS) {
+      const int pl = a / 225, j = a - pl * 225;
+      if (pl < 3 ? !with_normals : !with_depth) continue;
+      const int ch = K.C == 1 ? 0 : pr * K.per + pl;
+      *reinterpret_cast<uint4 *>(out + (size_t)ch * kPix + 16 * j) = reinterpret_cast<const uint4 *>(stage)[pl * 225 + j];
+    }
+    if (pr == 0) EXIT_AT(24);
+    __syncthreads();
     TICK(8);
+    if (pr == 0) EXIT_AT(15);
+    if (pr == 1) EXIT_AT(16);
   }
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
@@ -1713,6 +1765,7 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
   ip.status = im.d_status;
   static unsigned long long *d_dbg = nullptr;
   ip.dbg = nullptr;
+  ip.exit_after = getenv("GPD_IMG_EXIT") ? atoi(getenv("GPD_IMG_EXIT")) : 0;
   if (getenv("GPD_IMG_TIMING")) {
     if (!d_dbg) HIP_RET(hipMalloc(&d_dbg, 32 * sizeof(unsigned long long)));
     HIP_RET(hipMemsetAsync(d_dbg, 0, 32 * sizeof(unsigned long long), stream));
