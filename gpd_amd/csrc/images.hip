@@ -182,6 +182,26 @@ __device__ inline double uniform_f64(double v) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// wave-wide max / min of a float, the result in every lane: four DPP steps inside the rows of 16 lanes, two row
+// broadcasts, one v_readlane — 7 VALU instructions where six __shfl_xor steps are 6 ds_bpermute + ~25 VALU.  (A lane
+// whose DPP source is masked keeps its own value: max(v, v) = v.)
+template <class OP>
+__device__ inline float wave_reduce_f32(float v, OP op) {
+  auto dpp = [](float x, auto ctrl, auto rmask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+  };
+  using std::integral_constant;
+  v = op(v, dpp(v, integral_constant<int, 0xB1>(), integral_constant<int, 0xf>()));   // quad_perm [1,0,3,2]
+  v = op(v, dpp(v, integral_constant<int, 0x4E>(), integral_constant<int, 0xf>()));   // quad_perm [2,3,0,1]
+  v = op(v, dpp(v, integral_constant<int, 0x141>(), integral_constant<int, 0xf>()));  // row_half_mirror
+  v = op(v, dpp(v, integral_constant<int, 0x140>(), integral_constant<int, 0xf>()));  // row_mirror
+  v = op(v, dpp(v, integral_constant<int, 0x142>(), integral_constant<int, 0xa>()));  // row_bcast:15 into rows 1, 3
+  v = op(v, dpp(v, integral_constant<int, 0x143>(), integral_constant<int, 0xc>()));  // row_bcast:31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ inline float wave_max_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ inline float wave_min_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fminf(a, b); }); }
+
 // hand-frame coordinates of a world point: t = F^T (w - sample)  (image_strategy.cpp:36-40)
 __device__ inline void to_hand(const Box &B, double w0, double w1, double w2, double t[3]) {
   const double c0 = w0 - B.sample[0], c1 = w1 - B.sample[1], c2 = w2 - B.sample[2];
@@ -407,12 +427,9 @@ __device__ void finalize_planes(SM &S, const float *p012, const float *p3, uint8
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      mn[q] = fminf(mn[q], __shfl_xor(mn[q], o));
-      mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o));
-    }
+  for (int q = 0; q < 2; q++) {
+    mn[q] = wave_min_f32(mn[q]);
+    mx[q] = wave_max_f32(mx[q]);
   }
   __syncthreads();
   if ((tid & 63) == 0) {
@@ -492,11 +509,8 @@ __device__ inline void dilate_plane(const float *pl, float (&d)[GPT][4], float &
 template <class SM>
 __device__ inline void minmax_scale(SM &S, float mn, float mx, float &fs, float &fb) {
   const int tid = threadIdx.x;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, o));
-    mx = fmaxf(mx, __shfl_xor(mx, o));
-  }
+  mn = wave_min_f32(mn);
+  mx = wave_max_f32(mx);
   __syncthreads();
   if ((tid & 63) == 0) {
     S.red_f[2 * (tid >> 6)] = mn;
@@ -989,11 +1003,8 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     __syncthreads();
     TICK(10);
     if (pr == 0) EXIT_AT(5);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-      lany |= __shfl_xor(lany, o);
-    }
+    lmax = wave_max_f32(lmax);
+    lany = __ballot(lany != 0) != 0ull;
     __syncthreads();
     if (lane == 0) {
       S.red_f[tid >> 6] = lmax;
@@ -1193,12 +1204,15 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
   }
   TICK(5);
   EXIT_AT(11);
+  for (int c = tid; c < kPix / 4; c += IMG_THREADS) reinterpret_cast<uint4 *>(S.cells)[c] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
   for (int pr = 0; pr < K.nproj; pr++) {
-    for (int c = tid; c < kPix / 4; c += IMG_THREADS) reinterpret_cast<uint4 *>(S.cells)[c] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
+    // (the cell counters are zero: cleared above, then by the copy-out of the previous projection)
     for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(__float_as_uint(AN(e).w), pr)], 1u);
     __syncthreads();
+    if (pr == 0) EXIT_AT(31);
     scan_cells(S);
+    if (pr == 0) EXIT_AT(32);
     for (int e = tid; e < nb; e += IMG_THREADS) {
       const uint32_t key = __float_as_uint(AN(e).w);
       const uint32_t old = atomicAdd(&S.cells[cell_of_key(key, pr)], 1u);
@@ -1342,12 +1356,11 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     if (pr == 0) EXIT_AT(22);
     // createNormalsImage: the three planes are normalised as ONE 3-channel image; createDepthImage on its own
     // (image_strategy.cpp:144-153, 178-187; Image1ChannelsStrategy is the depth plane alone)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mn0 = fminf(mn0, __shfl_xor(mn0, o));
-      mx0 = fmaxf(mx0, __shfl_xor(mx0, o));
-      mn1 = fminf(mn1, __shfl_xor(mn1, o));
-      mx1 = fmaxf(mx1, __shfl_xor(mx1, o));
+    if (64 * (tid >> 6) < n_live) {  // (a wave without a live group holds the initial values in every lane)
+      mn0 = wave_min_f32(mn0);
+      mx0 = wave_max_f32(mx0);
+      mn1 = wave_min_f32(mn1);
+      mx1 = wave_max_f32(mx1);
     }
     if (lane == 0) {
       S.red_f[4 * (tid >> 6) + 0] = mn0;
@@ -1385,39 +1398,37 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     // (image row = 59 - cell row, image_strategy.cpp:128-129) — and leave as 16-byte stores, 15 per wave instead of 56
     // four-byte ones (the store phase was issue bound: 36 of the 158 us a projection costs, profiles/img_phases.sh).
     uint32_t *stage = S.cells;
-    auto stage_group = [&](int g, int pl, uint32_t packed) {
-      const int r = g / 15, cg = g - r * 15;
-      stage[pl * 900 + (kImg - 1 - r) * 15 + cg] = packed;
-    };
-#pragma unroll
-    for (int k = 0; k < GPT; k++) {
-      const int g = tid + k * IMG_THREADS;
-      if (g < 900 && !live[k]) {
-#pragma unroll
-        for (int pl = 0; pl < 4; pl++) stage_group(g, pl, bg[pl < 3 ? 0 : 1]);
-      }
+    uint4 *stage4 = reinterpret_cast<uint4 *>(S.cells);
+    for (int c = tid; c < 900; c += IMG_THREADS) {  // every pixel background ...
+      const uint32_t w = bg[c < 3 * 225 ? 0 : 1];
+      stage4[c] = make_uint4(w, w, w, w);
     }
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < GPT; k++) {
+    for (int k = 0; k < GPT; k++) {  // ... the live groups over it
       const int a = tid + k * IMG_THREADS;
       if (a < n_live) {
         const int g = (int)alist[a];
+        const int r = g / 15, cg = g - r * 15;
+        const int m = (kImg - 1 - r) * 15 + cg;
 #pragma unroll
         for (int pl = 0; pl < 4; pl++) {
           const int q = pl < 3 ? 0 : 1;
           uint32_t packed = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) packed |= to_byte(d[k][pl][j], fs[q], fb[q]) << (8 * j);
-          stage_group(g, pl, packed);
+          stage[pl * 900 + m] = packed;
         }
       }
     }
     __syncthreads();
     for (int a = tid; a < 900; a += IMG_THREADS) {
       const int pl = a / 225, j = a - pl * 225;
+      const uint4 v = stage4[a];
+      stage4[a] = make_uint4(0u, 0u, 0u, 0u);  // the cell counters of the next projection start from zero
       if (pl < 3 ? !with_normals : !with_depth) continue;
       const int ch = K.C == 1 ? 0 : pr * K.per + pl;
-      *reinterpret_cast<uint4 *>(out + (size_t)ch * kPix + 16 * j) = reinterpret_cast<const uint4 *>(stage)[pl * 225 + j];
+      *reinterpret_cast<uint4 *>(out + (size_t)ch * kPix + 16 * j) = v;
     }
     if (pr == 0) EXIT_AT(24);
     __syncthreads();
