@@ -202,6 +202,18 @@ __device__ inline float wave_reduce_f32(float v, OP op) {
 __device__ inline float wave_max_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fmaxf(a, b); }); }
 __device__ inline float wave_min_f32(float v) { return wave_reduce_f32(v, [](float a, float b) { return fminf(a, b); }); }
 
+// wave-wide inclusive prefix sum of an int: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then the row totals carried
+// over by row_bcast:15 / :31 — the sequence LLVM's atomic optimiser emits for gfx9; lanes without a source add 0
+__device__ inline int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // hand-frame coordinates of a world point: t = F^T (w - sample)  (image_strategy.cpp:36-40)
 __device__ inline void to_hand(const Box &B, double w0, double w1, double w2, double t[3]) {
   const double c0 = w0 - B.sample[0], c1 = w1 - B.sample[1], c2 = w2 - B.sample[2];
@@ -286,12 +298,7 @@ __device__ inline uint32_t lcg_jump(uint32_t s, unsigned long long n) {
 template <class SM>
 __device__ inline int block_excl_scan(SM &S, int v, int *total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int x = __shfl_up(incl, o);
-    if (lane >= o) incl += x;
-  }
+  const int incl = wave_incl_scan_i32(v);
   __syncthreads();
   if (lane == 63) S.red_i[wave] = incl;
   __syncthreads();
@@ -362,12 +369,7 @@ __device__ int list_nonempty_cells(SM &S, uint16_t *nz) {
   __syncthreads();
   if (tid < 64) {
     const int v = tid < 32 ? hist[tid] : 0;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      const int x = __shfl_up(incl, o);
-      if (tid >= o) incl += x;
-    }
+    const int incl = wave_incl_scan_i32(v);
     if (tid < 32) hist[tid] = incl - v;
     if (tid == 31) S.red_i[0] = incl;
   }
@@ -780,6 +782,22 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     // 46 bits starting at rowbit + zlo, clipped to the row [0, SD): the same z range for every row
     const int za = zlo < 0 ? 0 : zlo, zb = (zlo + VDIM < SD) ? zlo + VDIM : SD;
     const int nbits = zb - za;
+    // The row intervals below need the hand coordinates of a row's first voxel to ~1e-12 m only (EPS), so they come from
+    // the affine form tb_a = T0_a + ix * Ax_a + iy * Ay_a and the slab faces in z-steps from one face + the slab's width
+    // (24 f64 operations + two min / max per slab before); every number here is the same for the whole workgroup.
+    double T0[3], Ax[3], Ay[3], Lf[3], Wd[3];
+    {
+      const double wx = (double)x0 * K.voxel - B.sample[0], wy = (double)y0 * K.voxel - B.sample[1],
+                   wz = (double)(za - zlo + z0) * K.voxel - B.sample[2];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        T0[a] = uniform_f64(B.F[a] * wx + B.F[3 + a] * wy + B.F[6 + a] * wz);
+        Ax[a] = uniform_f64(B.F[a] * K.voxel);
+        Ay[a] = uniform_f64(B.F[3 + a] * K.voxel);
+        Lf[a] = invBz[a] > 0.0 ? B.lo[a] : B.hi[a];                       // the face the row crosses first
+        Wd[a] = uniform_f64(fabs((B.hi[a] - B.lo[a]) * invBz[a]));        // z-steps from that face to the other
+      }
+    }
     // Pass 1: the bit fields of all the thread's rows — straight-line loads at clamped addresses, 3 x RPT in flight
     // before the first use (inside the per-row loop below they were RPT dependent global round trips, one per row:
     // the bit loop of a row kept the next row's loads from being issued).
@@ -831,22 +849,21 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
         // the interval used to be tested exactly: ~35 VALU instructions per voxel and wave trip, a sixth of the kernel's
         // instructions — profiles/pmc_mix.sh: the kernel keeps the VALU pipe 56 % busy, it is instruction bound.)
         constexpr double EPS = 1e-3;
-        double tb[3];
-        to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(za - zlo + z0) * K.voxel, tb);
+        const double fx = (double)ix, fy = (double)iy;
         double dmin = 0.0, dmax = (double)(nbits - 1);  // may be inside
         double smin = 0.0, smax = (double)(nbits - 1);  // surely inside
 #pragma unroll
         for (int a = 0; a < 3; a++) {
+          const double tba = T0[a] + fx * Ax[a] + fy * Ay[a];
           if (invBz[a] != 0.0) {
-            const double d0 = (B.lo[a] - tb[a]) * invBz[a], d1 = (B.hi[a] - tb[a]) * invBz[a];
-            const double dl = fmin(d0, d1), dh = fmax(d0, d1);
+            const double dl = (Lf[a] - tba) * invBz[a], dh = dl + Wd[a];
             dmin = fmax(dmin, dl - EPS);
             dmax = fmin(dmax, dh + EPS);
             smin = fmax(smin, dl + EPS);
             smax = fmin(smax, dh - EPS);
-          } else if (tb[a] < B.lo[a] - 1e-6 || tb[a] > B.hi[a] + 1e-6) {
+          } else if (tba < B.lo[a] - 1e-6 || tba > B.hi[a] + 1e-6) {
             dmax = -1.0;  // the row runs parallel to this slab (it moves < 1e-7 m over its 64 voxels), outside it
-          } else if (!(tb[a] > B.lo[a] + 1e-6 && tb[a] < B.hi[a] - 1e-6)) {
+          } else if (!(tba > B.lo[a] + 1e-6 && tba < B.hi[a] - 1e-6)) {
             smax = -1.0;  // parallel and within a micrometre of a face: every voxel of the row is tested
           }
         }
