@@ -320,6 +320,7 @@ __device__ int scan_cells(SM &S) {
   constexpr int PER = 8;  // consecutive cells per thread: two 16-byte LDS accesses each way (450 threads hold the 3600 cells)
   static_assert(kPix % PER == 0 && kPix / PER <= IMG_THREADS, "scan_cells: cells per thread");
   uint4 *c4 = reinterpret_cast<uint4 *>(S.cells);
+  if (tid < 32) reinterpret_cast<int *>(S.red_f)[tid] = 0;  // the histogram of list_nonempty_cells (three barriers from here)
   uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
   if (tid < kPix / PER) {
     a = c4[2 * tid];
@@ -355,14 +356,18 @@ template <class SM>
 __device__ int list_nonempty_cells(SM &S, uint16_t *nz) {
   const int tid = threadIdx.x;
   constexpr int PER = (kPix + IMG_THREADS - 1) / IMG_THREADS;
-  int *hist = reinterpret_cast<int *>(S.red_f);  // 32 counters; red_f is idle until finalize_planes
-  if (tid < 32) hist[tid] = 0;
-  __syncthreads();
+  int *hist = reinterpret_cast<int *>(S.red_f);  // 32 counters, cleared by scan_cells; red_f is idle until the final phase
+  static_assert(PER == 8, "two 16-byte reads per thread");
+  uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
+  if (tid < kPix / PER) {
+    a = reinterpret_cast<const uint4 *>(S.cells)[2 * tid];
+    b = reinterpret_cast<const uint4 *>(S.cells)[2 * tid + 1];
+  }
+  const uint32_t cw[PER] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   int bucket[PER];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    const int i = tid * PER + k;
-    const int cn = i < kPix ? (int)(S.cells[i] & 0xffffu) : 0;
+    const int cn = (int)(cw[k] & 0xffffu);
     bucket[k] = cn ? 31 - (cn < 31 ? cn : 31) : -1;
     if (cn) atomicAdd(&hist[bucket[k]], 1);
   }
@@ -1022,8 +1027,7 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     if (pr == 0) EXIT_AT(5);
     lmax = wave_max_f32(lmax);
     lany = __ballot(lany != 0) != 0ull;
-    __syncthreads();
-    if (lane == 0) {
+    if (lane == 0) {  // (red_f / red_i were last read before the barrier above)
       S.red_f[tid >> 6] = lmax;
       S.red_i[tid >> 6] = lany;
     }
@@ -1037,10 +1041,16 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     }
     // minMaxLoc with mask -> max (0 if the mask is empty); image = max_img - image
     const double mxd = gany ? (double)gmax : 0.0;
-    __syncthreads();
-    for (int c = tid; c < kPix; c += IMG_THREADS) {
-      const float m = (S.cells[c] & 0xffffu) ? (float)mxd : 0.0f;
-      S.raster0[c] = m - S.raster0[c];
+    const float mxf = (float)mxd;
+    // (no barrier: red_f is rewritten behind the first barrier of finalize_planes only)
+    for (int c = tid; c < kPix / 4; c += IMG_THREADS) {
+      const uint4 w = reinterpret_cast<const uint4 *>(S.cells)[c];
+      float4 r = reinterpret_cast<float4 *>(S.raster0)[c];
+      r.x = ((w.x & 0xffffu) ? mxf : 0.0f) - r.x;
+      r.y = ((w.y & 0xffffu) ? mxf : 0.0f) - r.y;
+      r.z = ((w.z & 0xffffu) ? mxf : 0.0f) - r.z;
+      r.w = ((w.w & 0xffffu) ? mxf : 0.0f) - r.w;
+      reinterpret_cast<float4 *>(S.raster0)[c] = r;
     }
     __syncthreads();
     TICK(3);
