@@ -1283,34 +1283,84 @@ __device__ inline void mat3mul(const double *a, const double *b, double *c) {
     for (int j = 0; j < 3; j++) c[3 * i + j] = a[3 * i + 0] * b[0 + j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
 }
 
+// Wave-wide reductions through DPP (rows of 16 lanes: quad_perm x 2, row_half_mirror, row_mirror; then row_bcast:15 / :31;
+// the total is read from lane 63): 7 VALU steps per 32-bit word where six __shfl_xor steps are 6 ds_bpermute + ~25 VALU —
+// hand_eval_kernel is VALU bound (profiles/pmc_mix.sh) and runs up to nineteen block reductions per hand.
+template <int CTRL, int RMASK>
+__device__ inline unsigned dpp_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, RMASK, 0xf, false);  // a lane without a source keeps its own value
+}
+template <int CTRL, int RMASK>
+__device__ inline double dpp_f64(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = dpp_u32<CTRL, RMASK>((unsigned)b), hi = dpp_u32<CTRL, RMASK>((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL, int RMASK>
+__device__ inline long long dpp_i64(long long x) {
+  const unsigned long long b = (unsigned long long)x;
+  const unsigned lo = dpp_u32<CTRL, RMASK>((unsigned)b), hi = dpp_u32<CTRL, RMASK>((unsigned)(b >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+#define GPD_WAVE_REDUCE(v, OP, DPP)            \
+  v = OP(v, (DPP<0xB1, 0xf>(v)));  /* quad_perm [1,0,3,2] */ \
+  v = OP(v, (DPP<0x4E, 0xf>(v)));  /* quad_perm [2,3,0,1] */ \
+  v = OP(v, (DPP<0x141, 0xf>(v))); /* row_half_mirror */     \
+  v = OP(v, (DPP<0x140, 0xf>(v))); /* row_mirror */          \
+  v = OP(v, (DPP<0x142, 0xa>(v))); /* row_bcast:15 */        \
+  v = OP(v, (DPP<0x143, 0xc>(v)))  /* row_bcast:31: lane 63 holds the total */
+__device__ inline unsigned op_or(unsigned a, unsigned b) { return a | b; }
+__device__ inline double op_min(double a, double b) { return fmin(a, b); }
+__device__ inline double op_max(double a, double b) { return fmax(a, b); }
+// The sum is not idempotent: a lane without a DPP source must add 0, so the steps that reach across (row_bcast) and the
+// symmetric ones are replaced by the xor butterfly inside rows (every lane has a source) + two masked adds.
+__device__ inline long long wave_sum_i64(long long v) {
+  v += dpp_i64<0xB1, 0xf>(v);
+  v += dpp_i64<0x4E, 0xf>(v);
+  v += dpp_i64<0x141, 0xf>(v);
+  v += dpp_i64<0x140, 0xf>(v);  // every lane: the sum of its row
+  const unsigned long long b = (unsigned long long)v;
+  const unsigned l0 = __builtin_amdgcn_readlane((int)(unsigned)b, 0), h0 = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 0);
+  const unsigned l1 = __builtin_amdgcn_readlane((int)(unsigned)b, 16), h1 = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 16);
+  const unsigned l2 = __builtin_amdgcn_readlane((int)(unsigned)b, 32), h2 = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 32);
+  const unsigned l3 = __builtin_amdgcn_readlane((int)(unsigned)b, 48), h3 = __builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 48);
+  return (long long)((((unsigned long long)h0 << 32) | l0) + (((unsigned long long)h1 << 32) | l1) + (((unsigned long long)h2 << 32) | l2) +
+                     (((unsigned long long)h3 << 32) | l3));
+}
+__device__ inline unsigned lane63_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ inline double lane63_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = lane63_u32((unsigned)b), hi = lane63_u32((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // Block-wide helpers (256 threads = 4 waves).
 __device__ inline unsigned block_or(unsigned v, unsigned *s_tmp) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+  GPD_WAVE_REDUCE(v, op_or, dpp_u32);
+  v = lane63_u32(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
   __syncthreads();
   return s_tmp[0] | s_tmp[1] | s_tmp[2] | s_tmp[3];
 }
 __device__ inline double block_min(double v, double *s_tmp) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  GPD_WAVE_REDUCE(v, op_min, dpp_f64);
+  v = lane63_f64(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
   __syncthreads();
   return fmin(fmin(s_tmp[0], s_tmp[1]), fmin(s_tmp[2], s_tmp[3]));
 }
 __device__ inline double block_max(double v, double *s_tmp) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  GPD_WAVE_REDUCE(v, op_max, dpp_f64);
+  v = lane63_f64(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
   __syncthreads();
   return fmax(fmax(s_tmp[0], s_tmp[1]), fmax(s_tmp[2], s_tmp[3]));
 }
 __device__ inline long long block_sum(long long v, long long *s_tmp) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v = wave_sum_i64(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
   __syncthreads();

@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 export GPD_HIP_LIB=$ROOT/ab/libgpd_hip_exits.so GPD_IMG_SERIAL=1
 cd /tmp && export TMPDIR=/tmp
-for k in 1 2 3 4 5 6 7 11 31 32 12 13 14 21 22 23 24 15 16 0; do
+for k in 11 30 31 32 12 0; do
   rm -rf /tmp/pk; GPD_IMG_EXIT=$k rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d /tmp/pk -o b -- python $ROOT/bench.py --steps 2 --warmup 1 --cpu-samples 0 --batch-clouds 0 > /dev/null 2>&1
   python - "$k" <<PY
 import sqlite3, glob, sys
