@@ -421,8 +421,15 @@ constexpr int NB_BUCKETS = 1024;
 // 512 threads: sixteen waves per CU at two workgroups (72 KB of LDS each) — the kernel waits on dependent global
 // loads (cell bounds -> points) and on its barriers, more waves in flight is what hides them
 constexpr int NB_THREADS = 512, NB_WAVES = NB_THREADS / 64;
+// The keys — (d2 bits << 32) | index, or ~0 for padding — are compared as DOUBLES: a d2 below r2 has float bits under
+// 0x3f800000, so the key is the bit pattern of a non-negative finite (possibly denormal: f64 denormals are kept) double,
+// and those order like the 64-bit integers; the padding must be a number too (a NaN would be dropped by both v_min_f64 and
+// v_max_f64 in favour of the key, which would then appear twice): the largest finite double.  One compare-exchange = v_min_f64 + v_max_f64 instead of v_cmp_gt_u64 + four v_cndmask_b32.
 template <int N>
 __device__ inline void sort_regs64(unsigned long long (&k)[N]) {
+  double d[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) d[i] = __longlong_as_double((long long)k[i]);
 #pragma unroll
   for (int size = 2; size <= N; size <<= 1) {
 #pragma unroll
@@ -432,14 +439,15 @@ __device__ inline void sort_regs64(unsigned long long (&k)[N]) {
         const int j = i ^ stride;
         if (j > i) {
           const bool up = (i & size) == 0;
-          const unsigned long long a = k[i], b = k[j];
-          const bool sw = (a > b) == up;
-          k[i] = sw ? b : a;
-          k[j] = sw ? a : b;
+          const double lo = __builtin_fmin(d[i], d[j]), hi = __builtin_fmax(d[i], d[j]);
+          d[i] = up ? lo : hi;
+          d[j] = up ? hi : lo;
         }
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < N; i++) k[i] = (unsigned long long)__double_as_longlong(d[i]);
 }
 // GLOBAL: the slow path for neighbourhoods beyond the LDS list capacities (the reference has no limit:
 // hand_search.cpp:178 takes whatever radiusSearch returns).  The same bucket sort with the two index arrays in
@@ -700,7 +708,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
 #pragma unroll
         for (int q = 0; q < N; q++) {
           const int x = st + (q < nb ? q : 0);
-          k[q] = q < nb ? ((unsigned long long)d2bits_of_entry(x) << 32) | s_b[x] : ~0ull;
+          k[q] = q < nb ? ((unsigned long long)d2bits_of_entry(x) << 32) | s_b[x] : 0x7fefffffffffffffull;  // padding: the largest finite double
         }
         sort_regs64<N>(k);
 #pragma unroll
