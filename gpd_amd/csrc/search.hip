@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     if (ballot) {
       int base = 0;
       if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
-      base = __shfl(base, 0);
+      base = __builtin_amdgcn_readfirstlane(base);  // every lane is active here and lane 0 holds it
       if (hit) {
         const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
         if (pos < P.cap) {
@@ -641,12 +641,13 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       c4[q] = s_hist[PER * tid + q];
       sum += c4[q];
     }
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int x = __shfl_up(incl, o);
-      if (lane >= o) incl += x;
-    }
+    int incl = sum;  // wave-wide inclusive prefix sum through DPP (row_shr 1 / 2 / 4 / 8, then the row totals by row_bcast)
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
     if (lane == 63) s_wsum[tid >> 6] = incl;
     __syncthreads();
     int run = incl - sum;
@@ -1102,7 +1103,7 @@ __global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
     if (ballot) {
       int base = 0;
       if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
-      base = __shfl(base, 0);
+      base = __builtin_amdgcn_readfirstlane(base);  // every lane is active here and lane 0 holds it
       if (hit) {
         const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
         if (pos < CAP) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
@@ -1634,7 +1635,7 @@ __global__ __launch_bounds__(256) void height_list_kernel(HandParams P, int32_t 
     if (ballot) {
       int base = 0;
       if ((tid & 63) == 0) base = atomicAdd(&s_n, __popcll(ballot));
-      base = __shfl(base, 0);
+      base = __builtin_amdgcn_readfirstlane(base);  // every lane is active here and lane 0 holds it
       if (in) out[base + __popcll(ballot & ((1ull << (tid & 63)) - 1ull))] = make_float4(x, y, z, __int_as_float(e));
     }
   }
@@ -1750,7 +1751,7 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
       if (ballot) {
         int base = 0;
         if ((tid & 63) == 0) base = atomicAdd(&s_kc, __popcll(ballot));
-        base = __shfl(base, 0);
+        base = __builtin_amdgcn_readfirstlane(base);  // every lane is active here and lane 0 holds it
         if (in) {
           const int cpos = base + __popcll(ballot & ((1ull << (tid & 63)) - 1ull));
           if (cpos < HE_COMPACT) {
