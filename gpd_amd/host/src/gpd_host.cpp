@@ -85,8 +85,39 @@ Cloud::Cloud(const std::vector<float> &xyz, const std::vector<float> &normals, c
   if (camera_source_.empty()) camera_source_.assign(size() * std::max(1, numCameras()), 1);
 }
 
+namespace {
+// LZF (liblzf's stream format, what pcl::lzfDecompress reads): a control byte below 32 starts a run of ctrl + 1 literal
+// bytes; otherwise it is a back reference of length (ctrl >> 5) + 2 (length field 7: one more byte is added to it) at
+// distance ((ctrl & 31) << 8 | next byte) + 1.  Returns false unless exactly out_len bytes come out of a well-formed stream.
+bool lzfDecompress(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len) {
+  size_t ip = 0, op = 0;
+  while (ip < in_len) {
+    unsigned ctrl = in[ip++];
+    if (ctrl < 32) {
+      const size_t run = ctrl + 1;
+      if (ip + run > in_len || op + run > out_len) return false;
+      std::memcpy(out + op, in + ip, run);
+      ip += run;
+      op += run;
+    } else {
+      size_t len = ctrl >> 5;
+      if (len == 7) {
+        if (ip >= in_len) return false;
+        len += in[ip++];
+      }
+      if (ip >= in_len) return false;
+      const size_t dist = (((size_t)ctrl & 31) << 8 | in[ip++]) + 1;
+      len += 2;
+      if (dist > op || op + len > out_len) return false;
+      for (size_t k = 0; k < len; k++, op++) out[op] = out[op - dist];  // overlapping copies repeat the pattern
+    }
+  }
+  return op == out_len;
+}
+}  // namespace
+
 Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points) : view_points_(view_points) {
-  // pcl::io::loadPCDFile (cloud.cpp:643-660) for the ASCII and the uncompressed binary layout
+  // pcl::io::loadPCDFile (cloud.cpp:643-660): the ASCII, the binary and the binary_compressed (LZF, fields-major) layout
   std::ifstream f(filename.c_str(), std::ios::binary);
   if (!f) {
     printf("Couldn't read .pcd file: %s\n", filename.c_str());
@@ -121,8 +152,8 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
       break;
     }
   }
-  if (kind != "ascii" && kind != "binary") {
-    printf("Only ASCII and uncompressed binary .pcd files are supported (DATA %s): %s\n", kind.c_str(), filename.c_str());
+  if (kind != "ascii" && kind != "binary" && kind != "binary_compressed") {
+    printf("Unknown .pcd data layout (DATA %s): %s\n", kind.c_str(), filename.c_str());
     return;
   }
   // an untrusted header: field counts must agree, sizes are 1 / 2 / 4 / 8 bytes, counts at least 1 and small
@@ -185,31 +216,64 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
       offset[i] = stride;
       stride += (size_t)sizes[i] * (size_t)counts[i];
     }
-    std::vector<char> rec(stride);
-    for (size_t n = 0; n < points && f.read(rec.data(), (std::streamsize)stride); n++) {
-      for (size_t i = 0; i < fields.size(); i++) {
-        const char *p = rec.data() + offset[i];
-        double v = 0.0;
-        if (types[i] == "F" && sizes[i] == 4) {
-          float x;
-          std::memcpy(&x, p, 4);
-          v = x;
-        } else if (types[i] == "F" && sizes[i] == 8) {
-          std::memcpy(&v, p, 8);
-        } else if (sizes[i] == 4) {
-          int32_t x;
-          std::memcpy(&x, p, 4);
-          v = types[i] == "U" ? (double)(uint32_t)x : (double)x;
-        } else if (sizes[i] == 2) {
-          int16_t x;
-          std::memcpy(&x, p, 2);
-          v = types[i] == "U" ? (double)(uint16_t)x : (double)x;
-        } else if (sizes[i] == 1) {
-          v = types[i] == "U" ? (double)(uint8_t)p[0] : (double)(int8_t)p[0];
-        }
-        row[i] = v;
+    auto value = [&](size_t i, const char *p) {
+      double v = 0.0;
+      if (types[i] == "F" && sizes[i] == 4) {
+        float x;
+        std::memcpy(&x, p, 4);
+        v = x;
+      } else if (types[i] == "F" && sizes[i] == 8) {
+        std::memcpy(&v, p, 8);
+      } else if (sizes[i] == 4) {
+        int32_t x;
+        std::memcpy(&x, p, 4);
+        v = types[i] == "U" ? (double)(uint32_t)x : (double)x;
+      } else if (sizes[i] == 2) {
+        int16_t x;
+        std::memcpy(&x, p, 2);
+        v = types[i] == "U" ? (double)(uint16_t)x : (double)x;
+      } else if (sizes[i] == 1) {
+        v = types[i] == "U" ? (double)(uint8_t)p[0] : (double)(int8_t)p[0];
       }
-      keep(row.data());
+      return v;
+    };
+    if (kind == "binary") {
+      std::vector<char> rec(stride);
+      for (size_t n = 0; n < points && f.read(rec.data(), (std::streamsize)stride); n++) {
+        for (size_t i = 0; i < fields.size(); i++) row[i] = value(i, rec.data() + offset[i]);
+        keep(row.data());
+      }
+    } else {
+      // binary_compressed (PCDWriter::writeBinaryCompressed): two little-endian uint32 (compressed, uncompressed byte
+      // count), then one LZF stream of the cloud stored fields-major (all x, all y, ...; a field of COUNT n keeps its n
+      // values of a point together)
+      uint32_t head[2];
+      if (!f.read(reinterpret_cast<char *>(head), 8)) {
+        printf("PCD file ends inside the compression header: %s\n", filename.c_str());
+        return;
+      }
+      const size_t comp = head[0], raw = head[1];
+      if (raw != stride * points || comp > ((size_t)1 << 32)) {
+        printf("PCD compressed block does not match the header (%zu bytes for %zu points of %zu): %s\n", raw, points, stride,
+               filename.c_str());
+        return;
+      }
+      std::vector<unsigned char> in(comp);
+      if (comp && !f.read(reinterpret_cast<char *>(in.data()), (std::streamsize)comp)) {
+        printf("PCD file ends inside the compressed block: %s\n", filename.c_str());
+        return;
+      }
+      std::vector<char> out(raw);
+      if (!lzfDecompress(in.data(), comp, reinterpret_cast<unsigned char *>(out.data()), raw)) {
+        printf("PCD compressed block is corrupt: %s\n", filename.c_str());
+        return;
+      }
+      std::vector<size_t> base(fields.size());
+      for (size_t i = 0; i < fields.size(); i++) base[i] = offset[i] * points;
+      for (size_t n = 0; n < points; n++) {
+        for (size_t i = 0; i < fields.size(); i++) row[i] = value(i, out.data() + base[i] + n * (size_t)sizes[i] * (size_t)counts[i]);
+        keep(row.data());
+      }
     }
   }
   if (view_points_.empty()) view_points_.assign(3, 0.0);

@@ -1,5 +1,5 @@
-"""util::Cloud PCD reader of the host mirror (pcl::io::loadPCDFile, cloud.cpp:643-660): ASCII and
-uncompressed binary layouts, extra fields, NaN rows removed."""
+"""util::Cloud PCD reader of the host mirror (pcl::io::loadPCDFile, cloud.cpp:643-660): ASCII, binary and
+binary_compressed (LZF, fields-major) layouts, extra fields, NaN rows removed."""
 import numpy as np
 
 from gpd_amd import hostlib
@@ -50,9 +50,143 @@ def test_pcd_ascii_and_binary_roundtrip(tmp_path):
                     assert np.array_equal(gn, nrm[keep])
 
 
-def test_pcd_unsupported_or_missing_is_empty(tmp_path):
+def _lzf_compress(data):
+    """A small greedy LZF encoder (liblzf's stream format): literal runs of up to 32 bytes, back references of 3..264
+    bytes at distances up to 8192 found through a 3-byte hash of the last position."""
+    out = bytearray()
+    lit = bytearray()
+    last = {}
+    i, n = 0, len(data)
+
+    def flush():
+        for k in range(0, len(lit), 32):
+            run = lit[k:k + 32]
+            out.append(len(run) - 1)
+            out.extend(run)
+        lit.clear()
+
+    while i < n:
+        key = bytes(data[i:i + 3])
+        j = last.get(key, -1) if len(key) == 3 else -1
+        if len(key) == 3:
+            last[key] = i
+        if j >= 0 and i - j <= 8192:
+            length = 3
+            while i + length < n and length < 264 and data[j + length] == data[i + length]:
+                length += 1
+            flush()
+            dist, l2 = i - j - 1, length - 2
+            if l2 < 7:
+                out.append((l2 << 5) | (dist >> 8))
+            else:
+                out.append((7 << 5) | (dist >> 8))
+                out.append(l2 - 7)
+            out.append(dist & 255)
+            i += length
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
+def _lzf_decompress(comp):
+    out = bytearray()
+    i = 0
+    while i < len(comp):
+        c = comp[i]
+        i += 1
+        if c < 32:
+            out += comp[i:i + c + 1]
+            i += c + 1
+        else:
+            ln = c >> 5
+            if ln == 7:
+                ln += comp[i]
+                i += 1
+            d = ((c & 31) << 8 | comp[i]) + 1
+            i += 1
+            for _ in range(ln + 2):
+                out.append(out[-d])
+    return bytes(out)
+
+
+def _write_compressed(path, columns, fields, sizes, types, counts, n, comp=None):
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT 1\n"
+           "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary_compressed\n" % (" ".join(fields), " ".join(map(str, sizes)), " ".join(types),
+                                                                             " ".join(map(str, counts)), n, n))
+    raw = b"".join(columns)  # fields-major: every field's values of all points back to back
+    if comp is None:
+        comp = _lzf_compress(raw)
+        assert _lzf_decompress(comp) == raw
+    with open(path, "wb") as f:
+        f.write(hdr.encode() + np.array([len(comp), len(raw)], "<u4").tobytes() + comp)
+    return raw, comp
+
+
+def test_pcd_binary_compressed(tmp_path):
+    """DATA binary_compressed as PCDWriter::writeBinaryCompressed lays it out (what pcl_viewer / ROS tools save by
+    default): sizes, one LZF stream, fields-major.  A lattice cloud compresses through real back references (the
+    stream is checked to be shorter than the raw bytes), an rgb field and a COUNT-2 field sit between the
+    coordinates and the normals, NaN rows go."""
+    rng = np.random.RandomState(3)
+    n = 700
+    xyz = (rng.randint(-40, 40, (n, 3)) * 0.003).astype(np.float32)  # 3 mm lattice: few distinct values per column
+    nrm = np.zeros((n, 3), np.float32)
+    nrm[:, rng.randint(0, 3)] = 1.0
+    xyz[5] = np.nan
+    keep = np.ones(n, bool)
+    keep[5] = False
+    rgb = (0x00ff8040 + np.arange(n)).astype("<u4")
+    extra = rng.randint(0, 9, (n, 2)).astype("<i2")
+    cols = [xyz[:, 0].astype("<f4").tobytes(), xyz[:, 1].astype("<f4").tobytes(), xyz[:, 2].astype("<f4").tobytes(), rgb.tobytes(),
+            extra.tobytes(), nrm[:, 0].astype("<f4").tobytes(), nrm[:, 1].astype("<f4").tobytes(), nrm[:, 2].astype("<f4").tobytes()]
+    p = tmp_path / "comp.pcd"
+    raw, comp = _write_compressed(str(p), cols, ["x", "y", "z", "rgb", "pair", "normal_x", "normal_y", "normal_z"], [4, 4, 4, 4, 2, 4, 4, 4],
+                                  ["F", "F", "F", "U", "I", "F", "F", "F"], [1, 1, 1, 1, 2, 1, 1, 1], n)
+    assert len(comp) < len(raw) // 2 and any(c >= 32 for c in comp[:64])
+    gx, gn = hostlib.load_pcd(p)
+    assert np.array_equal(gx, xyz[keep]) and np.array_equal(gn, nrm[keep])
+    # a literal-only stream (incompressible data) and an overlapping back reference (run-length form: distance 1)
+    p2 = tmp_path / "lit.pcd"
+    xyz2 = rng.normal(0, 0.3, (9, 3)).astype(np.float32)
+    raw2 = b"".join(xyz2[:, k].astype("<f4").tobytes() for k in range(3))
+    lit = b"".join(bytes([len(raw2[k:k + 32]) - 1]) + raw2[k:k + 32] for k in range(0, len(raw2), 32))
+    _write_compressed(str(p2), [raw2], ["x", "y", "z"], [4, 4, 4], ["F", "F", "F"], [1, 1, 1], 9, comp=lit)
+    gx, gn = hostlib.load_pcd(p2)
+    assert np.array_equal(gx, xyz2) and gn is None
+    p3 = tmp_path / "rle.pcd"
+    zeros = np.zeros((50, 3), np.float32)
+    rle = bytes([0, 0]) + bytes([(7 << 5) | 0, 255, 0]) * 2 + bytes([(7 << 5) | 0, 600 - 1 - 2 * 264 - 9, 0])
+    assert _lzf_decompress(rle) == zeros.tobytes()
+    _write_compressed(str(p3), [zeros.tobytes()], ["x", "y", "z"], [4, 4, 4], ["F", "F", "F"], [1, 1, 1], 50, comp=rle)
+    gx, _ = hostlib.load_pcd(p3)
+    assert np.array_equal(gx, zeros)
+
+
+def test_pcd_corrupt_or_missing_is_empty(tmp_path):
+    head = b"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary_compressed\n"
+    sizes = lambda c, r: np.array([c, r], "<u4").tobytes()
+    good = bytes([11]) + np.array([1, 2, 3], "<f4").tobytes()
+    cases = {
+        "truncated_header": b"\x00\x00",
+        "size_mismatch": sizes(len(good), 16) + good,               # 16 bytes announced for one 12-byte point
+        "truncated_block": sizes(len(good), 12) + good[:5],
+        "reference_before_start": sizes(3, 12) + bytes([(3 << 5), 4, 0]),
+        "runs_past_the_end": sizes(len(good) + 2, 12) + good + bytes([0, 7]),
+        "short_output": sizes(5, 12) + bytes([3, 1, 2, 3, 4]),
+    }
+    for name, tail in cases.items():
+        p = tmp_path / (name + ".pcd")
+        p.write_bytes(head + tail)
+        gx, _ = hostlib.load_pcd(p)
+        assert len(gx) == 0, name
+    p = tmp_path / "ok.pcd"
+    p.write_bytes(head + sizes(len(good), 12) + good)
+    gx, _ = hostlib.load_pcd(p)
+    assert gx.tolist() == [[1, 2, 3]]
     p = tmp_path / "z.pcd"
-    p.write_bytes(b"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary_compressed\n\x00\x00")
+    p.write_bytes(head.replace(b"binary_compressed", b"binary_zipped") + b"\x00\x00")
     gx, _ = hostlib.load_pcd(p)
     assert len(gx) == 0
     gx, _ = hostlib.load_pcd(tmp_path / "does_not_exist.pcd")
