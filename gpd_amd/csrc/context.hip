@@ -119,6 +119,14 @@ struct gpd_hip_ctx {
   std::vector<hipEvent_t> replay_events;  // 6 per gpd_hip_replay call: start, images done, conv1, conv2, fc1, end
   float replay_kernel_ms[4] = {0, 0, 0, 0};  // conv1, conv2, fc1, fc2 sums of the replays of the last gpd_hip_replay_times
   size_t replay_used = 0;
+  // GPD_REPLAY_PIPE=1 (experiment): the image stage of replay k + 1 beside the LeNet stage of replay k —
+  // images on lane 0's stream into one of two image buffers, LeNet on `pipe_stream` behind the buffer's event
+  hipStream_t pipe_stream = nullptr;
+  uint8_t *pipe_images[2] = {nullptr, nullptr};  // [0] is lane 0's own buffer while the mode is on
+  size_t pipe_bytes = 0;
+  hipEvent_t pipe_filled[2] = {nullptr, nullptr}, pipe_read[2] = {nullptr, nullptr};
+  bool pipe_read_valid[2] = {false, false};
+  unsigned pipe_k = 0;
 };
 
 static int lane_init(Lane &L, hipStream_t shared = nullptr) {
@@ -498,6 +506,15 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
   for (float **p : ws)
     if (*p) (void)hipFree(*p);
   for (auto &e : ctx->replay_events) (void)hipEventDestroy(e);
+  if (ctx->pipe_stream) {
+    (void)hipStreamSynchronize(ctx->pipe_stream);
+    (void)hipStreamDestroy(ctx->pipe_stream);
+    if (ctx->pipe_images[1]) (void)hipFree(ctx->pipe_images[1]);
+    for (int b = 0; b < 2; b++) {
+      (void)hipEventDestroy(ctx->pipe_filled[b]);
+      (void)hipEventDestroy(ctx->pipe_read[b]);
+    }
+  }
   delete ctx;
 }
 
@@ -1033,6 +1050,43 @@ int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
   }
   hipEvent_t *ev = &ctx->replay_events[ctx->replay_used];
   ctx->replay_used += 6;
+  static const bool pipe = getenv("GPD_REPLAY_PIPE") && atoi(getenv("GPD_REPLAY_PIPE")) > 0;
+  if (pipe && stages == 3) {
+    const size_t bytes = (size_t)L.images.capacity * L.images.channels * 3600;
+    if (!ctx->pipe_stream) {
+      HIP_TRY(hipStreamCreate(&ctx->pipe_stream));
+      for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_filled[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->pipe_read[b], hipEventDisableTiming));
+      }
+    }
+    if (ctx->pipe_bytes != bytes || ctx->pipe_images[0] != L.images.d_images) {
+      // (re)start: the list was rebuilt since; lane 0's buffer is [0], a second one of the same size is [1]
+      HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
+      if (ctx->pipe_images[1]) HIP_TRY(hipFree(ctx->pipe_images[1]));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->pipe_images[1]), bytes));
+      ctx->pipe_images[0] = L.images.d_images;
+      ctx->pipe_bytes = bytes;
+      ctx->pipe_read_valid[0] = ctx->pipe_read_valid[1] = false;
+      ctx->pipe_k = 0;
+    }
+    const int b = (int)(ctx->pipe_k++ & 1);
+    if (ctx->pipe_read_valid[b]) HIP_TRY(hipStreamWaitEvent(L.stream, ctx->pipe_read[b], 0));  // LeNet of replay k - 2 has read it
+    HIP_TRY(hipEventRecord(ev[0], L.stream));
+    uint8_t *own = L.images.d_images;
+    L.images.d_images = ctx->pipe_images[b];
+    rc = images_launch(L.search, L.plan, L.images, L.stream);
+    L.images.d_images = own;
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[1], L.stream));
+    HIP_TRY(hipEventRecord(ctx->pipe_filled[b], L.stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->pipe_stream, ctx->pipe_filled[b], 0));
+    HIP_TRY(lenet_forward(ctx->lenet, L.lenet_scratch, ctx->pipe_images[b], n, L.d_scores, ctx->pipe_stream, ev + 2));
+    HIP_TRY(hipEventRecord(ev[5], ctx->pipe_stream));
+    HIP_TRY(hipEventRecord(ctx->pipe_read[b], ctx->pipe_stream));
+    ctx->pipe_read_valid[b] = true;
+    return GPD_OK;
+  }
   HIP_TRY(hipEventRecord(ev[0], L.stream));
   if (stages & 1) {
     rc = images_launch(L.search, L.plan, L.images, L.stream);
@@ -1053,6 +1107,7 @@ int gpd_hip_replay_times(gpd_hip_ctx *ctx, float ms[2], int *launches, float *sc
   HIP_TRY(hipSetDevice(ctx->device));
   Lane &L = ctx->lane[0];
   HIP_TRY(hipStreamSynchronize(L.stream));
+  if (ctx->pipe_stream) HIP_TRY(hipStreamSynchronize(ctx->pipe_stream));
   ms[0] = ms[1] = 0.f;
   for (int k = 0; k < 4; k++) ctx->replay_kernel_ms[k] = 0.f;
   for (size_t i = 0; i + 5 < ctx->replay_used; i += 6) {
