@@ -239,6 +239,10 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
     HIP_TRY(hipStreamSynchronize(L.stream));
   }
   const PlanSummary sm = *L.plan.h_summary;
+  static const bool plan_timing = getenv("GPD_PLAN_TIMING") != nullptr;
+  if (plan_timing)
+    fprintf(stderr, "[plan-timing] own sums %.2f us, look-back %.2f, tables + summary %.2f (last workgroup's thread 0, 100 MHz clock)\n",
+            (sm.pad_[0] & 0xffff) * 0.01, ((unsigned)sm.pad_[0] >> 16) * 0.01, (sm.pad_[1] & 0xffff) * 0.01);
   const int slots = ctx->params.num_hand_axes * ctx->params.num_orientations;
   J.num_sets = sm.num_sets;
   J.num_candidates = sm.num_candidates;

@@ -227,8 +227,23 @@ struct PlanSummary {  // copied to the host once per call (pinned)
   int32_t pad_[2];
   long long sum_set_ni, sum_cand_ni;  // for the algorithmic byte count of SURVEY §8d
 };
+struct PlanPart {  // what one workgroup of plan_kernel publishes for the workgroups after it (64 bytes)
+  int32_t sum[3];   // hand sets, candidates, shadow bitsets of its samples
+  int32_t worst;
+  unsigned long long draws;  // LCG draws of its samples
+  long long sum_set_ni, sum_cand_ni;
+  int32_t live, mismatch;
+  int32_t sets;          // caller flags: hand sets of its samples, published first
+  unsigned ready_sets;   // stamps: the launch number once `sets` / the rest is complete
+  unsigned ready;
+  unsigned pad_;
+};
+static_assert(sizeof(PlanPart) == 64, "PlanPart");
 struct Plan {
   int cap_samples = 0, cap_slots = 0, cap_cams = 0;
+  PlanPart *d_parts = nullptr;   // [cap_samples / 256 + 1]
+  unsigned *d_ticket = nullptr;  // arrival counter of plan_kernel's workgroups (never reset; `tickets` is its host copy)
+  unsigned tickets = 0, epoch = 0;
   int32_t *d_sample_of_set = nullptr;  // [S]
   int32_t *d_hand_cand = nullptr;      // [S][slots] candidate ordinal of a hand, -1: none
   int32_t *d_cand_hand = nullptr;      // [S*slots] hand (sample slot * slots + slot) of a candidate

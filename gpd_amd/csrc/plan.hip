@@ -13,8 +13,10 @@
 //   * the score write-back hands[i]->setScore(scores[i]) (grasp_detector.cpp:269-273),
 //   * selectGrasps (grasp_detector.cpp:405-420) over the device score array.
 //
-// plan_kernel is ONE workgroup: the tables are prefix sums over the samples in order (a few thousand
-// entries), a serial dependency that a single 1024-lane scan resolves in microseconds.
+// plan_kernel: the tables are prefix sums over the samples in order.  One workgroup per 256 samples; the workgroups
+// number themselves by a ticket (arrival order), publish the sums of their samples and add up the published sums of the
+// workgroups before them (decoupled look-back: nobody waits for a workgroup that has not started), so the table stores
+// — one scattered cache line per lane, what a single workgroup spent 40 of its 43 us on — spread over the chip.
 #include <cstddef>
 #include <cstring>
 
@@ -31,7 +33,7 @@ namespace gpd {
     }                                                                                       \
   } while (0)
 
-constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_THREADS = 256;
 
 struct PlanParams {
   const int32_t *counts;   // [S][8]: N_hands, N_images, k_frames, found, mask of cameras that see the image neighbourhood
@@ -45,6 +47,10 @@ struct PlanParams {
   int num_shadow;          // draws per neighbourhood point and camera (hand_set.cpp:127: floor(shadow_length / 0.003))
   int32_t *sample_of_set, *hand_cand, *cand_hand, *cand_out, *cand_meta, *set_meta;
   PlanSummary *summary;
+  PlanPart *parts;        // [workgroups] published sums (gpd_internal.h)
+  unsigned *ticket;       // arrival counter, never reset: this launch's tickets are ticket_base .. ticket_base + workgroups - 1
+  unsigned ticket_base;
+  unsigned epoch;         // stamp of this launch in PlanPart::ready_*
 };
 
 // exclusive scan of (a, b, c, d) over the workgroup; totals returned through the references
@@ -88,140 +94,245 @@ __device__ inline Scan4 block_scan4(Scan4 v, Scan4 &total, Scan4 *s_part) {
   return excl;
 }
 
+// valid flags of one row ([slots] bytes) as a bit mask.  Every load is requested before the first one is looked at (a
+// loop over a run-time slot count made them dependent round trips: 8 x ~1.5 us per chunk of samples, most of the
+// kernel's 43 us); rows of whole words — 8 orientations x 1..3 axes — come as aligned words.
+__device__ inline unsigned valid_mask(const uint8_t *row, int slots) {
+  unsigned m = 0;
+  static_assert(GPD_MAX_SLOTS % 4 == 0 && GPD_MAX_SLOTS <= 32, "slot mask");
+  if (!(slots & 3)) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(row);
+    uint32_t x[GPD_MAX_SLOTS / 4];
+#pragma unroll
+    for (int q = 0; q < GPD_MAX_SLOTS / 4; q++) x[q] = 4 * q < slots ? w[q] : 0u;
+#pragma unroll
+    for (int q = 0; q < GPD_MAX_SLOTS / 4; q++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if ((x[q] >> (8 * b)) & 0xffu) m |= 1u << (4 * q + b);
+  } else {
+    uint8_t x[GPD_MAX_SLOTS];
+#pragma unroll
+    for (int j = 0; j < GPD_MAX_SLOTS; j++) x[j] = j < slots ? row[j] : (uint8_t)0;
+#pragma unroll
+    for (int j = 0; j < GPD_MAX_SLOTS; j++)
+      if (x[j]) m |= 1u << j;
+  }
+  return m;
+}
+
+// sum of v over the workgroup, in every thread (s_red: PLAN_THREADS / 64 slots; barriers inside)
+__device__ inline long long block_sum_i64(long long v, long long *s_red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    v += (long long)(((unsigned long long)(unsigned)__shfl_xor((int)((unsigned long long)v >> 32), o) << 32) |
+                     (unsigned)__shfl_xor((int)(unsigned)(unsigned long long)v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  long long t = 0;
+#pragma unroll
+  for (int w = 0; w < PLAN_THREADS / 64; w++) t += s_red[w];
+  return t;
+}
+__device__ inline int block_max_i32(int v, long long *s_red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = (int)s_red[0];
+#pragma unroll
+  for (int w = 1; w < PLAN_THREADS / 64; w++) t = max(t, (int)s_red[w]);
+  return t;
+}
+// a published word of another workgroup: spin until it carries this launch's stamp (the writer fences before it stamps)
+__device__ inline void wait_stamp(const unsigned *flag, unsigned epoch) {
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(1);
+}
+
 __global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(PlanParams P) {
   __shared__ Scan4 s_part[PLAN_THREADS / 64];
-  __shared__ int s_worst, s_live, s_mismatch;
-  __shared__ unsigned long long s_sum[2];
+  __shared__ long long s_red[PLAN_THREADS / 64];
+  __shared__ int s_mismatch, s_blk;
   const int tid = threadIdx.x;
-  if (tid == 0) s_mismatch = 0x7fffffff;
-  Scan4 carry = {0, 0, 0, 0ull};  // sets, candidates, shadow bitsets, LCG draws before this chunk
-  int worst = 0, live_sets = 0;
-  long long sum_set_ni = 0, sum_cand_ni = 0;
-  const unsigned cam_mask = P.num_cams >= 32 ? 0xffffffffu : ((1u << P.num_cams) - 1u);
-  for (int base = 0; base < P.S; base += PLAN_THREADS) {
-    const int s = base + tid;
-    int has_set = 0, nv = 0, n_bits = 0, Ni = 0, ncam = 0;
-    unsigned seen = 0;
-    unsigned vmask = 0;  // valid slots (slots <= GPD_MAX_SLOTS = 24)
-    if (s < P.S) {
-      const int32_t *cn = P.counts + 8 * (size_t)s;
-      has_set = cn[2] > 0;
-      Ni = cn[1];
-      seen = (unsigned)cn[4] & cam_mask;
-      worst = max(worst, cn[3]);
-    }
-    int ns_pre = 0;
-    if (P.set_flags) {
-      // the caller's flags are numbered by hand set: the set number of a sample first (its own scan)
-      Scan4 v0 = {has_set, 0, 0, 0ull};
-      Scan4 t0;
-      ns_pre = carry.a + block_scan4(v0, t0, s_part).a;
-    }
-    if (s < P.S) {
-      if (has_set && !P.set_flags) {
-        for (int j = 0; j < P.slots; j++)
-          if (P.fvalid[(size_t)s * P.slots + j]) vmask |= 1u << j;
-      } else if (has_set && ns_pre < P.num_sets_given) {
-        for (int j = 0; j < P.slots; j++)
-          if (P.set_flags[(size_t)ns_pre * P.slots + j]) vmask |= 1u << j;
-        bool same = true;  // checked for the sets that contribute a candidate (the caller may pass husks for the others)
-        for (int r = 0; r < 3; r++) same &= P.set_samples[3 * (size_t)ns_pre + r] == P.frames[12 * (size_t)s + r];
-        if (vmask && !same) atomicMin(&s_mismatch, ns_pre);
-      }
-      nv = __popc(vmask);
-      if (nv && P.shadow && Ni > 0) {
-        // HandSet::calculateShadow (hand_set.cpp:118-185): every camera that sees a neighbourhood point casts
-        // Ni * num_shadow draws, in camera order.  One camera: its voxel set (empty if it sees nothing).  Several:
-        // camera 0's set (empty if camera 0 sees nothing) intersected with the sets of the other seeing cameras —
-        // the draws are consumed even when the result is discarded.
-        ncam = __popc(seen);
-        n_bits = (seen & 1u) ? ncam : 0;
-      }
-      if (nv) {
-        live_sets++;
-        sum_set_ni += Ni;
-        sum_cand_ni += (long long)Ni * nv;
-      }
-    }
-    Scan4 v = {has_set, nv, n_bits, (unsigned long long)Ni * (unsigned long long)P.num_shadow * (unsigned long long)ncam};
-    Scan4 total;
-    const Scan4 ex = block_scan4(v, total, s_part);
-    if (s < P.S) {
-      const int ns = carry.a + ex.a;
-      if (has_set) P.sample_of_set[ns] = s;
-      int cand = carry.b + ex.b;
-      const int first_bits = n_bits ? carry.c + ex.c : -1;
-      for (int j = 0; j < P.slots; j++) {
-        int hc = -1;
-        if (vmask >> j & 1u) {
-          hc = cand++;
-          P.cand_hand[hc] = s * P.slots + j;
-          P.cand_out[hc] = ns * P.slots + j;
-          int32_t *m = P.cand_meta + 4 * (size_t)hc;
-          m[0] = s;
-          m[1] = Ni;
-          m[2] = first_bits;
-          m[3] = n_bits;
-        }
-        P.hand_cand[(size_t)s * P.slots + j] = hc;
-      }
-      if (ncam) {
-        unsigned long long lcg = carry.d + ex.d;
-        int row = carry.c + ex.c;
-        for (int cam = 0; cam < P.num_cams; cam++) {
-          if (!(seen >> cam & 1u)) continue;
-          if (n_bits) {
-            int32_t *m = P.set_meta + 8 * (size_t)row++;
-            m[0] = s;
-            m[1] = Ni;
-            m[2] = (int32_t)(uint32_t)(lcg & 0xffffffffull);
-            m[3] = (int32_t)(uint32_t)(lcg >> 32);
-            m[4] = cam;
-            m[5] = m[6] = m[7] = 0;
-          }
-          lcg += (unsigned long long)Ni * (unsigned long long)P.num_shadow;
-        }
-      }
-    }
-    carry.a += total.a;
-    carry.b += total.b;
-    carry.c += total.c;
-    carry.d += total.d;
-  }
-  // reductions of the per-thread statistics
+  const unsigned long long tk0 = wall_clock64();
   if (tid == 0) {
-    s_worst = 0;
-    s_live = 0;
-    s_sum[0] = 0ull;
-    s_sum[1] = 0ull;
+    s_mismatch = 0x7fffffff;
+    s_blk = (int)(atomicAdd(P.ticket, 1u) - P.ticket_base);  // the workgroups are numbered in the order they start
   }
   __syncthreads();
-  atomicMax(&s_worst, worst);
-  if (live_sets) {
-    atomicAdd(&s_live, live_sets);
-    atomicAdd(&s_sum[0], (unsigned long long)sum_set_ni);
-    atomicAdd(&s_sum[1], (unsigned long long)sum_cand_ni);
+  const int blk = s_blk, nblk = (int)gridDim.x;
+  const int s = blk * PLAN_THREADS + tid;
+  const bool on = s < P.S;
+  PlanPart *mine_part = P.parts + blk;
+  const unsigned cam_mask = P.num_cams >= 32 ? 0xffffffffu : ((1u << P.num_cams) - 1u);
+
+  // ---- inputs of this thread's sample
+  int4 cn = make_int4(0, 0, 0, 0);  // N_hands, N_images, k_frames, found
+  int cams = 0;
+  if (on) {
+    cn = *reinterpret_cast<const int4 *>(P.counts + 8 * (size_t)s);
+    cams = P.counts[8 * (size_t)s + 4];
   }
-  __syncthreads();
+  const int has_set = on && cn.z > 0, Ni = cn.y;
+  const unsigned seen = (unsigned)cams & cam_mask;
+  unsigned vmask = 0;  // valid slots (slots <= GPD_MAX_SLOTS = 24)
+  bool mismatch = false;
+  int sets_before = 0;  // (caller flags only, below)
+  if (!P.set_flags) {
+    if (has_set) vmask = valid_mask(P.fvalid + (size_t)s * P.slots, P.slots);
+  } else {
+    // the caller's flags are numbered by hand set: the set number of the sample first — its own scan and look-back
+    Scan4 v0 = {has_set, 0, 0, 0ull}, t0;
+    const int ex0 = block_scan4(v0, t0, s_part).a;
+    if (tid == 0) {
+      mine_part->sets = t0.a;
+      __threadfence();
+      __hip_atomic_store(&mine_part->ready_sets, P.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    long long before = 0;
+    for (int b = tid; b < blk; b += PLAN_THREADS) {
+      wait_stamp(&P.parts[b].ready_sets, P.epoch);
+      before += P.parts[b].sets;
+    }
+    sets_before = (int)block_sum_i64(before, s_red);
+    const int set_no = sets_before + ex0;
+    if (has_set && set_no < P.num_sets_given) {
+      vmask = valid_mask(P.set_flags + (size_t)set_no * P.slots, P.slots);
+      double a[3], b[3];  // checked for the sets that contribute a candidate (the caller may pass husks for the others)
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        a[r] = P.set_samples[3 * (size_t)set_no + r];
+        b[r] = P.frames[12 * (size_t)s + r];
+      }
+      mismatch = vmask && !(a[0] == b[0] && a[1] == b[1] && a[2] == b[2]);
+      if (mismatch) atomicMin(&s_mismatch, set_no);
+    }
+  }
+  const int nv = __popc(vmask);
+  int ncam = 0, n_bits = 0;
+  if (nv && P.shadow && Ni > 0) {
+    // HandSet::calculateShadow (hand_set.cpp:118-185): every camera that sees a neighbourhood point casts
+    // Ni * num_shadow draws, in camera order.  One camera: its voxel set (empty if it sees nothing).  Several:
+    // camera 0's set (empty if camera 0 sees nothing) intersected with the sets of the other seeing cameras —
+    // the draws are consumed even when the result is discarded.
+    ncam = __popc(seen);
+    n_bits = (seen & 1u) ? ncam : 0;
+  }
+  const unsigned long long draws = (unsigned long long)Ni * (unsigned long long)P.num_shadow * (unsigned long long)ncam;
+
+  // ---- this workgroup's sums, published before anything is waited for
+  Scan4 v = {has_set, nv, n_bits, draws}, total;
+  const Scan4 ex = block_scan4(v, total, s_part);
+  const int g_worst = block_max_i32(on ? cn.w : 0, s_red);
+  const long long g_live = block_sum_i64(nv ? 1 : 0, s_red);
+  const long long g_set_ni = block_sum_i64(nv ? Ni : 0, s_red);
+  const long long g_cand_ni = block_sum_i64((long long)(nv ? Ni : 0) * nv, s_red);  // (the barriers order s_mismatch too)
+  if (tid == 0) {
+    mine_part->sum[0] = total.a;
+    mine_part->sum[1] = total.b;
+    mine_part->sum[2] = total.c;
+    mine_part->worst = g_worst;
+    mine_part->draws = total.d;
+    mine_part->live = (int)g_live;
+    mine_part->mismatch = s_mismatch;
+    mine_part->sum_set_ni = g_set_ni;
+    mine_part->sum_cand_ni = g_cand_ni;
+    __threadfence();
+    __hip_atomic_store(&mine_part->ready, P.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const unsigned long long tk1 = wall_clock64();
+  // ---- sums of the workgroups before this one (the last one also gathers the statistics of the summary)
+  const bool last = blk == nblk - 1;
+  long long pa = 0, pb = 0, pc = 0, pd = 0, p_live = 0, p_set_ni = 0, p_cand_ni = 0;
+  int p_worst = 0, p_mis = 0x7fffffff;
+  for (int b = tid; b < blk; b += PLAN_THREADS) {
+    const PlanPart *q = P.parts + b;
+    wait_stamp(&q->ready, P.epoch);
+    pa += q->sum[0];
+    pb += q->sum[1];
+    pc += q->sum[2];
+    pd += (long long)q->draws;
+    if (last) {
+      p_live += q->live;
+      p_set_ni += q->sum_set_ni;
+      p_cand_ni += q->sum_cand_ni;
+      p_worst = max(p_worst, q->worst);
+      p_mis = min(p_mis, q->mismatch);
+    }
+  }
+  Scan4 carry;  // sets, candidates, shadow bitsets, LCG draws before this workgroup's samples
+  if (blk > 0) {
+    carry.a = (int)block_sum_i64(pa, s_red);
+    carry.b = (int)block_sum_i64(pb, s_red);
+    carry.c = (int)block_sum_i64(pc, s_red);
+    carry.d = (unsigned long long)block_sum_i64(pd, s_red);
+  } else {
+    carry = Scan4{0, 0, 0, 0ull};
+  }
+  const unsigned long long tk2 = wall_clock64();
+
+  // ---- the tables of this thread's sample
+  if (on) {
+    const int ns = carry.a + ex.a;
+    if (has_set) P.sample_of_set[ns] = s;
+    int cand = carry.b + ex.b;
+    const int first_bits = n_bits ? carry.c + ex.c : -1;
+    for (int j = 0; j < P.slots; j++) {
+      int hc = -1;
+      if (vmask >> j & 1u) {
+        hc = cand++;
+        P.cand_hand[hc] = s * P.slots + j;
+        P.cand_out[hc] = ns * P.slots + j;
+        *reinterpret_cast<int4 *>(P.cand_meta + 4 * (size_t)hc) = make_int4(s, Ni, first_bits, n_bits);
+      }
+      P.hand_cand[(size_t)s * P.slots + j] = hc;
+    }
+    if (ncam) {
+      unsigned long long lcg = carry.d + ex.d;
+      int row = carry.c + ex.c;
+      for (int cam = 0; cam < P.num_cams; cam++) {
+        if (!(seen >> cam & 1u)) continue;
+        if (n_bits) {
+          int4 *m = reinterpret_cast<int4 *>(P.set_meta + 8 * (size_t)row++);
+          m[0] = make_int4(s, Ni, (int32_t)(uint32_t)(lcg & 0xffffffffull), (int32_t)(uint32_t)(lcg >> 32));
+          m[1] = make_int4(cam, 0, 0, 0);
+        }
+        lcg += (unsigned long long)Ni * (unsigned long long)P.num_shadow;
+      }
+    }
+  }
+  if (!last) return;
+  // ---- the summary, by the workgroup with the last ticket
+  const long long t_live = block_sum_i64(p_live, s_red) + g_live;
+  const long long t_set_ni = block_sum_i64(p_set_ni, s_red) + g_set_ni;
+  const long long t_cand_ni = block_sum_i64(p_cand_ni, s_red) + g_cand_ni;
+  const int t_worst = max(block_max_i32(p_worst, s_red), g_worst);
+  const int t_mis = min(-block_max_i32(-p_mis, s_red), s_mismatch);
   if (tid == 0) {
     PlanSummary sm;
-    sm.num_sets = carry.a;
-    sm.num_candidates = carry.b;
-    sm.num_shadow_sets = carry.c;
-    sm.worst_found = s_worst;
-    sm.live_sets = s_live;
-    sm.mismatch_set = s_mismatch != 0x7fffffff ? s_mismatch : -1;
-    if (P.set_flags && P.num_sets_given > carry.a && sm.mismatch_set < 0) sm.mismatch_set = carry.a;  // more sets than the search has
-    sm.pad_[0] = sm.pad_[1] = 0;
-    sm.sum_set_ni = (long long)s_sum[0];
-    sm.sum_cand_ni = (long long)s_sum[1];
+    sm.num_sets = carry.a + total.a;
+    sm.num_candidates = carry.b + total.b;
+    sm.num_shadow_sets = carry.c + total.c;
+    sm.worst_found = t_worst;
+    sm.live_sets = (int)t_live;
+    sm.mismatch_set = t_mis != 0x7fffffff ? t_mis : -1;
+    if (P.set_flags && P.num_sets_given > sm.num_sets && sm.mismatch_set < 0) sm.mismatch_set = sm.num_sets;  // more sets than the search has
+    // profiling aid (GPD_PLAN_TIMING=1 prints them): phase times of the last workgroup's thread 0 in 10 ns ticks, 16 bits each
+    const unsigned long long tk3 = wall_clock64();
+    auto tick = [](unsigned long long a, unsigned long long b) { return (int32_t)((b - a) > 0xffffull ? 0xffffull : (b - a)); };
+    sm.pad_[0] = tick(tk0, tk1) | (tick(tk1, tk2) << 16);
+    sm.pad_[1] = tick(tk2, tk3);
+    sm.sum_set_ni = t_set_ni;
+    sm.sum_cand_ni = t_cand_ni;
     *P.summary = sm;
   }
 }
 
 void plan_free(Plan &pl) {
   void *ptrs[] = {pl.d_sample_of_set, pl.d_hand_cand, pl.d_cand_hand, pl.d_cand_out, pl.d_cand_meta, pl.d_set_meta, pl.d_summary,
-                  pl.d_set_flags, pl.d_set_samples};
+                  pl.d_set_flags, pl.d_set_samples, pl.d_parts, pl.d_ticket};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (pl.h_summary) (void)hipHostFree(pl.h_summary);
@@ -245,6 +356,14 @@ int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &
     HIP_RET(hipMalloc(&pl.d_cand_meta, H * 4 * sizeof(int32_t)));
     HIP_RET(hipMalloc(&pl.d_set_meta, (size_t)capS * capC * 8 * sizeof(int32_t)));
     HIP_RET(hipMalloc(&pl.d_summary, sizeof(PlanSummary)));
+    // look-back state of plan_kernel: zeroed once (stamps are compared with a launch number that starts at 1)
+    const size_t nparts = (size_t)(capS + PLAN_THREADS - 1) / PLAN_THREADS + 1;
+    HIP_RET(hipMalloc(&pl.d_parts, nparts * sizeof(PlanPart)));
+    HIP_RET(hipMalloc(&pl.d_ticket, sizeof(unsigned)));
+    HIP_RET(hipMemsetAsync(pl.d_parts, 0, nparts * sizeof(PlanPart), stream));
+    HIP_RET(hipMemsetAsync(pl.d_ticket, 0, sizeof(unsigned), stream));
+    pl.tickets = 0;
+    pl.epoch = 0;
     HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&pl.h_summary), sizeof(PlanSummary), 0));
     pl.cap_samples = capS;
     pl.cap_slots = capL;
@@ -292,7 +411,14 @@ int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &
   pp.cand_meta = pl.d_cand_meta;
   pp.set_meta = pl.d_set_meta;
   pp.summary = pl.d_summary;
-  plan_kernel<<<1, PLAN_THREADS, 0, stream>>>(pp);
+  const int workgroups = S > 0 ? (S + PLAN_THREADS - 1) / PLAN_THREADS : 1;
+  if (++pl.epoch == 0u) pl.epoch = 1u;  // (after 2^32 launches a stale stamp could match: the state would have to be cleared here)
+  pp.parts = pl.d_parts;
+  pp.ticket = pl.d_ticket;
+  pp.ticket_base = pl.tickets;
+  pp.epoch = pl.epoch;
+  pl.tickets += (unsigned)workgroups;
+  plan_kernel<<<workgroups, PLAN_THREADS, 0, stream>>>(pp);
   HIP_RET(hipGetLastError());
   HIP_RET(hipMemcpyAsync(pl.h_summary, pl.d_summary, sizeof(PlanSummary), hipMemcpyDeviceToHost, stream));
   return GPD_OK;
