@@ -1,0 +1,11 @@
+"""Per-phase cycle sums of the search kernels (GPD_NB_TIMING=1 / GPD_HE_TIMING=1 print them from libgpd_hip.so)."""
+import os
+import sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from gpd_amd import api, synth
+cl = synth.make_cloud(1234, 30000)
+si = synth.sample_indices(cl, 2564)
+ctx = api.Context(api.default_params(15))
+ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+for _ in range(2):
+    ctx.search(si)
