@@ -91,7 +91,9 @@ int cluster_run(ClusterState &s, const gpd_hand *hands, const double *scores, in
 
 // ---- Cloud (search.hip) -----------------------------------------------------
 // Device copy of what the path reads from util::Cloud, as SoA for coalesced streaming.
-constexpr int kMaxCams = 8;
+// cameras of a cloud: the kernels carry "which cameras see this neighbourhood" as a 32-bit mask and the view points
+// as a kernel argument (768 bytes)
+constexpr int kMaxCams = 32;
 // largest neighbourhood the search handles: hand_eval_kernel keeps neighbour ranks in 16 bits
 constexpr int kNnCapMax = 65535;
 struct Cloud {

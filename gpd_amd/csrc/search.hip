@@ -867,8 +867,8 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       on[5 * P.cap + t1] = b1.z;
     }
     for (int cam = 0; cam < P.num_cams; cam++) {
-      if (t0 < n_img) seen |= (P.cam_source[(size_t)cam * P.num_points + i0] != 0) << cam;
-      if (two && t1 < n_img) seen |= (P.cam_source[(size_t)cam * P.num_points + i1] != 0) << cam;
+      if (t0 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + i0] != 0) << cam);
+      if (two && t1 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + i1] != 0) << cam);
     }
   }
   if (seen) atomicOr(&s_seen, seen);

@@ -250,6 +250,56 @@ def test_two_cameras_shadow_intersection(oracle_mod, cloud30k):
         ctx.close()
 
 
+def test_twelve_cameras(oracle_mod):
+    """More cameras than any rig has (the reference's camera_source is an n_cams x N matrix without a bound,
+    cloud.h:330-350; the kernels carry the seeing cameras as a 32-bit mask): normals flipped towards the first
+    seeing camera, one shadow voxel set per seeing camera in camera order, their intersection, the LCG draws of
+    every camera consumed — normals, records, images and scores against the oracle.  A 33rd camera is refused."""
+    cl = synth.make_cloud(77, 12000)
+    P = len(cl["xyz"])
+    rng = np.random.RandomState(12)
+    n_cams = 12
+    cam = (rng.uniform(size=(n_cams, P)) < 0.93).astype(np.int32)
+    cam[5] = 0                                  # a camera that sees nothing: no voxel set, no draws
+    cam[7] = cl["xyz"][:, 0] < 0.1              # a camera that misses one side of the scene
+    none = np.flatnonzero(cam.sum(axis=0) == 0)
+    cam[0, none] = 1
+    vp = np.array([[0.0, 0.0, 0.0]]) + rng.uniform(-0.04, 0.04, (n_cams, 3))
+    vp[9] = [0.0, 0.0, 1.7]                     # one camera on the far side: normals of points only it sees flip
+    only9 = rng.choice(P, 300, replace=False)
+    cam[:, only9] = 0
+    cam[9, only9] = 1
+    w = _weights(15)
+    p = oracle_mod.default_params(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(cl["xyz"], np.zeros_like(cl["xyz"]), cam, vp)
+        nrm = ctx.estimate_normals(0.03)
+        want_n = oracle_mod.estimate_normals(cl["xyz"], cam, vp, 0.03)
+        assert np.array_equal(nrm, want_n)
+        assert not np.array_equal(nrm, oracle_mod.estimate_normals(cl["xyz"], cam[:1], vp[:1], 0.03))
+        si = synth.sample_indices(cl, 120)
+        hands, n_cand = ctx.detect(si)
+        ohands, on_cand, _ = oracle_mod.detect(p, cl["xyz"], nrm, cam, vp, si, w)
+        assert n_cand == on_cand and n_cand > 100
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes()
+        fw = oracle_mod.filter_workspace(p, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(p, cl["xyz"], nrm, cam, vp, fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
+        assert img[..., 4].any() and img[..., 9].any()  # the intersection of eleven voxel sets is not empty
+        big = np.ones((33, P), np.int32)
+        with pytest.raises(api.GpdHipError, match="cameras"):
+            ctx.upload_cloud(cl["xyz"], cl["normals"], big, np.zeros((33, 3)))
+    finally:
+        ctx.close()
+
+
 def _locally_dense_cloud(copies):
     """The 30k cloud with `copies` jittered duplicates of everything within 6 cm of one object point."""
     from scipy.spatial import cKDTree
