@@ -844,31 +844,65 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   // The last wave computes the local frame (a serial fp64 chain + the eigensolver on one lane: ~20 k cycles) while the
   // other seven gather; it reads its ~40 normals through the sorted indices, not through the rows being written.
   constexpr int GW = NB_WAVES - 1, GT = 64 * GW;  // gathering waves / threads
-  if (tid < GT)
-  for (int t0 = tid; t0 < n; t0 += 2 * GT) {  // two entries per round: their loads are in flight together
+  // Two entries per thread and round, and the loads of round r + 1 are requested BEFORE the stores of round r go out
+  // (two register sets, A and B): gfx9 counts loads and stores in one in-order counter, so a round that stores first and
+  // then asks for the next points waits for its 14 store acknowledgements before it sees them — that was a third of
+  // this phase (31 -> kcycles per sample, GPD_NB_TIMING).  The first camera's flags ride with the point loads.
+  struct Rnd {
+    int t0, i0, i1, c0, c1;
+    float4 a0, b0, a1, b1;
+  };
+  auto fetch = [&](int t0, Rnd &r) {
+    r.t0 = t0;
     const int t1 = t0 + GT;
+    r.i0 = index_at(t0 < n ? t0 : 0);
+    r.i1 = index_at(t1 < n ? t1 : 0);
+    r.a0 = P.pxyz[r.i0];
+    r.b0 = P.pnrm[r.i0];
+    r.a1 = P.pxyz[r.i1];
+    r.b1 = P.pnrm[r.i1];
+    r.c0 = P.cam_source[r.i0];
+    r.c1 = P.cam_source[r.i1];
+  };
+  auto put = [&](const Rnd &r) {
+    const int t0 = r.t0, t1 = r.t0 + GT;
+    if (t0 >= n) return;
     const bool two = t1 < n;
-    const int i0 = index_at(t0), i1 = two ? index_at(t1) : i0;
-    const float4 a0 = P.pxyz[i0], b0 = P.pnrm[i0], a1 = P.pxyz[i1], b1 = P.pnrm[i1];
-    oi[t0] = i0;
-    on[0 * P.cap + t0] = a0.x;
-    on[1 * P.cap + t0] = a0.y;
-    on[2 * P.cap + t0] = a0.z;
-    on[3 * P.cap + t0] = b0.x;
-    on[4 * P.cap + t0] = b0.y;
-    on[5 * P.cap + t0] = b0.z;
+    oi[t0] = r.i0;
+    on[0 * P.cap + t0] = r.a0.x;
+    on[1 * P.cap + t0] = r.a0.y;
+    on[2 * P.cap + t0] = r.a0.z;
+    on[3 * P.cap + t0] = r.b0.x;
+    on[4 * P.cap + t0] = r.b0.y;
+    on[5 * P.cap + t0] = r.b0.z;
     if (two) {
-      oi[t1] = i1;
-      on[0 * P.cap + t1] = a1.x;
-      on[1 * P.cap + t1] = a1.y;
-      on[2 * P.cap + t1] = a1.z;
-      on[3 * P.cap + t1] = b1.x;
-      on[4 * P.cap + t1] = b1.y;
-      on[5 * P.cap + t1] = b1.z;
+      oi[t1] = r.i1;
+      on[0 * P.cap + t1] = r.a1.x;
+      on[1 * P.cap + t1] = r.a1.y;
+      on[2 * P.cap + t1] = r.a1.z;
+      on[3 * P.cap + t1] = r.b1.x;
+      on[4 * P.cap + t1] = r.b1.y;
+      on[5 * P.cap + t1] = r.b1.z;
     }
-    for (int cam = 0; cam < P.num_cams; cam++) {
-      if (t0 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + i0] != 0) << cam);
-      if (two && t1 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + i1] != 0) << cam);
+    if (t0 < n_img) seen |= (int)(r.c0 != 0);
+    if (two && t1 < n_img) seen |= (int)(r.c1 != 0);
+    for (int cam = 1; cam < P.num_cams; cam++) {  // further cameras: not pipelined
+      if (t0 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + r.i0] != 0) << cam);
+      if (two && t1 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + r.i1] != 0) << cam);
+    }
+  };
+  if (tid < GT && n > 0) {
+    Rnd A, B;
+    fetch(tid, A);
+    for (int t0 = tid; t0 < n; t0 += 4 * GT) {
+      fetch(t0 + 2 * GT, B);
+      __builtin_amdgcn_sched_barrier(0);
+      put(A);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(t0 + 4 * GT, A);
+      __builtin_amdgcn_sched_barrier(0);
+      put(B);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (seen) atomicOr(&s_seen, seen);
@@ -882,15 +916,24 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     const int cp = lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? 1 : lane == 3 ? 2 : lane == 4 ? 2 : lane == 5 ? 2 : lane == 6 ? 0 : lane == 7 ? 1 : 2;
     const int cq = lane == 0 ? 0 : lane == 1 ? 0 : lane == 2 ? 1 : lane == 3 ? 0 : lane == 4 ? 1 : lane == 5 ? 2 : -1;
     double acc = 0.0;
-    if (lane < 9)
-      for (int t = 0; t < kf; t++) {
-        const float4 nv = P.pnrm[index_at(t)];
-        const float xs = cp == 0 ? nv.x : (cp == 1 ? nv.y : nv.z);
-        const float ys = cq == 0 ? nv.x : (cq == 1 ? nv.y : nv.z);
+    // the ~40 normals come in ONE round trip — lane t asks for the t-th neighbour's — and are handed to the nine chain
+    // lanes through v_readlane (a loop of kf dependent LDS + global round trips on the chain lanes was this wave's, and
+    // with it the workgroup's, critical path: ~30 of ~110 kcycles)
+    for (int base = 0; base < kf; base += 64) {
+      const int tl = base + lane;
+      const float4 nl = P.pnrm[index_at(tl < kf ? tl : base)];
+      const int m = kf - base < 64 ? kf - base : 64;
+      for (int u = 0; u < m; u++) {
+        const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.x), u));
+        const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.y), u));
+        const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.z), u));
+        const float xs = cp == 0 ? ux : (cp == 1 ? uy : uz);
+        const float ys = cq == 0 ? ux : (cq == 1 ? uy : uz);
         const double x = (double)xs;
         const double y = cq >= 0 ? (double)ys : 1.0;
-        acc += x * y;
+        if (lane < 9) acc += x * y;
       }
+    }
     auto chain = [&](int c) {
       const unsigned long long b = (unsigned long long)__double_as_longlong(acc);
       const unsigned lo = __shfl((unsigned)b, c), hi = __shfl((unsigned)(b >> 32), c);
@@ -995,17 +1038,32 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   if (P.hl) {
     while (*(volatile int *)&s_hl_ready == 0) __builtin_amdgcn_s_sleep(2);
     __threadfence_block();
+    NTICK(8);
     const int Nh = *(volatile int *)&s_hl_n;
     const double ax0 = s_hl_axis[0], ax1 = s_hl_axis[1], ax2 = s_hl_axis[2], lim = s_hl_axis[3];
     float4 *out = P.hl + (size_t)s * P.cap;
-    for (;;) {
+    // a wave's next chunk is drawn, and its points are requested, before the current chunk is tested and stored: the
+    // draw (an LDS atomic round trip) and the L2 round trip of the points then overlap the previous chunk's work
+    auto draw = [&] {
       int chunk = 0;
       if (lane == 0) chunk = atomicAdd(&s_hl_next, 1);
-      chunk = __builtin_amdgcn_readfirstlane(chunk);
-      const int e0 = chunk * 128;
-      if (e0 >= Nh) break;
-      const int ea = e0 + lane, eb = e0 + 64 + lane;  // two entries per lane: their loads are in flight together
-      const float4 pa = P.pxyz[index_at(ea < Nh ? ea : Nh - 1)], pb = P.pxyz[index_at(eb < Nh ? eb : Nh - 1)];
+      return __builtin_amdgcn_readfirstlane(chunk) * 128;
+    };
+    int e0 = draw();
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+    if (e0 < Nh) {
+      pa = P.pxyz[index_at(e0 + lane < Nh ? e0 + lane : Nh - 1)];
+      pb = P.pxyz[index_at(e0 + 64 + lane < Nh ? e0 + 64 + lane : Nh - 1)];
+    }
+    while (e0 < Nh) {
+      const int e1 = draw();
+      float4 na = pa, nb = pb;
+      if (e1 < Nh) {
+        na = P.pxyz[index_at(e1 + lane < Nh ? e1 + lane : Nh - 1)];
+        nb = P.pxyz[index_at(e1 + 64 + lane < Nh ? e1 + 64 + lane : Nh - 1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int ea = e0 + lane, eb = e0 + 64 + lane;  // two entries per lane
       const double za = ax0 * ((double)pa.x - sx) + ax1 * ((double)pa.y - sy) + ax2 * ((double)pa.z - sz);
       const double zb = ax0 * ((double)pb.x - sx) + ax1 * ((double)pb.y - sy) + ax2 * ((double)pb.z - sz);
       const bool ina = ea < Nh && za > -lim && za < lim, inb = eb < Nh && zb > -lim && zb < lim;
@@ -1016,7 +1074,12 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       const unsigned long long below = (1ull << lane) - 1ull;
       if (ina) out[base + __popcll(ba & below)] = make_float4(pa.x, pa.y, pa.z, __int_as_float(ea));
       if (inb) out[base + __popcll(ba) + __popcll(bb & below)] = make_float4(pb.x, pb.y, pb.z, __int_as_float(eb));
+      __builtin_amdgcn_sched_barrier(0);
+      e0 = e1;
+      pa = na;
+      pb = nb;
     }
+    NTICK(9);
   }
   __syncthreads();
   NTICK(7);
@@ -1972,8 +2035,8 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   static unsigned long long *d_nbdbg = nullptr;
   np.dbg = nullptr;
   if (getenv("GPD_NB_TIMING")) {
-    if (!d_nbdbg) HIP_RET(hipMalloc(&d_nbdbg, 8 * sizeof(unsigned long long)));
-    HIP_RET(hipMemsetAsync(d_nbdbg, 0, 8 * sizeof(unsigned long long), stream));
+    if (!d_nbdbg) HIP_RET(hipMalloc(&d_nbdbg, 10 * sizeof(unsigned long long)));
+    HIP_RET(hipMemsetAsync(d_nbdbg, 0, 10 * sizeof(unsigned long long), stream));
     np.dbg = d_nbdbg;
   }
   // 8192-entry lists are bucket-sorted (64 + 8 KB of LDS: two workgroups per CU); the 16384-entry
@@ -1994,11 +2057,12 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   }
   HIP_RET(hipGetLastError());
   if (np.dbg) {
-    unsigned long long h[8];
+    unsigned long long h[10];
     HIP_RET(hipMemcpyAsync(h, d_nbdbg, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_RET(hipStreamSynchronize(stream));
-    static const char *names[8] = {"visit", "scan", "scatter", "bucket sort", "crowded buckets", "prefix lengths", "gather", "frame"};
-    for (int i = 0; i < 8; i++) fprintf(stderr, "[nb-timing] %-16s %8.1f kcycles/sample\n", names[i], (double)h[i] / S / 1e3);
+    static const char *names[10] = {"visit", "scan", "scatter", "bucket sort", "crowded buckets", "prefix lengths", "gather",
+                                    "last barrier", "wait for the frame", "height list"};
+    for (int i = 0; i < 10; i++) fprintf(stderr, "[nb-timing] %-16s %8.1f kcycles/sample\n", names[i], (double)h[i] / S / 1e3);
   }
   // the centre sums fork off to the side stream; search_join() brings them back
   if (!s.aux) {
