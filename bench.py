@@ -74,11 +74,22 @@ def main():
     ap.add_argument("--batch-clouds", type=int, default=None,
                     help="replay mode: clouds per rank of the batch_end_to_end leg (default 12 on one GPU, 64 on several; 0 disables)")
     ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
+    ap.add_argument("--live-pmc", dest="live_pmc", action="store_true", default=None,
+                    help="measure roofline.traffic / pmc_traffic here (two rocprofv3 --pmc child runs of this file after the timed region, "
+                         "~20 s) instead of reading profiles/r03_traffic.json; default: on for the default line on one GPU, unless this "
+                         "process is itself being profiled")
+    ap.add_argument("--no-live-pmc", dest="live_pmc", action="store_false")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: one process per GPU under torch.distributed.run (RCCL / gloo rendezvous on
         # 127.0.0.1), same arguments; rank 0 of the children prints the ONE line
         sys.exit(_self_launch(args.gpus))
+    if args.live_pmc is None:
+        # the headline line measures its HBM traffic itself; not under a profiler (rocprofv3 around this process: the
+        # collection scripts), not for the side configs, not on several GPUs
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+        args.live_pmc = (args.gpus == 1 and args.config is None and args.mode == "replay" and args.points is None and args.candidates is None
+                         and args.channels is None and not args.clutter and not profiled and not os.environ.get("GPD_BENCH_DRYRUN"))
     if args.batch_clouds is None:
         args.batch_clouds = 12 if args.gpus == 1 else 64
     if args.steps is None:
@@ -303,7 +314,7 @@ def main():
             kernels[name] = {"ms": k_s * 1e3, "algorithmic_flops": fl * n_cand,
                              "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None,
                              "frac_f32": fl * n_cand / k_s / 1e12 / F32_PEAK_TFLOPS if k_s > 0 else None}
-        traffic = _pmc_traffic(n_cand, C)
+        traffic = _pmc_traffic(n_cand, C, live=args.live_pmc and args.gpus == 1)
         sq = _pmc_sq()
         if sq:
             # the image kernels are latency / LDS bound, not HBM bound: their LDS roofline is the share of
@@ -479,27 +490,92 @@ def _fc1_tile(n):
         r += 1
 
 
-def _pmc_traffic(n_images, channels=15):
+def _live_pmc_kernels():
+    """--live-pmc: the two PMC passes of profiles/collect_r03.sh run from inside this process, on this box — `rocprofv3 --pmc
+    FETCH_SIZE` and `--pmc WRITE_SIZE` (counters only, their own runs) around a short child run of this file — and reduced as
+    profiles/summarize.py --traffic does (KiB per launch; reads x2 per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
+    Returns the per-kernel dict of profiles/r03_traffic.json, or None when rocprofv3 is missing / a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="gpd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {}
+    try:
+        for counter, key in (("FETCH_SIZE", "fetch_KiB_raw"), ("WRITE_SIZE", "write_KiB")):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "bench", "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
+                   "--cpu-samples", "0", "--batch-clouds", "0", "--no-live-pmc"]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(p.pid, signal.SIGKILL)  # its own session: exactly the processes started here
+                p.wait()
+                return None
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                return None
+            c = sqlite3.connect(dbs[0])
+            cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+            nm = "kernel_name" if "kernel_name" in cols else "name"
+            for name, avg in c.execute("select %s, avg(value) from counters_collection where counter_name = ? group by %s" % (nm, nm), (counter,)):
+                res.setdefault(str(name), {})[key] = avg
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for v in res.values():
+        v["read_bytes_corrected"] = 2.0 * v.get("fetch_KiB_raw", 0.0) * 1024.0
+        v["write_bytes"] = v.get("write_KiB", 0.0) * 1024.0
+        v["hbm_bytes_per_launch"] = v["read_bytes_corrected"] + v["write_bytes"]
+    return res or None
+
+
+def _pmc_traffic(n_images, channels=15, live=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json, produced by
     profiles/collect_r03.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
-    on: when a kernel file has changed since, the numbers are stale and dropped."""
-    if not os.path.exists(TRAFFIC_FILE):
-        return {"note": "no PMC traffic file"}
+    on: when a kernel file has changed since, the numbers are stale and dropped.  live (--live-pmc): measured here and now
+    instead (_live_pmc_kernels), the file's figures next to them."""
     if channels != 15 or n_images != 5000:
         return {"note": "the PMC passes were collected on the default workload (15 channels, 5000 candidates) only"}
-    d = json.load(open(TRAFFIC_FILE))
-    if d.get("source_hashes") != source_hashes():
+    filed = None
+    if os.path.exists(TRAFFIC_FILE):
+        filed = json.load(open(TRAFFIC_FILE))
+        filed = filed["kernels"] if filed.get("source_hashes") == source_hashes() else None
+    if live:
+        try:
+            d = _live_pmc_kernels()
+        except Exception as e:  # a measurement aid must not take the bench line down with it
+            sys.stderr.write("bench.py: live PMC passes failed (%s): the committed profile is reported\n" % e)
+            d = None
+        if d is not None:
+            out = _traffic_totals(d, n_images, "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes run by this process on this box (a "
+                                  "3-step child run each; reads x2 per the gfx950 note)")
+            if filed is not None:
+                out["committed_file"] = {k: v for k, v in _traffic_totals(filed, n_images, "").items() if k != "source"}
+            return out
+    if not os.path.exists(TRAFFIC_FILE):
+        return {"note": "no PMC traffic file"}
+    if filed is None:
         return {"note": "%s was measured on other kernel sources: stale, not reported" % os.path.relpath(TRAFFIC_FILE, ROOT)}
-    d = d["kernels"]
-    out = {"source": "profiles/r03_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; reads x2 per "
-                     "the gfx950 note; same kernel sources as this run, by SHA-1)"}
+    return _traffic_totals(filed, n_images, "profiles/r03_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; "
+                           "reads x2 per the gfx950 note; same kernel sources as this run, by SHA-1)")
+
+
+def _traffic_totals(d, n_images, source):
+    out = {"source": source}
     fc1 = "fc1_mfma_kernel<%d>" % _fc1_tile(n_images)
 
     def total(names):
         vals = [v["hbm_bytes_per_launch"] for k, v in d.items() if any(s in k for s in names)]
         return float(sum(vals)) if vals else None
 
-    out["image"] = total(("grasp_image_kernel<false>", "shadow_image_kernel<6144>", "shadow_set_kernel"))
+    out["image"] = total(("grasp_image_kernel<false>", "shadow_image_kernel<6144", "shadow_set_kernel"))
     out["lenet"] = total(("conv1_mfma", "conv2_mfma", fc1, "fc2_score"))
     out["conv1_mfma"] = total(("conv1_mfma",))
     out["conv2_mfma"] = total(("conv2_mfma",))
@@ -519,7 +595,7 @@ def _pmc_sq():
     out = {"source": "profiles/r03_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
            "peak": "256 B/clk/CU = %.1f TB/s at 2.4 GHz" % (LDS_PEAK_GBS * 2 / 1e3)}
     for k, v in d["kernels"].items():
-        for name in ("shadow_image_kernel<6144>", "grasp_image_kernel<false>", "shadow_set_kernel"):
+        for name in ("shadow_image_kernel<6144", "grasp_image_kernel<false>", "shadow_set_kernel"):
             if name in k:
                 out[name] = {"frac": v["lds_util"], "conflict_share": v["lds_conflict"], "wait_any": v["wait_any"]}
     return out

@@ -17,9 +17,9 @@ timeout 400 python bench.py --mode batch --clouds 64 --steps 2 --warmup 1 > $OUT
 cd /tmp && export TMPDIR=/tmp
 P=$OUT/prof
 mkdir -p $P
-timeout 300 rocprofv3 --kernel-trace --stats -d $P/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-samples 0 --batch-clouds 0 > $P/stats.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d $P/pmc_fetch -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $P/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $P/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $P/stats -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-samples 0 --batch-clouds 0 --no-live-pmc > $P/stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $P/pmc_fetch -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 --no-live-pmc > $P/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $P/pmc_write -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 --no-live-pmc > $P/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $P/batch -o batch -- python $ROOT/bench.py --mode batch --clouds 16 --steps 2 --warmup 1 > $P/batch.log 2>&1
 cd $ROOT
 python profiles/summarize.py $P > $OUT/rocprof_summary.txt 2>&1
