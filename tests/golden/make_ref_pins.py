@@ -7,6 +7,7 @@ HIP path (GPU suite) with them.  Nothing in here calls the oracle: the pins are 
 
     python tests/golden/make_ref_pins.py            # all
     python tests/golden/make_ref_pins.py variants   # or: extras
+    python tests/golden/make_ref_pins.py variants twelve_cameras   # these cases only
 """
 import os
 import subprocess
@@ -35,8 +36,10 @@ def _stamp():
     return np.array("reference sources at %s through oracle/shim (oracle/build_ref.sh A), repository %s" % (REFERENCE, rev))
 
 
-def variants():
+def variants(only=None):
     for name in rcs.VARIANTS:
+        if only and name not in only:
+            continue
         p, cl, si, cam, vp = rcs.case_inputs(name, default_params)
         C = p.image_num_channels
         det = ref.Detector(p, weights=rcs.weights(15) if C == 15 else None)
@@ -187,6 +190,6 @@ if __name__ == "__main__":
         sys.exit("oracle/_ref/libgpd_ref.so cannot be built here (no reference tree): the committed pins stay as they are")
     what = sys.argv[1:] or ["variants", "extras"]
     if "variants" in what:
-        variants()
+        variants(only=[w for w in what if w in rcs.VARIANTS])
     if "extras" in what:
         extras()

@@ -38,6 +38,14 @@ def _cams(n, P, seed=9):
         cam[0] = rng.random(P) < 0.7
         cam[1] = (rng.random(P) < 0.6) | (cam[0] == 0)
         return cam, np.array([[0.0, 0.0, 0.8], [0.5, -0.4, 0.3]])
+    if n > 3:
+        # a rig of n cameras around the first view point: most see most of the scene, one sees nothing, one only one side
+        cam = (rng.random((n, P)) < 0.93).astype(np.int32)
+        cam[n // 2] = 0
+        cam[0, cam.sum(axis=0) == 0] = 1
+        vp = np.array([[0.0, 0.0, 0.8]]) + rng.uniform(-0.05, 0.05, (n, 3))
+        vp[n - 1] = [0.4, -0.3, 0.5]
+        return cam, vp
     cam = np.zeros((3, P), np.int32)
     cam[0] = rng.random(P) < 0.5
     cam[1] = rng.random(P) < 0.5
@@ -65,6 +73,7 @@ VARIANTS = {
     "frame_radius": (15, dict(nn_radius_frames=0.02), 1),
     "two_cameras": (15, {}, 2),
     "three_cameras": (15, {}, 3),
+    "twelve_cameras": (15, {}, 12),  # the reference's camera_source has no bound on its rows (cloud.h); the kernels take 32
 }
 FULL_IMAGES = ("default_c15", "default_c12", "default_c3", "default_c1", "two_cameras")  # the others are pinned by digest
 
