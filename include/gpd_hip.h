@@ -120,7 +120,8 @@ int gpd_hip_score(gpd_hip_ctx *ctx, const uint8_t *images, int n, float *scores)
  * ImageGenerator::createImages read from util::Cloud (hand_search.cpp:28-31,
  * 160-165; image_generator.cpp:24-29): float32 xyz (AoS), float32 normals
  * (AoS), camera source n_cams x P (row per camera, 0/1), view points 3 doubles
- * per camera. */
+ * per camera.  1 <= num_cams <= 32 (GPD_ERR_INVALID beyond: the kernels carry the
+ * cameras that see a neighbourhood as a 32-bit mask). */
 int gpd_hip_upload_cloud(gpd_hip_ctx *ctx, const float *xyz, const float *normals,
                          int num_points, const int32_t *cam_source, int num_cams,
                          const double *view_points);
