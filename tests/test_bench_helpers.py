@@ -72,6 +72,47 @@ def test_committed_profiles_belong_to_the_committed_kernels():
             pytest.skip(name + " is stale: a kernel source changed since it was collected; bench.py reports no PMC numbers until it is re-collected")
 
 
+def test_traffic_totals_take_every_kernel_of_a_stage():
+    """The per-stage totals pick their kernels by name: with the committed profile every kernel of the image stage, of
+    LeNet and of the search must be found (the shadow image kernel once dropped out of `image` when it gained a second
+    template argument: 505 instead of 623 MB), and a live measurement reports the committed figures next to its own."""
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed traffic profile")
+    d = json.load(open(path))["kernels"]
+    t = bench._traffic_totals(d, 5000, "x")
+
+    def one(sub):
+        hits = [v["hbm_bytes_per_launch"] for k, v in d.items() if sub in k]
+        assert len(hits) == 1, (sub, [k for k in d if sub in k])
+        return hits[0]
+
+    img = one("grasp_image_kernel<false>") + one("shadow_image_kernel<6144") + one("shadow_set_kernel")
+    assert t["image"] == pytest.approx(img) and one("shadow_image_kernel<6144") > 5e7
+    assert t["lenet"] == pytest.approx(one("conv1_mfma") + one("conv2_mfma") + one("fc1_mfma_kernel<5>") + one("fc2_score"))
+    assert t["search"] == pytest.approx(one("neighbourhood_kernel<false>") + one("hand_eval_kernel") + one("plan_kernel") + one("centre_kernel"))
+
+
+def test_live_pmc_falls_back_to_the_committed_profile(monkeypatch):
+    """--live-pmc without a working rocprofv3 (no GPU here): the committed, stamped profile is reported instead, and an
+    exception inside the measurement does not take the bench line down."""
+    monkeypatch.setattr(bench, "_live_pmc_kernels", lambda: None)
+    a = bench._pmc_traffic(5000, live=True)
+    b = bench._pmc_traffic(5000, live=False)
+    assert a == b
+
+    def boom():
+        raise RuntimeError("no counters")
+    monkeypatch.setattr(bench, "_live_pmc_kernels", boom)
+    assert bench._pmc_traffic(5000, live=True) == b
+    fake = {"void gpd::conv1_mfma_kernel<15>(x)": {"hbm_bytes_per_launch": 7e8}}
+    monkeypatch.setattr(bench, "_live_pmc_kernels", lambda: fake)
+    c = bench._pmc_traffic(5000, live=True)
+    assert c["conv1_mfma"] == 7e8 and c["source"].startswith("live")
+    if "conv1_mfma" in b:
+        assert c["committed_file"]["conv1_mfma"] == b["conv1_mfma"]
+
+
 def test_batch_mode_cloud_assignment():
     for world in (1, 2, 4, 8):
         seen = sorted(c for r in range(world) for c in gdist.clouds_of_rank(256, r, world))
