@@ -150,7 +150,7 @@ struct SearchState {
   int32_t *d_sample_idx = nullptr;    // [S]
   double *d_sample_xyz = nullptr;     // [S][3] samples given by coordinates (used instead of the indices)
   int32_t *d_counts = nullptr;        // [S][8]: N_hands, N_images, k_frames, total found, seen by camera 0
-  int32_t *d_nn_idx = nullptr;        // [S][nn_cap] sorted by (d2, index)
+  int32_t *d_nn_idx = nullptr;        // [S][nn_cap] scratch of the global-memory lists (neighbourhoods beyond the LDS capacities)
   float *d_nn = nullptr;              // [S][6][nn_cap] gathered px,py,pz,nx,ny,nz in that order
   double *d_frames = nullptr;         // [S][12] sample, normal, binormal, curvature
   double *d_centers = nullptr;        // [S][3] mean of the image neighbourhood

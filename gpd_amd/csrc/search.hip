@@ -54,8 +54,10 @@ namespace gpd {
 // ---------------------------------------------------------------------------
 // Cloud upload: AoS (caller layout) -> SoA planes.
 // ---------------------------------------------------------------------------
-__global__ void split_soa_kernel(const float *__restrict__ xyz, const float *__restrict__ nrm, int n, float *px, float *py,
-                                 float *pz, float *nx, float *ny, float *nz, float4 *pxyz, float4 *pnrm) {
+// pxyz.w carries the first camera's flag of the point (bits of the int): the gather of neighbourhood_kernel then needs no
+// third random access per neighbour (that phase is bound by the address unit: one lane per cycle and load)
+__global__ void split_soa_kernel(const float *__restrict__ xyz, const float *__restrict__ nrm, const int32_t *__restrict__ cam0, int n,
+                                 float *px, float *py, float *pz, float *nx, float *ny, float *nz, float4 *pxyz, float4 *pnrm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -66,7 +68,7 @@ __global__ void split_soa_kernel(const float *__restrict__ xyz, const float *__r
   nx[i] = a;
   ny[i] = b;
   nz[i] = c;
-  pxyz[i] = make_float4(x, y, z, 0.f);
+  pxyz[i] = make_float4(x, y, z, __int_as_float(cam0[i]));
   pnrm[i] = make_float4(a, b, c, 0.f);
 }
 
@@ -205,8 +207,8 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
   std::memcpy(c.view_points, view_points, sizeof(double) * 3 * num_cams);
   HIP_RET(hipMemcpyAsync(c.staging, hx, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, stream));
   HIP_RET(hipMemcpyAsync(c.cam_source, hc, (size_t)n * num_cams * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  split_soa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c.staging, c.staging + (size_t)n * 3, n, c.px, c.py, c.pz, c.nx, c.ny,
-                                                         c.nz, c.pxyz, c.pnrm);
+  split_soa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c.staging, c.staging + (size_t)n * 3, c.cam_source, n, c.px, c.py, c.pz, c.nx,
+                                                         c.ny, c.nz, c.pxyz, c.pnrm);
   HIP_RET(hipGetLastError());
   // uniform grid: bounds from the pass above, counting sort on the device
   c.g_cell = 0.02f;
@@ -467,8 +469,14 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   __shared__ int s_bounds[3];
   __shared__ int s_seen;
   __shared__ double s_hl_axis[4];  // height list: hand axis of slot 0 and the limit h + margin (published by the frame wave)
-  __shared__ int s_hl_n, s_hl_ready, s_hl_next, s_hl_count;
+  __shared__ int s_hl_ready, s_hl_next, s_hl_count;
   __shared__ int s_ncrowd;
+  // the frame wave's own list of the frame neighbourhood (d2 < r2_frames): keys (d2 bits, index) in visit order, the point
+  // indices in FLANN order; s_fkf = their number once the frame is done (more than FCAP: -1, the frame waits for the workgroup's sorted list)
+  constexpr int FCAP = 160;
+  __shared__ unsigned long long s_fk[FCAP];
+  __shared__ int s_fidx[FCAP];
+  __shared__ int s_fkf;
   const int s = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -505,11 +513,11 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     s_bounds[1] = 0;
     s_bounds[2] = 0;
     s_seen = 0;
-    s_hl_n = 0;
     s_hl_ready = 0;
     s_hl_next = 0;
     s_hl_count = 0;
     s_ncrowd = 0;
+    s_fkf = -1;
   }
   // bucket mode: two u32 arrays in the key storage, counters behind them
   uint32_t *s_a, *s_b;  // indices in visit order, then sorted d2 bits / indices in bucket order, then sorted
@@ -543,6 +551,210 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   if (P.bucket)
     for (int i = tid; i < NBK; i += NB_THREADS) s_hist[i] = 0;
   __syncthreads();
+  constexpr int VW = NB_WAVES - 1;  // visiting waves
+  // frames (frame_estimator.cpp:66-86 + local_frame.cpp:14-41) from the kf nearest neighbours in FLANN order, idx_of(t) =
+  // point index of the t-th; one whole wave.  M = sum n n^T and sum n are nine sequential fp64 chains in neighbour
+  // order: the normals come in ONE round trip per 64 — lane t asks for the t-th neighbour's — and are handed to the
+  // nine chain lanes through v_readlane (the same adds in the same order per chain); the wave's first lane runs the
+  // eigensolver, stores the frame and, for the height list, publishes the hand axis of slot 0 and the limit.
+  auto frame_of = [&](int kf, auto idx_of) {
+    const int cp = lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? 1 : lane == 3 ? 2 : lane == 4 ? 2 : lane == 5 ? 2 : lane == 6 ? 0 : lane == 7 ? 1 : 2;
+    const int cq = lane == 0 ? 0 : lane == 1 ? 0 : lane == 2 ? 1 : lane == 3 ? 0 : lane == 4 ? 1 : lane == 5 ? 2 : -1;
+    double acc = 0.0;
+    for (int base = 0; base < kf; base += 64) {
+      const int tl = base + lane;
+      const float4 nl = P.pnrm[idx_of(tl < kf ? tl : base)];
+      const int m = kf - base < 64 ? kf - base : 64;
+      for (int u = 0; u < m; u++) {
+        const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.x), u));
+        const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.y), u));
+        const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.z), u));
+        const float xs = cp == 0 ? ux : (cp == 1 ? uy : uz);
+        const float ys = cq == 0 ? ux : (cq == 1 ? uy : uz);
+        const double x = (double)xs;
+        const double y = cq >= 0 ? (double)ys : 1.0;
+        if (lane < 9) acc += x * y;
+      }
+    }
+    auto chain = [&](int c) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(acc);
+      const unsigned lo = __shfl((unsigned)b, c), hi = __shfl((unsigned)(b >> 32), c);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    double m00 = chain(0), m10 = chain(1), m11 = chain(2), m20 = chain(3), m21 = chain(4), m22 = chain(5);
+    double a0 = chain(6), a1 = chain(7), a2 = chain(8);
+    double *f = P.frames + 12 * (size_t)s;
+    if (lane == 0) {
+      f[0] = sx;
+      f[1] = sy;
+      f[2] = sz;
+      if (kf > 0) {
+        double ev[3], Q[9];
+        eigen3(m00, m10, m11, m20, m21, m22, ev, Q);
+        int mn = 0, mx = 0;
+        for (int i = 1; i < 3; i++) {
+          if (ev[i] < ev[mn]) mn = i;
+          if (ev[i] > ev[mx]) mx = i;
+        }
+        double curv[3], nor[3];
+        for (int r = 0; r < 3; r++) {
+          curv[r] = Q[3 * r + mn];
+          nor[r] = Q[3 * r + mx];
+        }
+        const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
+        a0 /= nrm;
+        a1 /= nrm;
+        a2 /= nrm;
+        const double dot = a0 * nor[0] + a1 * nor[1] + a2 * nor[2];
+        if (dot < 0)
+          for (int r = 0; r < 3; r++) nor[r] *= -1.0;
+        f[3] = nor[0];
+        f[4] = nor[1];
+        f[5] = nor[2];
+        f[6] = curv[1] * nor[2] - curv[2] * nor[1];
+        f[7] = curv[2] * nor[0] - curv[0] * nor[2];
+        f[8] = curv[0] * nor[1] - curv[1] * nor[0];
+        f[9] = curv[0];
+        f[10] = curv[1];
+        f[11] = curv[2];
+      }
+    }
+    // hl_note.  The height crop shared by the orientations of a sample: cropByHandHeight (point_list.cpp:35-55) keeps the
+    // points whose coordinate along the hand frame's third axis lies in (-h, h); that axis is the one the orientations
+    // rotate about, so the frames of a sample's slots have the same third column up to rounding.  The points with
+    // |z| < h + margin for the axis of slot 0 — margin = (largest deviation of any slot's axis from it) x radius + 1e-12,
+    // a superset of every orientation's exact crop, which hand_eval_kernel then decides with its own frame — are listed
+    // in this kernel, by the gathering waves as they pass (coordinates in registers; order of the list: none, the entries
+    // carry their rank).  This was a kernel of its own that read the gathered rows back from HBM (110 MB per 2564
+    // samples), then a pass of its own behind the frame.
+    if (P.hl && kf > 0) {
+      auto bc = [&](double v) {  // lane 0's value to the wave
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      };
+      // lane 0 holds the frame it has just stored: F = [normal | binormal | curvature] (hand_set.cpp:39-40)
+      double F[9];
+      __threadfence_block();
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        F[3 * r + 0] = bc(lane == 0 ? f[3 + r] : 0.0);
+        F[3 * r + 1] = bc(lane == 0 ? f[6 + r] : 0.0);
+        F[3 * r + 2] = bc(lane == 0 ? f[9 + r] : 0.0);
+      }
+      double axis[3] = {0.0, 0.0, 0.0}, dev = 0.0;
+      for (int slot = 0; slot < P.hl_slots; slot++) {
+        double a[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+          a[r] = F[3 * r] * P.hl_col[slot][0] + F[3 * r + 1] * P.hl_col[slot][1] + F[3 * r + 2] * P.hl_col[slot][2];
+        if (slot == 0) {
+          axis[0] = a[0];
+          axis[1] = a[1];
+          axis[2] = a[2];
+        }
+        dev = fmax(dev, fabs(a[0] - axis[0]) + fabs(a[1] - axis[1]) + fabs(a[2] - axis[2]));
+      }
+      if (lane == 0) {
+        s_hl_axis[0] = axis[0];
+        s_hl_axis[1] = axis[1];
+        s_hl_axis[2] = axis[2];
+        s_hl_axis[3] = P.hl_height + dev * P.hl_radius + 1e-12;
+      }
+    }
+  };
+  auto early_frame = [&] {
+    // the cells within the frame radius (same distance arithmetic as the visit), hits appended to s_fk in visit order
+    const float rfr = sqrtf(P.r2_frames) * 1.001f + 1e-5f;
+    int fn = 0;  // hits so far: the same in every lane (it only ever grows by a ballot's population)
+    auto visit_f = [&](bool in, int i, float x, float y, float z) {
+      float d = qx - x;
+      float d2 = 0.f;
+      d2 += d * d;
+      d = qy - y;
+      d2 += d * d;
+      d = qz - z;
+      d2 += d * d;
+      const bool hit = in && d2 < P.r2_frames;
+      const unsigned long long ballot = __ballot(hit);
+      if (hit) {
+        const int pos = fn + __popcll(ballot & ((1ull << lane) - 1ull));
+        if (pos < FCAP) s_fk[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+      }
+      fn += __popcll(ballot);
+    };
+    {
+      const GridView &g = P.grid;
+      const int x0 = grid_coord(g, 0, qx - rfr), x1 = grid_coord(g, 0, qx + rfr);
+      const int y0 = grid_coord(g, 1, qy - rfr), y1 = grid_coord(g, 1, qy + rfr);
+      const int z0 = grid_coord(g, 2, qz - rfr), z1 = grid_coord(g, 2, qz + rfr);
+      const int ny = y1 - y0 + 1;
+      const int ncol = (x1 - x0 + 1) * ny;
+      if (ncol <= 64) {
+        // the point ranges of all columns in one round trip (a lane per column), then four columns' points at a time
+        int cbv = 0, cev = 0;
+        if (lane < ncol) {
+          const int cx = x0 + lane / ny, cy = y0 + lane % ny;
+          const int cbase = (cx * g.dim[1] + cy) * g.dim[2];
+          cbv = g.start[cbase + z0];
+          cev = g.start[cbase + z1 + 1];
+        }
+        for (int c0 = 0; c0 < ncol; c0 += 4) {
+          int cb[4], ce[4];
+          float4 p[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int col = c0 + q < ncol ? c0 + q : c0;
+            cb[q] = __builtin_amdgcn_readlane(cbv, col);
+            ce[q] = c0 + q < ncol ? __builtin_amdgcn_readlane(cev, col) : cb[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int t = cb[q] + lane;
+            p[q] = g.p[t < ce[q] ? t : 0];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (cb[q] < ce[q]) visit_f(cb[q] + lane < ce[q], __float_as_int(p[q].w), p[q].x, p[q].y, p[q].z);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            for (int t0 = cb[q] + 64; t0 < ce[q]; t0 += 64) {
+              const int t = t0 + lane;
+              const bool in = t < ce[q];
+              const float4 pt = g.p[in ? t : cb[q]];
+              visit_f(in, __float_as_int(pt.w), pt.x, pt.y, pt.z);
+            }
+        }
+      } else {
+        grid_visit(g, qx, qy, qz, rfr, 0, 1, lane, visit_f);
+      }
+    }
+    const int kf = fn;
+    if (kf > FCAP) return;  // left to the sorted list (the late path below)
+    __threadfence_block();  // the keys were written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    // FLANN's order, (d2, index) ascending: the rank of a key is the number of smaller keys (they are distinct)
+    constexpr int KPL = (FCAP + 63) / 64;
+    unsigned long long mine[KPL];
+    int rank[KPL];
+#pragma unroll
+    for (int q = 0; q < KPL; q++) {
+      mine[q] = lane + 64 * q < kf ? s_fk[lane + 64 * q] : ~0ull;
+      rank[q] = 0;
+    }
+    for (int u = 0; u < kf; u++) {
+      const unsigned long long ku = s_fk[u];
+#pragma unroll
+      for (int q = 0; q < KPL; q++) rank[q] += ku < mine[q] ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < KPL; q++)
+      if (lane + 64 * q < kf) s_fidx[rank[q]] = (int)(unsigned)mine[q];
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    frame_of(kf, [&](int t) { return s_fidx[t]; });
+    if (lane == 0) s_fkf = kf;
+  };
   // 1. visit the grid cells around the sample; FLANN L2_Simple<float>: d2 accumulated over x,y,z, strict <.
   //    The point ranges of the (x, y) cell columns are fetched up front, one column per lane, into LDS (a column holds
   //    ~45 points: one dependent global round trip less per column and wave).
@@ -598,12 +810,13 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       // iteration was one dependent global round trip per column, 18 in a row per wave: 30 of the kernel's ~110 kcycles);
       // the few columns with more than 64 points finish in the tail loop.  The visit order is free: the list is sorted.
       constexpr int CU_ = 4;
-      for (int c0 = tid >> 6; c0 < ncol; c0 += CU_ * NB_WAVES) {
+      if ((tid >> 6) < VW)
+      for (int c0 = tid >> 6; c0 < ncol; c0 += CU_ * VW) {
         int cb[CU_], ce[CU_];
         float4 p[CU_];
 #pragma unroll
         for (int q = 0; q < CU_; q++) {
-          const int col = c0 + q * NB_WAVES;
+          const int col = c0 + q * VW;
           cb[q] = col < ncol ? s_cb[col] : 0;
           ce[q] = col < ncol ? s_ce[col] : 0;
         }
@@ -624,10 +837,15 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
             visit(in, __float_as_int(pt.w), pt.x, pt.y, pt.z);
           }
       }
-    } else {
-      grid_visit(g, qx, qy, qz, P.reach, tid >> 6, NB_WAVES, lane, visit);
+    } else if ((tid >> 6) < VW) {
+      grid_visit(g, qx, qy, qz, P.reach, tid >> 6, VW, lane, visit);
     }
   }
+  // The last wave does not visit: it finds the frame neighbourhood on its own (the few cells within the frame radius,
+  // ~40 points), orders it and computes the local frame while the other seven walk the 144 cell columns — the 3 x 3
+  // eigensolver is a chain of ~2-3 k dependent f64 instructions on one lane, and started after the sort it kept the
+  // gathering waves waiting at the end of the kernel (GPD_NB_TIMING: 7 of 108 kcycles) and the height list behind it.
+  if ((tid >> 6) == VW) early_frame();
   hand_over();
   NTICK(0);
   const int found = s_count;
@@ -835,19 +1053,29 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   }
   __syncthreads();
   NTICK(5);
-  // 4. sorted index list + gathered SoA neighbourhood.  Each key slot is then reused
-  //    for (px, py) of its entry so that the centre sum below reads LDS.
-  int32_t *oi = P.nn_idx + (size_t)s * P.cap;
+  // 4. sorted index list + gathered SoA neighbourhood, and the height list of the hand search on the way
+  // (the sorted index list itself has no reader on the device: nn_idx is the GLOBAL mode's scratch only — 43 MB of the
+  //  303 MB this phase used to write per 2564 samples)
   float *on = P.nn + (size_t)s * 6 * P.cap;
-  const int n_img = s_bounds[0];
+  const int n_img = s_bounds[0], kf = s_bounds[1], Nh = s_bounds[2];
+  // the frame wave's own neighbourhood must be the sorted list's prefix; when it is not there (more than FCAP points
+  // inside the frame radius) or differs, the frame is computed from the sorted list after the gather, as it used to be
+  const bool late = s_fkf != kf;
+  if (tid == 0) {
+    P.counts[8 * s + 0] = Nh;
+    P.counts[8 * s + 1] = n_img;
+    P.counts[8 * s + 2] = kf;
+    P.counts[8 * s + 3] = found;
+  }
+  const bool list_here = P.hl && !late && kf > 0 && Nh > 0;
+  const double ax0 = s_hl_axis[0], ax1 = s_hl_axis[1], ax2 = s_hl_axis[2], lim = s_hl_axis[3];  // (read by list_here only)
+  float4 *hl_out = P.hl ? P.hl + (size_t)s * P.cap : nullptr;
   int seen = 0;
-  // The last wave computes the local frame (a serial fp64 chain + the eigensolver on one lane: ~20 k cycles) while the
-  // other seven gather; it reads its ~40 normals through the sorted indices, not through the rows being written.
-  constexpr int GW = NB_WAVES - 1, GT = 64 * GW;  // gathering waves / threads
   // Two entries per thread and round, and the loads of round r + 1 are requested BEFORE the stores of round r go out
   // (two register sets, A and B): gfx9 counts loads and stores in one in-order counter, so a round that stores first and
-  // then asks for the next points waits for its 14 store acknowledgements before it sees them — that was a third of
-  // this phase (31 -> kcycles per sample, GPD_NB_TIMING).  The first camera's flags ride with the point loads.
+  // then asks for the next points waits for its 14 store acknowledgements before it sees them.  The first camera's
+  // flag comes with the coordinates (pxyz.w).
+  constexpr int GT = NB_THREADS;  // every wave gathers
   struct Rnd {
     int t0, i0, i1, c0, c1;
     float4 a0, b0, a1, b1;
@@ -861,40 +1089,59 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     r.b0 = P.pnrm[r.i0];
     r.a1 = P.pxyz[r.i1];
     r.b1 = P.pnrm[r.i1];
-    r.c0 = P.cam_source[r.i0];
-    r.c1 = P.cam_source[r.i1];
+    r.c0 = __float_as_int(r.a0.w);  // the first camera's flag (split_soa_kernel)
+    r.c1 = __float_as_int(r.a1.w);
   };
-  auto put = [&](const Rnd &r) {
+  auto put = [&](const Rnd &r) {  // (wave-uniform control flow around the ballots)
     const int t0 = r.t0, t1 = r.t0 + GT;
-    if (t0 >= n) return;
-    const bool two = t1 < n;
-    oi[t0] = r.i0;
-    on[0 * P.cap + t0] = r.a0.x;
-    on[1 * P.cap + t0] = r.a0.y;
-    on[2 * P.cap + t0] = r.a0.z;
-    on[3 * P.cap + t0] = r.b0.x;
-    on[4 * P.cap + t0] = r.b0.y;
-    on[5 * P.cap + t0] = r.b0.z;
+    const bool one = t0 < n, two = t1 < n;
+    if (one) {
+      on[0 * P.cap + t0] = r.a0.x;
+      on[1 * P.cap + t0] = r.a0.y;
+      on[2 * P.cap + t0] = r.a0.z;
+      on[3 * P.cap + t0] = r.b0.x;
+      on[4 * P.cap + t0] = r.b0.y;
+      on[5 * P.cap + t0] = r.b0.z;
+      if (t0 < n_img) seen |= (int)(r.c0 != 0);
+    }
     if (two) {
-      oi[t1] = r.i1;
       on[0 * P.cap + t1] = r.a1.x;
       on[1 * P.cap + t1] = r.a1.y;
       on[2 * P.cap + t1] = r.a1.z;
       on[3 * P.cap + t1] = r.b1.x;
       on[4 * P.cap + t1] = r.b1.y;
       on[5 * P.cap + t1] = r.b1.z;
+      if (t1 < n_img) seen |= (int)(r.c1 != 0);
     }
-    if (t0 < n_img) seen |= (int)(r.c0 != 0);
-    if (two && t1 < n_img) seen |= (int)(r.c1 != 0);
     for (int cam = 1; cam < P.num_cams; cam++) {  // further cameras: not pipelined
-      if (t0 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + r.i0] != 0) << cam);
+      if (one && t0 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + r.i0] != 0) << cam);
       if (two && t1 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + r.i1] != 0) << cam);
     }
+    if (list_here && (t0 & ~63) < Nh) {  // uniform: some entry of the wave's first row is a hand-search neighbour
+      bool ina = false, inb = false;
+      if (t0 < Nh) {
+        const double za = ax0 * ((double)r.a0.x - sx) + ax1 * ((double)r.a0.y - sy) + ax2 * ((double)r.a0.z - sz);
+        ina = za > -lim && za < lim;
+      }
+      if (t1 < Nh) {
+        const double zb = ax0 * ((double)r.a1.x - sx) + ax1 * ((double)r.a1.y - sy) + ax2 * ((double)r.a1.z - sz);
+        inb = zb > -lim && zb < lim;
+      }
+      const unsigned long long ba = __ballot(ina), bb = __ballot(inb);
+      if (ba | bb) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_hl_count, __popcll(ba) + __popcll(bb));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ina) hl_out[base + __popcll(ba & below)] = make_float4(r.a0.x, r.a0.y, r.a0.z, __int_as_float(t0));
+        if (inb) hl_out[base + __popcll(ba) + __popcll(bb & below)] = make_float4(r.a1.x, r.a1.y, r.a1.z, __int_as_float(t1));
+      }
+    }
   };
-  if (tid < GT && n > 0) {
+  if (n > 0) {
     Rnd A, B;
     fetch(tid, A);
-    for (int t0 = tid; t0 < n; t0 += 4 * GT) {
+    for (int t0 = tid; (t0 & ~63) < n; t0 += 4 * GT) {  // whole waves stay in the loop (the ballots in put)
       fetch(t0 + 2 * GT, B);
       __builtin_amdgcn_sched_barrier(0);
       put(A);
@@ -907,179 +1154,39 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   }
   if (seen) atomicOr(&s_seen, seen);
   NTICK(6);
-  // 5. local frame (local_frame.cpp:14-41).  M = sum n n^T and sum n are nine sequential fp64 chains in neighbour
-  //    order: nine lanes walk one chain each (the same adds in the same order per chain), the wave's first lane collects
-  //    them and runs the eigensolver.
-  if (tid >= GT) {
-    const int kf = s_bounds[1];
-    // chain c accumulates n[p] * n[q] (c < 6: m00 m10 m11 m20 m21 m22) or n[p] * 1.0 == n[p] (a0 a1 a2)
-    const int cp = lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? 1 : lane == 3 ? 2 : lane == 4 ? 2 : lane == 5 ? 2 : lane == 6 ? 0 : lane == 7 ? 1 : 2;
-    const int cq = lane == 0 ? 0 : lane == 1 ? 0 : lane == 2 ? 1 : lane == 3 ? 0 : lane == 4 ? 1 : lane == 5 ? 2 : -1;
-    double acc = 0.0;
-    // the ~40 normals come in ONE round trip — lane t asks for the t-th neighbour's — and are handed to the nine chain
-    // lanes through v_readlane (a loop of kf dependent LDS + global round trips on the chain lanes was this wave's, and
-    // with it the workgroup's, critical path: ~30 of ~110 kcycles)
-    for (int base = 0; base < kf; base += 64) {
-      const int tl = base + lane;
-      const float4 nl = P.pnrm[index_at(tl < kf ? tl : base)];
-      const int m = kf - base < 64 ? kf - base : 64;
-      for (int u = 0; u < m; u++) {
-        const float ux = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.x), u));
-        const float uy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.y), u));
-        const float uz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nl.z), u));
-        const float xs = cp == 0 ? ux : (cp == 1 ? uy : uz);
-        const float ys = cq == 0 ? ux : (cq == 1 ? uy : uz);
-        const double x = (double)xs;
-        const double y = cq >= 0 ? (double)ys : 1.0;
-        if (lane < 9) acc += x * y;
-      }
-    }
-    auto chain = [&](int c) {
-      const unsigned long long b = (unsigned long long)__double_as_longlong(acc);
-      const unsigned lo = __shfl((unsigned)b, c), hi = __shfl((unsigned)(b >> 32), c);
-      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-    };
-    double m00 = chain(0), m10 = chain(1), m11 = chain(2), m20 = chain(3), m21 = chain(4), m22 = chain(5);
-    double a0 = chain(6), a1 = chain(7), a2 = chain(8);
-    if (lane == 0) {
-    P.counts[8 * s + 0] = s_bounds[2];
-    P.counts[8 * s + 1] = s_bounds[0];
-    P.counts[8 * s + 2] = kf;
-    P.counts[8 * s + 3] = found;
-    double *f = P.frames + 12 * (size_t)s;
-    f[0] = sx;
-    f[1] = sy;
-    f[2] = sz;
-    if (kf > 0) {
-      double ev[3], Q[9];
-      eigen3(m00, m10, m11, m20, m21, m22, ev, Q);
-      int mn = 0, mx = 0;
-      for (int i = 1; i < 3; i++) {
-        if (ev[i] < ev[mn]) mn = i;
-        if (ev[i] > ev[mx]) mx = i;
-      }
-      double curv[3], nor[3];
-      for (int r = 0; r < 3; r++) {
-        curv[r] = Q[3 * r + mn];
-        nor[r] = Q[3 * r + mx];
-      }
-      const double nrm = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
-      a0 /= nrm;
-      a1 /= nrm;
-      a2 /= nrm;
-      const double dot = a0 * nor[0] + a1 * nor[1] + a2 * nor[2];
-      if (dot < 0)
-        for (int r = 0; r < 3; r++) nor[r] *= -1.0;
-      f[3] = nor[0];
-      f[4] = nor[1];
-      f[5] = nor[2];
-      f[6] = curv[1] * nor[2] - curv[2] * nor[1];
-      f[7] = curv[2] * nor[0] - curv[0] * nor[2];
-      f[8] = curv[0] * nor[1] - curv[1] * nor[0];
-      f[9] = curv[0];
-      f[10] = curv[1];
-      f[11] = curv[2];
-    }
-    }
-    // hl_note.  The height crop shared by the orientations of a sample: cropByHandHeight (point_list.cpp:35-55) keeps the
-    // points whose coordinate along the hand frame's third axis lies in (-h, h); that axis is the one the orientations
-    // rotate about, so the frames of a sample's slots have the same third column up to rounding.  The points with
-    // |z| < h + margin for the axis of slot 0 — margin = (largest deviation of any slot's axis from it) x radius + 1e-12,
-    // a superset of every orientation's exact crop, which hand_eval_kernel then decides with its own frame — are listed
-    // in this kernel: the frame wave publishes the axis and the limit, and every wave, once it is out of the gather,
-    // takes chunks of the sorted list (coordinates through the sorted indices: L2 hits; order of the list: none, the
-    // entries carry their rank).  This was a kernel of its own that read the gathered rows back from HBM (110 MB per
-    // 2564 samples); done by the frame wave alone it made that wave the kernel's critical path (260 -> 334 us).
-    if (P.hl) {
-      const int Nh = s_bounds[2];
-      auto bc = [&](double v) {  // lane 0's value to the wave
-        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-      };
-      if (kf > 0 && Nh > 0) {
-        // lane 0 holds the frame it has just stored: F = [normal | binormal | curvature] (hand_set.cpp:39-40)
-        const double *f = P.frames + 12 * (size_t)s;
-        double F[9];
-        __threadfence_block();
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          F[3 * r + 0] = bc(lane == 0 ? f[3 + r] : 0.0);
-          F[3 * r + 1] = bc(lane == 0 ? f[6 + r] : 0.0);
-          F[3 * r + 2] = bc(lane == 0 ? f[9 + r] : 0.0);
-        }
-        double axis[3] = {0.0, 0.0, 0.0}, dev = 0.0;
-        for (int slot = 0; slot < P.hl_slots; slot++) {
-          double a[3];
-#pragma unroll
-          for (int r = 0; r < 3; r++)
-            a[r] = F[3 * r] * P.hl_col[slot][0] + F[3 * r + 1] * P.hl_col[slot][1] + F[3 * r + 2] * P.hl_col[slot][2];
-          if (slot == 0) {
-            axis[0] = a[0];
-            axis[1] = a[1];
-            axis[2] = a[2];
-          }
-          dev = fmax(dev, fabs(a[0] - axis[0]) + fabs(a[1] - axis[1]) + fabs(a[2] - axis[2]));
-        }
-        if (lane == 0) {
-          s_hl_axis[0] = axis[0];
-          s_hl_axis[1] = axis[1];
-          s_hl_axis[2] = axis[2];
-          s_hl_axis[3] = P.hl_height + dev * P.hl_radius + 1e-12;
-          s_hl_n = Nh;
-        }
-      }
+  if (late) {
+    // 5'. the frame from the sorted list (more than FCAP points inside the frame radius), then the height list as a pass
+    //     of its own: every wave takes chunks of 128 hand-search neighbours until none is left
+    if ((tid >> 6) == VW) {
+      frame_of(kf, index_at);
       __threadfence_block();
       if (lane == 0) *(volatile int *)&s_hl_ready = 1;
     }
-  }
-  // the height list itself: every wave, as it comes out of the gather (or the frame), takes chunks of 128 neighbours
-  // until none is left — the frame is long done by the time the gathering waves arrive (hl_note above)
-  if (P.hl) {
-    while (*(volatile int *)&s_hl_ready == 0) __builtin_amdgcn_s_sleep(2);
-    __threadfence_block();
-    NTICK(8);
-    const int Nh = *(volatile int *)&s_hl_n;
-    const double ax0 = s_hl_axis[0], ax1 = s_hl_axis[1], ax2 = s_hl_axis[2], lim = s_hl_axis[3];
-    float4 *out = P.hl + (size_t)s * P.cap;
-    // a wave's next chunk is drawn, and its points are requested, before the current chunk is tested and stored: the
-    // draw (an LDS atomic round trip) and the L2 round trip of the points then overlap the previous chunk's work
-    auto draw = [&] {
-      int chunk = 0;
-      if (lane == 0) chunk = atomicAdd(&s_hl_next, 1);
-      return __builtin_amdgcn_readfirstlane(chunk) * 128;
-    };
-    int e0 = draw();
-    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
-    if (e0 < Nh) {
-      pa = P.pxyz[index_at(e0 + lane < Nh ? e0 + lane : Nh - 1)];
-      pb = P.pxyz[index_at(e0 + 64 + lane < Nh ? e0 + 64 + lane : Nh - 1)];
-    }
-    while (e0 < Nh) {
-      const int e1 = draw();
-      float4 na = pa, nb = pb;
-      if (e1 < Nh) {
-        na = P.pxyz[index_at(e1 + lane < Nh ? e1 + lane : Nh - 1)];
-        nb = P.pxyz[index_at(e1 + 64 + lane < Nh ? e1 + 64 + lane : Nh - 1)];
+    if (P.hl) {
+      while (*(volatile int *)&s_hl_ready == 0) __builtin_amdgcn_s_sleep(2);
+      __threadfence_block();
+      NTICK(8);
+      const double lx0 = s_hl_axis[0], lx1 = s_hl_axis[1], lx2 = s_hl_axis[2], llim = s_hl_axis[3];
+      while (kf > 0 && Nh > 0) {
+        int chunk = 0;
+        if (lane == 0) chunk = atomicAdd(&s_hl_next, 1);
+        const int e0 = __builtin_amdgcn_readfirstlane(chunk) * 128;
+        if (e0 >= Nh) break;
+        const int ea = e0 + lane, eb = e0 + 64 + lane;  // two entries per lane: their loads are in flight together
+        const float4 pa = P.pxyz[index_at(ea < Nh ? ea : Nh - 1)], pb = P.pxyz[index_at(eb < Nh ? eb : Nh - 1)];
+        const double za = lx0 * ((double)pa.x - sx) + lx1 * ((double)pa.y - sy) + lx2 * ((double)pa.z - sz);
+        const double zb = lx0 * ((double)pb.x - sx) + lx1 * ((double)pb.y - sy) + lx2 * ((double)pb.z - sz);
+        const bool ina = ea < Nh && za > -llim && za < llim, inb = eb < Nh && zb > -llim && zb < llim;
+        const unsigned long long ba = __ballot(ina), bb = __ballot(inb);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_hl_count, __popcll(ba) + __popcll(bb));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ina) hl_out[base + __popcll(ba & below)] = make_float4(pa.x, pa.y, pa.z, __int_as_float(ea));
+        if (inb) hl_out[base + __popcll(ba) + __popcll(bb & below)] = make_float4(pb.x, pb.y, pb.z, __int_as_float(eb));
       }
-      __builtin_amdgcn_sched_barrier(0);
-      const int ea = e0 + lane, eb = e0 + 64 + lane;  // two entries per lane
-      const double za = ax0 * ((double)pa.x - sx) + ax1 * ((double)pa.y - sy) + ax2 * ((double)pa.z - sz);
-      const double zb = ax0 * ((double)pb.x - sx) + ax1 * ((double)pb.y - sy) + ax2 * ((double)pb.z - sz);
-      const bool ina = ea < Nh && za > -lim && za < lim, inb = eb < Nh && zb > -lim && zb < lim;
-      const unsigned long long ba = __ballot(ina), bb = __ballot(inb);
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&s_hl_count, __popcll(ba) + __popcll(bb));
-      base = __builtin_amdgcn_readfirstlane(base);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      if (ina) out[base + __popcll(ba & below)] = make_float4(pa.x, pa.y, pa.z, __int_as_float(ea));
-      if (inb) out[base + __popcll(ba) + __popcll(bb & below)] = make_float4(pb.x, pb.y, pb.z, __int_as_float(eb));
-      __builtin_amdgcn_sched_barrier(0);
-      e0 = e1;
-      pa = na;
-      pb = nb;
+      NTICK(9);
     }
-    NTICK(9);
   }
   __syncthreads();
   NTICK(7);
@@ -1299,8 +1406,8 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     rc = GPD_ERR_CAPACITY;
   } else {
     // keep the device copy of the cloud consistent: planes nx, ny, nz
-    split_soa_kernel<<<(c.num_points + 255) / 256, 256, 0, stream>>>(c.staging, d_out, c.num_points, c.px, c.py, c.pz, c.nx, c.ny,
-                                                                       c.nz, c.pxyz, c.pnrm);
+    split_soa_kernel<<<(c.num_points + 255) / 256, 256, 0, stream>>>(c.staging, d_out, c.cam_source, c.num_points, c.px, c.py, c.pz,
+                                                                       c.nx, c.ny, c.nz, c.pxyz, c.pnrm);
     HIP_RET(hipGetLastError());
     HIP_RET(hipStreamSynchronize(stream));
     c.generation++;
