@@ -1522,8 +1522,10 @@ __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
     __syncthreads();
   }
   const double *smp = P.frames + 12 * (size_t)slot_s;
-  const int ox = (int)floor(smp[0] * K.voxel_mult) - SR, oy = (int)floor(smp[1] * K.voxel_mult) - SR,
-            oz = (int)floor(smp[2] * K.voxel_mult) - SR;
+  int ox = (int)floor(smp[0] * K.voxel_mult) - SR, oy = (int)floor(smp[1] * K.voxel_mult) - SR,
+      oz = (int)floor(smp[2] * K.voxel_mult) - SR;
+  // opaque to the optimiser: it re-associated v - (floor - SR) into (v - floor) + SR, two operations per coordinate and draw
+  asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz));
   // shadow_vec = shadow_length * (center - view_point) / norm (hand_set.cpp:147-150)
   const double *cen = P.centers + 3 * (size_t)slot_s;
   double vec[3];
@@ -1540,7 +1542,10 @@ __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
       const int vy = (int)((p1 + t * vec[1]) * K.voxel_mult) - oy;
       const int vz = (int)((p2 + t * vec[2]) * K.voxel_mult) - oz;
       if ((unsigned)vx < (unsigned)SD && (unsigned)vy < (unsigned)SD && (unsigned)vz < (unsigned)SD) {
-        const int bit = (vx * SD + vy) * SD + vz;
+        // 24-bit multiply-adds, spelled out: the compiler picks v_mad_u64_u32 for a 32-bit multiply-add
+        unsigned bit;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(bit) : "v"(vx), "s"(SD), "v"(vy));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(bit) : "v"(bit), "s"(SD), "v"(vz));
         atomicOr(&bits[bit >> 5], 1u << (bit & 31));
       }
     }
