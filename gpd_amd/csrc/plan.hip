@@ -412,14 +412,19 @@ int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &
   pp.set_meta = pl.d_set_meta;
   pp.summary = pl.d_summary;
   const int workgroups = S > 0 ? (S + PLAN_THREADS - 1) / PLAN_THREADS : 1;
-  if (++pl.epoch == 0u) pl.epoch = 1u;  // (after 2^32 launches a stale stamp could match: the state would have to be cleared here)
+  if (++pl.epoch == 0u) {
+    // the launch number has wrapped (2^32 launches): a stamp of the first lap could pass for this one — clear them
+    const size_t nparts = (size_t)(pl.cap_samples + PLAN_THREADS - 1) / PLAN_THREADS + 1;
+    HIP_RET(hipMemsetAsync(pl.d_parts, 0, nparts * sizeof(PlanPart), stream));
+    pl.epoch = 1u;
+  }
   pp.parts = pl.d_parts;
   pp.ticket = pl.d_ticket;
   pp.ticket_base = pl.tickets;
   pp.epoch = pl.epoch;
-  pl.tickets += (unsigned)workgroups;
   plan_kernel<<<workgroups, PLAN_THREADS, 0, stream>>>(pp);
   HIP_RET(hipGetLastError());
+  pl.tickets += (unsigned)workgroups;  // (a refused launch has drawn no tickets)
   HIP_RET(hipMemcpyAsync(pl.h_summary, pl.d_summary, sizeof(PlanSummary), hipMemcpyDeviceToHost, stream));
   return GPD_OK;
 }
