@@ -606,6 +606,21 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   cluster_grasps_ = min_inliers > 0;
   num_selected_ = config_file.getValueOfKey<int>("num_selected", 100);
   use_file_normals_ = config_file.getValueOfKey<int>("use_file_normals", 0) != 0;
+  // Preprocessing steps of CandidatesGenerator::preprocessPointCloud that are PCL algorithms of their own and are not
+  // restated here (candidates_generator.cpp:28-34, grasp_detector.cpp:52-63; all off in the shipped cfg files): a cloud
+  // that needs them has to go through them before it gets here.  Refused, not skipped: a silently different cloud would
+  // give silently different grasps.
+  const struct {
+    const char *key, *what;
+  } unsupported[] = {{"remove_outliers", "pcl::StatisticalOutlierRemoval (cloud.cpp:166-174)"},
+                     {"sample_above_plane", "a RANSAC plane fit, pcl::SACSegmentation (cloud.cpp:407-436)"},
+                     {"refine_normals_k", "pcl::NormalRefinement (cloud.cpp:176-204)"}};
+  for (const auto &u : unsupported)
+    if (config_file.getValueOfKey<int>(u.key, 0) != 0) {
+      printf("ERROR: %s = %d asks for %s, which this build does not have; unset it or preprocess the cloud beforehand\n", u.key,
+             config_file.getValueOfKey<int>(u.key, 0), u.what);
+      return;  // ok() stays false
+    }
   printf("============ CANDIDATE GENERATION ============\n");
   printf("num_samples: %d\nnn_radius: %3.2f\nnum_orientations: %d\nnum_finger_placements: %d\ndeepen_hand: %s\n", num_samples_,
          params_.nn_radius_frames, params_.num_orientations, params_.num_finger_placements, params_.deepen_hand ? "true" : "false");

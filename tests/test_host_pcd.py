@@ -229,6 +229,23 @@ def test_cli_argument_errors_without_a_gpu(tmp_path):
         assert out.returncode == 255 and "Not enough input arguments" in out.stdout, name
 
 
+def test_unsupported_preprocessing_options_are_refused(tmp_path):
+    """remove_outliers / sample_above_plane / refine_normals_k are PCL algorithms of their own (candidates_generator.cpp:28-34)
+    that the mirror does not have: a cfg that asks for one is refused with a message — before the device is touched —
+    instead of yielding grasps on a silently different cloud."""
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpd_amd", "host")
+    pcd = tmp_path / "three.pcd"
+    _write(str(pcd), np.eye(3, dtype=np.float32), np.eye(3, dtype=np.float32), False)
+    for key in ("remove_outliers", "sample_above_plane", "refine_normals_k"):
+        cfg = tmp_path / (key + ".cfg")
+        cfg.write_text("num_samples = 5\nimage_num_channels = 15\n%s = 1\n" % key)
+        out = subprocess.run([os.path.join(host, "detect_grasps"), str(cfg), str(pcd)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 255, (key, out.stdout[-300:])
+        assert ("ERROR: %s = 1 asks for" % key) in out.stdout and "hip" not in out.stdout.lower().split("asks for")[0], out.stdout[-300:]
+
+
 def test_pcd_reader_refuses_malformed_headers(tmp_path):
     """An untrusted PCD header (negative / huge SIZE, COUNT 0, absurd POINTS, mismatched field lists) yields an empty
     cloud and a message, never a crash or a giant allocation."""
