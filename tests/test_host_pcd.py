@@ -164,6 +164,27 @@ def test_pcd_binary_compressed(tmp_path):
     assert np.array_equal(gx, zeros)
 
 
+def test_pcd_binary_compressed_random_streams(tmp_path):
+    """Round trips of the LZF reader on clouds drawn from small alphabets (many back references of every length class,
+    overlapping ones included) and from noise (literal runs only): 60 files."""
+    rng = np.random.RandomState(11)
+    for case in range(60):
+        n = int(rng.randint(1, 400))
+        kind = case % 3
+        if kind == 0:
+            xyz = rng.choice(np.array([0.0, 0.003, -0.006, 1.5], np.float32), (n, 3))   # long repeats
+        elif kind == 1:
+            xyz = (rng.randint(-3, 3, (n, 3)) * 0.25).astype(np.float32)
+            xyz[n // 2:] = xyz[: n - n // 2]                                         # a far back reference
+        else:
+            xyz = rng.normal(0, 1, (n, 3)).astype(np.float32)                        # incompressible
+        cols = [xyz[:, k].astype("<f4").tobytes() for k in range(3)]
+        p = tmp_path / ("r%d.pcd" % case)
+        _write_compressed(str(p), cols, ["x", "y", "z"], [4, 4, 4], ["F", "F", "F"], [1, 1, 1], n)
+        gx, gn = hostlib.load_pcd(p)
+        assert np.array_equal(gx, xyz) and gn is None, case
+
+
 def test_pcd_corrupt_or_missing_is_empty(tmp_path):
     head = b"# .PCD v0.7\nVERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary_compressed\n"
     sizes = lambda c, r: np.array([c, r], "<u4").tobytes()
