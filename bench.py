@@ -630,8 +630,7 @@ def _preprocess_leg(ctx):
                  "note": "Cloud::filterWorkspace + Cloud::voxelizeCloud: cut, voxel keys and the gather of the kept voxels on the device; the "
                          "voxeliser's keep / drop decisions are a strictly sequential chain and run as a table-driven spine walk on ONE host "
                          "core between two small copies (kernel_ms = first to last device operation, the walk included; "
-                         "voxel_accept_kernel, the same walk on one wavefront, took 20 ms and stays as GPD_VOXEL_DEVICE=1 for the parity "
-                         "tests).  cpu_baseline.preprocess_ms is the reference's std::set on one core.  normals: gpd_hip_estimate_normals on a "
+                         "the same walk on one wavefront took 20 ms in rounds 1-2).  cpu_baseline.preprocess_ms is the reference's std::set on one core.  normals: gpd_hip_estimate_normals on a "
                          "30k-point cloud of the benchmark's density"}
 
 

@@ -239,7 +239,7 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
     HIP_TRY(hipStreamSynchronize(L.stream));
   }
   const PlanSummary sm = *L.plan.h_summary;
-  static const bool plan_timing = getenv("GPD_PLAN_TIMING") != nullptr;
+  static const bool plan_timing = prof_env("GPD_PLAN_TIMING") != nullptr;
   if (plan_timing)
     fprintf(stderr, "[plan-timing] own sums %.2f us, look-back %.2f, tables + summary %.2f (last workgroup's thread 0, 100 MHz clock)\n",
             (sm.pad_[0] & 0xffff) * 0.01, ((unsigned)sm.pad_[0] >> 16) * 0.01, (sm.pad_[1] & 0xffff) * 0.01);
@@ -844,7 +844,7 @@ static int detect_any(gpd_hip_ctx *ctx, const char *who, const int32_t *sample_i
   if (rc) return rc;
   HIP_TRY(hipSetDevice(ctx->device));
   // GPD_DETECT_TIMING=1: wall time of the three steps, to stderr
-  const bool timing = getenv("GPD_DETECT_TIMING") != nullptr;
+  const bool timing = prof_env("GPD_DETECT_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   Job J;
@@ -1054,7 +1054,7 @@ int gpd_hip_replay(gpd_hip_ctx *ctx, int stages) {
   }
   hipEvent_t *ev = &ctx->replay_events[ctx->replay_used];
   ctx->replay_used += 6;
-  static const bool pipe = getenv("GPD_REPLAY_PIPE") && atoi(getenv("GPD_REPLAY_PIPE")) > 0;
+  static const bool pipe = prof_env("GPD_REPLAY_PIPE") && atoi(prof_env("GPD_REPLAY_PIPE")) > 0;
   if (pipe && stages == 3) {
     const size_t bytes = (size_t)L.images.capacity * L.images.channels * 3600;
     if (!ctx->pipe_stream) {

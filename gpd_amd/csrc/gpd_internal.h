@@ -7,7 +7,10 @@
 
 #include <vector>
 
+#ifdef GPD_PROFILING
+#include <cstdlib>
 #include <rocprofiler-sdk-roctx/roctx.h>
+#endif
 
 #include "../../include/gpd_hip.h"
 
@@ -50,12 +53,26 @@ void set_error(const char *fmt, ...);
 
 // roctx range around a stage of the path (host side: what the stage enqueues); `rocprofv3 --marker-trace --kernel-trace`
 // shows them over the kernel timeline (the reference times its stages with omp_get_wtime, grasp_detector.cpp:223-273)
+// — in the profiling build only (make prof -> libgpd_hip_prof.so, -DGPD_PROFILING).  The release library links no
+// profiler and reads no environment variable: the measurement switches (GPD_*_TIMING, GPD_IMG_SERIAL, GPD_IMG_EXIT,
+// GPD_IMG_LDS_PAD, GPD_REPLAY_PIPE, GPD_DETECT_TIMING, GPD_PLAN_TIMING) and the watchdog's fault injector
+// (GPD_C1_FAULT) go through prof_env(), which is a constant nullptr there.
+#ifdef GPD_PROFILING
 struct StageRange {
   explicit StageRange(const char *name) { roctxRangePushA(name); }
   ~StageRange() { roctxRangePop(); }
   StageRange(const StageRange &) = delete;
   StageRange &operator=(const StageRange &) = delete;
 };
+inline const char *prof_env(const char *name) { return getenv(name); }
+#else
+struct StageRange {
+  explicit StageRange(const char *) {}
+  StageRange(const StageRange &) = delete;
+  StageRange &operator=(const StageRange &) = delete;
+};
+inline const char *prof_env(const char *) { return nullptr; }
+#endif
 
 // ---- point-cloud preparation (preprocess.hip): workspace cut + the reference's voxeliser ------------------------
 struct PreState {
@@ -65,8 +82,6 @@ struct PreState {
           *d_out_src = nullptr;
   int4 *d_keys = nullptr;
   void *d_meta = nullptr;
-  void *d_ops = nullptr;      // int8 per kept point: the voxeliser's spine table (preprocess.hip spine_ops)
-  size_t ops_on_device = 0;
   std::vector<char> h_keys;     // host route of the voxeliser's chain: the voxel keys of the points inside the workspace ...
   std::vector<int32_t> h_rank;  // ... and what the walk decided (rank among the kept points, -1: dropped)
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -244,8 +259,8 @@ static_assert(sizeof(PlanPart) == 64, "PlanPart");
 struct Plan {
   int cap_samples = 0, cap_slots = 0, cap_cams = 0;
   PlanPart *d_parts = nullptr;   // [cap_samples / 256 + 1]
-  unsigned *d_ticket = nullptr;  // arrival counter of plan_kernel's workgroups (never reset; `tickets` is its host copy)
-  unsigned tickets = 0, epoch = 0;
+  unsigned *d_ticket = nullptr;  // arrival counter of plan_kernel's workgroups (0 between launches: the kernel resets it)
+  unsigned epoch = 0;
   int32_t *d_sample_of_set = nullptr;  // [S]
   int32_t *d_hand_cand = nullptr;      // [S][slots] candidate ordinal of a hand, -1: none
   int32_t *d_cand_hand = nullptr;      // [S*slots] hand (sample slot * slots + slot) of a candidate

@@ -1808,8 +1808,8 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
   ip.status = im.d_status;
   static unsigned long long *d_dbg = nullptr;
   ip.dbg = nullptr;
-  ip.exit_after = getenv("GPD_IMG_EXIT") ? atoi(getenv("GPD_IMG_EXIT")) : 0;
-  if (getenv("GPD_IMG_TIMING")) {
+  ip.exit_after = prof_env("GPD_IMG_EXIT") ? atoi(prof_env("GPD_IMG_EXIT")) : 0;
+  if (prof_env("GPD_IMG_TIMING")) {
     if (!d_dbg) HIP_RET(hipMalloc(&d_dbg, 32 * sizeof(unsigned long long)));
     HIP_RET(hipMemsetAsync(d_dbg, 0, 32 * sizeof(unsigned long long), stream));
     ip.dbg = d_dbg;
@@ -1828,9 +1828,9 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     HIP_RET(hipEventCreateWithFlags(&im.ev_fork, hipEventDisableTiming));
     HIP_RET(hipEventCreateWithFlags(&im.ev_join, hipEventDisableTiming));
   }
-  static const bool serial = getenv("GPD_IMG_SERIAL") != nullptr;  // profiling aid: each image kernel alone on the chip
+  static const bool serial = prof_env("GPD_IMG_SERIAL") != nullptr;  // profiling aid: each image kernel alone on the chip
   // profiling aid: unused dynamic LDS per workgroup of the two per-candidate kernels (8192: one workgroup per CU instead of two)
-  static const size_t lds_pad = getenv("GPD_IMG_LDS_PAD") ? (size_t)atoi(getenv("GPD_IMG_LDS_PAD")) : 0;
+  static const size_t lds_pad = prof_env("GPD_IMG_LDS_PAD") ? (size_t)atoi(prof_env("GPD_IMG_LDS_PAD")) : 0;
   hipStream_t pts_stream = (im.channels == 15 && !ip.dbg && im.side_stream && !serial) ? im.aux : stream;
   if (pts_stream != stream) {
     HIP_RET(hipEventRecord(im.ev_fork, stream));

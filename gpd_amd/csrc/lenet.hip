@@ -741,7 +741,7 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     const int m = (n - off < kChunk) ? (n - off) : kChunk;
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
     // persistent conv1: one workgroup per CU, at least two images each
-    const int fault = getenv("GPD_C1_FAULT") != nullptr;  // test hook of the slot watchdog (tests/test_gpu_lenet_stress.py)
+    const int fault = prof_env("GPD_C1_FAULT") != nullptr;  // test hook of the slot watchdog (tests/test_gpu_lenet_stress.py)
     const int c1_grid = m / 2 < 1 ? 1 : (m / 2 < num_cus ? m / 2 : num_cus);
     switch (w.channels) {
       case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;

@@ -48,8 +48,7 @@ struct PlanParams {
   int32_t *sample_of_set, *hand_cand, *cand_hand, *cand_out, *cand_meta, *set_meta;
   PlanSummary *summary;
   PlanPart *parts;        // [workgroups] published sums (gpd_internal.h)
-  unsigned *ticket;       // arrival counter, never reset: this launch's tickets are ticket_base .. ticket_base + workgroups - 1
-  unsigned ticket_base;
+  unsigned *ticket;       // arrival counter: 0 at launch, put back to 0 by the workgroup that draws the last ticket
   unsigned epoch;         // stamp of this launch in PlanPart::ready_*
 };
 
@@ -159,10 +158,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(PlanParams P) {
   const unsigned long long tk0 = wall_clock64();
   if (tid == 0) {
     s_mismatch = 0x7fffffff;
-    s_blk = (int)(atomicAdd(P.ticket, 1u) - P.ticket_base);  // the workgroups are numbered in the order they start
+    // the workgroups are numbered in the order they start.  The counter looks after itself: whoever draws the last
+    // ticket of the launch knows that all are taken and puts it back to 0 for the next launch on this stream — no host
+    // mirror that a failed / mis-reported launch could leave out of step
+    const unsigned t = atomicAdd(P.ticket, 1u);
+    if (t + 1u >= gridDim.x) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_blk = (int)t;
   }
   __syncthreads();
   const int blk = s_blk, nblk = (int)gridDim.x;
+  if (blk >= nblk) return;  // cannot happen with a counter that starts at 0; never index parts[] beyond the launch
   const int s = blk * PLAN_THREADS + tid;
   const bool on = s < P.S;
   PlanPart *mine_part = P.parts + blk;
@@ -362,7 +367,6 @@ int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &
     HIP_RET(hipMalloc(&pl.d_ticket, sizeof(unsigned)));
     HIP_RET(hipMemsetAsync(pl.d_parts, 0, nparts * sizeof(PlanPart), stream));
     HIP_RET(hipMemsetAsync(pl.d_ticket, 0, sizeof(unsigned), stream));
-    pl.tickets = 0;
     pl.epoch = 0;
     HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&pl.h_summary), sizeof(PlanSummary), 0));
     pl.cap_samples = capS;
@@ -420,11 +424,9 @@ int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &
   }
   pp.parts = pl.d_parts;
   pp.ticket = pl.d_ticket;
-  pp.ticket_base = pl.tickets;
   pp.epoch = pl.epoch;
   plan_kernel<<<workgroups, PLAN_THREADS, 0, stream>>>(pp);
   HIP_RET(hipGetLastError());
-  pl.tickets += (unsigned)workgroups;  // (a refused launch has drawn no tickets)
   HIP_RET(hipMemcpyAsync(pl.h_summary, pl.d_summary, sizeof(PlanSummary), hipMemcpyDeviceToHost, stream));
   return GPD_OK;
 }

@@ -15,11 +15,12 @@
 //     grandparent, which takes the grandparent off the spine and makes it the parent's (red) right child.
 // (krylon.pcd: 4467 points in 2373 voxels -> 3366 points kept; checked against std::set itself in
 // tests/test_gpu_preprocess.py through oracle/gpd_oracle.cpp.)
-// That chain of decisions is sequential — which spine a point meets depends on how many points before it were kept —
-// so ONE wavefront walks the points in order with the spine spread over its lanes: a point's voxel is compared
-// with all spine nodes at once (one ballot); the colours are two uniform bit masks, so the rebalancing is scalar.
-// ~2 log2(m) <= 64 lanes hold the spine of any cloud that fits the device.  Everything around it (keys, minimum,
-// gather of the kept voxels) is data parallel.
+// That chain of decisions is strictly sequential — which spine a point meets depends on how many points before it were
+// kept — a job for one scalar core: the keys go to the host (16 bytes per point inside the workspace), one core walks
+// the <= 64-node spine with a table of what the m-th insertion does to it (spine_ops: data independent), the ranks come
+// back.  (Rounds 1-2 ran the walk on ONE wavefront, the spine in its lanes: ~400 cycles per point, 20 ms per 120k points
+// against 1.5 ms this way and 7.9 ms for the std::set itself — DESIGN §8.)  Everything around it (keys, minimum, gather
+// of the kept voxels) is data parallel and stays on the device.
 #include "gpd_internal.h"
 #include <cfloat>
 #include <cmath>
@@ -180,72 +181,17 @@ __global__ __launch_bounds__(PP_THREADS) void ws_scatter_kernel(const float *__r
   }
 }
 
-// The sequential part of voxelizeCloud: which points the std::set keeps (see the head of the file).  One wavefront;
-// lane d holds the voxel of the spine node at depth d (0 = root, L - 1 = the leftmost leaf).  How the spine is
-// rebuilt by the m-th kept point does not depend on the data — recolouring and the one rotation are a function of m
-// alone — so the host tabulates it once (spine_ops: the depth that leaves the spine at the m-th insertion, or -1) and
-// the kernel's step is: compare with the spine (one ballot), append the voxel, close the gap the table names.
-// rank[pos] = how many points were kept before this one, -1 for a dropped point.
-__global__ __launch_bounds__(64) void voxel_accept_kernel(const int4 *__restrict__ keys, const int8_t *__restrict__ ops, PreMeta *meta,
-                                                          int32_t *__restrict__ rank) {
-  const int lane = threadIdx.x;
-  const int n = meta->kept;
-  int kx = 0, ky = 0, kz = 0;
-  int L = 0, m = 0, m_base = 0;
-  auto rd = [](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
-  int4 k_next = lane < n ? keys[lane] : make_int4(0, 0, 0, 0);
-  int op_cur = lane < n ? (int)ops[lane] : -1, op_next = 64 + lane < n ? (int)ops[64 + lane] : -1;  // lane t: ops[m_base + t]
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    const int4 k = k_next;
-    if (i + 64 < n) k_next = keys[i + 64];  // the next 64 voxels travel while these are walked
-    int my_rank = -1;
-    const int cnt = n - base < 64 ? n - base : 64;
-    for (int j = 0; j < cnt; j++) {
-      const int qx = rd(k.x, j), qy = rd(k.y, j), qz = rd(k.z, j);
-      const bool hit = lane < L && kx == qx && ky == qy && kz == qz;
-      if (__builtin_amdgcn_ballot_w64(hit) != 0ull) continue;  // an equal voxel on the spine: the set rejects the point
-      if (lane == j) my_rank = m;
-      if (lane == L) {  // the new leftmost node
-        kx = qx;
-        ky = qy;
-        kz = qz;
-      }
-      const int g = rd(op_cur, m - m_base);
-      m++;
-      L++;
-      if (g >= 0) {  // the node at depth g leaves the spine, the ones below move up
-        // wave_shl:1 — lane l reads lane l + 1 over the whole wavefront (a DPP move: no LDS round trip as ds_bpermute)
-        const int sx = __builtin_amdgcn_update_dpp(kx, kx, 0x130, 0xf, 0xf, false), sy = __builtin_amdgcn_update_dpp(ky, ky, 0x130, 0xf, 0xf, false),
-                  sz = __builtin_amdgcn_update_dpp(kz, kz, 0x130, 0xf, 0xf, false);
-        if (lane >= g) {
-          kx = sx;
-          ky = sy;
-          kz = sz;
-        }
-        L--;
-      }
-      if (m - m_base == 64) {
-        m_base = m;
-        op_cur = op_next;
-        op_next = m_base + 64 + lane < n ? (int)ops[m_base + 64 + lane] : -1;
-      }
-    }
-    if (i < n) rank[i] = my_rank;
-  }
-  if (lane == 0) meta->voxels = m;
-}
-
 // pass 5: the kept voxels in the set's iteration order (reverse order of insertion): voxel -> point
 // (cloud.cpp:322: min_pt + cell_size * voxel), camera source of the point that opened the voxel (:325-327: == 1 ? 1 : 0)
 __global__ __launch_bounds__(PP_THREADS) void voxel_emit_kernel(const int4 *__restrict__ keys, const int32_t *__restrict__ rank, const PreMeta *meta,
                                                                 float cell, const int32_t *__restrict__ cam, int n, int num_cams,
                                                                 float *__restrict__ out_xyz, int32_t *__restrict__ out_cam, int32_t *__restrict__ out_src) {
   const int pos = blockIdx.x * PP_THREADS + threadIdx.x;
-  if (pos >= meta->kept) return;
+  if (meta->bad || pos >= meta->kept) return;  // a refused cloud has no ranks (the host route never wrote them)
   const int r = rank[pos];
-  if (r < 0) return;
-  const int M = meta->voxels, o = M - 1 - r;
+  const int M = meta->voxels;
+  if (r < 0 || r >= M) return;
+  const int o = M - 1 - r;
   const int4 k = keys[pos];
   out_xyz[3 * (size_t)o] = meta->lo[0] + cell * (float)k.x;
   out_xyz[3 * (size_t)o + 1] = meta->lo[1] + cell * (float)k.y;
@@ -301,11 +247,8 @@ static bool spine_ops(std::vector<int8_t> &ops, size_t n, unsigned long long &C,
   return true;
 }
 
-// The same walk on the host: the chain is strictly sequential (which spine a point meets depends on how many points
-// before it were kept), a job for one scalar core rather than for one wavefront — ~400 cycles per point in
-// voxel_accept_kernel against a few dozen here (and ~150 for the std::set the reference itself uses, which allocates a
-// node per kept point).  Default route of gpd_hip_preprocess_cloud; the kernel stays as GPD_VOXEL_DEVICE=1 and the tests
-// hold the two against each other and against std::set.
+// The walk: a few dozen cycles per point (~150 for the std::set the reference itself uses, which allocates a node per
+// kept point).  rank[pos] = how many points were kept before this one, -1 for a dropped point.
 static int voxel_accept_host(const int4 *keys, int n, const int8_t *ops, int32_t *rank) {
   int sx[64], sy[64], sz[64];
   int L = 0, m = 0;
@@ -341,7 +284,7 @@ static int voxel_accept_host(const int4 *keys, int n, const int8_t *ops, int32_t
 }
 
 void preprocess_free(PreState &s) {
-  void *dev[] = {s.d_xyz, s.d_cam, s.d_block_count, s.d_block_off, s.d_block_lo, s.d_src, s.d_keys, s.d_rank, s.d_out_xyz, s.d_out_cam, s.d_out_src, s.d_meta, s.d_ops};
+  void *dev[] = {s.d_xyz, s.d_cam, s.d_block_count, s.d_block_off, s.d_block_lo, s.d_src, s.d_keys, s.d_rank, s.d_out_xyz, s.d_out_cam, s.d_out_src, s.d_meta};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   hipEvent_t e0 = s.ev[0], e1 = s.ev[1];  // the events outlive a re-allocation
@@ -371,7 +314,6 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
     HIP_RET(hipMalloc(&s.d_out_cam, (size_t)cap * (cams > 0 ? cams : 1) * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_out_src, (size_t)cap * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_meta, sizeof(PreMeta)));
-    HIP_RET(hipMalloc(&s.d_ops, (size_t)cap));
     s.capacity = cap;
     s.cap_cams = cams;
   }
@@ -401,22 +343,25 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
         set_error("preprocess_cloud: more points than the voxeliser's tree walk supports");
         return GPD_ERR_CAPACITY;
       }
-      if (s.ops_on_device < (size_t)n) {
-        HIP_RET(hipMemcpyAsync(s.d_ops, ops.data(), (size_t)n, hipMemcpyHostToDevice, stream));
-        HIP_RET(hipStreamSynchronize(stream));  // `ops` may grow (re-allocate) under another context's call
-        s.ops_on_device = (size_t)n;
-      }
     }
-    const bool on_device = getenv("GPD_VOXEL_DEVICE") != nullptr;  // read per call: the tests switch routes inside one process
-    if (on_device) {
-      voxel_accept_kernel<<<1, 64, 0, stream>>>(s.d_keys, static_cast<const int8_t *>(s.d_ops), meta, s.d_rank);
-    } else {
+    {
       // keys to the host (16 bytes per point inside the workspace), the walk, the ranks back (4 bytes per point)
       PreMeta hm;
       HIP_RET(hipMemcpyAsync(&hm, s.d_meta, sizeof(hm), hipMemcpyDeviceToHost, stream));
       HIP_RET(hipStreamSynchronize(stream));
+      // a refused cloud (non-finite coordinate, voxel index beyond int32) stops here: no ranks exist for it, and
+      // voxel_emit_kernel must not run on the ranks an earlier call left in d_rank
+      if (hm.bad & 1) {
+        set_error("preprocess_cloud: the cloud holds non-finite coordinates (remove NaN/Inf points first)");
+        return GPD_ERR_INVALID;
+      }
+      if (hm.bad & 6) {
+        set_error("preprocess_cloud: %s", (hm.bad & 2) ? "a voxel index does not fit 32 bits (voxel size too small for the cloud's extent)"
+                                                       : "more points than the voxeliser's tree walk supports");
+        return GPD_ERR_CAPACITY;
+      }
       const int kept = hm.kept;
-      if (kept > 0 && !(hm.bad & 3)) {
+      if (kept > 0) {
         s.h_keys.resize((size_t)kept * sizeof(int4));
         s.h_rank.resize((size_t)kept);
         HIP_RET(hipMemcpyAsync(s.h_keys.data(), s.d_keys, (size_t)kept * sizeof(int4), hipMemcpyDeviceToHost, stream));

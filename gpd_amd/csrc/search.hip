@@ -1448,7 +1448,7 @@ struct HandParams {
   int cap;
   gpd_hand *hands;
   uint8_t *fvalid;  // hand_eval_kernel: [S][slots] is_valid after filterGraspsWorkspace
-  float4 *hl;       // [S][cap] height_list_kernel -> hand_eval_kernel; its length per sample in counts[8 s + 6]
+  float4 *hl;       // [S][cap] neighbourhood_kernel's gather -> hand_eval_kernel; its length per sample in counts[8 s + 6]
   double radius;    // of the hand-search neighbourhood (bounds |p - sample|)
   int num_samples;
   int32_t *labels;  // reeval_kernel only: [n][8] rows of the counts table, column 5
@@ -1748,71 +1748,6 @@ __global__ __launch_bounds__(256) void reeval_kernel(HandParams P) {
   }
 }
 
-// The height crop shared by the orientations of a sample.  cropByHandHeight (point_list.cpp:35-55) keeps the points
-// whose coordinate along the hand frame's third axis lies in (-h, h); that axis is the one the orientations rotate
-// about, so the eight frames of a sample have the same third column up to rounding ((1 - c) + c instead of 1) — every
-// orientation transformed all N neighbours to keep the same third of them.  One workgroup per sample lists the points
-// with |z| < h + margin for the axis of slot 0, margin = (largest deviation of any slot's axis from it) x radius +
-// 1e-12: a superset of every orientation's exact crop, which hand_eval_kernel then decides with its own frame.  When
-// the slots' axes differ (hand_axes other than the rotation axis) the margin is large and the list is everything.
-__global__ __launch_bounds__(256) void height_list_kernel(HandParams P, int32_t *counts) {
-  const HandConsts &K = c_hand;
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const int N = P.counts[8 * s + 0], kf = P.counts[8 * s + 2];
-  __shared__ int s_n;
-  if (tid == 0) s_n = 0;
-  __syncthreads();
-  if (kf == 0 || N == 0) {
-    if (tid == 0) counts[8 * s + 6] = 0;
-    return;
-  }
-  const double *fr = P.frames + 12 * (size_t)s;
-  double F[9], FRB[9], FR[9], sample[3], axis[3] = {0, 0, 0};
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    sample[r] = fr[r];
-    F[3 * r + 0] = fr[3 + r];
-    F[3 * r + 1] = fr[6 + r];
-    F[3 * r + 2] = fr[9 + r];
-  }
-  mat3mul(F, K.rot_binormal, FRB);
-  double dev = 0.0;
-  for (int slot = 0; slot < K.slots; slot++) {
-    mat3mul(FRB, K.rot[slot], FR);
-    if (slot == 0) {
-      axis[0] = FR[2];
-      axis[1] = FR[5];
-      axis[2] = FR[8];
-    }
-    dev = fmax(dev, fabs(FR[2] - axis[0]) + fabs(FR[5] - axis[1]) + fabs(FR[8] - axis[2]));
-  }
-  const double margin = dev * P.radius + 1e-12;
-  const double lim = K.hand_height + margin;
-  const float *nn = P.nn + (size_t)s * 6 * P.cap;
-  float4 *out = P.hl + (size_t)s * P.cap;
-  for (int e0 = 0; e0 < N; e0 += 256) {
-    const int e = e0 + tid;
-    bool in = false;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (e < N) {
-      x = nn[0 * P.cap + e];
-      y = nn[1 * P.cap + e];
-      z = nn[2 * P.cap + e];
-      const double z0 = axis[0] * ((double)x - sample[0]) + axis[1] * ((double)y - sample[1]) + axis[2] * ((double)z - sample[2]);
-      in = z0 > -lim && z0 < lim;
-    }
-    const unsigned long long ballot = __ballot(in);
-    if (ballot) {
-      int base = 0;
-      if ((tid & 63) == 0) base = atomicAdd(&s_n, __popcll(ballot));
-      base = __builtin_amdgcn_readfirstlane(base);  // every lane is active here and lane 0 holds it
-      if (in) out[base + __popcll(ballot & ((1ull << (tid & 63)) - 1ull))] = make_float4(x, y, z, __int_as_float(e));
-    }
-  }
-  __syncthreads();
-  if (tid == 0) counts[8 * s + 6] = s_n;
-}
-
 __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   __shared__ unsigned s_u[4];
   __shared__ double s_d[4];
@@ -1894,7 +1829,7 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
   L.ct1 = nullptr;
   L.ce = nullptr;
   L.kc = 0;
-  // The points come from the sample's height list (height_list_kernel: the superset of every orientation's crop, one
+  // The points come from the sample's height list (written by neighbourhood_kernel's gather: the superset of every orientation's crop, one
   // 16-byte record per point); two rounds are in flight per thread.
   const float4 *hl = P.hl + (size_t)s * P.cap;
   const int NL = P.counts[8 * s + 6];
@@ -2141,7 +2076,7 @@ static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &
   np.hl_radius = hc.nn_radius_hands * 1.001 + 1e-6;
   static unsigned long long *d_nbdbg = nullptr;
   np.dbg = nullptr;
-  if (getenv("GPD_NB_TIMING")) {
+  if (prof_env("GPD_NB_TIMING")) {
     if (!d_nbdbg) HIP_RET(hipMalloc(&d_nbdbg, 10 * sizeof(unsigned long long)));
     HIP_RET(hipMemsetAsync(d_nbdbg, 0, 10 * sizeof(unsigned long long), stream));
     np.dbg = d_nbdbg;
@@ -2324,7 +2259,7 @@ int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_
   hp.num_samples = S;
   static unsigned long long *d_hedbg = nullptr;
   hp.dbg = nullptr;
-  if (getenv("GPD_HE_TIMING")) {
+  if (prof_env("GPD_HE_TIMING")) {
     if (!d_hedbg) HIP_RET(hipMalloc(&d_hedbg, 16 * sizeof(unsigned long long)));
     HIP_RET(hipMemsetAsync(d_hedbg, 0, 16 * sizeof(unsigned long long), stream));
     hp.dbg = d_hedbg;

@@ -6,6 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/${1:-pipe}
 mkdir -p $OUT
 cd $ROOT
+export GPD_HIP_LIB=${GPD_HIP_LIB:-$ROOT/gpd_amd/libgpd_hip_prof.so}  # the measurement switches exist in the profiling build only (make -C gpd_amd/csrc prof)
 for rep in 1 2 3; do
   for mode in 0 1; do
     GPD_REPLAY_PIPE=$mode timeout 300 python bench.py --steps 40 --warmup 5 --cpu-samples 0 --batch-clouds 0 > $OUT/b_${mode}_$rep.json 2> $OUT/b_${mode}_$rep.err

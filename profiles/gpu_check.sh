@@ -11,7 +11,7 @@ cd $ROOT
 timeout 1500 python -m pytest tests -m gpu -x -q "$@" > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest.log
 tail -5 $OUT/pytest.log
-GPD_DETECT_TIMING=1 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench rc=$?"
 grep detect-timing $OUT/bench.err | tail -2
 python - <<PY

@@ -1,5 +1,6 @@
 """Per-phase cycle counters of the image kernels (GPD_IMG_TIMING=1) on the benchmark's 5000-candidate list."""
 import os, sys
+os.environ.setdefault("GPD_HIP_LIB", os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpd_amd", "libgpd_hip_prof.so"))  # the timing switches exist in the profiling build only
 os.environ["GPD_IMG_TIMING"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

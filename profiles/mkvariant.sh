@@ -12,6 +12,7 @@ else
   cp $ROOT/gpd_amd/csrc/*.hip $ROOT/gpd_amd/csrc/*.h $ROOT/gpd_amd/csrc/*.cpp $ROOT/gpd_amd/csrc/Makefile $T/gpd_amd/csrc/; cp $ROOT/include/*.h $T/include/
 fi
 make -s -C $T/gpd_amd/csrc -j8 > /dev/null
-cp $T/gpd_amd/libgpd_hip.so $ROOT/ab/libgpd_hip_$NAME.so
+# the profiling build when the revision has one (round 4 on: the measurement switches live there), else the only library
+if [ -f $T/gpd_amd/libgpd_hip_prof.so ]; then cp $T/gpd_amd/libgpd_hip_prof.so $ROOT/ab/libgpd_hip_$NAME.so; else cp $T/gpd_amd/libgpd_hip.so $ROOT/ab/libgpd_hip_$NAME.so; fi
 rm -rf $T
 echo "ab/libgpd_hip_$NAME.so"

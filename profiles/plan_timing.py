@@ -1,4 +1,5 @@
 import sys, os
+os.environ.setdefault("GPD_HIP_LIB", os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpd_amd", "libgpd_hip_prof.so"))  # the timing switches exist in the profiling build only
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from gpd_amd import api, synth
 cl = synth.make_cloud(1234, 30000)

@@ -8,6 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/mix_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export GPD_HIP_LIB=${GPD_HIP_LIB:-$ROOT/gpd_amd/libgpd_hip_prof.so}  # the measurement switches exist in the profiling build only (make -C gpd_amd/csrc prof)
 export GPD_IMG_SERIAL=1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/p1 -o b -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $OUT/log1.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_LDS_ATOMIC SQ_INSTS_VMEM -d $OUT/p2 -o b -- python $ROOT/bench.py --steps 3 --warmup 1 --cpu-samples 0 --batch-clouds 0 > $OUT/log2.txt 2>&1

@@ -1,6 +1,7 @@
 """Per-phase cycle sums of the search kernels (GPD_NB_TIMING=1 / GPD_HE_TIMING=1 print them from libgpd_hip.so)."""
 import os
 import sys
+os.environ.setdefault("GPD_HIP_LIB", os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpd_amd", "libgpd_hip_prof.so"))  # the timing switches exist in the profiling build only
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from gpd_amd import api, synth
 cl = synth.make_cloud(1234, 30000)

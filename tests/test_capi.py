@@ -57,3 +57,20 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"import oracle|from oracle|libgpd_oracle|gpd_oracle_|libgpd_ref|gpd_ref_|oracle/shim|GPD_REF_SHIM", txt):
                         bad.append(f)
     assert not bad, bad
+
+
+def test_release_library_reads_no_environment_and_links_no_profiler():
+    """The shipped .so carries neither getenv switches nor the roctx dependency; the profiling
+    build (libgpd_hip_prof.so, -DGPD_PROFILING) has both and exports the same C-ABI."""
+    import subprocess
+    rel = os.path.join(ROOT, "gpd_amd", "libgpd_hip.so")
+    out = subprocess.run(["nm", "-D", "--undefined-only", rel], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out and "roctx" not in out, out
+    txt = "".join(open(os.path.join(ROOT, "gpd_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "gpd_amd", "csrc"))
+                  if f.endswith((".hip", ".cpp")))
+    assert not re.search(r"[^_\w]getenv\s*\(", txt), "a source of the release library calls getenv directly (use prof_env)"
+    prof = os.path.join(ROOT, "gpd_amd", "libgpd_hip_prof.so")
+    assert os.path.exists(prof)
+    pout = subprocess.run(["nm", "-D", "--defined-only", prof], capture_output=True, text=True, check=True).stdout
+    for n in _declared():
+        assert n in pout

@@ -25,15 +25,9 @@ def _inside(xyz, ws):
 
 
 def _check(ctx, oracle_mod, xyz, cam, ws, cell):
-    """Both routes of the voxeliser's sequential chain — the host walk (default) and voxel_accept_kernel
-    (GPD_VOXEL_DEVICE=1, read per call) — against the oracle, and so against each other."""
-    os.environ["GPD_VOXEL_DEVICE"] = "1"
-    try:
-        dev = ctx.preprocess_cloud(xyz, cam, ws, cell)
-    finally:
-        del os.environ["GPD_VOXEL_DEVICE"]
+    """gpd_hip_preprocess_cloud (cut + keys + gather on the device, the voxeliser's sequential chain as a spine walk on
+    one host core) against the oracle — which IS std::set under the reference's comparator."""
     got_xyz, got_cam, got_src, ms = ctx.preprocess_cloud(xyz, cam, ws, cell)
-    assert dev[0].tobytes() == got_xyz.tobytes() and np.array_equal(dev[1], got_cam) and np.array_equal(dev[2], got_src)
     keep = np.flatnonzero(_inside(xyz, ws)) if ws is not None else np.arange(len(xyz))
     if cell > 0:
         want_xyz, src = oracle_mod.voxelize(xyz[keep], cell) if len(keep) else (np.zeros((0, 3), np.float32), np.zeros(0, np.int32))
