@@ -61,7 +61,7 @@ def source_hashes():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default 20 (replay) / 2 passes over the rank's clouds (batch)")
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (replay) / 3 passes over the rank's clouds (batch)")
     ap.add_argument("--warmup", type=int, default=None, help="default 3 (replay) / 1 (batch)")
     ap.add_argument("--mode", choices=("replay", "batch"), default="replay")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE config preset (default: 2)")
@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--clouds", type=int, default=256, help="--mode batch: clouds of the whole job (cloud i -> rank i mod N)")
     ap.add_argument("--batch-samples", type=int, default=2564, help="samples per cloud of the batch legs")
     ap.add_argument("--batch-clouds", type=int, default=None,
-                    help="replay mode: clouds per rank of the batch_end_to_end leg (default 12 on one GPU, 64 on several; 0 disables)")
+                    help="replay mode: clouds per rank and pass of the batch_end_to_end leg (default 24 on one GPU, 32 on several; 0 disables)")
+    ap.add_argument("--batch-passes", type=int, default=4, help="replay mode: timed passes of the batch_end_to_end leg (after one full untimed pass)")
     ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
     ap.add_argument("--live-pmc", dest="live_pmc", action="store_true", default=None,
                     help="measure roofline.traffic / pmc_traffic here (two rocprofv3 --pmc child runs of this file after the timed region, "
@@ -91,9 +92,9 @@ def main():
         args.live_pmc = (args.gpus == 1 and args.config is None and args.mode == "replay" and args.points is None and args.candidates is None
                          and args.channels is None and not args.clutter and not profiled and not os.environ.get("GPD_BENCH_DRYRUN"))
     if args.batch_clouds is None:
-        args.batch_clouds = 12 if args.gpus == 1 else 64
+        args.batch_clouds = 24 if args.gpus == 1 else 32
     if args.steps is None:
-        args.steps = 20 if args.mode == "replay" else 2
+        args.steps = 20 if args.mode == "replay" else 3
     if args.warmup is None:
         args.warmup = 3 if args.mode == "replay" else 1
     preset = CONFIGS[args.config or "2"]
@@ -171,19 +172,32 @@ def main():
     ctx.set_lenet_weights(w)                       # weights copied once per device at init
 
     def batch_leg(cloud_ids, passes, warm):
-        """gpd_hip_detect_batch over the listed clouds (seed 1234 + id), `passes` times, barrier-bracketed."""
+        """gpd_hip_detect_batch over the listed clouds (seed 1234 + id): `warm` untimed FULL passes (every lane buffer at its
+        final size, clocks up), then `passes` timed ones, barrier-bracketed as a whole and timed one by one (a pass = one call;
+        its results are on the host when it returns).  The whole-job figure is all candidates / the bracketed time; the
+        per-pass spread says whether that figure can be trusted (a single 75 ms pass after a 3-cloud warm-up gave
+        565 k/s on one box and 1.0 M/s on three others)."""
         clouds = [synth.make_cloud(1234 + cid, 30000) for cid in cloud_ids]
         samples = [synth.sample_indices(cl, args.batch_samples) for cl in clouds]
-        for _ in range(warm):
-            ctx.detect_batch(clouds[: max(2, len(clouds) // 4)], samples[: max(2, len(clouds) // 4)], 0)
+        for _ in range(max(warm, 1)):
+            ctx.detect_batch(clouds, samples, 0)
         barrier()
         t0 = time.perf_counter()
         n_cand = 0
         stage = np.zeros(3)
+        pass_s, pass_cand, pass_allocs, pass_host = [], [], [], []
         for _ in range(passes):
+            tp = time.perf_counter()
+            nc_pass = 0
             for hands, ns, nc, ms in ctx.detect_batch(clouds, samples, 0):
-                n_cand += nc
+                nc_pass += nc
                 stage += ms
+            pass_s.append(time.perf_counter() - tp)
+            pass_cand.append(nc_pass)
+            n_cand += nc_pass
+            tl = ctx.last_batch_timeline
+            pass_allocs.append(sum(a for _, a in tl))
+            pass_host.append(_host_split([h for h, _ in tl]))
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -192,10 +206,19 @@ def main():
         _, ncl = reduce(elapsed, len(clouds) * passes)
         mine = len(clouds) * passes / elapsed  # this rank's own rate: a host-side limiter shows as a spread
         rmin, rmax = minmax(mine)
+        rates = sorted(c / t for c, t in zip(pass_cand, pass_s))
+        slow = int(np.argmax(pass_s))
         return dict(clouds=int(ncl), clouds_per_rank=len(clouds) * passes, candidates=int(tot), wall_s=el, clouds_per_s=ncl / el,
                     cand_per_s=tot / el, rank_clouds_per_s={"min": rmin, "max": rmax},
+                    passes={"n": passes, "warmup_passes": max(warm, 1), "clouds_per_pass": len(clouds),
+                            "wall_ms_rank0": [t * 1e3 for t in pass_s],
+                            "cand_per_s_rank0": {"min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1]},
+                            "buffer_growths_in_timed_passes": int(sum(pass_allocs)),
+                            "host_ms_slowest_pass": pass_host[slow], "host_ms_fastest_pass": pass_host[int(np.argmin(pass_s))],
+                            "note": "one pass = one gpd_hip_detect_batch call over the rank's clouds (pipeline filled and drained per call); "
+                                    "host_ms: the calling thread's time enqueuing / copying vs blocked on the device (gpd_detect_job.host_ms)"},
                     kernel_ms_rank0={"search": float(stage[0]), "images": float(stage[1]), "lenet": float(stage[2]),
-                                     "note": "summed per cloud; two clouds are in flight, so the sum exceeds the wall time"})
+                                     "note": "summed per cloud over the timed passes; two clouds are in flight, so the sum exceeds the wall time"})
 
     if args.mode == "batch":
         mine = gdist.clouds_of_rank(args.clouds, rank, world)
@@ -287,7 +310,7 @@ def main():
 
     batch = None
     if args.batch_clouds > 0 and C == 15 and not clutter:
-        batch = batch_leg([rank + world * k for k in range(args.batch_clouds)], 1, 1)
+        batch = batch_leg([rank + world * k for k in range(args.batch_clouds)], args.batch_passes, 1)
 
     if rank == 0:
         value = total_cand * args.steps / elapsed
@@ -371,8 +394,9 @@ def main():
         if trained is not None:
             out["scores_trained_magnitude"] = trained
         if batch is not None:
-            batch["note"] = ("gpd_hip_detect_batch, %d clouds per rank x %d samples, two clouds in flight per context: upload + grid + "
-                             "search + filter + images + LeNet + scored candidates back to the host" % (args.batch_clouds, args.batch_samples))
+            batch["note"] = ("gpd_hip_detect_batch, %d clouds per rank and pass x %d samples, %d timed passes after one full untimed pass, two clouds "
+                             "in flight per context: upload + grid + search + filter + images + LeNet + scored candidates back to the host"
+                             % (args.batch_clouds, args.batch_samples, args.batch_passes))
             out["batch_end_to_end"] = batch
         raw = None
         if args.config is None and C == 15 and not clutter:  # the widened row before the path, on the default line only
@@ -388,6 +412,36 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _host_split(tl):
+    """gpd_detect_job.host_ms of one gpd_hip_detect_batch call -> where its host thread spent the call: enqueuing / copying
+    (`work`) or blocked on the device (`wait`: the plan summary of cloud i, the results of cloud i - 1).  The entry orders its
+    steps begin(i + 1), middle(i), end(i - 1); the stamps are [0] begin done, [1] plan arrived, [2] middle enqueued, [3] results
+    arrived, [4] records copied."""
+    n = len(tl)
+    seq = [(tl[0][0], "work")] if n else []
+    for i in range(n):
+        if i + 1 < n:
+            seq.append((tl[i + 1][0], "work"))
+        seq.append((tl[i][1], "wait"))
+        seq.append((tl[i][2], "work"))
+        if i >= 1:
+            seq.append((tl[i - 1][3], "wait"))
+            seq.append((tl[i - 1][4], "work"))
+    if n:
+        seq.append((tl[n - 1][3], "wait"))
+        seq.append((tl[n - 1][4], "work"))
+    out = {"work": 0.0, "wait": 0.0}
+    prev = 0.0
+    longest = {"work": 0.0, "wait": 0.0}
+    for t, kind in seq:
+        d = max(0.0, t - prev)
+        out[kind] += d
+        longest[kind] = max(longest[kind], d)
+        prev = max(prev, t)
+    return {"enqueue_and_copy": out["work"], "blocked_on_device": out["wait"], "longest_enqueue_step": longest["work"],
+            "longest_wait": longest["wait"], "total": prev}
 
 
 def _filter_workspace(hands, p):

@@ -43,7 +43,7 @@ class DetectJob(C.Structure):
         ("sample_indices", C.c_void_p), ("hands", C.c_void_p),
         ("num_points", C.c_int32), ("num_cams", C.c_int32), ("num_samples", C.c_int32), ("num_selected", C.c_int32),
         ("hands_capacity", C.c_int32), ("num_sets", C.c_int32), ("num_candidates", C.c_int32), ("num_hands", C.c_int32),
-        ("status", C.c_int32), ("stage_ms", C.c_float * 3),
+        ("status", C.c_int32), ("stage_ms", C.c_float * 3), ("host_ms", C.c_float * 5), ("allocs", C.c_int32),
     ]
 
 
@@ -55,7 +55,7 @@ EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_h
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
-           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters"]
+           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters", "gpd_hip_reserve"]
 
 
 def build():
@@ -98,6 +98,7 @@ def lib():
         L.gpd_hip_last_images_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_conv1_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.gpd_hip_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         _LIB = L
     return _LIB
@@ -248,8 +249,14 @@ class Context:
         -> list of (hands[k], n_sets, n_candidates, stage_ms[3]) in cloud order."""
         jobs, keep = self._jobs(clouds, samples, num_selected)
         self._check(lib().gpd_hip_detect_batch(self._h, jobs, len(clouds)))
+        # where the host was per cloud (ms since entry) and the buffer growths booked on it: kept for the caller that asks
+        self.last_batch_timeline = [([float(x) for x in j.host_ms], int(j.allocs)) for j in jobs]
         return [(k[5][: j.num_hands], j.num_sets, j.num_candidates, [float(x) for x in j.stage_ms])
                 for j, k in zip(jobs, keep)]
+
+    def reserve(self, max_points, max_cams=1, max_samples=0, max_candidates=0, max_selected=0):
+        """gpd_hip_reserve: size every buffer of the context once (no allocation in later calls within these sizes)."""
+        self._check(lib().gpd_hip_reserve(self._h, int(max_points), int(max_cams), int(max_samples), int(max_candidates), int(max_selected)))
 
     def detect_batch_multi(self, others, clouds, samples, num_selected=0):
         """gpd_hip_detect_batch_multi over this context and `others` (one host thread per context, cloud i ->

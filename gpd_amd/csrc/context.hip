@@ -40,6 +40,9 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+static thread_local int g_allocs = 0;
+void note_alloc() { g_allocs++; }
+
 }  // namespace gpd
 
 using namespace gpd;
@@ -104,6 +107,8 @@ struct Job {
   int num_sets = 0, num_candidates = 0, num_hands = 0;
   bool live = false;       // device work enqueued, end() still has to collect it
   int out_records = 0;
+  double t_plan_ms = 0.0;  // host clock when the plan summary had arrived (job_middle past its wait)
+  double copy_ms = 0.0;    // job_end: handing the records over (after the wait)
 };
 
 }  // namespace
@@ -167,6 +172,7 @@ static void lane_free(Lane &L) {
 
 static int reserve_scores(Lane &L, int n) {
   if (n <= L.d_scores_cap) return GPD_OK;
+  note_alloc();
   if (L.d_scores) (void)hipFree(L.d_scores);
   L.d_scores = nullptr;
   L.d_scores_cap = 0;
@@ -178,6 +184,7 @@ static int reserve_scores(Lane &L, int n) {
 
 static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
   if (records > L.d_out_cap) {
+    note_alloc();
     if (L.d_out) (void)hipFree(L.d_out);
     L.d_out = nullptr;
     L.d_out_cap = 0;
@@ -187,6 +194,7 @@ static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
   }
   const size_t bytes = L.d_out_cap * sizeof(gpd_hand) + extra_bytes;
   if (bytes > L.h_out_bytes) {
+    note_alloc();
     if (L.h_out) (void)hipHostFree(L.h_out);
     L.h_out = nullptr;
     L.h_out_bytes = 0;
@@ -195,6 +203,69 @@ static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
     L.h_out_bytes = cap;
   }
   return GPD_OK;
+}
+
+// selections (num_selected > 0): the winners' ordinals + tie flag, and the job's own list of every scored candidate
+static int reserve_selection(Lane &L, int k, int n) {
+  if (k + 1 > L.d_sel_cap) {
+    note_alloc();
+    if (L.d_sel) (void)hipFree(L.d_sel);
+    L.d_sel = nullptr;
+    L.d_sel_cap = 0;
+    const int cap = k + 1 + k / 4;
+    HIP_TRY(hipMalloc(&L.d_sel, (size_t)cap * sizeof(int32_t)));
+    L.d_sel_cap = cap;
+  }
+  if ((size_t)n > L.d_all_cap) {
+    note_alloc();
+    if (L.d_all) (void)hipFree(L.d_all);
+    L.d_all = nullptr;
+    L.d_all_cap = 0;
+    const size_t cap = (size_t)n + (size_t)n / 4;
+    HIP_TRY(hipMalloc(&L.d_all, cap * sizeof(gpd_hand)));
+    L.d_all_cap = cap;
+  }
+  return GPD_OK;
+}
+
+// Every buffer of a lane for clouds of up to `points` points / `cams` cameras, `samples` samples and `candidates`
+// scored hands (selections of up to `selected` winners; -1: none), so that no call within those sizes allocates:
+// growing a buffer is hipFree + hipMalloc, which waits for the whole device — in a batch that is a hole in BOTH
+// lanes' queues.  gpd_hip_reserve and gpd_hip_detect_batch call this ahead of the first cloud.
+static int lane_reserve(gpd_hip_ctx *ctx, Lane &L, int points, int cams, int samples, int candidates, int selected);
+
+constexpr int kLeNetChunk = 65536;                // lenet_forward's images per pass (lenet.hip)
+constexpr size_t kReserveBudget = 16ull << 30;   // candidate-sized buffers of a lane when the caller names no bound
+
+// the most candidates `samples` samples can give (every slot a valid hand), cut to what kReserveBudget holds
+static int candidate_bound(const gpd_params &p, int samples) {
+  const long long upper = (long long)samples * p.num_hand_axes * p.num_orientations;
+  const size_t per = (size_t)kPix * p.image_num_channels + (20 * 784 + kFc1In + kFc1Out + 1) * sizeof(float) + 2 * sizeof(gpd_hand);
+  const long long fit = (long long)(kReserveBudget / per);
+  return (int)std::min(upper, fit);
+}
+
+static int lane_reserve(gpd_hip_ctx *ctx, Lane &L, int points, int cams, int samples, int candidates, int selected) {
+  const gpd_params &p = ctx->params;
+  const int slots = p.num_hand_axes * p.num_orientations;
+  int rc = cloud_reserve(L.cloud, points, cams);
+  if (!rc && samples > 0) rc = search_reserve_samples(L.search, samples, slots);
+  if (!rc && samples > 0) rc = plan_reserve(L.plan, L.search.capacity_samples, slots, cams, L.stream);
+  if (rc || candidates <= 0) return rc;
+  const long long sets = std::min((long long)samples, (long long)candidates) * cams;  // (live hand set, camera) voxel bitsets
+  rc = images_reserve(p, L.images, candidates, p.image_num_channels == 15 ? (int)sets : 0);
+  if (rc) return rc;
+  HIP_TRY(lenet_scratch_reserve(L.lenet_scratch, std::min(candidates, kLeNetChunk)));
+  rc = reserve_scores(L, candidates);
+  if (rc) return rc;
+  if (selected >= 0) {
+    const int k = selected > 0 ? std::min(selected, candidates) : candidates;
+    rc = reserve_out(L, (size_t)k, selected > 0 ? (size_t)candidates * sizeof(float) : 0);
+    if (!rc && selected > 0) rc = reserve_selection(L, k, candidates);
+  } else {
+    rc = reserve_out(L, (size_t)samples * slots, 0);  // gpd_hip_detect: every slot of every set
+  }
+  return rc;
 }
 
 // ---- the three steps of a fused detect -------------------------------------------------------
@@ -224,6 +295,7 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   if (!J.live) return GPD_OK;
   J.live = false;  // set again once everything is enqueued
   HIP_TRY(hipEventSynchronize(L.ev_plan));  // not the stream: in a batch the next cloud's search is already queued behind
+  J.t_plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   if (L.plan.h_summary->worst_found > L.search.nn_cap) {
     // a neighbourhood overflowed the list capacity of the search kernel: once more with the large lists
     const int cap = search_next_capacity(L.search, L.plan.h_summary->worst_found);
@@ -287,21 +359,8 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   if (J.mode == 0) {
     rc = plan_emit_hands(ctx->params, L.search, L.plan, n > 0 ? L.d_scores : nullptr, L.d_out, false, L.stream);
   } else if (k > 0) {
-    if (k + 1 > L.d_sel_cap) {
-      if (L.d_sel) (void)hipFree(L.d_sel);
-      L.d_sel = nullptr;
-      L.d_sel_cap = 0;
-      HIP_TRY(hipMalloc(&L.d_sel, (size_t)(k + 1) * sizeof(int32_t)));
-      L.d_sel_cap = k + 1;
-    }
-    if ((size_t)n > L.d_all_cap) {
-      if (L.d_all) (void)hipFree(L.d_all);
-      L.d_all = nullptr;
-      L.d_all_cap = 0;
-      const size_t cap = (size_t)n + (size_t)n / 4;
-      HIP_TRY(hipMalloc(&L.d_all, cap * sizeof(gpd_hand)));
-      L.d_all_cap = cap;
-    }
+    rc = reserve_selection(L, k, n);
+    if (rc) return rc;
     // every candidate record, scored, in a list of this job's own: the selection gathers from it, and so does the
     // std::partial_sort rerun of job_end — by then, in a batch, the lane's search / plan buffers already hold the
     // cloud after next (begin(i + 1) is enqueued before end(i - 1))
@@ -337,6 +396,7 @@ static int job_end(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   if (!J.live) return GPD_OK;
   J.live = false;
   HIP_TRY(hipEventSynchronize(L.ev_done));
+  const auto t_done = std::chrono::steady_clock::now();
   (void)hipEventElapsedTime(&L.stage_ms[1], L.ev[4], L.ev[2]);
   (void)hipEventElapsedTime(&L.stage_ms[2], L.ev[2], L.ev[3]);
   if (L.h_flags->status) {
@@ -366,6 +426,7 @@ static int job_end(gpd_hip_ctx *ctx, Lane &L, Job &J) {
     HIP_TRY(hipStreamSynchronize(L.stream));
   }
   if (J.out_records > 0) std::memcpy(J.hands, L.h_out, (size_t)J.out_records * sizeof(gpd_hand));
+  J.copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_done).count();
   return GPD_OK;
 }
 
@@ -520,6 +581,30 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
     }
   }
   delete ctx;
+}
+
+int gpd_hip_reserve(gpd_hip_ctx *ctx, int max_points, int max_cams, int max_samples, int max_candidates, int max_selected) {
+  if (!ctx || max_points < 1 || max_cams < 1 || max_cams > kMaxCams || max_samples < 0 || max_candidates < 0 || max_selected < 0) {
+    set_error("gpd_hip_reserve: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int cand = max_candidates > 0 ? max_candidates : candidate_bound(ctx->params, max_samples);
+  for (int l = 0; l < kLanes; l++) {
+    int rc = lane_init(ctx->lane[l]);
+    if (rc) return rc;
+    Lane &L = ctx->lane[l];
+    HIP_TRY(hipStreamSynchronize(L.stream));
+    // lane 0 also serves the single-cloud entries (all slots of all sets back); both serve the batch (candidates / winners)
+    if (l == 0) {
+      rc = lane_reserve(ctx, L, max_points, max_cams, max_samples, cand, -1);
+      if (rc) return rc;
+    }
+    rc = lane_reserve(ctx, L, max_points, max_cams, max_samples, cand, 0);
+    if (!rc && max_selected > 0) rc = lane_reserve(ctx, L, max_points, max_cams, max_samples, cand, max_selected);
+    if (rc) return rc;
+  }
+  return GPD_OK;
 }
 
 int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1_w, const float *conv1_b, const float *conv2_w,
@@ -919,6 +1004,8 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     j.status = GPD_OK;
     j.num_sets = j.num_candidates = j.num_hands = 0;
     j.stage_ms[0] = j.stage_ms[1] = j.stage_ms[2] = 0.f;
+    j.allocs = 0;
+    for (float &t : j.host_ms) t = 0.f;
     if (!j.xyz || !j.normals || j.num_points <= 0 || !j.cam_source || j.num_cams < 1 || !j.view_points || !j.sample_indices ||
         j.num_samples < 0 || !j.hands || j.hands_capacity < 0 || j.num_selected < 0) {
       set_error("gpd_hip_detect_batch: job %d has a bad argument", i);
@@ -928,6 +1015,37 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
   for (int l = 1; l < kLanes; l++) {
     const int rc = lane_init(ctx->lane[l]);
     if (rc) return rc;
+  }
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_entry = now_ms();
+  {
+    // Both lanes sized once for the largest cloud of the batch before anything is enqueued: a buffer that grows in the
+    // middle of the batch is a hipFree + hipMalloc, which waits for the whole device (both lanes).  Points, cameras and
+    // samples are known; the candidate-sized buffers (images, LeNet scratch, records) take the upper bound
+    // samples x slots, cut to kReserveBudget per lane — a cloud beyond that still grows its lane, and says so in `allocs`.
+    int maxP = 0, maxC = 0, maxS = 0, maxSel = 0;
+    bool all_selected = num_jobs > 0;
+    for (int i = 0; i < num_jobs; i++) {
+      maxP = std::max(maxP, jobs[i].num_points);
+      maxC = std::max(maxC, jobs[i].num_cams);
+      maxS = std::max(maxS, jobs[i].num_samples);
+      maxSel = std::max(maxSel, jobs[i].num_selected);
+      all_selected = all_selected && jobs[i].num_selected > 0;
+    }
+    if (maxC > kMaxCams) {
+      set_error("gpd_hip_detect_batch: at most %d cameras are supported", kMaxCams);
+      return GPD_ERR_INVALID;
+    }
+    const int before = g_allocs;
+    for (int l = 0; l < kLanes && l < num_jobs; l++) {
+      Lane &L = ctx->lane[l];
+      const int cand = candidate_bound(ctx->params, maxS);
+      int rc = GPD_OK;
+      if (!all_selected) rc = lane_reserve(ctx, L, maxP, maxC, maxS, cand, 0);
+      if (!rc && maxSel > 0) rc = lane_reserve(ctx, L, maxP, maxC, maxS, cand, maxSel);
+      if (rc) return rc;
+    }
+    if (num_jobs > 0) jobs[0].allocs = g_allocs - before;  // the pre-sizing is booked on the first cloud
   }
   std::vector<Job> J((size_t)num_jobs);
   ctx->in_batch = true;
@@ -947,6 +1065,7 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
   auto begin = [&](int i) {
     gpd_detect_job &j = jobs[i];
     Lane &L = ctx->lane[i % kLanes];
+    const int allocs0 = g_allocs;
     int rc = check_samples(ctx, L, "gpd_hip_detect_batch", j.sample_indices, nullptr, j.num_samples, j.num_points);
     if (!rc) rc = cloud_upload(L.cloud, j.xyz, j.normals, j.num_points, j.cam_source, j.num_cams, j.view_points, L.stream, /*sync=*/false);
     if (rc) return fail(i, rc);
@@ -957,11 +1076,15 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     J[i].hands = j.hands;
     J[i].capacity = j.hands_capacity;
     rc = job_begin(ctx, L, J[i]);
+    j.allocs += g_allocs - allocs0;
+    j.host_ms[0] = (float)(now_ms() - t_entry);
     if (rc) fail(i, rc);
   };
   auto end = [&](int i) {
     Lane &L = ctx->lane[i % kLanes];
     const int rc = job_end(ctx, L, J[i]);
+    jobs[i].host_ms[4] = (float)(now_ms() - t_entry);
+    jobs[i].host_ms[3] = jobs[i].host_ms[4] - (float)J[i].copy_ms;
     if (rc) return fail(i, rc);
     jobs[i].num_sets = J[i].num_sets;
     jobs[i].num_candidates = J[i].num_candidates;
@@ -977,7 +1100,11 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
   for (int i = 0; i < num_jobs; i++) {
     if (i + 1 < num_jobs) begin(i + 1);
     if (jobs[i].status == GPD_OK) {
+      const int allocs0 = g_allocs;
       const int rc = job_middle(ctx, ctx->lane[i % kLanes], J[i]);
+      jobs[i].allocs += g_allocs - allocs0;
+      jobs[i].host_ms[1] = (float)(J[i].t_plan_ms - t_entry);
+      jobs[i].host_ms[2] = (float)(now_ms() - t_entry);
       if (rc) fail(i, rc);
     }
     if (i >= 1) end(i - 1);

@@ -50,6 +50,10 @@ int lenet_check(LeNetScratch &s);
 void lenet_scratch_free(LeNetScratch &s);
 
 void set_error(const char *fmt, ...);
+// every growth of a device / pinned buffer (hipFree + hipMalloc: a device stall) is counted per host thread; the batch
+// entry reports the count per cloud (gpd_detect_job::allocs) so that a pass that was supposed to run on pre-sized lanes
+// can be seen to have done so
+void note_alloc();
 
 // roctx range around a stage of the path (host side: what the stage enqueues); `rocprofv3 --marker-trace --kernel-trace`
 // shows them over the kernel timeline (the reference times its stages with omp_get_wtime, grasp_detector.cpp:223-273)
@@ -154,6 +158,7 @@ inline GridView grid_view(const Cloud &c) {
 }
 int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
                  const double *view_points, hipStream_t stream, bool sync);
+int cloud_reserve(Cloud &c, int n, int num_cams);
 void cloud_free(Cloud &c);
 int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream);
 
@@ -187,6 +192,7 @@ struct SearchState {
 int search_run(const gpd_params &p, const Cloud &c, SearchState &s, const int32_t *sample_idx, const double *sample_xyz, int S,
                hipStream_t stream, bool sync_counts = true);
 // list capacity the next search_run would use after a neighbourhood of `worst` entries; 0: beyond every capacity
+int search_reserve_samples(SearchState &s, int S, int slots);  // buffers for S samples at the current list capacity
 int search_next_capacity(const SearchState &s, int worst);
 int search_force_capacity(SearchState &s, int cap);
 // HandSearch::reevaluateHypotheses on the uploaded cloud; invalidates the search state
@@ -274,6 +280,7 @@ struct Plan {
   int cap_set_flags = 0;
 };
 void plan_free(Plan &pl);
+int plan_reserve(Plan &pl, int want_samples, int slots, int cams, hipStream_t stream);
 // Enqueues plan_kernel + the summary copy on `stream`; the caller waits for the stream before reading pl.h_summary.
 // set_flags == nullptr: the validity flags are the ones hand_eval_kernel left (search + workspace filter).
 // Otherwise (gpd_hip_images) the caller's flags, set-major [num_sets_given][slots], and the samples of its sets
@@ -318,6 +325,7 @@ struct ImageState {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_stream = true;  // off inside gpd_hip_detect_batch: the other cloud's kernels already fill the gaps (measured)
 };
+int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets);
 // Sizes the image buffers for the plan's candidate list (summary already on the host) and launches the image kernels.
 int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream);
 // Re-launches them on the resident list.  Nothing waits for the device: capacity flags accumulate in im.d_status.

@@ -1629,27 +1629,16 @@ void images_free(ImageState &im) {
   im = ImageState();
 }
 
-// The candidate list itself (which hands, in which order, where each hand set starts in the LCG stream) is
-// built on the device by plan_kernel; its sizes are in pl.h_summary by now.  This sizes the image buffers,
-// prepares the constant block of the image geometry and launches the kernels.
-int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream) {
+// Image buffers for up to n candidates and `shadow_sets` (live hand set, camera) voxel bitsets of the geometry in p
+// (grow with 25 % slack, never shrink; a growth stalls the device).
+int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) {
   const int C = p.image_num_channels;
-  const PlanSummary &sm = *pl.h_summary;
-  const int n = sm.num_candidates;
-  im.num_candidates = n;
-  im.channels = C;
-  im.stat_sets = sm.live_sets;
-  im.stat_sum_set_ni = sm.sum_set_ni;
-  im.stat_sum_cand_ni = sm.sum_cand_ni;
-  im.num_shadow_sets = sm.num_shadow_sets;
-  std::memcpy(im.view_points, c.view_points, sizeof(im.view_points));
   if (!im.d_status) {
     HIP_RET(hipMalloc(&im.d_status, sizeof(int32_t)));
     HIP_RET(hipMalloc(&im.d_pts_scratch, (size_t)LGRID * PTS_SCRATCH_BYTES));
   }
-  HIP_RET(hipMemsetAsync(im.d_status, 0, sizeof(int32_t), stream));
-  if (n == 0) return GPD_OK;
   if (n > im.capacity) {
+    note_alloc();
     void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_overflow, im.d_pts_overflow};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
@@ -1676,15 +1665,40 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
     const double reach = std::sqrt(rx * rx + ry * ry + p.volume_height * p.volume_height);
     im.wide = std::ceil(diag / vox) + 3.0 > (double)Vox<false>::VD || std::ceil(reach / vox) + 1.0 > (double)(Vox<false>::SR - 1);
   }
-  if (im.num_shadow_sets > im.cap_shadow_sets || (im.wide && !im.cap_wide)) {
+  if (C == 15 && (shadow_sets > im.cap_shadow_sets || (im.wide && !im.cap_wide))) {
+    note_alloc();
     if (im.d_set_bits) (void)hipFree(im.d_set_bits);
     im.d_set_bits = nullptr;
     im.cap_shadow_sets = 0;
-    const int cap = im.num_shadow_sets + im.num_shadow_sets / 4;
+    const int want = shadow_sets > im.cap_shadow_sets ? shadow_sets : im.cap_shadow_sets;
+    const int cap = want + want / 4;
     HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * (im.wide ? Vox<true>::SETWORDS : Vox<false>::SETWORDS) * sizeof(uint32_t)));
     im.cap_shadow_sets = cap;
     im.cap_wide = im.wide;  // (a wide allocation also serves the default windows)
   }
+  return GPD_OK;
+}
+
+// The candidate list itself (which hands, in which order, where each hand set starts in the LCG stream) is
+// built on the device by plan_kernel; its sizes are in pl.h_summary by now.  This sizes the image buffers,
+// prepares the constant block of the image geometry and launches the kernels.
+int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream) {
+  const int C = p.image_num_channels;
+  const PlanSummary &sm = *pl.h_summary;
+  const int n = sm.num_candidates;
+  im.num_candidates = n;
+  im.channels = C;
+  im.stat_sets = sm.live_sets;
+  im.stat_sum_set_ni = sm.sum_set_ni;
+  im.stat_sum_cand_ni = sm.sum_cand_ni;
+  im.num_shadow_sets = sm.num_shadow_sets;
+  std::memcpy(im.view_points, c.view_points, sizeof(im.view_points));
+  {
+    const int rc = images_reserve(p, im, n, im.num_shadow_sets);
+    if (rc) return rc;
+  }
+  HIP_RET(hipMemsetAsync(im.d_status, 0, sizeof(int32_t), stream));
+  if (n == 0) return GPD_OK;
   ImgConsts k;
   std::memset(&k, 0, sizeof(k));
   k.vol_depth = p.volume_depth;

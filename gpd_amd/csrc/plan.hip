@@ -344,34 +344,43 @@ void plan_free(Plan &pl) {
   pl = Plan();
 }
 
+// Tables for up to capS samples x slots hands and `cams` cameras (grow only; a growth stalls the device).
+int plan_reserve(Plan &pl, int want_samples, int slots, int cams, hipStream_t stream) {
+  if (want_samples <= pl.cap_samples && slots <= pl.cap_slots && cams <= pl.cap_cams) return GPD_OK;
+  note_alloc();
+  const int capS = want_samples > pl.cap_samples ? want_samples : pl.cap_samples;
+  const int capC = cams > pl.cap_cams ? cams : pl.cap_cams;
+  const int capL = slots > pl.cap_slots ? slots : pl.cap_slots;
+  plan_free(pl);
+  const size_t H = (size_t)capS * capL;
+  HIP_RET(hipMalloc(&pl.d_sample_of_set, (size_t)capS * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&pl.d_hand_cand, H * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&pl.d_cand_hand, H * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&pl.d_cand_out, H * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&pl.d_cand_meta, H * 4 * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&pl.d_set_meta, (size_t)capS * capC * 8 * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&pl.d_summary, sizeof(PlanSummary)));
+  // look-back state of plan_kernel: zeroed once (stamps are compared with a launch number that starts at 1)
+  const size_t nparts = (size_t)(capS + PLAN_THREADS - 1) / PLAN_THREADS + 1;
+  HIP_RET(hipMalloc(&pl.d_parts, nparts * sizeof(PlanPart)));
+  HIP_RET(hipMalloc(&pl.d_ticket, sizeof(unsigned)));
+  HIP_RET(hipMemsetAsync(pl.d_parts, 0, nparts * sizeof(PlanPart), stream));
+  HIP_RET(hipMemsetAsync(pl.d_ticket, 0, sizeof(unsigned), stream));
+  pl.epoch = 0;
+  HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&pl.h_summary), sizeof(PlanSummary), 0));
+  pl.cap_samples = capS;
+  pl.cap_slots = capL;
+  pl.cap_cams = capC;
+  return GPD_OK;
+}
+
 int plan_build(const gpd_params &p, const Cloud &c, const SearchState &s, Plan &pl, hipStream_t stream, const uint8_t *set_flags,
                const double *set_samples, int num_sets_given) {
   const int slots = p.num_hand_axes * p.num_orientations;
   const int S = s.num_samples;
-  if (s.capacity_samples > pl.cap_samples || slots > pl.cap_slots || c.num_cams > pl.cap_cams) {
-    const int capS = s.capacity_samples > pl.cap_samples ? s.capacity_samples : pl.cap_samples;
-    const int capC = c.num_cams > pl.cap_cams ? c.num_cams : pl.cap_cams;
-    const int capL = slots > pl.cap_slots ? slots : pl.cap_slots;
-    plan_free(pl);
-    const size_t H = (size_t)capS * capL;
-    HIP_RET(hipMalloc(&pl.d_sample_of_set, (size_t)capS * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&pl.d_hand_cand, H * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&pl.d_cand_hand, H * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&pl.d_cand_out, H * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&pl.d_cand_meta, H * 4 * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&pl.d_set_meta, (size_t)capS * capC * 8 * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&pl.d_summary, sizeof(PlanSummary)));
-    // look-back state of plan_kernel: zeroed once (stamps are compared with a launch number that starts at 1)
-    const size_t nparts = (size_t)(capS + PLAN_THREADS - 1) / PLAN_THREADS + 1;
-    HIP_RET(hipMalloc(&pl.d_parts, nparts * sizeof(PlanPart)));
-    HIP_RET(hipMalloc(&pl.d_ticket, sizeof(unsigned)));
-    HIP_RET(hipMemsetAsync(pl.d_parts, 0, nparts * sizeof(PlanPart), stream));
-    HIP_RET(hipMemsetAsync(pl.d_ticket, 0, sizeof(unsigned), stream));
-    pl.epoch = 0;
-    HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&pl.h_summary), sizeof(PlanSummary), 0));
-    pl.cap_samples = capS;
-    pl.cap_slots = capL;
-    pl.cap_cams = capC;
+  {
+    const int rc = plan_reserve(pl, s.capacity_samples, slots, c.num_cams, stream);
+    if (rc) return rc;
   }
   PlanParams pp;
   pp.set_flags = nullptr;

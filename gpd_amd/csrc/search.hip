@@ -156,6 +156,35 @@ void cloud_free(Cloud &c) {
   c = Cloud();
 }
 
+// Device + pinned staging buffers for clouds of up to n points / num_cams cameras (grows with 25 % slack, never
+// shrinks).  A growth is hipFree + hipMalloc, i.e. a device stall: gpd_hip_reserve / gpd_hip_detect_batch size the lanes
+// once, ahead of the first cloud.
+int cloud_reserve(Cloud &c, int n, int num_cams) {
+  if (n <= c.capacity && num_cams <= c.cap_cams) return GPD_OK;
+  note_alloc();
+  const uint64_t gen = c.generation;
+  const int cap = n > c.capacity ? n + n / 4 : c.capacity;  // slack: clouds of a batch differ by a few points
+  const int cams = num_cams > c.cap_cams ? num_cams : c.cap_cams;
+  const int cells_cap = c.g_cells_cap;
+  cloud_free(c);  // hipFree waits for the device: kernels of an earlier cloud on this stream are done
+  c.generation = gen;
+  float **planes[] = {&c.px, &c.py, &c.pz, &c.nx, &c.ny, &c.nz};
+  for (float **p : planes) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float)));
+  float4 **quads[] = {&c.g_p, &c.pxyz, &c.pnrm};
+  for (float4 **p : quads) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float4)));
+  HIP_RET(hipMalloc(&c.cam_source, (size_t)cap * cams * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&c.staging, (size_t)cap * 6 * sizeof(float)));
+  HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&c.h_pin), (size_t)cap * (6 * sizeof(float) + cams * sizeof(int32_t)), 0));
+  c.capacity = cap;
+  c.cap_cams = cams;
+  if (cells_cap > 0) {  // the grid tables keep their size across a growth of the point buffers
+    HIP_RET(hipMalloc(&c.g_start, (size_t)(cells_cap + 1) * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&c.g_cursor, (size_t)cells_cap * sizeof(int32_t)));
+    c.g_cells_cap = cells_cap;
+  }
+  return GPD_OK;
+}
+
 // The caller's arrays are copied into a pinned staging buffer (one pass that also takes the bounds of the
 // uniform grid and rejects non-finite coordinates), so the three host-to-device copies are truly
 // asynchronous: with sync == false nothing here waits for the device and the upload of the next cloud
@@ -166,21 +195,9 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
     set_error("upload_cloud: at most %d cameras are supported", kMaxCams);
     return GPD_ERR_INVALID;
   }
-  if (n > c.capacity || num_cams > c.cap_cams) {
-    const uint64_t gen = c.generation;
-    const int cap = n > c.capacity ? n + n / 4 : c.capacity;  // slack: clouds of a batch differ by a few points
-    const int cams = num_cams > c.cap_cams ? num_cams : c.cap_cams;
-    cloud_free(c);  // hipFree waits for the device: kernels of an earlier cloud on this stream are done
-    c.generation = gen;
-    float **planes[] = {&c.px, &c.py, &c.pz, &c.nx, &c.ny, &c.nz};
-    for (float **p : planes) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float)));
-    float4 **quads[] = {&c.g_p, &c.pxyz, &c.pnrm};
-    for (float4 **p : quads) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float4)));
-    HIP_RET(hipMalloc(&c.cam_source, (size_t)cap * cams * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&c.staging, (size_t)cap * 6 * sizeof(float)));
-    HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&c.h_pin), (size_t)cap * (6 * sizeof(float) + cams * sizeof(int32_t)), 0));
-    c.capacity = cap;
-    c.cap_cams = cams;
+  {
+    const int rc = cloud_reserve(c, n, num_cams);
+    if (rc) return rc;
   }
   float *hx = reinterpret_cast<float *>(c.h_pin), *hn = hx + (size_t)3 * n;
   int32_t *hc = reinterpret_cast<int32_t *>(hx + (size_t)6 * n);
@@ -224,6 +241,7 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
   }
   const int cells = c.g_dim[0] * c.g_dim[1] * c.g_dim[2];
   if (cells > c.g_cells_cap) {
+    note_alloc();
     if (c.g_start) (void)hipFree(c.g_start);
     if (c.g_cursor) (void)hipFree(c.g_cursor);
     c.g_start = nullptr;
@@ -2025,6 +2043,7 @@ void search_free(SearchState &s) {
 static int search_reserve(SearchState &s, int S, int cap, int slots) {
   if (S <= s.capacity_samples && cap == s.nn_cap) return GPD_OK;
   const int newS = S > s.capacity_samples ? S + S / 8 : s.capacity_samples;  // slack: the clouds of a batch differ a little
+  note_alloc();
   search_free(s);
   HIP_RET(hipMalloc(&s.d_sample_idx, (size_t)newS * sizeof(int32_t)));
   HIP_RET(hipMalloc(&s.d_sample_xyz, (size_t)newS * 3 * sizeof(double)));
@@ -2040,6 +2059,8 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
   s.nn_cap = cap;
   return GPD_OK;
 }
+
+int search_reserve_samples(SearchState &s, int S, int slots) { return search_reserve(s, S, s.nn_cap ? s.nn_cap : 8192, slots); }
 
 static int run_neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, int S, int cap, bool by_xyz,
                               int slots, bool want_height_list, hipStream_t stream, bool sync_counts) {

@@ -220,6 +220,15 @@ int gpd_hip_detect_select(gpd_hip_ctx *ctx, const int32_t *sample_indices, int n
                           gpd_hand *hands, int hands_capacity, int *num_sets, int *num_candidates,
                           int *num_hands);
 
+/* Sizes every buffer of the context — both lanes of the batch entry — for clouds of up to max_points points,
+ * max_cams cameras and max_samples samples, so that no later call within those sizes allocates (growing a buffer is
+ * a hipFree + hipMalloc, which waits for the whole device).  max_candidates: scored hands per cloud, 0 = the upper
+ * bound max_samples x slots (cut to 16 GB of candidate-sized buffers per lane); max_selected: the largest
+ * num_selected that will be asked for (0: none).  Optional: gpd_hip_detect_batch sizes its lanes itself from the
+ * jobs it is given; the single-cloud entries grow their buffers on demand (25 % slack, never shrinking).  No
+ * reference counterpart: the reference allocates per call. */
+int gpd_hip_reserve(gpd_hip_ctx *ctx, int max_points, int max_cams, int max_samples, int max_candidates, int max_selected);
+
 /* One independent cloud of a batch: the arguments of gpd_hip_upload_cloud + gpd_hip_detect_select. */
 typedef struct gpd_detect_job {
   const float *xyz;            /* in */
@@ -234,6 +243,12 @@ typedef struct gpd_detect_job {
   int32_t num_sets, num_candidates, num_hands; /* out */
   int32_t status;              /* out: GPD_OK or the error of this cloud */
   float stage_ms[3];           /* out: search, images, LeNet kernel time of this cloud */
+  /* out: where the HOST was, in ms since the entry of gpd_hip_detect_batch: [0] upload + search + plan enqueued,
+   * [1] plan summary arrived (the only mid-pipeline wait), [2] images + LeNet + gather enqueued, [3] results on the
+   * host, [4] records handed over.  A host-side limiter shows here, not in stage_ms. */
+  float host_ms[5];
+  int32_t allocs;              /* out: buffer growths (hipFree + hipMalloc = a device stall) booked on this cloud;
+                                  0 everywhere but the first cloud of a batch whose lanes were not yet sized */
 } gpd_detect_job;
 
 /* detect_grasps over a batch of independent clouds (src/detect_grasps.cpp:20-86 called once per

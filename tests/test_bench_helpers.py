@@ -35,7 +35,7 @@ def test_bench_launches_itself_for_several_gpus(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d == {"dryrun": True, "n_gpus": 2, "world": 2, "max": 2.0, "sum": 30.0, "batch_clouds": 64}
+    assert d == {"dryrun": True, "n_gpus": 2, "world": 2, "max": 2.0, "sum": 30.0, "batch_clouds": 32}
     # a launcher that disagrees with --gpus is refused with a message, not an AssertionError
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)

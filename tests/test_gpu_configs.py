@@ -486,3 +486,52 @@ def test_two_contexts_with_different_constants_on_one_device(oracle_mod):
     finally:
         A.close()
         B.close()
+
+
+def test_bench_headline_list_exactly(oracle_mod, cloud30k):
+    """The list bench.py times (configs[1] as quoted by `value`): cloud seed 1234, 2564 samples, the FIRST 5000 valid
+    candidates after the workspace filter.  All 5000 images byte for byte and all 5000 scores against the oracle, with the
+    benchmark's weights (|score| ~ 1000: bit-identical, relative 8e-6 of float64) and with the trained-magnitude set
+    (north_star's absolute 1e-4).  Scores are also read back from gpd_hip_replay — the call the timed region is made of."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cl = cloud30k
+    n_samples = min(int(5000 / 2.0) + 64, int(cl["is_object"].sum()))
+    assert n_samples == 2564
+    si = synth.sample_indices(cl, n_samples)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+        hands = ctx.search(si)
+        hf = hands.copy()
+        bench._filter_workspace(hf, ctx.params)
+        flat = hf.reshape(-1)
+        vidx = np.flatnonzero(flat["valid"])
+        assert len(vidx) > 5000
+        flat["valid"][vidx[5000:]] = 0
+        p = oracle_mod.default_params(15)
+        oh = oracle_mod.search(p, cl["xyz"], cl["normals"], si)
+        ohf = oracle_mod.filter_workspace(p, oh.copy())
+        of = ohf.reshape(-1)
+        ov = np.flatnonzero(of["valid"])
+        of["valid"][ov[5000:]] = 0
+        assert np.array_equal(hf["valid"], ohf["valid"])  # the numpy filter of bench.py == the oracle's == the reference's (pins)
+        img, cand = ctx.images(hf, download=True)
+        oimg, ocand = oracle_mod.images(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], ohf)
+        assert len(cand) == 5000 and np.array_equal(cand, ocand)
+        assert np.array_equal(img, oimg)
+        for tm in (False, True):
+            w = synth.lenet_weights(15, real=dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "lenet15_params.npz"))),
+                                    trained_magnitude=tm)
+            ctx.set_lenet_weights(w)
+            ctx.replay(3)
+            _, _, launches, sc = ctx.replay_times(n_scores=5000)
+            want = oracle_mod.lenet(oimg, w)
+            assert launches == 1 and np.array_equal(sc, want), (tm, float(np.abs(sc - want).max()))
+            if tm:
+                f64 = bench._lenet_f64(oimg, w)
+                assert np.abs(f64).max() < 20.0 and np.abs(sc - f64).max() <= 1e-4
+    finally:
+        ctx.close()

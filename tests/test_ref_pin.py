@@ -58,6 +58,9 @@ def _check_case(name, pin, hands, valid_f, img, cand, scores=None, scores_traine
         assert np.abs(scores_trained - pin["scores_ld_trained"]).max() <= 1e-4
         # the reference's plain float products (a*b rounded, then added) sit inside the same bar
         assert np.abs(pin["scores_plain_trained"] - pin["scores_ld_trained"]).max() <= 1e-4
+        # north_star's bar itself, asserted directly: |ours - what the reference's own code returns with its plain float
+        # products (eigen_classifier.cpp:59-79 through the Eigen interface subset, product_mode 0)| <= 1e-4
+        assert np.abs(scores_trained - pin["scores_plain_trained"]).max() <= 1e-4
 
 
 @pytest.mark.parametrize("name", sorted(rcs.VARIANTS))
