@@ -33,6 +33,7 @@ class Params(C.Structure):
         ("workspace_grasps", C.c_double * 6), ("image_size", C.c_int32), ("image_num_channels", C.c_int32),
         ("num_orientations", C.c_int32), ("num_finger_placements", C.c_int32), ("num_hand_axes", C.c_int32),
         ("hand_axes", C.c_int32 * 3), ("deepen_hand", C.c_int32), ("min_viable", C.c_int32),
+        ("filter_approach_direction", C.c_int32), ("reserved_", C.c_int32), ("direction", C.c_double * 3), ("thresh_rad", C.c_double),
     ]
 
 
@@ -243,16 +244,26 @@ class Context:
             j.num_selected, j.hands_capacity = int(num_selected), cap
         return jobs, keep
 
-    def detect_batch(self, clouds, samples, num_selected=0):
-        """detect_grasps over independent clouds (two in flight per context).  clouds: dicts with xyz, normals,
-        cam_source, view_points; samples: one int32 index array per cloud.
-        -> list of (hands[k], n_sets, n_candidates, stage_ms[3]) in cloud order."""
-        jobs, keep = self._jobs(clouds, samples, num_selected)
-        self._check(lib().gpd_hip_detect_batch(self._h, jobs, len(clouds)))
+    def batch(self, clouds, samples, num_selected=0):
+        """The job array of gpd_hip_detect_batch with its input views and output buffers, built once and reusable: a
+        caller that runs batch after batch (bench.py's passes) allocates nothing per call."""
+        return self._jobs(clouds, samples, num_selected)
+
+    def run_batch(self, batch):
+        """gpd_hip_detect_batch on a prepared batch -> list of (hands[k], n_sets, n_candidates, stage_ms[3]) in cloud
+        order; the hands are views into the batch's own buffers (overwritten by the next run)."""
+        jobs, keep = batch
+        self._check(lib().gpd_hip_detect_batch(self._h, jobs, len(jobs)))
         # where the host was per cloud (ms since entry) and the buffer growths booked on it: kept for the caller that asks
         self.last_batch_timeline = [([float(x) for x in j.host_ms], int(j.allocs)) for j in jobs]
         return [(k[5][: j.num_hands], j.num_sets, j.num_candidates, [float(x) for x in j.stage_ms])
                 for j, k in zip(jobs, keep)]
+
+    def detect_batch(self, clouds, samples, num_selected=0):
+        """detect_grasps over independent clouds (two in flight per context).  clouds: dicts with xyz, normals,
+        cam_source, view_points; samples: one int32 index array per cloud.
+        -> list of (hands[k], n_sets, n_candidates, stage_ms[3]) in cloud order."""
+        return self.run_batch(self.batch(clouds, samples, num_selected))
 
     def reserve(self, max_points, max_cams=1, max_samples=0, max_candidates=0, max_selected=0):
         """gpd_hip_reserve: size every buffer of the context once (no allocation in later calls within these sizes)."""

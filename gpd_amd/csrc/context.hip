@@ -480,6 +480,9 @@ void gpd_hip_default_params(gpd_params *p) {
   p->hand_axes[0] = 2;
   p->deepen_hand = 1;
   p->min_viable = 6;
+  p->filter_approach_direction = 0;  // cfg/eigen_params.cfg:60-62
+  p->direction[0] = 1.0;
+  p->thresh_rad = 2.0;
 }
 
 const char *gpd_hip_last_error(void) { return g_err; }
@@ -526,6 +529,12 @@ int gpd_hip_create(int device, const gpd_params *params, gpd_hip_ctx **out) {
         set_error("gpd_hip_create: NaN in friction_coeff / apertures / workspace_grasps");
         return GPD_ERR_INVALID;
       }
+    if (params->filter_approach_direction)
+      for (double v : {params->direction[0], params->direction[1], params->direction[2], params->thresh_rad})
+        if (!std::isfinite(v)) {
+          set_error("gpd_hip_create: direction / thresh_rad must be finite when filter_approach_direction is set");
+          return GPD_ERR_INVALID;
+        }
     if (!(params->hand_outer_diameter > params->finger_width)) {
       set_error("gpd_hip_create: hand_outer_diameter must exceed finger_width");
       return GPD_ERR_INVALID;

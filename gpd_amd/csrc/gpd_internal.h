@@ -200,22 +200,22 @@ int reevaluate_run(const gpd_params &p, const Cloud &c, SearchState &s, gpd_hand
 int search_download(const gpd_params &p, SearchState &s, gpd_hand *hands, int *num_sets, hipStream_t stream);
 void search_free(SearchState &s);
 
-// GraspDetector::filterGraspsWorkspace (grasp_detector.cpp:334-398) for one valid hand: aperture and the
-// workspace box around the hand's outline.  The reference computes right_top from left_bottom
+// GraspDetector::filterGraspsWorkspace (grasp_detector.cpp:334-398) [+ filterGraspsDirection, :423-456] for one valid
+// hand: aperture and the workspace box around the hand's outline [, then the approach direction].  The reference computes right_top from left_bottom
 // (:360-363); kept.  Evaluated with the same unfused fp64 operations on the host and on the device.
 struct FilterConsts {
   double min_aperture, max_aperture, half_width, hand_depth;
   double workspace[6];
+  // filterGraspsDirection (grasp_detector.cpp:423-456): a hand is dropped when acos(direction . approach) > thresh_rad.
+  // The device has no glibc acos, and a one-ulp difference between two acos implementations would be a different
+  // candidate list; so the HOST turns the test into one on the dot product itself: dot_drop_max = the largest double x
+  // in [-1, 1] with acos(x) > thresh_rad by the host's libm (bisection over the doubles; acos is monotone), and a hand is
+  // dropped iff -1 <= dot <= dot_drop_max.  A dot product outside [-1, 1] (acos = NaN) keeps the hand, as the reference does.
+  int dir_on;
+  double dir[3];
+  double dot_drop_max;
 };
-inline FilterConsts filter_consts(const gpd_params &p) {
-  FilterConsts f;
-  f.min_aperture = p.min_aperture;
-  f.max_aperture = p.max_aperture;
-  f.half_width = 0.5 * p.hand_outer_diameter;
-  f.hand_depth = p.hand_depth;
-  for (int i = 0; i < 6; i++) f.workspace[i] = p.workspace_grasps[i];
-  return f;
-}
+FilterConsts filter_consts(const gpd_params &p);  // host_math.cpp
 __host__ __device__ inline bool workspace_ok(const FilterConsts &f, const gpd_hand &h) {
   bool ok = h.grasp_width >= f.min_aperture && h.grasp_width <= f.max_aperture;
   for (int r = 0; r < 3 && ok; r++) {
@@ -228,6 +228,10 @@ __host__ __device__ inline bool workspace_ok(const FilterConsts &f, const gpd_ha
     const double mn = fmin(fmin(fmin(lb, rb), fmin(lt, rt)), ap);
     const double mx = fmax(fmax(fmax(lb, rb), fmax(lt, rt)), ap);
     ok = mn >= f.workspace[2 * r] && mx <= f.workspace[2 * r + 1];
+  }
+  if (ok && f.dir_on) {
+    const double dot = f.dir[0] * h.frame[0] + f.dir[1] * h.frame[3] + f.dir[2] * h.frame[6];  // direction^T * approach, unfused
+    ok = !(dot >= -1.0 && dot <= f.dot_drop_max);
   }
   return ok;
 }

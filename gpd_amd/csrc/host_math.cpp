@@ -56,6 +56,51 @@ void host_consts(const gpd_params &p, HostConsts &h) {
   h.nn_radius_images = std::fmax(std::fmax(p.volume_depth, p.volume_height / 2.0), p.volume_width);
 }
 
+// doubles <-> integers in the same order (bisection over representable values)
+static long long ord_of(double x) {
+  long long b;
+  std::memcpy(&b, &x, sizeof(b));
+  return b < 0 ? -(b & 0x7fffffffffffffffll) : b;
+}
+static double of_ord(long long k) {
+  long long b = k < 0 ? ((-k) | (long long)0x8000000000000000ull) : k;
+  double x;
+  std::memcpy(&x, &b, sizeof(x));
+  return x;
+}
+
+FilterConsts filter_consts(const gpd_params &p) {
+  FilterConsts f;
+  std::memset(&f, 0, sizeof(f));
+  f.min_aperture = p.min_aperture;
+  f.max_aperture = p.max_aperture;
+  f.half_width = 0.5 * p.hand_outer_diameter;
+  f.hand_depth = p.hand_depth;
+  for (int i = 0; i < 6; i++) f.workspace[i] = p.workspace_grasps[i];
+  f.dir_on = p.filter_approach_direction ? 1 : 0;
+  for (int i = 0; i < 3; i++) f.dir[i] = p.direction[i];
+  f.dot_drop_max = -2.0;  // nothing dropped
+  if (f.dir_on) {
+    // largest x in [-1, 1] with acos(x) > thresh_rad, by THIS machine's libm — the one the reference's
+    // filterGraspsDirection (grasp_detector.cpp:438) would call
+    auto drop = [&](double x) { return std::acos(x) > p.thresh_rad; };
+    if (drop(1.0)) {
+      f.dot_drop_max = 1.0;
+    } else if (drop(-1.0)) {
+      long long lo = ord_of(-1.0), hi = ord_of(1.0);  // drop(lo), !drop(hi)
+      while (hi - lo > 1) {
+        const long long mid = lo + (hi - lo) / 2;
+        if (drop(of_ord(mid)))
+          lo = mid;
+        else
+          hi = mid;
+      }
+      f.dot_drop_max = of_ord(lo);
+    }
+  }
+  return f;
+}
+
 // GraspDetector::filterGraspsWorkspace — grasp_detector.cpp:334-398 (workspace_ok in gpd_internal.h).
 void filter_workspace_host(const gpd_params &p, gpd_hand *hands, int num_sets) {
   const int slots = p.num_hand_axes * p.num_orientations;

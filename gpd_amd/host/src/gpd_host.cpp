@@ -601,6 +601,10 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
   approach.resize(3, 0.0);
   direction_ = {approach[0], approach[1], approach[2]};
   thresh_rad_ = config_file.getValueOfKey<double>("thresh_rad", 2.3);
+  // the fused device entries apply the direction filter themselves, right after the workspace filter (gpd_params)
+  params_.filter_approach_direction = filter_approach_direction_ ? 1 : 0;
+  for (int i = 0; i < 3; i++) params_.direction[i] = direction_[i];
+  params_.thresh_rad = thresh_rad_;
   const int min_inliers = config_file.getValueOfKey<int>("min_inliers", 1);
   clustering_ = std::make_unique<Clustering>(min_inliers);  // runs on ctx_ once that exists (below)
   cluster_grasps_ = min_inliers > 0;
@@ -614,7 +618,9 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
     const char *key, *what;
   } unsupported[] = {{"remove_outliers", "pcl::StatisticalOutlierRemoval (cloud.cpp:166-174)"},
                      {"sample_above_plane", "a RANSAC plane fit, pcl::SACSegmentation (cloud.cpp:407-436)"},
-                     {"refine_normals_k", "pcl::NormalRefinement (cloud.cpp:176-204)"}};
+                     {"refine_normals_k", "pcl::NormalRefinement (cloud.cpp:176-204)"},
+                     {"remove_plane_before_image_calculation",
+                      "ImageGenerator::removePlane, pcl::SACSegmentation (image_generator.cpp:32, 101-125): it changes the point list behind every grasp image"}};
   for (const auto &u : unsupported)
     if (config_file.getValueOfKey<int>(u.key, 0) != 0) {
       printf("ERROR: %s = %d asks for %s, which this build does not have; unset it or preprocess the cloud beforehand\n", u.key,
@@ -1144,30 +1150,15 @@ std::vector<std::unique_ptr<candidate::Hand>> GraspDetector::detectGrasps(const 
     const std::vector<float> scores = classifier_->classifyImages(images);
     ms[2] = (float)((now_s() - tc) * 1e3);
     for (size_t i = 0; i < hands.size(); i++) hands[i]->setScore(scores[i]);
-  } else if (!filter_approach_direction_) {
-    // steps 1-4 fused on the device (grasp_detector.cpp:222-273)
+  } else {
+    // steps 1-4 fused on the device (grasp_detector.cpp:222-273), filterGraspsWorkspace and — when the cfg asks for it —
+    // filterGraspsDirection (:247-250) included: both run at the end of the hand kernel, before the candidate list is built
     if (!searchDevice(cloud, true, recs, n_sets, n_cand)) return hands_out;
     printf("Generated %d hand sets.\n", n_sets);
+    if (filter_approach_direction_) printf("Number of grasp candidates with correct approach direction: %d\n", n_cand);
     gpd_hip_last_stage_ms(ctx_, ms);
     for (size_t i = 0; i < (size_t)n_sets * slots; i++)
       if (recs[i].valid) hands.push_back(std::make_unique<candidate::Hand>(recs[i]));
-  } else {
-    // the approach-direction filter sits between the stages (grasp_detector.cpp:247-255): search,
-    // both host filters, then images and scores for what is left
-    if (!searchDevice(cloud, false, recs, n_sets, n_cand)) return hands_out;
-    printf("Generated %d hand sets.\n", n_sets);
-    float t[3];
-    gpd_hip_last_stage_ms(ctx_, t);
-    ms[0] = t[0];
-    auto sets = to_sets(recs, n_sets, slots);
-    auto filtered = filterGraspsWorkspace(sets, workspace_grasps_);
-    if (filtered.empty()) return hands_out;
-    filtered = filterGraspsDirection(filtered, direction_, thresh_rad_);
-    if (filtered.empty()) return hands_out;
-    hands = pruneGraspCandidates(cloud, filtered, -FLT_MAX);
-    gpd_hip_last_stage_ms(ctx_, t);
-    ms[1] = t[1];
-    ms[2] = t[2];
   }
   // 5. select the highest scoring grasps
   hands = selectGrasps(hands);

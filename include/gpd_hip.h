@@ -63,6 +63,13 @@ typedef struct gpd_params {
   int32_t hand_axes[3];       /* {2} */
   int32_t deepen_hand;        /* 1 */
   int32_t min_viable;         /* 6 */
+  /* GraspDetector::filterGraspsDirection (grasp_detector.cpp:247-250, 423-456; cfg keys filter_approach_direction,
+   * direction, thresh_rad): a valid hand whose approach axis makes an angle acos(direction . approach) > thresh_rad
+   * with `direction` is dropped — in the fused entries, on the device, right after the workspace filter. */
+  int32_t filter_approach_direction; /* 0 */
+  int32_t reserved_;
+  double direction[3];        /* 1 0 0 */
+  double thresh_rad;          /* 2.0 */
 } gpd_params;
 
 /*

@@ -1022,6 +1022,17 @@ static void filterWorkspace(const gpd_params &P, gpd_hand *hands, int n_sets, in
     }
 }
 
+// GraspDetector::filterGraspsDirection — grasp_detector.cpp:423-456: angle = acos(direction^T * approach), dropped when
+// angle > thresh_rad.  acos is not clamped: a dot product a hair outside [-1, 1] gives NaN, and NaN > thresh is false.
+static void filterDirection(const gpd_params &P, gpd_hand *hands, int n_sets, int n_slots) {
+  for (size_t i = 0; i < (size_t)n_sets * n_slots; i++) {
+    gpd_hand &h = hands[i];
+    if (!h.valid) continue;
+    const double angle = std::acos(P.direction[0] * h.frame[0] + P.direction[1] * h.frame[3] + P.direction[2] * h.frame[6]);
+    if (angle > P.thresh_rad) h.valid = 0;
+  }
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -1053,6 +1064,9 @@ void gpd_oracle_default_params(gpd_params *p) {
   p->hand_axes[0] = 2;
   p->deepen_hand = 1;
   p->min_viable = 6;
+  p->filter_approach_direction = 0;  // cfg/eigen_params.cfg:60-62
+  p->direction[0] = 1.0;
+  p->thresh_rad = 2.0;
 }
 
 int gpd_oracle_sizeof_hand() { return (int)sizeof(gpd_hand); }
@@ -1205,8 +1219,11 @@ void gpd_oracle_reevaluate(const gpd_params *P, const float *xyz, const float *n
   }
 }
 
+// detectGrasps step 2 (grasp_detector.cpp:236-255): the workspace / aperture filter, then the approach-direction
+// filter when the cfg asks for it
 void gpd_oracle_filter(const gpd_params *P, gpd_hand *hands, int n_sets) {
   filterWorkspace(*P, hands, n_sets, P->num_hand_axes * P->num_orientations);
+  if (P->filter_approach_direction) filterDirection(*P, hands, n_sets, P->num_hand_axes * P->num_orientations);
 }
 
 // ImageGenerator::createImages (image_generator.cpp:17-99).  Sets without a

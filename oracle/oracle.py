@@ -27,6 +27,7 @@ class Params(C.Structure):
         ("workspace_grasps", C.c_double * 6), ("image_size", C.c_int32), ("image_num_channels", C.c_int32),
         ("num_orientations", C.c_int32), ("num_finger_placements", C.c_int32), ("num_hand_axes", C.c_int32),
         ("hand_axes", C.c_int32 * 3), ("deepen_hand", C.c_int32), ("min_viable", C.c_int32),
+        ("filter_approach_direction", C.c_int32), ("reserved_", C.c_int32), ("direction", C.c_double * 3), ("thresh_rad", C.c_double),
     ]
 
 

@@ -26,6 +26,10 @@ def set_params(p, **kw):
         elif k == "workspace_grasps":
             for i, a in enumerate(v):
                 p.workspace_grasps[i] = a
+        elif k == "direction":  # filterGraspsDirection: setting a direction switches the filter on
+            p.filter_approach_direction = 1
+            for i, a in enumerate(v):
+                p.direction[i] = a
         else:
             setattr(p, k, v)
     return p

@@ -175,6 +175,10 @@ def test_oracle_direction_filter_and_clustering_match_reference_detectGrasps(ora
     n_before = int(hands["valid"].sum())
     hands["valid"] &= (~(ang > 1.2)).astype(np.uint8)
     assert 0 < hands["valid"].sum() < n_before
+    # the oracle's own step 2 with the filter switched on in the params (what the fused device entries are compared with)
+    pd = rcs.set_params(oracle_mod.default_params(15), direction=[0.0, 0.0, -1.0], thresh_rad=1.2)
+    own = oracle_mod.filter_workspace(pd, oracle_mod.search(pd, cl["xyz"], cl["normals"], si))
+    assert np.array_equal(own["valid"], hands["valid"])
     img, cand = oracle_mod.images(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], hands)
     sc = oracle_mod.lenet(img, w)
     flat = hands.reshape(-1)[cand]
@@ -313,6 +317,51 @@ def test_hip_direction_filter_and_clustering_match_reference_detectGrasps(oracle
         assert len(clusters) == len(rh) and key(clusters, csc) == key(rh, rh["score"])
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_fused_direction_filter_matches_reference_detectGrasps(oracle_mod):
+    """filter_approach_direction = 1 through the FUSED device entries (gpd_params.direction / thresh_rad: the filter runs at
+    the end of hand_eval_kernel, behind the workspace filter): flags, candidates and scores against the oracle with the
+    same params, then selectGrasps on the device + findClusters against what the reference's own detectGrasps returned
+    (pin `dirfilter_hands`).  Also through the batch entry, and with thresholds at which nothing / everything is dropped."""
+    from gpd_amd import api
+    pin = _pin("extras")
+    rh = pin["dirfilter_hands"].view(_hand_dtype()).reshape(-1)
+    cl = synth.make_cloud(99, 12000)
+    si = synth.sample_indices(cl, 300)
+    w = rcs.weights(15, trained_magnitude=True)
+    for direction, thresh in (([0.0, 0.0, -1.0], 1.2), ([0.3, -0.5, 0.8], 0.7), ([0.0, 0.0, -1.0], 4.0), ([0.0, 0.0, -1.0], -0.5)):
+        p = rcs.set_params(api.default_params(15), direction=direction, thresh_rad=thresh)
+        po = rcs.set_params(oracle_mod.default_params(15), direction=direction, thresh_rad=thresh)
+        ctx = api.Context(p)
+        try:
+            ctx.set_lenet_weights(w)
+            ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+            hands, n_cand = ctx.detect(si)
+            oh, on, _ = oracle_mod.detect(po, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, w)
+            assert n_cand == on and np.array_equal(hands["valid"], oh["valid"])
+            v = oh["valid"].astype(bool)
+            assert np.array_equal(hands["score"][v], oh["score"][v])
+            if thresh == 4.0:  # acos never exceeds pi: the filter drops nothing
+                plain, n_plain = api.Context(api.default_params(15)), None
+                try:
+                    plain.set_lenet_weights(w)
+                    plain.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+                    assert plain.detect(si)[0].tobytes() == hands.tobytes()
+                finally:
+                    plain.close()
+            if thresh < 0:    # every angle is > a negative threshold: everything goes (but for NaN angles, |dot| a hair above 1)
+                assert n_cand <= 2
+            (bh, bns, bnc, _), = ctx.detect_batch([cl], [si], 0)
+            assert bnc == n_cand and bh.tobytes() == hands.reshape(-1)[np.flatnonzero(hands.reshape(-1)["valid"])].tobytes()
+            if (direction, thresh) == ([0.0, 0.0, -1.0], 1.2):
+                sel, _, _ = ctx.detect_select(si, 120)
+                clusters, csc, _ = ctx.find_clusters(sel, sel["score"].astype(np.float64), 1, False)
+                key = lambda a, s_: sorted(zip(np.asarray(s_, np.float32).tolist(), map(tuple, a["position"].tolist())))
+                assert len(clusters) == len(rh) and key(clusters, csc) == key(rh, rh["score"])
+        finally:
+            ctx.close()
 
 
 # ---- live library (build container only): randomised cases beyond the committed pins ---------------------------------
