@@ -75,6 +75,10 @@ def main():
                     help="replay mode: clouds per rank and pass of the batch_end_to_end leg (default 24 on one GPU, 32 on several; 0 disables)")
     ap.add_argument("--batch-passes", type=int, default=4, help="replay mode: timed passes of the batch_end_to_end leg (after one full untimed pass)")
     ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
+    ap.add_argument("--devices", default=None,
+                    help="comma list: the HIP device of local rank r is devices[r %% len] (default: r).  `--devices 0,0` runs two ranks on ONE "
+                         "GPU — the N > 1 code path on a one-GPU box (tests); it needs --dist-backend gloo (RCCL refuses two ranks on a device)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the barrier / reductions")
     ap.add_argument("--live-pmc", dest="live_pmc", action="store_true", default=None,
                     help="measure roofline.traffic / pmc_traffic here (two rocprofv3 --pmc child runs of this file after the timed region, "
                          "~20 s) instead of reading profiles/r03_traffic.json; default: on for the default line on one GPU, unless this "
@@ -132,10 +136,18 @@ def main():
         dist.destroy_process_group()
         return
     dist = None
+    device = local_rank
+    if args.devices:
+        devs = [int(x) for x in args.devices.split(",")]
+        device = devs[local_rank % len(devs)]
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"  # where the reduction tensors live
     if world > 1 or os.environ.get("GPD_BENCH_FORCE_DIST"):  # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     from gpd_amd import api, synth
     from gpd_amd import dist as gdist
@@ -153,7 +165,7 @@ def main():
     def reduce(elapsed, units):
         if dist is None:
             return float(elapsed), float(units)
-        t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(units)], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         dist.all_reduce(tmax[0:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
@@ -162,13 +174,19 @@ def main():
     def minmax(x):
         if dist is None:
             return float(x), float(x)
-        lo = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        lo = torch.tensor([float(x)], dtype=torch.float64, device=red_dev)
         hi = lo.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         return float(lo[0]), float(hi[0])
 
-    ctx = api.Context(api.default_params(C), device=local_rank)
+    # N > 1: this process feeds ONE GPU — keep its host thread on that GPU's socket (gpd_hip_bind_host_thread; SURVEY 8e: eight
+    # feeding processes on a two-socket host).  Not at N = 1: the cpu_baseline leg of the same process wants every host core.
+    numa = None
+    if world > 1:
+        node, ncpu = api.bind_host_thread(device)
+        numa = {"node": node, "cpus": ncpu} if node >= 0 else {"node": None, "note": "the host exposes no NUMA topology for this device"}
+    ctx = api.Context(api.default_params(C), device=device)
     ctx.set_lenet_weights(w)                       # weights copied once per device at init
 
     def batch_leg(cloud_ids, passes, warm):
@@ -239,7 +257,7 @@ def main():
                            % (args.clouds, args.batch_samples, leg["candidates"] // max(1, leg["clouds"]), world),
                            "clouds": args.clouds, "samples_per_cloud": args.batch_samples, "channels": C,
                            "sharding": "independent clouds, no collective"},
-                "batch_end_to_end": leg,
+                "batch_end_to_end": leg, "host_binding_rank0": numa,
                 "roofline": {"kernel": "LeNet stage of the batch (conv1+conv2+ip1+ip2), rank 0", "bound": "mfma", "achieved": net_tflops,
                              "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tflops / F32_PEAK_TFLOPS if net_tflops else None,
                              "traffic": None},
@@ -392,6 +410,8 @@ def main():
                                   "note": "gpd_hip_detect: all candidates of the sample set, host buffers in, scored hands out; "
                                           "filter / compaction / score scatter on the device"},
         }
+        if numa is not None:
+            out["host_binding_rank0"] = numa
         if trained is not None:
             out["scores_trained_magnitude"] = trained
         if batch is not None:

@@ -52,11 +52,18 @@ class GpdHipError(RuntimeError):
     pass
 
 
+def bind_host_thread(device):
+    """gpd_hip_bind_host_thread: the calling thread onto the CPUs of the device's NUMA node -> (node or -1, cpus)."""
+    n = C.c_int(0)
+    node = lib().gpd_hip_bind_host_thread(int(device), C.byref(n))
+    return int(node), int(n.value)
+
+
 EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
-           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters", "gpd_hip_reserve"]
+           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters", "gpd_hip_reserve", "gpd_hip_bind_host_thread"]
 
 
 def build():
@@ -100,6 +107,7 @@ def lib():
         L.gpd_hip_replay_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_conv1_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.gpd_hip_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.gpd_hip_bind_host_thread.argtypes = [C.c_int, C.POINTER(C.c_int)]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         _LIB = L
     return _LIB

@@ -18,6 +18,7 @@
 //   end     wait, hand the records to the caller
 // Between the stages nothing crosses PCIe but that summary.
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -26,6 +27,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include "gpd_internal.h"
 
@@ -1125,6 +1129,59 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
   return first_error;
 }
 
+// The CPUs of the NUMA node a device hangs off (sysfs: the PCI function's numa_node, the node's cpulist).  Eight
+// processes / threads feeding eight GPUs from a two-socket host is SURVEY 8e's expected limiter: a feeding thread that
+// runs on the far socket pays the inter-socket hop on every staging copy and every doorbell.
+static int device_numa_cpus(int device, cpu_set_t *set) {
+  char bdf[64] = "";
+  if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) return -1;
+  for (char *c = bdf; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  if (node < 0) return -1;  // a single-node host (or a VM that hides the topology): nothing to bind to
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  f = fopen(path, "r");
+  if (!f) return -1;
+  CPU_ZERO(set);
+  int a = 0, b = 0, n = 0;
+  for (;;) {  // "0-63,128-191"
+    if (fscanf(f, "%d", &a) != 1) break;
+    b = a;
+    int c = fgetc(f);
+    if (c == '-') {
+      if (fscanf(f, "%d", &b) != 1) break;
+      c = fgetc(f);
+    }
+    for (int k = a; k <= b && k < CPU_SETSIZE; k++) {
+      CPU_SET(k, set);
+      n++;
+    }
+    if (c != ',') break;
+  }
+  fclose(f);
+  return n > 0 ? node : -1;
+}
+
+int gpd_hip_bind_host_thread(int device, int *num_cpus) {
+  if (num_cpus) *num_cpus = 0;
+  cpu_set_t set;
+  const int node = device_numa_cpus(device, &set);
+  if (node < 0) return -1;
+  // only within what the process is allowed to use (a container's cpuset)
+  cpu_set_t allowed, both;
+  if (pthread_getaffinity_np(pthread_self(), sizeof(allowed), &allowed) != 0) return -1;
+  CPU_AND(&both, &set, &allowed);
+  if (CPU_COUNT(&both) == 0) return -1;
+  if (pthread_setaffinity_np(pthread_self(), sizeof(both), &both) != 0) return -1;
+  if (num_cpus) *num_cpus = CPU_COUNT(&both);
+  return node;
+}
+
 // One host thread per context (one context per GPU; more than one on a device is allowed), job i -> context i mod
 // num_ctx: the in-process form of "independent clouds shard over the GPUs of a node" (the reference's unit
 // of work is one detect_grasps run per cloud, src/detect_grasps.cpp:20-86).  No device talks to another.
@@ -1151,6 +1208,7 @@ int gpd_hip_detect_batch_multi(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect
   std::vector<std::thread> threads;
   for (int c = 0; c < num_ctx; c++)
     threads.emplace_back([&, c]() {
+      (void)gpd_hip_bind_host_thread(ctxs[c]->device, nullptr);  // this worker feeds ONE device: keep it on that device's socket
       rcs[(size_t)c] = gpd_hip_detect_batch(ctxs[c], mine[(size_t)c].data(), (int)mine[(size_t)c].size());
       if (rcs[(size_t)c]) texts[(size_t)c] = g_err;  // the error text is per thread
     });

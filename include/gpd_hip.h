@@ -275,6 +275,14 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs);
  * (the shadow LCG restarts per cloud, so they do not depend on the sharding).  Returns the first error. */
 int gpd_hip_detect_batch_multi(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect_job *jobs, int num_jobs);
 
+/* Binds the CALLING host thread to the CPUs of the NUMA node `device` hangs off (sysfs numa_node / cpulist, within the
+ * process's allowed set): the thread that feeds a GPU — staging copies, launches, result copies — should run on that
+ * GPU's socket (8 feeding processes on a two-socket host).  Returns the node, or -1 when the host exposes no
+ * topology (nothing changed); *num_cpus (may be NULL) receives the size of the new mask.  gpd_hip_detect_batch_multi does
+ * this for its worker threads; one-process-per-GPU launchers (bench.py) call it before gpd_hip_create.  Pinned staging
+ * memory is placed by hipHostMalloc near the current device already.  No reference counterpart. */
+int gpd_hip_bind_host_thread(int device, int *num_cpus);
+
 /* gpd_hip_detect for samples given by coordinates (see gpd_hip_search_samples). */
 int gpd_hip_detect_samples(gpd_hip_ctx *ctx, const double *samples_xyz, int num_samples,
                            gpd_hand *hands, int *num_sets, int *num_candidates);

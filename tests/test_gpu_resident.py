@@ -226,6 +226,29 @@ def test_detect_batch_multi_two_contexts_on_one_device(ctx, lenet15_real):
         other.close()
 
 
+def test_detect_batch_multi_three_contexts_uneven_jobs(ctx, lenet15_real):
+    """Three contexts (stand-ins for three GPUs), seven and then two clouds: job i -> context i mod 3 gives shares of
+    3 / 2 / 2 and 1 / 1 / 0 — an idle context, uneven lanes — and the results stay those of the single-context batch in
+    cloud order.  Every worker thread binds itself to its device's NUMA node on the way (gpd_hip_bind_host_thread)."""
+    clouds = [synth.make_cloud(800 + cid, 9000 + 700 * cid) for cid in range(7)]
+    samples = [synth.sample_indices(cl, 40 + 7 * cid) for cid, cl in enumerate(clouds)]
+    want = ctx.detect_batch(clouds, samples, 0)
+    others = [api.Context(api.default_params(15)) for _ in range(2)]
+    try:
+        for o in others:
+            o.set_lenet_weights(lenet15_real)
+        for n in (7, 2, 1):
+            got = ctx.detect_batch_multi(others, clouds[:n], samples[:n], 0)
+            assert len(got) == n
+            for g, r in zip(got, want[:n]):
+                assert g[1:3] == r[1:3] and g[0].tobytes() == r[0].tobytes()
+        node, ncpu = api.bind_host_thread(0)  # -1: the box exposes no topology; otherwise a non-empty CPU set
+        assert node == -1 or ncpu > 0
+    finally:
+        for o in others:
+            o.close()
+
+
 def test_detect_batch_reports_a_bad_cloud(ctx, cloud30k):
     cl = cloud30k
     si = synth.sample_indices(cl, 40)
