@@ -737,7 +737,12 @@ def _cpu_baseline(cloud, w, C, n_samples):
     oracle.detect(p, cloud["xyz"], cloud["normals"], cloud["cam_source"], cloud["view_points"], si[:16], w)  # warm-up
     _, n_cand, times = oracle.detect(p, cloud["xyz"], cloud["normals"], cloud["cam_source"], cloud["view_points"], si, w)
     t = float(times[1] + times[2])
+    ref_file = os.path.join(ROOT, "profiles", "r04_ref_cpu_baseline.json")
+    ref_own = json.load(open(ref_file)) if os.path.exists(ref_file) else None
     return {"value": n_cand / t, "unit": "candidates/s", "cores": cores, "kind": "port",
+            "reference_sources": ref_own and dict(ref_own, note="NOT measured in this run: the reference's own translation units (through the test-only "
+                                                  "Eigen / PCL / OpenCV subsets, one thread) exist in the build container only; timed there on this "
+                                                  "workload's list by profiles/ref_cpu_baseline.py and committed as profiles/r04_ref_cpu_baseline.json"),
             "sample": "%d samples -> %d candidates of the same cloud; images %.2fs + LeNet %.2fs (search %.2fs not counted); "
                       "OpenMP CPU restatement (oracle/), not the reference binary" % (n_samples, n_cand, times[1], times[2], times[0])}
 

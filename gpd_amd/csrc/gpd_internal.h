@@ -115,6 +115,18 @@ int cluster_run(ClusterState &s, const gpd_hand *hands, const double *scores, in
 constexpr int kMaxCams = 32;
 // largest neighbourhood the search handles: hand_eval_kernel keeps neighbour ranks in 16 bits
 constexpr int kNnCapMax = 65535;
+// scratch of Cloud::calculateNormals on the device (search.hip normals_run): per-point neighbour lists in one array
+struct NormalsScratch {
+  int cap_points = 0;
+  long long lists_cap = 0;         // float4 entries
+  int32_t *d_count = nullptr, *d_big = nullptr, *d_status = nullptr;
+  long long *d_offset = nullptr;
+  float4 *d_lists = nullptr;
+  float *d_out = nullptr;
+  int last_queued = 0;             // of the last run: points that went through the large-neighbourhood kernel
+  long long last_total = 0;        // ... and the sum of all neighbourhood sizes
+};
+void normals_free(NormalsScratch &s);
 struct Cloud {
   int num_points = 0, num_cams = 0, capacity = 0, cap_cams = 0;
   char *h_pin = nullptr;              // pinned staging of the caller's arrays (xyz, normals, cam_source)
@@ -137,6 +149,7 @@ struct Cloud {
   float4 *g_p = nullptr;              // [P] the points in cell order: x, y, z and, as bits in w, the original index (one
                                       // 16-byte load per visited point instead of four dword loads)
   float4 *pxyz = nullptr, *pnrm = nullptr;  // [P] AoS copies (x, y, z, 0) / (nx, ny, nz, 0): one load per random access
+  NormalsScratch normals;
 };
 struct GridView {
   float lo[3];

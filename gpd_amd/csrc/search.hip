@@ -24,7 +24,7 @@
 //     counts).  The reference's cropByHandHeight quirk (point_list.cpp:44-55 pads with
 //     copies of column 0) is reproduced by a ghost point with multiplicity N-k.
 // reeval_kernel          HandSearch::reevaluateHypotheses (hand_search.cpp:66-134, 190-228).
-// normals_kernel         Cloud::calculateNormals (util/cloud.cpp:451-604).
+// normals_*_kernel       Cloud::calculateNormals (util/cloud.cpp:451-604): count, scan, lists, finish.
 //
 // All fp64 expressions are evaluated unfused, left to right (-ffp-contract=off),
 // exactly as oracle/gpd_oracle.cpp defines them.
@@ -149,6 +149,7 @@ __device__ inline void grid_visit(const GridView &g, float qx, float qy, float q
 }
 
 void cloud_free(Cloud &c) {
+  normals_free(c.normals);
   void *ptrs[] = {c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.cam_source, c.staging, c.g_start, c.g_cursor, c.g_p, c.pxyz, c.pnrm};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -1245,194 +1246,443 @@ __global__ __launch_bounds__(64) void centre_kernel(const float *__restrict__ nn
 }
 
 // ---------------------------------------------------------------------------
-// normals_kernel — Cloud::calculateNormals (util/cloud.cpp:451-476): the radius-search normal
-// estimation of calculateNormalsOMP (:497-535, pcl::NormalEstimationOMP) followed by
-// reverseNormals (:573-604).  One workgroup per point: stream the cloud, sort the neighbourhood
-// in FLANN order, centroid and covariance as sequential fp64 sums in that order (one lane per
-// component), 3x3 eigensolver, eigenvector of the smallest eigenvalue, flip towards the view
-// point of the camera that sees the point, then the reference's reversal rule.
+// Cloud::calculateNormals (util/cloud.cpp:451-476): the radius-search normal estimation of calculateNormalsOMP
+// (:497-535, pcl::NormalEstimationOMP) followed by reverseNormals (:573-604).  Per point: the neighbours within the
+// radius in FLANN order (d2, index), centroid and covariance as sequential fp64 sums IN THAT ORDER (the oracle's
+// definition: nine serial chains as long as the neighbourhood), Eigen's 3x3 eigensolver, eigenvector of the smallest
+// eigenvalue, flipped towards the view point of the first camera that sees the point, then the reference's reversal rule.
+//
+// Rounds 1-3 gave every point a workgroup of its own that did all of this behind barriers: 1.40 ms per 30k points, 75 % of
+// it three lanes walking the chains one LDS round trip per step, the eigensolver on one lane of 256.  Now the parts run
+// where each is parallel:
+//   normals_count_kernel   a WAVE per point (cell order: neighbouring waves share grid cells in L1): size of the
+//                          neighbourhood; points whose list does not fit a wave's LDS sort are queued for the big kernel
+//   normals_scan_kernel    offsets of the per-point lists (64-bit) in one scratch array
+//   normals_list_kernel    a wave per point: visit again, (d2 bits, index) keys into the wave's 4 KB of LDS, bitonic sort
+//                          wave-synchronously (no workgroup barrier anywhere), gather the coordinates, write the list as
+//                          float4 rows — 1 KB per store instruction
+//   normals_list_big_kernel  the queued points (more than 512 neighbours: un-voxelised scans), a workgroup each, keys
+//                          sorted IN the point's own row of the scratch array (8 m <= 16 n bytes), any size: no capacity
+//   normals_finish_kernel  a LANE per point: the nine chains of 64 points side by side in one wave (all lanes useful, ILP
+//                          9 against the add latency), then 64 eigensolvers side by side, flips, store
 // ---------------------------------------------------------------------------
-constexpr int NRM_CAP = 2048;      // neighbours per point on the four-per-CU instantiation (voxelised clouds: ~340)
-constexpr int NRM_CAP_BIG = 7680;  // the retry for un-voxelised scans (tutorials/table_mug.pcd as shipped: up to 3987): 150 KB of LDS, one per CU
+constexpr int NL_CAP = 512;        // neighbours a wave sorts in its LDS (voxelised clouds: ~340 at radius 0.03)
+constexpr int NL_WAVES = 4;        // points per workgroup of the wave-per-point kernels
 struct NormalsParams {
-  const float *px, *py, *pz;
+  GridView grid;
+  const float4 *pxyz;              // [P] by original index
   int num_points;
   const int32_t *cam_source;
   int num_cams;
   double view_points[3 * kMaxCams];
   float r2;
-  GridView grid;
   float reach;
-  float *out;  // AoS [P][3]
-  int32_t *overflow;
+  int32_t *count;                  // [P] by cell-order position
+  long long *offset;               // [P + 1]
+  float4 *lists;                   // the per-point lists, neighbour order
+  long long lists_cap;             // entries
+  int32_t *big;                    // [0] number of queued points, [1 ..] their cell-order positions
+  int32_t *status;                 // bit 0: the lists do not fit lists_cap (the host grows the scratch and runs again)
+  float *out;                      // AoS [P][3] by original index
 };
 
-template <int CAP>
-__global__ __launch_bounds__(256) void normals_kernel(NormalsParams P) {
-  __shared__ unsigned long long s_keys[CAP];
-  __shared__ float s_xyz[3][CAP];
-  __shared__ int s_count;
-  __shared__ double s_c[3], s_m[6];
-  const int pi = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const float qx = P.px[pi], qy = P.py[pi], qz = P.pz[pi];
-  if (tid == 0) s_count = 0;
-  __syncthreads();
-  grid_visit(P.grid, qx, qy, qz, P.reach, tid >> 6, 4, lane, [&](bool in, int i, float x, float y, float z) {
-    float d = qx - x;
+// the hits of one query among the cells around it, a wave at work: visit(in, index, d2) for every candidate, 64 at a time
+template <typename Hit>
+__device__ inline void normals_visit(const NormalsParams &P, float qx, float qy, float qz, int lane, Hit hit) {
+  auto test = [&](bool in, int i, float x, float y, float z) {
+    float d = qx - x;  // FLANN L2_Simple<float>: d2 accumulated over x, y, z, strict <
     float d2 = 0.f;
     d2 += d * d;
     d = qy - y;
     d2 += d * d;
     d = qz - z;
     d2 += d * d;
-    const bool hit = in && d2 < P.r2;
-    const unsigned long long ballot = __ballot(hit);
-    if (ballot) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
-      base = __builtin_amdgcn_readfirstlane(base);  // every lane is active here and lane 0 holds it
-      if (hit) {
-        const int pos = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (pos < CAP) s_keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+    hit(in && d2 < P.r2, i, d2);
+  };
+  const GridView &g = P.grid;
+  const int x0 = grid_coord(g, 0, qx - P.reach), x1 = grid_coord(g, 0, qx + P.reach);
+  const int y0 = grid_coord(g, 1, qy - P.reach), y1 = grid_coord(g, 1, qy + P.reach);
+  const int z0 = grid_coord(g, 2, qz - P.reach), z1 = grid_coord(g, 2, qz + P.reach);
+  const int ny = y1 - y0 + 1;
+  const int ncol = (x1 - x0 + 1) * ny;
+  if (ncol <= 64) {
+    // the point ranges of all (x, y) cell columns in one round trip (a lane per column), then two columns at a time
+    int cbv = 0, cev = 0;
+    if (lane < ncol) {
+      const int cx = x0 + lane / ny, cy = y0 + lane % ny;
+      const int cbase = (cx * g.dim[1] + cy) * g.dim[2];
+      cbv = g.start[cbase + z0];
+      cev = g.start[cbase + z1 + 1];
+    }
+    for (int c0 = 0; c0 < ncol; c0 += 2) {
+      const int c1 = c0 + 1 < ncol ? c0 + 1 : c0;
+      const int b0 = __builtin_amdgcn_readlane(cbv, c0), e0 = __builtin_amdgcn_readlane(cev, c0);
+      const int b1 = __builtin_amdgcn_readlane(cbv, c1), e1 = c0 + 1 < ncol ? __builtin_amdgcn_readlane(cev, c1) : b1;
+      const int n0 = e0 - b0, n1 = e1 - b1;
+      for (int t0 = 0; t0 < n0 || t0 < n1; t0 += 64) {
+        const int t = t0 + lane;
+        const bool in0 = t < n0, in1 = t < n1;
+        const float4 p0 = g.p[in0 ? b0 + t : 0], p1 = g.p[in1 ? b1 + t : 0];  // both requests before either is used
+        if (t0 < n0) test(in0, __float_as_int(p0.w), p0.x, p0.y, p0.z);
+        if (t0 < n1) test(in1, __float_as_int(p1.w), p1.x, p1.y, p1.z);
       }
     }
-  });
-  __syncthreads();
-  const int found = s_count;
-  if (found > CAP) {
-    if (tid == 0) atomicMax(P.overflow, found);
-    return;
-  }
-  const int n = found;
-  int m = 1;
-  while (m < n) m <<= 1;
-  for (int i = n + tid; i < m; i += 256) s_keys[i] = ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= m; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (m >> 1); t += 256) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const unsigned long long a = s_keys[lo], b = s_keys[hi];
-        if ((a > b) == up) {
-          s_keys[lo] = b;
-          s_keys[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int t = tid; t < n; t += 256) {
-    const int i = (int)(unsigned)(s_keys[t] & 0xffffffffull);
-    s_xyz[0][t] = P.px[i];
-    s_xyz[1][t] = P.py[i];
-    s_xyz[2][t] = P.pz[i];
-  }
-  __syncthreads();
-  if (tid < 3) {  // centroid, one lane per coordinate
-    double acc = 0.0;
-    for (int t = 0; t < n; t++) acc += (double)s_xyz[tid][t];
-    s_c[tid] = acc / (double)n;
-  }
-  __syncthreads();
-  if (tid < 6) {  // covariance entries 00, 10, 11, 20, 21, 22, one lane each
-    const int a = tid == 0 ? 0 : (tid < 3 ? 1 : 2);
-    const int b = tid == 0 ? 0 : (tid == 1 ? 0 : (tid == 2 ? 1 : tid - 3));
-    const double ca = s_c[a], cb = s_c[b];
-    double acc = 0.0;
-    for (int t = 0; t < n; t++) acc += ((double)s_xyz[a][t] - ca) * ((double)s_xyz[b][t] - cb);
-    s_m[tid] = acc;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double ev[3], Q[9];
-    eigen3(s_m[0], s_m[1], s_m[2], s_m[3], s_m[4], s_m[5], ev, Q);
-    int mn = 0;
-    for (int q = 1; q < 3; q++)
-      if (ev[q] < ev[mn]) mn = q;
-    const double nx = Q[mn], ny = Q[3 + mn], nz = Q[6 + mn];
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    // estimated once, with the view point of the FIRST camera that sees the point (convertCameraSourceMatrixToLists,
-    // cloud.cpp:606-620: `== 1` and a break); NormalEstimation::setViewPoint takes floats (cloud.cpp:513)
-    for (int cam = 0; cam < P.num_cams; cam++) {
-      if (P.cam_source[(size_t)cam * P.num_points + pi] != 1) continue;
-      const double *vp = P.view_points + 3 * cam;
-      const double dot = ((double)(float)vp[0] - (double)qx) * nx + ((double)(float)vp[1] - (double)qy) * ny + ((double)(float)vp[2] - (double)qz) * nz;
-      o0 = (float)(dot < 0 ? -nx : nx);
-      o1 = (float)(dot < 0 ? -ny : ny);
-      o2 = (float)(dot < 0 ? -nz : nz);
-      break;
-    }
-    bool needs_reverse = true;  // reverseNormals (cloud.cpp:573-604)
-    for (int cam = 0; cam < P.num_cams && needs_reverse; cam++) {
-      if (P.cam_source[(size_t)cam * P.num_points + pi] != 1) continue;
-      const double *vp = P.view_points + 3 * cam;
-      const double d = (double)o0 * ((double)qx - vp[0]) + (double)o1 * ((double)qy - vp[1]) + (double)o2 * ((double)qz - vp[2]);
-      if (d < 0) needs_reverse = false;
-    }
-    if (needs_reverse) {
-      o0 = (float)((double)o0 * -1.0);
-      o1 = (float)((double)o1 * -1.0);
-      o2 = (float)((double)o2 * -1.0);
-    }
-    P.out[3 * (size_t)pi + 0] = o0;
-    P.out[3 * (size_t)pi + 1] = o1;
-    P.out[3 * (size_t)pi + 2] = o2;
+  } else {
+    grid_visit(g, qx, qy, qz, P.reach, 0, 1, lane, test);
   }
 }
 
-// Host wrapper: normals of the uploaded cloud (uses its device planes), result to the host and
-// into the context's device copy.
+__global__ __launch_bounds__(64 * NL_WAVES) void normals_count_kernel(NormalsParams P) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * NL_WAVES + (threadIdx.x >> 6);
+  if (w >= P.num_points) return;
+  const float4 q = P.grid.p[w];
+  int n = 0;
+  normals_visit(P, q.x, q.y, q.z, lane, [&](bool hit, int, float) { n += __popcll(__ballot(hit)); });
+  if (lane == 0) {
+    P.count[w] = n;
+    if (n > NL_CAP) P.big[1 + atomicAdd(P.big, 1)] = w;
+  }
+}
+
+// exclusive 64-bit scan of the list lengths, one workgroup with a running carry; raises status bit 0 when the lists do
+// not fit the scratch array (every later kernel then returns at once)
+__global__ __launch_bounds__(1024) void normals_scan_kernel(NormalsParams P) {
+  __shared__ long long s_part[16];
+  __shared__ long long s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = P.num_points;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const long long v = i < n ? (long long)P.count[i] : 0ll;
+    long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned lo = __shfl_up((unsigned)incl, o), hi = __shfl_up((unsigned)((unsigned long long)incl >> 32), o);
+      if (lane >= o) incl += (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    long long off = s_carry;
+    for (int k = 0; k < wave; k++) off += s_part[k];
+    if (i < n) P.offset[i] = off + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    P.offset[n] = s_carry;
+    if (s_carry > P.lists_cap) atomicOr(P.status, 1);
+  }
+}
+
+// (d2 bits, index) ascending = FLANN's result order; positive floats order as their bit patterns
+__device__ inline void wave_bitonic_lds(unsigned long long *keys, int m, int lane) {
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (m >> 1); t += 64) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == up) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+      __threadfence_block();  // the next stage reads what other lanes of this wave wrote
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__global__ __launch_bounds__(64 * NL_WAVES) void normals_list_kernel(NormalsParams P) {
+  __shared__ unsigned long long s_keys[NL_WAVES][NL_CAP];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x * NL_WAVES + wv;
+  if (w >= P.num_points) return;
+  if (P.offset[P.num_points] > P.lists_cap) return;
+  const int n = P.count[w];
+  if (n > NL_CAP) return;  // queued for normals_list_big_kernel
+  unsigned long long *keys = s_keys[wv];
+  const float4 q = P.grid.p[w];
+  int base = 0;  // wave-uniform: the entries appended so far
+  normals_visit(P, q.x, q.y, q.z, lane, [&](bool hit, int i, float d2) {
+    const unsigned long long ballot = __ballot(hit);
+    if (hit) keys[base + __popcll(ballot & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+    base += __popcll(ballot);
+  });
+  int m = 64;
+  while (m < n) m <<= 1;
+  for (int t = n + lane; t < m; t += 64) keys[t] = ~0ull;
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  wave_bitonic_lds(keys, m, lane);
+  float4 *row = P.lists + P.offset[w];
+  for (int t0 = 0; t0 < n; t0 += 128) {  // two gathers in flight per lane
+    const int ta = t0 + lane, tb = t0 + 64 + lane;
+    const float4 va = P.pxyz[(unsigned)(keys[ta < n ? ta : 0] & 0xffffffffull)];
+    const float4 vb = P.pxyz[(unsigned)(keys[tb < n ? tb : 0] & 0xffffffffull)];
+    if (ta < n) row[ta] = va;
+    if (tb < n) row[tb] = vb;
+  }
+}
+
+// The queued points: a workgroup each (a persistent launch walks the queue, whose length stays on the device).  The keys
+// are sorted in the point's own row of the list array — m <= 2 n - 1 keys of 8 bytes in n entries of 16 — and then turned
+// into coordinates from the last batch of 256 entries to the first: entry t overwrites the keys 2 t and 2 t + 1, which a
+// batch further down never needs.
+constexpr int NL_BIG_LDS = 8192;  // keys the big kernel sorts in LDS (64 KB); longer lists are sorted in their own row
+__global__ __launch_bounds__(256) void normals_list_big_kernel(NormalsParams P) {
+  __shared__ unsigned long long s_big[NL_BIG_LDS];
+  __shared__ int s_count;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (P.offset[P.num_points] > P.lists_cap) return;
+  const int queued = P.big[0];
+  for (int b = blockIdx.x; b < queued; b += gridDim.x) {
+    const int w = P.big[1 + b];
+    const int n = P.count[w];
+    float4 *row = P.lists + P.offset[w];
+    int m = 1;
+    while (m < n) m <<= 1;
+    unsigned long long *keys = m <= NL_BIG_LDS ? s_big : reinterpret_cast<unsigned long long *>(row);
+    const float4 q = P.grid.p[w];
+    __syncthreads();
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    const GridView &g = P.grid;
+    grid_visit(g, q.x, q.y, q.z, P.reach, tid >> 6, 4, lane, [&](bool in, int i, float x, float y, float z) {
+      float d = q.x - x;
+      float d2 = 0.f;
+      d2 += d * d;
+      d = q.y - y;
+      d2 += d * d;
+      d = q.z - z;
+      d2 += d * d;
+      const bool hit = in && d2 < P.r2;
+      const unsigned long long ballot = __ballot(hit);
+      if (ballot) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_count, __popcll(ballot));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (hit) keys[base + __popcll(ballot & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+      }
+    });
+    for (int t = n + tid; t < m; t += 256) keys[t] = ~0ull;
+    __threadfence_block();
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (m >> 1); t += 256) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool up = (lo & k) == 0;
+          const unsigned long long ka = keys[lo], kb = keys[hi];
+          if ((ka > kb) == up) {
+            keys[lo] = kb;
+            keys[hi] = ka;
+          }
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+    for (int t0 = ((n - 1) / 256) * 256; t0 >= 0; t0 -= 256) {
+      const int t = t0 + tid;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < n) v = P.pxyz[(unsigned)(keys[t] & 0xffffffffull)];
+      __syncthreads();  // every key of this batch has been read
+      if (t < n) row[t] = v;
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= P.num_points) return;
+  if (P.offset[P.num_points] > P.lists_cap) return;
+  const int n = P.count[w];
+  const float4 *row = P.lists + P.offset[w];
+  const float4 q = P.grid.p[w];
+  const int pi = __float_as_int(q.w);
+  // centroid: three sequential sums in neighbour order, four rows requested at a time
+  double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+  int t = 0;
+  for (; t + 4 <= n; t += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = row[t + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      c0 += (double)v[i].x;
+      c1 += (double)v[i].y;
+      c2 += (double)v[i].z;
+    }
+  }
+  for (; t < n; t++) {
+    const float4 v = row[t];
+    c0 += (double)v.x;
+    c1 += (double)v.y;
+    c2 += (double)v.z;
+  }
+  c0 /= (double)n;
+  c1 /= (double)n;
+  c2 /= (double)n;
+  // covariance entries 00, 10, 11, 20, 21, 22 about it: six sequential sums
+  double m00 = 0.0, m10 = 0.0, m11 = 0.0, m20 = 0.0, m21 = 0.0, m22 = 0.0;
+  auto acc = [&](const float4 &v) {
+    const double d0 = (double)v.x - c0, d1 = (double)v.y - c1, d2 = (double)v.z - c2;
+    m00 += d0 * d0;
+    m10 += d1 * d0;
+    m11 += d1 * d1;
+    m20 += d2 * d0;
+    m21 += d2 * d1;
+    m22 += d2 * d2;
+  };
+  t = 0;
+  for (; t + 4 <= n; t += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = row[t + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc(v[i]);
+  }
+  for (; t < n; t++) acc(row[t]);
+  double ev[3], Q[9];
+  eigen3(m00, m10, m11, m20, m21, m22, ev, Q);
+  int mn = 0;
+  for (int k = 1; k < 3; k++)
+    if (ev[k] < ev[mn]) mn = k;
+  const double nx = mn == 0 ? Q[0] : (mn == 1 ? Q[1] : Q[2]), ny = mn == 0 ? Q[3] : (mn == 1 ? Q[4] : Q[5]),
+               nz = mn == 0 ? Q[6] : (mn == 1 ? Q[7] : Q[8]);
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  // estimated once, with the view point of the FIRST camera that sees the point (convertCameraSourceMatrixToLists,
+  // cloud.cpp:606-620: `== 1` and a break); NormalEstimation::setViewPoint takes floats (cloud.cpp:513)
+  for (int cam = 0; cam < P.num_cams; cam++) {
+    if (P.cam_source[(size_t)cam * P.num_points + pi] != 1) continue;
+    const double *vp = P.view_points + 3 * cam;
+    const double dot = ((double)(float)vp[0] - (double)q.x) * nx + ((double)(float)vp[1] - (double)q.y) * ny + ((double)(float)vp[2] - (double)q.z) * nz;
+    o0 = (float)(dot < 0 ? -nx : nx);
+    o1 = (float)(dot < 0 ? -ny : ny);
+    o2 = (float)(dot < 0 ? -nz : nz);
+    break;
+  }
+  bool needs_reverse = true;  // reverseNormals (cloud.cpp:573-604)
+  for (int cam = 0; cam < P.num_cams && needs_reverse; cam++) {
+    if (P.cam_source[(size_t)cam * P.num_points + pi] != 1) continue;
+    const double *vp = P.view_points + 3 * cam;
+    const double d = (double)o0 * ((double)q.x - vp[0]) + (double)o1 * ((double)q.y - vp[1]) + (double)o2 * ((double)q.z - vp[2]);
+    if (d < 0) needs_reverse = false;
+  }
+  if (needs_reverse) {
+    o0 = (float)((double)o0 * -1.0);
+    o1 = (float)((double)o1 * -1.0);
+    o2 = (float)((double)o2 * -1.0);
+  }
+  P.out[3 * (size_t)pi + 0] = o0;
+  P.out[3 * (size_t)pi + 1] = o1;
+  P.out[3 * (size_t)pi + 2] = o2;
+}
+
+void normals_free(NormalsScratch &s) {
+  void *ptrs[] = {s.d_count, s.d_offset, s.d_lists, s.d_big, s.d_status, s.d_out};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  s = NormalsScratch();
+}
+
+// Host wrapper: normals of the uploaded cloud, result to the host and into the context's device copy.  Nothing waits
+// for the device between the five kernels; the scratch array of the lists grows when a cloud needs more (the scan says
+// so through the status word, which comes back with the result).
 int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream) {
-  float *d_out = nullptr;
-  int32_t *d_ovf = nullptr;
-  HIP_RET(hipMalloc(&d_out, (size_t)c.num_points * 3 * sizeof(float)));
-  HIP_RET(hipMalloc(&d_ovf, sizeof(int32_t)));
-  HIP_RET(hipMemsetAsync(d_ovf, 0, sizeof(int32_t), stream));
-  HIP_RET(hipMemsetAsync(d_out, 0, (size_t)c.num_points * 3 * sizeof(float), stream));
+  NormalsScratch &s = c.normals;
+  const int P = c.num_points;
+  if (P > s.cap_points) {
+    note_alloc();
+    const long long lists_cap = s.lists_cap;
+    float4 *lists = s.d_lists;
+    s.d_lists = nullptr;
+    normals_free(s);
+    s.d_lists = lists;
+    s.lists_cap = lists_cap;
+    const int cap = P + P / 4;
+    HIP_RET(hipMalloc(&s.d_count, (size_t)cap * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_offset, ((size_t)cap + 1) * sizeof(long long)));
+    HIP_RET(hipMalloc(&s.d_big, ((size_t)cap + 1) * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_status, sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_out, (size_t)cap * 3 * sizeof(float)));
+    s.cap_points = cap;
+  }
+  if (!s.d_lists) {
+    // first guess: 512 neighbours per point (a voxelised cloud at the reference's radius holds ~340)
+    note_alloc();
+    const long long want = (long long)s.cap_points * 512;
+    HIP_RET(hipMalloc(&s.d_lists, (size_t)want * sizeof(float4)));
+    s.lists_cap = want;
+  }
   NormalsParams np;
-  np.px = c.px; np.py = c.py; np.pz = c.pz;
-  np.num_points = c.num_points;
+  np.grid = grid_view(c);
+  np.pxyz = c.pxyz;
+  np.num_points = P;
   np.cam_source = c.cam_source;
   np.num_cams = c.num_cams;
   std::memcpy(np.view_points, c.view_points, sizeof(np.view_points));
   np.r2 = (float)(radius * radius);
-  np.grid = grid_view(c);
   np.reach = (float)radius * 1.001f + 1e-5f;
-  np.out = d_out;
-  np.overflow = d_ovf;
-  normals_kernel<NRM_CAP><<<c.num_points, 256, 0, stream>>>(np);
+  np.count = s.d_count;
+  np.offset = s.d_offset;
+  np.big = s.d_big;
+  np.status = s.d_status;
+  np.out = s.d_out;
+  struct {
+    int32_t status;
+    int32_t queued;
+    long long total;
+  } h = {0, 0, 0};
+  for (int attempt = 0; attempt < 2; attempt++) {
+    np.lists = s.d_lists;
+    np.lists_cap = s.lists_cap;
+    HIP_RET(hipMemsetAsync(s.d_status, 0, sizeof(int32_t), stream));
+    HIP_RET(hipMemsetAsync(s.d_big, 0, sizeof(int32_t), stream));
+    HIP_RET(hipMemsetAsync(s.d_out, 0, (size_t)P * 3 * sizeof(float), stream));
+    const int groups = (P + NL_WAVES - 1) / NL_WAVES;
+    normals_count_kernel<<<groups, 64 * NL_WAVES, 0, stream>>>(np);
+    normals_scan_kernel<<<1, 1024, 0, stream>>>(np);
+    normals_list_kernel<<<groups, 64 * NL_WAVES, 0, stream>>>(np);
+    normals_list_big_kernel<<<256, 256, 0, stream>>>(np);
+    normals_finish_kernel<<<(P + 63) / 64, 64, 0, stream>>>(np);
+    HIP_RET(hipGetLastError());
+    HIP_RET(hipMemcpyAsync(&h.status, s.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipMemcpyAsync(&h.queued, s.d_big, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipMemcpyAsync(&h.total, s.d_offset + P, sizeof(long long), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipMemcpyAsync(normals_out, s.d_out, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipStreamSynchronize(stream));
+    if (!(h.status & 1)) break;
+    // a denser cloud than the scratch array was sized for: grow it to what the scan found (+ 1/8) and run once more
+    note_alloc();
+    (void)hipFree(s.d_lists);
+    s.d_lists = nullptr;
+    s.lists_cap = 0;
+    const long long want = h.total + h.total / 8;
+    if (hipMalloc(&s.d_lists, (size_t)want * sizeof(float4)) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("normals: the neighbour lists of this cloud (%lld entries within %.3f m) do not fit the device memory", h.total, radius);
+      return GPD_ERR_CAPACITY;
+    }
+    s.lists_cap = want;
+  }
+  s.last_queued = h.queued;
+  s.last_total = h.total;
+  // keep the device copy of the cloud consistent: planes nx, ny, nz
+  split_soa_kernel<<<(P + 255) / 256, 256, 0, stream>>>(c.staging, s.d_out, c.cam_source, P, c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.pxyz,
+                                                         c.pnrm);
   HIP_RET(hipGetLastError());
-  int32_t ovf = 0;
-  HIP_RET(hipMemcpyAsync(&ovf, d_ovf, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   HIP_RET(hipStreamSynchronize(stream));
-  if (ovf > NRM_CAP && ovf <= NRM_CAP_BIG) {
-    // a denser cloud than the lists of the fast instantiation hold: once more, every point, with the large ones
-    HIP_RET(hipMemsetAsync(d_ovf, 0, sizeof(int32_t), stream));
-    normals_kernel<NRM_CAP_BIG><<<c.num_points, 256, 0, stream>>>(np);
-    HIP_RET(hipGetLastError());
-    HIP_RET(hipMemcpyAsync(&ovf, d_ovf, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipStreamSynchronize(stream));
-  }
-  HIP_RET(hipMemcpyAsync(normals_out, d_out, (size_t)c.num_points * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
-  HIP_RET(hipStreamSynchronize(stream));
-  int rc = GPD_OK;
-  if (ovf) {
-    set_error("normals: a %.3f m neighbourhood holds %d points, more than the capacity %d", radius, ovf, NRM_CAP_BIG);
-    rc = GPD_ERR_CAPACITY;
-  } else {
-    // keep the device copy of the cloud consistent: planes nx, ny, nz
-    split_soa_kernel<<<(c.num_points + 255) / 256, 256, 0, stream>>>(c.staging, d_out, c.cam_source, c.num_points, c.px, c.py, c.pz,
-                                                                       c.nx, c.ny, c.nz, c.pxyz, c.pnrm);
-    HIP_RET(hipGetLastError());
-    HIP_RET(hipStreamSynchronize(stream));
-    c.generation++;
-  }
-  (void)hipFree(d_out);
-  (void)hipFree(d_ovf);
-  return rc;
+  c.generation++;
+  return GPD_OK;
 }
 
 // ---------------------------------------------------------------------------

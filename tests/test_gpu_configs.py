@@ -535,3 +535,28 @@ def test_bench_headline_list_exactly(oracle_mod, cloud30k):
                 assert np.abs(f64).max() < 20.0 and np.abs(sc - f64).max() <= 1e-4
     finally:
         ctx.close()
+
+
+def test_normals_of_neighbourhoods_beyond_every_lds_capacity(oracle_mod):
+    """Cloud::calculateNormals has no size limit in the reference (cloud.cpp:497-535).  A 24k-point blob of 5 cm radius
+    searched with radius 0.06: the central points have more than 16 000 neighbours (> the 512-entry wave sort, > the
+    8192-entry LDS sort of the big kernel: the keys are sorted in the point's own row of the list array), next to a sparse
+    shell whose points take the wave path — normals bit for bit against the oracle on all of them."""
+    rng = np.random.RandomState(11)
+    d = rng.randn(24000, 3)
+    blob = (d / np.linalg.norm(d, axis=1, keepdims=True) * (0.05 * rng.rand(24000, 1) ** (1.0 / 3.0))).astype(np.float32)
+    s = rng.randn(3000, 3)
+    shell = (s / np.linalg.norm(s, axis=1, keepdims=True) * 0.6).astype(np.float32)
+    xyz = np.concatenate([blob, shell]) + np.float32(0.7)
+    cam = np.ones((1, len(xyz)), np.int32)
+    vp = np.zeros((1, 3))
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.upload_cloud(xyz, np.zeros_like(xyz), cam, vp)
+        got = ctx.estimate_normals(0.06)
+        want = oracle_mod.estimate_normals(xyz, cam, vp, 0.06)
+        assert np.array_equal(got, want)
+        got2 = ctx.estimate_normals(0.02)  # same context, smaller lists: the scratch array is reused
+        assert np.array_equal(got2, oracle_mod.estimate_normals(xyz, cam, vp, 0.02))
+    finally:
+        ctx.close()
