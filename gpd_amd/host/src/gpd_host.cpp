@@ -253,17 +253,34 @@ Cloud::Cloud(const std::string &filename, const std::vector<double> &view_points
         return;
       }
       const size_t comp = head[0], raw = head[1];
-      if (raw != stride * points || comp > ((size_t)1 << 32)) {
+      if (raw != stride * points) {
         printf("PCD compressed block does not match the header (%zu bytes for %zu points of %zu): %s\n", raw, points, stride,
                filename.c_str());
         return;
       }
-      std::vector<unsigned char> in(comp);
+      // the 8-byte block header is not trusted: the compressed size cannot exceed what is left of the file (a crafted
+      // header would otherwise ask for up to 4 GiB before a single byte is read)
+      const std::streampos here = f.tellg();
+      f.seekg(0, std::ios::end);
+      const std::streampos end = f.tellg();
+      f.seekg(here);
+      if (here < 0 || end < here || comp > (size_t)(end - here)) {
+        printf("PCD file ends inside the compressed block: %s\n", filename.c_str());
+        return;
+      }
+      std::vector<unsigned char> in;
+      std::vector<char> out;
+      try {
+        in.resize(comp);
+        out.resize(raw);
+      } catch (const std::bad_alloc &) {
+        printf("PCD compressed block is corrupt (%zu / %zu bytes cannot be held): %s\n", comp, raw, filename.c_str());
+        return;
+      }
       if (comp && !f.read(reinterpret_cast<char *>(in.data()), (std::streamsize)comp)) {
         printf("PCD file ends inside the compressed block: %s\n", filename.c_str());
         return;
       }
-      std::vector<char> out(raw);
       if (!lzfDecompress(in.data(), comp, reinterpret_cast<unsigned char *>(out.data()), raw)) {
         printf("PCD compressed block is corrupt: %s\n", filename.c_str());
         return;
