@@ -118,13 +118,12 @@ constexpr int kNnCapMax = 65535;
 // scratch of Cloud::calculateNormals on the device (search.hip normals_run): per-point neighbour lists in one array
 struct NormalsScratch {
   int cap_points = 0;
-  long long lists_cap = 0;         // float4 entries
-  int32_t *d_count = nullptr, *d_big = nullptr, *d_status = nullptr;
-  long long *d_offset = nullptr;
-  float4 *d_lists = nullptr;
+  long long arena_cap = 0;         // 8-byte units
+  int32_t *d_count = nullptr, *d_rows = nullptr, *d_big = nullptr;
+  long long *d_big_off = nullptr;
+  unsigned long long *d_arena = nullptr, *d_ctl = nullptr;
   float *d_out = nullptr;
   int last_queued = 0;             // of the last run: points that went through the large-neighbourhood kernel
-  long long last_total = 0;        // ... and the sum of all neighbourhood sizes
 };
 void normals_free(NormalsScratch &s);
 struct Cloud {

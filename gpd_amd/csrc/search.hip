@@ -1253,21 +1253,22 @@ __global__ __launch_bounds__(64) void centre_kernel(const float *__restrict__ nn
 // eigenvalue, flipped towards the view point of the first camera that sees the point, then the reference's reversal rule.
 //
 // Rounds 1-3 gave every point a workgroup of its own that did all of this behind barriers: 1.40 ms per 30k points, 75 % of
-// it three lanes walking the chains one LDS round trip per step, the eigensolver on one lane of 256.  Now the parts run
-// where each is parallel:
-//   normals_count_kernel   a WAVE per point (cell order: neighbouring waves share grid cells in L1): size of the
-//                          neighbourhood; points whose list does not fit a wave's LDS sort are queued for the big kernel
-//   normals_scan_kernel    offsets of the per-point lists (64-bit) in one scratch array
-//   normals_list_kernel    a wave per point: visit again, (d2 bits, index) keys into the wave's 4 KB of LDS, bitonic sort
-//                          wave-synchronously (no workgroup barrier anywhere), gather the coordinates, write the list as
-//                          float4 rows — 1 KB per store instruction
-//   normals_list_big_kernel  the queued points (more than 512 neighbours: un-voxelised scans), a workgroup each, keys
-//                          sorted IN the point's own row of the scratch array (8 m <= 16 n bytes), any size: no capacity
-//   normals_finish_kernel  a LANE per point: the nine chains of 64 points side by side in one wave (all lanes useful, ILP
-//                          9 against the add latency), then 64 eigensolvers side by side, flips, store
+// it three lanes walking the chains one LDS round trip per step, the eigensolver on one lane of 256.  Now every part runs
+// where it is parallel:
+//   normals_list_kernel    a WAVE per point (cell order: neighbouring waves share grid cells in L1): the hits' (d2 bits,
+//                          index) keys go to the wave's LDS, then into registers — 4, 8 or 16 keys per lane — for a bitonic
+//                          network that never touches memory (in-lane stages on registers, cross-lane stages through
+//                          ds_bpermute); the sorted indices leave as 16-byte stores into the point's row.  No workgroup
+//                          barrier anywhere.  A point with more than 1024 neighbours is queued
+//   normals_list_big_kernel  the queued points (un-voxelised scans), a workgroup each: keys sorted in LDS (up to 8192) or
+//                          in the point's own slice of an arena in global memory — ANY size: no capacity
+//   normals_finish_kernel  a LANE per point: the nine chains of 64 points side by side in one wave (every lane useful, nine
+//                          independent chains per lane against the add latency), coordinates gathered from the L2-resident
+//                          point table with 32 rows in flight per lane, then 64 eigensolvers side by side, flips, store
 // ---------------------------------------------------------------------------
-constexpr int NL_CAP = 512;        // neighbours a wave sorts in its LDS (voxelised clouds: ~340 at radius 0.03)
-constexpr int NL_WAVES = 4;        // points per workgroup of the wave-per-point kernels
+constexpr int NL_CAP = 1024;       // neighbours a wave sorts in registers (voxelised clouds at radius 0.03: ~340, up to ~950)
+constexpr int NL_WAVES = 4;        // points per workgroup of the wave-per-point kernel
+constexpr int NL_BIG_LDS = 8192;   // keys the big kernel sorts in LDS (64 KB); longer lists are sorted in their arena slice
 struct NormalsParams {
   GridView grid;
   const float4 *pxyz;              // [P] by original index
@@ -1278,15 +1279,17 @@ struct NormalsParams {
   float r2;
   float reach;
   int32_t *count;                  // [P] by cell-order position
-  long long *offset;               // [P + 1]
-  float4 *lists;                   // the per-point lists, neighbour order
-  long long lists_cap;             // entries
+  int32_t *rows;                   // [P][NL_CAP] neighbour indices in FLANN order (points with at most NL_CAP neighbours)
   int32_t *big;                    // [0] number of queued points, [1 ..] their cell-order positions
-  int32_t *status;                 // bit 0: the lists do not fit lists_cap (the host grows the scratch and runs again)
+  long long *big_off;              // [P] slice of a queued point in the arena (8-byte units)
+  unsigned long long *arena;       // sort space + sorted indices of the queued points
+  unsigned long long *arena_top;   // bump allocator (8-byte units)
+  long long arena_cap;
+  int32_t *status;                 // bit 0: the arena is too small (the host grows it and runs again)
   float *out;                      // AoS [P][3] by original index
 };
 
-// the hits of one query among the cells around it, a wave at work: visit(in, index, d2) for every candidate, 64 at a time
+// the hits of one query among the cells around it, a wave at work: hit(is a hit, index, d2) for every candidate, 64 at a time
 template <typename Hit>
 __device__ inline void normals_visit(const NormalsParams &P, float qx, float qy, float qz, int lane, Hit hit) {
   auto test = [&](bool in, int i, float x, float y, float z) {
@@ -1332,69 +1335,53 @@ __device__ inline void normals_visit(const NormalsParams &P, float qx, float qy,
   }
 }
 
-__global__ __launch_bounds__(64 * NL_WAVES) void normals_count_kernel(NormalsParams P) {
-  const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * NL_WAVES + (threadIdx.x >> 6);
-  if (w >= P.num_points) return;
-  const float4 q = P.grid.p[w];
-  int n = 0;
-  normals_visit(P, q.x, q.y, q.z, lane, [&](bool hit, int, float) { n += __popcll(__ballot(hit)); });
-  if (lane == 0) {
-    P.count[w] = n;
-    if (n > NL_CAP) P.big[1 + atomicAdd(P.big, 1)] = w;
-  }
-}
-
-// exclusive 64-bit scan of the list lengths, one workgroup with a running carry; raises status bit 0 when the lists do
-// not fit the scratch array (every later kernel then returns at once)
-__global__ __launch_bounds__(1024) void normals_scan_kernel(NormalsParams P) {
-  __shared__ long long s_part[16];
-  __shared__ long long s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = P.num_points;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const long long v = i < n ? (long long)P.count[i] : 0ll;
-    long long incl = v;
+// Bitonic sort of 64 K keys held K per lane, element e = lane * K + r, ascending.  Stages whose partner distance is
+// below K exchange registers of one lane (directions known at compile time where they depend on r alone); the others
+// fetch the partner lane's register through ds_bpermute.  (d2 bits, index) ascending = FLANN's result order; positive
+// floats order as their bit patterns.
+template <int K>
+__device__ __forceinline__ void wave_sort_regs(unsigned long long (&key)[K], int lane) {
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned lo = __shfl_up((unsigned)incl, o), hi = __shfl_up((unsigned)((unsigned long long)incl >> 32), o);
-      if (lane >= o) incl += (long long)(((unsigned long long)hi << 32) | lo);
-    }
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    long long off = s_carry;
-    for (int k = 0; k < wave; k++) off += s_part[k];
-    if (i < n) P.offset[i] = off + incl - v;
-    __syncthreads();
-    if (tid == 1023) s_carry = off + incl;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    P.offset[n] = s_carry;
-    if (s_carry > P.lists_cap) atomicOr(P.status, 1);
-  }
-}
-
-// (d2 bits, index) ascending = FLANN's result order; positive floats order as their bit patterns
-__device__ inline void wave_bitonic_lds(unsigned long long *keys, int m, int lane) {
-  for (int k = 2; k <= m; k <<= 1) {
+  for (int k = 2; k <= 64 * K; k <<= 1) {
+#pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = lane; t < (m >> 1); t += 64) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int hi = lo | j;
-        const bool up = (lo & k) == 0;
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == up) {
-          keys[lo] = b;
-          keys[hi] = a;
+      if (j >= K) {
+        const int lj = j / K;
+        const bool up = (lane & (k / K)) == 0;   // k > j >= K: bit k of e is a bit of the lane number
+        const bool keep_min = ((lane & lj) == 0) == up;
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+          const unsigned lo = __shfl_xor((unsigned)key[r], lj), hi = __shfl_xor((unsigned)(key[r] >> 32), lj);
+          const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+          key[r] = ((key[r] < other) == keep_min) ? key[r] : other;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+          if ((r & j) == 0) {
+            const bool up = k < K ? ((r & k) == 0) : ((lane & (k / K)) == 0);
+            const unsigned long long a = key[r], b = key[r | j];
+            const bool sw = (a > b) == up;
+            key[r] = sw ? b : a;
+            key[r | j] = sw ? a : b;
+          }
         }
       }
-      __threadfence_block();  // the next stage reads what other lanes of this wave wrote
-      __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// sort the n keys of the wave's LDS row through registers and store the indices, 16 bytes per lane and instruction
+template <int K>
+__device__ __forceinline__ void normals_sort_store(const unsigned long long *keys, int n, int lane, int32_t *row) {
+  unsigned long long key[K];
+#pragma unroll
+  for (int r = 0; r < K; r++) key[r] = lane * K + r < n ? keys[lane * K + r] : ~0ull;
+  wave_sort_regs<K>(key, lane);
+#pragma unroll
+  for (int r = 0; r < K; r += 4) {
+    if (lane * K + r < n)  // rows are NL_CAP entries long: a partly filled quad is written whole
+      *reinterpret_cast<int4 *>(row + lane * K + r) = make_int4((int)(unsigned)key[r], (int)(unsigned)key[r + 1], (int)(unsigned)key[r + 2], (int)(unsigned)key[r + 3]);
   }
 }
 
@@ -1403,57 +1390,61 @@ __global__ __launch_bounds__(64 * NL_WAVES) void normals_list_kernel(NormalsPara
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int w = blockIdx.x * NL_WAVES + wv;
   if (w >= P.num_points) return;
-  if (P.offset[P.num_points] > P.lists_cap) return;
-  const int n = P.count[w];
-  if (n > NL_CAP) return;  // queued for normals_list_big_kernel
   unsigned long long *keys = s_keys[wv];
   const float4 q = P.grid.p[w];
-  int base = 0;  // wave-uniform: the entries appended so far
+  int n = 0;  // wave-uniform: the hits so far
   normals_visit(P, q.x, q.y, q.z, lane, [&](bool hit, int i, float d2) {
     const unsigned long long ballot = __ballot(hit);
-    if (hit) keys[base + __popcll(ballot & ((1ull << lane) - 1ull))] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
-    base += __popcll(ballot);
+    const int pos = n + __popcll(ballot & ((1ull << lane) - 1ull));
+    if (hit && pos < NL_CAP) keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
+    n += __popcll(ballot);
   });
-  int m = 64;
-  while (m < n) m <<= 1;
-  for (int t = n + lane; t < m; t += 64) keys[t] = ~0ull;
-  __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
-  wave_bitonic_lds(keys, m, lane);
-  float4 *row = P.lists + P.offset[w];
-  for (int t0 = 0; t0 < n; t0 += 128) {  // two gathers in flight per lane
-    const int ta = t0 + lane, tb = t0 + 64 + lane;
-    const float4 va = P.pxyz[(unsigned)(keys[ta < n ? ta : 0] & 0xffffffffull)];
-    const float4 vb = P.pxyz[(unsigned)(keys[tb < n ? tb : 0] & 0xffffffffull)];
-    if (ta < n) row[ta] = va;
-    if (tb < n) row[tb] = vb;
+  if (lane == 0) P.count[w] = n;
+  if (n > NL_CAP) {  // a neighbourhood for the big kernel (it searches again)
+    if (lane == 0) P.big[1 + atomicAdd(P.big, 1)] = w;
+    return;
   }
+  __threadfence_block();  // the keys were written by other lanes of this wave
+  __builtin_amdgcn_wave_barrier();
+  int32_t *row = P.rows + (size_t)w * NL_CAP;
+  if (n <= 256)
+    normals_sort_store<4>(keys, n, lane, row);
+  else if (n <= 512)
+    normals_sort_store<8>(keys, n, lane, row);
+  else
+    normals_sort_store<16>(keys, n, lane, row);
 }
 
-// The queued points: a workgroup each (a persistent launch walks the queue, whose length stays on the device).  The keys
-// are sorted in the point's own row of the list array — m <= 2 n - 1 keys of 8 bytes in n entries of 16 — and then turned
-// into coordinates from the last batch of 256 entries to the first: entry t overwrites the keys 2 t and 2 t + 1, which a
-// batch further down never needs.
-constexpr int NL_BIG_LDS = 8192;  // keys the big kernel sorts in LDS (64 KB); longer lists are sorted in their own row
+// The queued points: a workgroup each (a persistent launch walks the queue, whose length stays on the device).  The list
+// length is known from the first kernel; a slice of m = 2^ceil(log2 n) eight-byte units is drawn from the arena, the keys
+// are sorted in LDS (m <= 8192) or in the slice itself, and the sorted indices are written over the slice's first 4 n
+// bytes from the front: index t lands on key t / 2, which has been read by then.
 __global__ __launch_bounds__(256) void normals_list_big_kernel(NormalsParams P) {
   __shared__ unsigned long long s_big[NL_BIG_LDS];
   __shared__ int s_count;
+  __shared__ long long s_off;
   const int tid = threadIdx.x, lane = tid & 63;
-  if (P.offset[P.num_points] > P.lists_cap) return;
   const int queued = P.big[0];
   for (int b = blockIdx.x; b < queued; b += gridDim.x) {
     const int w = P.big[1 + b];
     const int n = P.count[w];
-    float4 *row = P.lists + P.offset[w];
     int m = 1;
     while (m < n) m <<= 1;
-    unsigned long long *keys = m <= NL_BIG_LDS ? s_big : reinterpret_cast<unsigned long long *>(row);
+    __syncthreads();
+    if (tid == 0) {
+      s_count = 0;
+      const long long off = (long long)atomicAdd(P.arena_top, (unsigned long long)m);
+      s_off = off;
+      P.big_off[w] = off;
+      if (off + m > P.arena_cap) atomicOr(P.status, 1);
+    }
+    __syncthreads();
+    const long long off = s_off;
+    if (off + m > P.arena_cap) continue;  // the host grows the arena and runs again
+    unsigned long long *slice = P.arena + off;
+    unsigned long long *keys = m <= NL_BIG_LDS ? s_big : slice;
     const float4 q = P.grid.p[w];
-    __syncthreads();
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-    const GridView &g = P.grid;
-    grid_visit(g, q.x, q.y, q.z, P.reach, tid >> 6, 4, lane, [&](bool in, int i, float x, float y, float z) {
+    grid_visit(P.grid, q.x, q.y, q.z, P.reach, tid >> 6, 4, lane, [&](bool in, int i, float x, float y, float z) {
       float d = q.x - x;
       float d2 = 0.f;
       d2 += d * d;
@@ -1488,12 +1479,12 @@ __global__ __launch_bounds__(256) void normals_list_big_kernel(NormalsParams P) 
         __threadfence_block();
         __syncthreads();
       }
-    for (int t0 = ((n - 1) / 256) * 256; t0 >= 0; t0 -= 256) {
+    int32_t *row = reinterpret_cast<int32_t *>(slice);
+    for (int t0 = 0; t0 < n; t0 += 256) {
       const int t = t0 + tid;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < n) v = P.pxyz[(unsigned)(keys[t] & 0xffffffffull)];
+      const int idx = t < n ? (int)(unsigned)keys[t] : 0;
       __syncthreads();  // every key of this batch has been read
-      if (t < n) row[t] = v;
+      if (t < n) row[t] = idx;
       __threadfence_block();
       __syncthreads();
     }
@@ -1503,54 +1494,65 @@ __global__ __launch_bounds__(256) void normals_list_big_kernel(NormalsParams P) 
 __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
   const int w = blockIdx.x * 64 + threadIdx.x;
   if (w >= P.num_points) return;
-  if (P.offset[P.num_points] > P.lists_cap) return;
+  if (*P.status & 1) return;  // the arena was too small: this run is repeated
   const int n = P.count[w];
-  const float4 *row = P.lists + P.offset[w];
+  const int32_t *row = n <= NL_CAP ? P.rows + (size_t)w * NL_CAP : reinterpret_cast<const int32_t *>(P.arena + P.big_off[w]);
   const float4 q = P.grid.p[w];
   const int pi = __float_as_int(q.w);
-  // centroid: three sequential sums in neighbour order, four rows requested at a time
+  constexpr int B = 16;  // rows per batch; the next batch's indices and coordinates are requested before this one is summed
+  // centroid: three sequential sums in neighbour order
   double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-  int t = 0;
-  for (; t + 4 <= n; t += 4) {
-    float4 v[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = row[t + i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      c0 += (double)v[i].x;
-      c1 += (double)v[i].y;
-      c2 += (double)v[i].z;
-    }
-  }
-  for (; t < n; t++) {
-    const float4 v = row[t];
-    c0 += (double)v.x;
-    c1 += (double)v.y;
-    c2 += (double)v.z;
-  }
-  c0 /= (double)n;
-  c1 /= (double)n;
-  c2 /= (double)n;
   // covariance entries 00, 10, 11, 20, 21, 22 about it: six sequential sums
   double m00 = 0.0, m10 = 0.0, m11 = 0.0, m20 = 0.0, m21 = 0.0, m22 = 0.0;
-  auto acc = [&](const float4 &v) {
-    const double d0 = (double)v.x - c0, d1 = (double)v.y - c1, d2 = (double)v.z - c2;
-    m00 += d0 * d0;
-    m10 += d1 * d0;
-    m11 += d1 * d1;
-    m20 += d2 * d0;
-    m21 += d2 * d1;
-    m22 += d2 * d2;
-  };
-  t = 0;
-  for (; t + 4 <= n; t += 4) {
-    float4 v[4];
+  for (int pass = 0; pass < 2; pass++) {
+    float4 cur[B], nxt[B];
+    auto fetch = [&](int t0, float4 (&v)[B]) {
+      int id[B];
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = row[t + i];
+      for (int i = 0; i < B; i += 4) {
+        // rows are 16-byte aligned and at least a multiple of four entries long (NL_CAP rows; arena slices of 2^k units)
+        const int4 q4 = t0 + i < n ? *reinterpret_cast<const int4 *>(row + t0 + i) : make_int4(0, 0, 0, 0);
+        id[i] = q4.x;
+        id[i + 1] = q4.y;
+        id[i + 2] = q4.z;
+        id[i + 3] = q4.w;
+      }
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc(v[i]);
+      for (int i = 0; i < B; i++) v[i] = P.pxyz[t0 + i < n ? id[i] : 0];
+    };
+    fetch(0, cur);
+    for (int t0 = 0; t0 < n; t0 += B) {
+      if (t0 + B < n) fetch(t0 + B, nxt);
+      if (pass == 0) {
+#pragma unroll
+        for (int i = 0; i < B; i++)
+          if (t0 + i < n) {
+            c0 += (double)cur[i].x;
+            c1 += (double)cur[i].y;
+            c2 += (double)cur[i].z;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < B; i++)
+          if (t0 + i < n) {
+            const double d0 = (double)cur[i].x - c0, d1 = (double)cur[i].y - c1, d2 = (double)cur[i].z - c2;
+            m00 += d0 * d0;
+            m10 += d1 * d0;
+            m11 += d1 * d1;
+            m20 += d2 * d0;
+            m21 += d2 * d1;
+            m22 += d2 * d2;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < B; i++) cur[i] = nxt[i];
+    }
+    if (pass == 0) {
+      c0 /= (double)n;
+      c1 /= (double)n;
+      c2 /= (double)n;
+    }
   }
-  for (; t < n; t++) acc(row[t]);
   double ev[3], Q[9];
   eigen3(m00, m10, m11, m20, m21, m22, ev, Q);
   int mn = 0;
@@ -1588,40 +1590,40 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
 }
 
 void normals_free(NormalsScratch &s) {
-  void *ptrs[] = {s.d_count, s.d_offset, s.d_lists, s.d_big, s.d_status, s.d_out};
+  void *ptrs[] = {s.d_count, s.d_rows, s.d_big, s.d_big_off, s.d_arena, s.d_ctl, s.d_out};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   s = NormalsScratch();
 }
 
 // Host wrapper: normals of the uploaded cloud, result to the host and into the context's device copy.  Nothing waits
-// for the device between the five kernels; the scratch array of the lists grows when a cloud needs more (the scan says
-// so through the status word, which comes back with the result).
+// for the device between the three kernels; the arena of the large neighbourhoods grows when a cloud needs more (the
+// status word comes back with the result, and the run is repeated once with the size the first one asked for).
 int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream) {
   NormalsScratch &s = c.normals;
   const int P = c.num_points;
   if (P > s.cap_points) {
     note_alloc();
-    const long long lists_cap = s.lists_cap;
-    float4 *lists = s.d_lists;
-    s.d_lists = nullptr;
+    unsigned long long *arena = s.d_arena;
+    const long long arena_cap = s.arena_cap;
+    s.d_arena = nullptr;
     normals_free(s);
-    s.d_lists = lists;
-    s.lists_cap = lists_cap;
+    s.d_arena = arena;
+    s.arena_cap = arena_cap;
     const int cap = P + P / 4;
     HIP_RET(hipMalloc(&s.d_count, (size_t)cap * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&s.d_offset, ((size_t)cap + 1) * sizeof(long long)));
+    HIP_RET(hipMalloc(&s.d_rows, (size_t)cap * NL_CAP * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_big, ((size_t)cap + 1) * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&s.d_status, sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_big_off, (size_t)cap * sizeof(long long)));
+    HIP_RET(hipMalloc(&s.d_ctl, 4 * sizeof(unsigned long long)));  // [0] arena top, [1] status
     HIP_RET(hipMalloc(&s.d_out, (size_t)cap * 3 * sizeof(float)));
     s.cap_points = cap;
   }
-  if (!s.d_lists) {
-    // first guess: 512 neighbours per point (a voxelised cloud at the reference's radius holds ~340)
+  if (!s.d_arena) {
     note_alloc();
-    const long long want = (long long)s.cap_points * 512;
-    HIP_RET(hipMalloc(&s.d_lists, (size_t)want * sizeof(float4)));
-    s.lists_cap = want;
+    const long long want = 1ll << 20;  // 8 MB: a voxelised cloud needs none of it
+    HIP_RET(hipMalloc(&s.d_arena, (size_t)want * sizeof(unsigned long long)));
+    s.arena_cap = want;
   }
   NormalsParams np;
   np.grid = grid_view(c);
@@ -1633,49 +1635,45 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
   np.r2 = (float)(radius * radius);
   np.reach = (float)radius * 1.001f + 1e-5f;
   np.count = s.d_count;
-  np.offset = s.d_offset;
+  np.rows = s.d_rows;
   np.big = s.d_big;
-  np.status = s.d_status;
+  np.big_off = s.d_big_off;
+  np.arena_top = s.d_ctl;
+  np.status = reinterpret_cast<int32_t *>(s.d_ctl + 1);
   np.out = s.d_out;
   struct {
-    int32_t status;
-    int32_t queued;
-    long long total;
-  } h = {0, 0, 0};
+    unsigned long long top, status;
+  } h = {0, 0};
+  int32_t queued = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
-    np.lists = s.d_lists;
-    np.lists_cap = s.lists_cap;
-    HIP_RET(hipMemsetAsync(s.d_status, 0, sizeof(int32_t), stream));
+    np.arena = s.d_arena;
+    np.arena_cap = s.arena_cap;
+    HIP_RET(hipMemsetAsync(s.d_ctl, 0, 2 * sizeof(unsigned long long), stream));
     HIP_RET(hipMemsetAsync(s.d_big, 0, sizeof(int32_t), stream));
     HIP_RET(hipMemsetAsync(s.d_out, 0, (size_t)P * 3 * sizeof(float), stream));
-    const int groups = (P + NL_WAVES - 1) / NL_WAVES;
-    normals_count_kernel<<<groups, 64 * NL_WAVES, 0, stream>>>(np);
-    normals_scan_kernel<<<1, 1024, 0, stream>>>(np);
-    normals_list_kernel<<<groups, 64 * NL_WAVES, 0, stream>>>(np);
+    normals_list_kernel<<<(P + NL_WAVES - 1) / NL_WAVES, 64 * NL_WAVES, 0, stream>>>(np);
     normals_list_big_kernel<<<256, 256, 0, stream>>>(np);
     normals_finish_kernel<<<(P + 63) / 64, 64, 0, stream>>>(np);
     HIP_RET(hipGetLastError());
-    HIP_RET(hipMemcpyAsync(&h.status, s.d_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipMemcpyAsync(&h.queued, s.d_big, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipMemcpyAsync(&h.total, s.d_offset + P, sizeof(long long), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipMemcpyAsync(&h, s.d_ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_RET(hipMemcpyAsync(&queued, s.d_big, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIP_RET(hipMemcpyAsync(normals_out, s.d_out, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIP_RET(hipStreamSynchronize(stream));
     if (!(h.status & 1)) break;
-    // a denser cloud than the scratch array was sized for: grow it to what the scan found (+ 1/8) and run once more
+    // more / larger neighbourhoods beyond a wave's reach than the arena holds: grow it to what this run asked for
     note_alloc();
-    (void)hipFree(s.d_lists);
-    s.d_lists = nullptr;
-    s.lists_cap = 0;
-    const long long want = h.total + h.total / 8;
-    if (hipMalloc(&s.d_lists, (size_t)want * sizeof(float4)) != hipSuccess) {
+    (void)hipFree(s.d_arena);
+    s.d_arena = nullptr;
+    s.arena_cap = 0;
+    const long long want = (long long)h.top + (long long)h.top / 8;
+    if (attempt == 1 || hipMalloc(&s.d_arena, (size_t)want * sizeof(unsigned long long)) != hipSuccess) {
       (void)hipGetLastError();
-      set_error("normals: the neighbour lists of this cloud (%lld entries within %.3f m) do not fit the device memory", h.total, radius);
+      set_error("normals: the neighbour lists of this cloud (%llu sort slots within %.3f m) do not fit the device memory", h.top, radius);
       return GPD_ERR_CAPACITY;
     }
-    s.lists_cap = want;
+    s.arena_cap = want;
   }
-  s.last_queued = h.queued;
-  s.last_total = h.total;
+  s.last_queued = queued;
   // keep the device copy of the cloud consistent: planes nx, ny, nz
   split_soa_kernel<<<(P + 255) / 256, 256, 0, stream>>>(c.staging, s.d_out, c.cam_source, P, c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.pxyz,
                                                          c.pnrm);
