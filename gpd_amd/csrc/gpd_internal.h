@@ -119,7 +119,8 @@ constexpr int kNnCapMax = 65535;
 struct NormalsScratch {
   int cap_points = 0;
   long long arena_cap = 0;         // 8-byte units
-  int32_t *d_count = nullptr, *d_rows = nullptr, *d_big = nullptr;
+  int32_t *d_count = nullptr, *d_big = nullptr;
+  float4 *d_lists = nullptr;        // [P / 64][1024][64] transposed neighbour lists
   long long *d_big_off = nullptr;
   unsigned long long *d_arena = nullptr, *d_ctl = nullptr;
   float *d_out = nullptr;

@@ -1279,7 +1279,7 @@ struct NormalsParams {
   float r2;
   float reach;
   int32_t *count;                  // [P] by cell-order position
-  int32_t *rows;                   // [P][NL_CAP] neighbour indices in FLANN order (points with at most NL_CAP neighbours)
+  float4 *lists;                   // [P / 64][NL_CAP][64] neighbour coordinates in FLANN order, transposed per block of 64 points
   int32_t *big;                    // [0] number of queued points, [1 ..] their cell-order positions
   long long *big_off;              // [P] slice of a queued point in the arena (8-byte units)
   unsigned long long *arena;       // sort space + sorted indices of the queued points
@@ -1335,53 +1335,96 @@ __device__ inline void normals_visit(const NormalsParams &P, float qx, float qy,
   }
 }
 
-// Bitonic sort of 64 K keys held K per lane, element e = lane * K + r, ascending.  Stages whose partner distance is
-// below K exchange registers of one lane (directions known at compile time where they depend on r alone); the others
-// fetch the partner lane's register through ds_bpermute.  (d2 bits, index) ascending = FLANN's result order; positive
-// floats order as their bit patterns.
+// Bitonic sort of 64 K keys held K per lane, element e = lane * K + r, ascending — in the formulation whose every
+// compare-exchange puts the minimum at the lower index: a merge of width k starts with the "flip" step (partner e ^ (k - 1))
+// and goes on with partners e ^ j, j = k / 4 .. 1.  Partners inside a lane exchange registers (v_min_f64 + v_max_f64: the keys
+// are compared AS DOUBLES — sign bit clear, never a NaN, so the order is the order of the bit patterns — at the full f64 rate,
+// where a 64-bit integer compare plus selects costs four times as much); partners in another lane come through ds_bpermute.
+// (d2 bits, index) ascending = FLANN's result order; positive floats order as their bit patterns.
+__device__ __forceinline__ double key_min(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));  // (no canonicalisation of the operands: they are never NaNs)
+  return r;
+}
+__device__ __forceinline__ double key_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+constexpr unsigned long long NL_PAD_KEY = 0x7fefffffffffffffull;  // above every key, and a finite double
 template <int K>
-__device__ __forceinline__ void wave_sort_regs(unsigned long long (&key)[K], int lane) {
+__device__ __forceinline__ void wave_sort_regs(double (&key)[K], int lane) {
+  auto from_lane = [&](double v, int xor_mask) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __shfl_xor((unsigned)b, xor_mask), hi = __shfl_xor((unsigned)(b >> 32), xor_mask);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  };
 #pragma unroll
   for (int k = 2; k <= 64 * K; k <<= 1) {
+    // ---- the flip step: partner e ^ (k - 1)
+    if (k <= K) {
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int r = 0; r < K; r++)
+        if ((r & (k >> 1)) == 0) {  // the lower half of its block of k
+          const int r2 = r ^ (k - 1);
+          const double a = key[r], b = key[r2];
+          key[r] = key_min(a, b);
+          key[r2] = key_max(a, b);
+        }
+    } else {
+      const int lm = k / K - 1;                       // lanes of a block of k elements: flip them all, and r within the lane
+      const bool lower = (lane & (k / K / 2)) == 0;   // the lower half of the block holds the minima
+      double other[K];
+#pragma unroll
+      for (int r = 0; r < K; r++) other[r] = from_lane(key[K - 1 - r], lm);
+#pragma unroll
+      for (int r = 0; r < K; r++) key[r] = ((other[r] < key[r]) == lower) ? other[r] : key[r];
+    }
+    // ---- partners e ^ j
+#pragma unroll
+    for (int j = k >> 2; j > 0; j >>= 1) {
       if (j >= K) {
         const int lj = j / K;
-        const bool up = (lane & (k / K)) == 0;   // k > j >= K: bit k of e is a bit of the lane number
-        const bool keep_min = ((lane & lj) == 0) == up;
+        const bool lower = (lane & lj) == 0;
 #pragma unroll
         for (int r = 0; r < K; r++) {
-          const unsigned lo = __shfl_xor((unsigned)key[r], lj), hi = __shfl_xor((unsigned)(key[r] >> 32), lj);
-          const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-          key[r] = ((key[r] < other) == keep_min) ? key[r] : other;
+          const double other = from_lane(key[r], lj);
+          key[r] = ((other < key[r]) == lower) ? other : key[r];
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < K; r++) {
+        for (int r = 0; r < K; r++)
           if ((r & j) == 0) {
-            const bool up = k < K ? ((r & k) == 0) : ((lane & (k / K)) == 0);
-            const unsigned long long a = key[r], b = key[r | j];
-            const bool sw = (a > b) == up;
-            key[r] = sw ? b : a;
-            key[r | j] = sw ? a : b;
+            const double a = key[r], b = key[r | j];
+            key[r] = key_min(a, b);
+            key[r | j] = key_max(a, b);
           }
-        }
       }
     }
   }
 }
 
-// sort the n keys of the wave's LDS row through registers and store the indices, 16 bytes per lane and instruction
+// sort the n keys of the wave's LDS row through registers, fetch the coordinates and store the list TRANSPOSED: entry e of
+// the p-th point of a block of 64 points at [block][e][p], so that normals_finish_kernel — a lane per point — reads one
+// contiguous kilobyte per step and wave
 template <int K>
-__device__ __forceinline__ void normals_sort_store(const unsigned long long *keys, int n, int lane, int32_t *row) {
-  unsigned long long key[K];
+__device__ __forceinline__ void normals_sort_store(const NormalsParams &P, const unsigned long long *keys, int n, int lane, int w) {
+  double key[K];
 #pragma unroll
-  for (int r = 0; r < K; r++) key[r] = lane * K + r < n ? keys[lane * K + r] : ~0ull;
+  for (int r = 0; r < K; r++) key[r] = __longlong_as_double((long long)(lane * K + r < n ? keys[lane * K + r] : NL_PAD_KEY));
   wave_sort_regs<K>(key, lane);
+  float4 *col = P.lists + (size_t)(w >> 6) * NL_CAP * 64 + (w & 63);
 #pragma unroll
-  for (int r = 0; r < K; r += 4) {
-    if (lane * K + r < n)  // rows are NL_CAP entries long: a partly filled quad is written whole
-      *reinterpret_cast<int4 *>(row + lane * K + r) = make_int4((int)(unsigned)key[r], (int)(unsigned)key[r + 1], (int)(unsigned)key[r + 2], (int)(unsigned)key[r + 3]);
+  for (int r0 = 0; r0 < K; r0 += 4) {  // four gathers in flight, then their four stores
+    const int e = lane * K + r0;
+    const float4 v0 = P.pxyz[e + 0 < n ? (unsigned)__double_as_longlong(key[r0 + 0]) : 0u];
+    const float4 v1 = P.pxyz[e + 1 < n ? (unsigned)__double_as_longlong(key[r0 + 1]) : 0u];
+    const float4 v2 = P.pxyz[e + 2 < n ? (unsigned)__double_as_longlong(key[r0 + 2]) : 0u];
+    const float4 v3 = P.pxyz[e + 3 < n ? (unsigned)__double_as_longlong(key[r0 + 3]) : 0u];
+    if (e + 0 < n) col[(size_t)(e + 0) * 64] = v0;
+    if (e + 1 < n) col[(size_t)(e + 1) * 64] = v1;
+    if (e + 2 < n) col[(size_t)(e + 2) * 64] = v2;
+    if (e + 3 < n) col[(size_t)(e + 3) * 64] = v3;
   }
 }
 
@@ -1406,13 +1449,12 @@ __global__ __launch_bounds__(64 * NL_WAVES) void normals_list_kernel(NormalsPara
   }
   __threadfence_block();  // the keys were written by other lanes of this wave
   __builtin_amdgcn_wave_barrier();
-  int32_t *row = P.rows + (size_t)w * NL_CAP;
   if (n <= 256)
-    normals_sort_store<4>(keys, n, lane, row);
+    normals_sort_store<4>(P, keys, n, lane, w);
   else if (n <= 512)
-    normals_sort_store<8>(keys, n, lane, row);
+    normals_sort_store<8>(P, keys, n, lane, w);
   else
-    normals_sort_store<16>(keys, n, lane, row);
+    normals_sort_store<16>(P, keys, n, lane, w);
 }
 
 // The queued points: a workgroup each (a persistent launch walks the queue, whose length stays on the device).  The list
@@ -1496,29 +1538,25 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
   if (w >= P.num_points) return;
   if (*P.status & 1) return;  // the arena was too small: this run is repeated
   const int n = P.count[w];
-  const int32_t *row = n <= NL_CAP ? P.rows + (size_t)w * NL_CAP : reinterpret_cast<const int32_t *>(P.arena + P.big_off[w]);
   const float4 q = P.grid.p[w];
   const int pi = __float_as_int(q.w);
-  constexpr int B = 16;  // rows per batch; the next batch's indices and coordinates are requested before this one is summed
-  // centroid: three sequential sums in neighbour order
+  constexpr int B = 16;  // list entries per batch; the next batch is requested before this one is summed
+  // centroid: three sequential sums in neighbour order; covariance entries 00, 10, 11, 20, 21, 22 about it: six more
   double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-  // covariance entries 00, 10, 11, 20, 21, 22 about it: six sequential sums
   double m00 = 0.0, m10 = 0.0, m11 = 0.0, m20 = 0.0, m21 = 0.0, m22 = 0.0;
+  const bool small = n <= NL_CAP;
+  const float4 *col = P.lists + (size_t)(w >> 6) * NL_CAP * 64 + (w & 63);  // this point's column of its block's transposed lists
+  const int32_t *row = small ? nullptr : reinterpret_cast<const int32_t *>(P.arena + P.big_off[w]);  // a queued point: its index row
   for (int pass = 0; pass < 2; pass++) {
     float4 cur[B], nxt[B];
     auto fetch = [&](int t0, float4 (&v)[B]) {
-      int id[B];
+      if (small) {
 #pragma unroll
-      for (int i = 0; i < B; i += 4) {
-        // rows are 16-byte aligned and at least a multiple of four entries long (NL_CAP rows; arena slices of 2^k units)
-        const int4 q4 = t0 + i < n ? *reinterpret_cast<const int4 *>(row + t0 + i) : make_int4(0, 0, 0, 0);
-        id[i] = q4.x;
-        id[i + 1] = q4.y;
-        id[i + 2] = q4.z;
-        id[i + 3] = q4.w;
+        for (int i = 0; i < B; i++) v[i] = col[(size_t)(t0 + i < n ? t0 + i : 0) * 64];  // the wave reads 1 KB per entry: its lanes' columns are adjacent
+      } else {
+#pragma unroll
+        for (int i = 0; i < B; i++) v[i] = P.pxyz[t0 + i < n ? row[t0 + i] : 0];
       }
-#pragma unroll
-      for (int i = 0; i < B; i++) v[i] = P.pxyz[t0 + i < n ? id[i] : 0];
     };
     fetch(0, cur);
     for (int t0 = 0; t0 < n; t0 += B) {
@@ -1590,7 +1628,7 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
 }
 
 void normals_free(NormalsScratch &s) {
-  void *ptrs[] = {s.d_count, s.d_rows, s.d_big, s.d_big_off, s.d_arena, s.d_ctl, s.d_out};
+  void *ptrs[] = {s.d_count, s.d_lists, s.d_big, s.d_big_off, s.d_arena, s.d_ctl, s.d_out};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   s = NormalsScratch();
@@ -1612,7 +1650,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     s.arena_cap = arena_cap;
     const int cap = P + P / 4;
     HIP_RET(hipMalloc(&s.d_count, (size_t)cap * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&s.d_rows, (size_t)cap * NL_CAP * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&s.d_lists, ((size_t)cap + 63) / 64 * 64 * NL_CAP * sizeof(float4)));  // 16 KB of address space per point; a point touches 16 B per neighbour
     HIP_RET(hipMalloc(&s.d_big, ((size_t)cap + 1) * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_big_off, (size_t)cap * sizeof(long long)));
     HIP_RET(hipMalloc(&s.d_ctl, 4 * sizeof(unsigned long long)));  // [0] arena top, [1] status
@@ -1635,7 +1673,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
   np.r2 = (float)(radius * radius);
   np.reach = (float)radius * 1.001f + 1e-5f;
   np.count = s.d_count;
-  np.rows = s.d_rows;
+  np.lists = s.d_lists;
   np.big = s.d_big;
   np.big_off = s.d_big_off;
   np.arena_top = s.d_ctl;
