@@ -1309,7 +1309,10 @@ __device__ inline void normals_visit(const NormalsParams &P, float qx, float qy,
   const int ny = y1 - y0 + 1;
   const int ncol = (x1 - x0 + 1) * ny;
   if (ncol <= 64) {
-    // the point ranges of all (x, y) cell columns in one round trip (a lane per column), then two columns at a time
+    // the point ranges of all (x, y) cell columns in one round trip (a lane per column); then the first 64 points of
+    // EIGHT columns are requested before any of them is tested — a column of a voxelised cloud holds ~45 points, so
+    // a 4 x 4-column neighbourhood costs three dependent round trips instead of nine (the kernel waits for memory, not
+    // for its ALUs: 30k waves of a few hundred instructions each)
     int cbv = 0, cev = 0;
     if (lane < ncol) {
       const int cx = x0 + lane / ny, cy = y0 + lane % ny;
@@ -1317,18 +1320,27 @@ __device__ inline void normals_visit(const NormalsParams &P, float qx, float qy,
       cbv = g.start[cbase + z0];
       cev = g.start[cbase + z1 + 1];
     }
-    for (int c0 = 0; c0 < ncol; c0 += 2) {
-      const int c1 = c0 + 1 < ncol ? c0 + 1 : c0;
-      const int b0 = __builtin_amdgcn_readlane(cbv, c0), e0 = __builtin_amdgcn_readlane(cev, c0);
-      const int b1 = __builtin_amdgcn_readlane(cbv, c1), e1 = c0 + 1 < ncol ? __builtin_amdgcn_readlane(cev, c1) : b1;
-      const int n0 = e0 - b0, n1 = e1 - b1;
-      for (int t0 = 0; t0 < n0 || t0 < n1; t0 += 64) {
-        const int t = t0 + lane;
-        const bool in0 = t < n0, in1 = t < n1;
-        const float4 p0 = g.p[in0 ? b0 + t : 0], p1 = g.p[in1 ? b1 + t : 0];  // both requests before either is used
-        if (t0 < n0) test(in0, __float_as_int(p0.w), p0.x, p0.y, p0.z);
-        if (t0 < n1) test(in1, __float_as_int(p1.w), p1.x, p1.y, p1.z);
+    for (int c0 = 0; c0 < ncol; c0 += 8) {
+      int cb[8], cn[8];
+      float4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int c = c0 + u < ncol ? c0 + u : c0;
+        cb[u] = __builtin_amdgcn_readlane(cbv, c);
+        cn[u] = c0 + u < ncol ? __builtin_amdgcn_readlane(cev, c) - cb[u] : 0;
       }
+#pragma unroll
+      for (int u = 0; u < 8; u++) p[u] = g.p[lane < cn[u] ? cb[u] + lane : 0];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (cn[u] > 0) test(lane < cn[u], __float_as_int(p[u].w), p[u].x, p[u].y, p[u].z);
+#pragma unroll
+      for (int u = 0; u < 8; u++)  // fuller columns (a wall seen edge-on, an un-voxelised scan): the rest, 64 at a time
+        for (int t0 = 64; t0 < cn[u]; t0 += 64) {
+          const bool in = t0 + lane < cn[u];
+          const float4 pt = g.p[in ? cb[u] + t0 + lane : 0];
+          test(in, __float_as_int(pt.w), pt.x, pt.y, pt.z);
+        }
     }
   } else {
     grid_visit(g, qx, qy, qz, P.reach, 0, 1, lane, test);
@@ -1412,7 +1424,13 @@ __device__ __forceinline__ void normals_sort_store(const NormalsParams &P, const
   double key[K];
 #pragma unroll
   for (int r = 0; r < K; r++) key[r] = __longlong_as_double((long long)(lane * K + r < n ? keys[lane * K + r] : NL_PAD_KEY));
+#ifndef NL_SKIP_SORT  // (timing experiments only: profiles/r04_normals_ab.sh)
   wave_sort_regs<K>(key, lane);
+#endif
+#ifdef NL_SKIP_STORE
+  if (key[0] == 12345.0) P.count[w] = 0;
+  return;
+#endif
   float4 *col = P.lists + (size_t)(w >> 6) * NL_CAP * 64 + (w & 63);
 #pragma unroll
   for (int r0 = 0; r0 < K; r0 += 4) {  // four gathers in flight, then their four stores
@@ -1548,8 +1566,11 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
   const float4 *col = P.lists + (size_t)(w >> 6) * NL_CAP * 64 + (w & 63);  // this point's column of its block's transposed lists
   const int32_t *row = small ? nullptr : reinterpret_cast<const int32_t *>(P.arena + P.big_off[w]);  // a queued point: its index row
   for (int pass = 0; pass < 2; pass++) {
-    float4 cur[B], nxt[B];
+    // a ring of three batches: 32 list entries per lane are always on their way while 16 are summed (469 waves feed a
+    // thousand SIMDs here: one wave per SIMD at best, so the loads in flight per wave are what hides the memory latency)
+    float4 ba[B], bb[B], bc[B];
     auto fetch = [&](int t0, float4 (&v)[B]) {
+      if (t0 >= n) return;
       if (small) {
 #pragma unroll
         for (int i = 0; i < B; i++) v[i] = col[(size_t)(t0 + i < n ? t0 + i : 0) * 64];  // the wave reads 1 KB per entry: its lanes' columns are adjacent
@@ -1558,22 +1579,20 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
         for (int i = 0; i < B; i++) v[i] = P.pxyz[t0 + i < n ? row[t0 + i] : 0];
       }
     };
-    fetch(0, cur);
-    for (int t0 = 0; t0 < n; t0 += B) {
-      if (t0 + B < n) fetch(t0 + B, nxt);
+    auto consume = [&](int t0, const float4 (&v)[B]) {
       if (pass == 0) {
 #pragma unroll
         for (int i = 0; i < B; i++)
           if (t0 + i < n) {
-            c0 += (double)cur[i].x;
-            c1 += (double)cur[i].y;
-            c2 += (double)cur[i].z;
+            c0 += (double)v[i].x;
+            c1 += (double)v[i].y;
+            c2 += (double)v[i].z;
           }
       } else {
 #pragma unroll
         for (int i = 0; i < B; i++)
           if (t0 + i < n) {
-            const double d0 = (double)cur[i].x - c0, d1 = (double)cur[i].y - c1, d2 = (double)cur[i].z - c2;
+            const double d0 = (double)v[i].x - c0, d1 = (double)v[i].y - c1, d2 = (double)v[i].z - c2;
             m00 += d0 * d0;
             m10 += d1 * d0;
             m11 += d1 * d1;
@@ -1582,8 +1601,16 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
             m22 += d2 * d2;
           }
       }
-#pragma unroll
-      for (int i = 0; i < B; i++) cur[i] = nxt[i];
+    };
+    fetch(0, ba);
+    fetch(B, bb);
+    for (int t0 = 0; t0 < n; t0 += 3 * B) {
+      fetch(t0 + 2 * B, bc);
+      consume(t0, ba);
+      fetch(t0 + 3 * B, ba);
+      consume(t0 + B, bb);
+      fetch(t0 + 4 * B, bb);
+      consume(t0 + 2 * B, bc);
     }
     if (pass == 0) {
       c0 /= (double)n;
