@@ -1448,13 +1448,21 @@ __device__ __forceinline__ void normals_sort_store(const NormalsParams &P, const
 
 __global__ __launch_bounds__(64 * NL_WAVES) void normals_list_kernel(NormalsParams P) {
   __shared__ unsigned long long s_keys[NL_WAVES][NL_CAP];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // the point of this wave, told to the compiler as what it is — wave-uniform: the cell ranges, column counts and loop
+  // bounds derived from it then live in scalar registers and the visit's control flow is scalar branches (left as
+  // per-lane values they became exec-mask regions with a vmcnt(0) at every join: the loads of a column batch were waited
+  // for one by one)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int w = blockIdx.x * NL_WAVES + wv;
   if (w >= P.num_points) return;
   unsigned long long *keys = s_keys[wv];
-  const float4 q = P.grid.p[w];
+  const float4 q4 = P.grid.p[w];
+  const float qx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q4.x))),
+              qy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q4.y))),
+              qz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q4.z)));
   int n = 0;  // wave-uniform: the hits so far
-  normals_visit(P, q.x, q.y, q.z, lane, [&](bool hit, int i, float d2) {
+  normals_visit(P, qx, qy, qz, lane, [&](bool hit, int i, float d2) {
     const unsigned long long ballot = __ballot(hit);
     const int pos = n + __popcll(ballot & ((1ull << lane) - 1ull));
     if (hit && pos < NL_CAP) keys[pos] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)i;
@@ -1562,60 +1570,93 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
   // centroid: three sequential sums in neighbour order; covariance entries 00, 10, 11, 20, 21, 22 about it: six more
   double c0 = 0.0, c1 = 0.0, c2 = 0.0;
   double m00 = 0.0, m10 = 0.0, m11 = 0.0, m20 = 0.0, m21 = 0.0, m22 = 0.0;
-  const bool small = n <= NL_CAP;
   const float4 *col = P.lists + (size_t)(w >> 6) * NL_CAP * 64 + (w & 63);  // this point's column of its block's transposed lists
-  const int32_t *row = small ? nullptr : reinterpret_cast<const int32_t *>(P.arena + P.big_off[w]);  // a queued point: its index row
-  for (int pass = 0; pass < 2; pass++) {
-    // a ring of three batches: 32 list entries per lane are always on their way while 16 are summed (469 waves feed a
-    // thousand SIMDs here: one wave per SIMD at best, so the loads in flight per wave are what hides the memory latency)
+  int nmax = n;  // the longest list of this wave: the loop below is uniform, shorter lists are masked out arithmetically
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+  if (nmax <= NL_CAP) {
+    // The common case, straight-line: every lane's list is a column of the block's transposed array, so entry t of all 64
+    // points is ONE contiguous kilobyte.  Two batches of 16 entries are in flight while one is summed; nothing in the loop
+    // depends on a lane (addresses are clamped, a list that has ended adds +0.0 — exact: no sum here can be -0.0), so the
+    // loads are counted, not waited for at branch joins.
+    auto load = [&](int t0, float4 (&v)[B]) {
+#pragma unroll
+      for (int i = 0; i < B; i++) v[i] = col[(size_t)min(t0 + i, NL_CAP - 1) * 64];
+    };
     float4 ba[B], bb[B], bc[B];
-    auto fetch = [&](int t0, float4 (&v)[B]) {
-      if (t0 >= n) return;
-      if (small) {
+    {
+      auto sum = [&](int t0, const float4 (&v)[B]) {
 #pragma unroll
-        for (int i = 0; i < B; i++) v[i] = col[(size_t)(t0 + i < n ? t0 + i : 0) * 64];  // the wave reads 1 KB per entry: its lanes' columns are adjacent
-      } else {
-#pragma unroll
-        for (int i = 0; i < B; i++) v[i] = P.pxyz[t0 + i < n ? row[t0 + i] : 0];
+        for (int i = 0; i < B; i++) {
+          const bool on = t0 + i < n;
+          c0 += on ? (double)v[i].x : 0.0;
+          c1 += on ? (double)v[i].y : 0.0;
+          c2 += on ? (double)v[i].z : 0.0;
+        }
+      };
+      load(0, ba);
+      load(B, bb);
+      for (int t0 = 0; t0 < nmax; t0 += 3 * B) {
+        load(t0 + 2 * B, bc);
+        sum(t0, ba);
+        load(t0 + 3 * B, ba);
+        sum(t0 + B, bb);
+        load(t0 + 4 * B, bb);
+        sum(t0 + 2 * B, bc);
       }
-    };
-    auto consume = [&](int t0, const float4 (&v)[B]) {
-      if (pass == 0) {
-#pragma unroll
-        for (int i = 0; i < B; i++)
-          if (t0 + i < n) {
-            c0 += (double)v[i].x;
-            c1 += (double)v[i].y;
-            c2 += (double)v[i].z;
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < B; i++)
-          if (t0 + i < n) {
-            const double d0 = (double)v[i].x - c0, d1 = (double)v[i].y - c1, d2 = (double)v[i].z - c2;
-            m00 += d0 * d0;
-            m10 += d1 * d0;
-            m11 += d1 * d1;
-            m20 += d2 * d0;
-            m21 += d2 * d1;
-            m22 += d2 * d2;
-          }
-      }
-    };
-    fetch(0, ba);
-    fetch(B, bb);
-    for (int t0 = 0; t0 < n; t0 += 3 * B) {
-      fetch(t0 + 2 * B, bc);
-      consume(t0, ba);
-      fetch(t0 + 3 * B, ba);
-      consume(t0 + B, bb);
-      fetch(t0 + 4 * B, bb);
-      consume(t0 + 2 * B, bc);
     }
-    if (pass == 0) {
-      c0 /= (double)n;
-      c1 /= (double)n;
-      c2 /= (double)n;
+    c0 /= (double)n;
+    c1 /= (double)n;
+    c2 /= (double)n;
+    {
+      auto sum = [&](int t0, const float4 (&v)[B]) {
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+          const bool on = t0 + i < n;
+          const double d0 = on ? (double)v[i].x - c0 : 0.0, d1 = on ? (double)v[i].y - c1 : 0.0, d2 = on ? (double)v[i].z - c2 : 0.0;
+          m00 += d0 * d0;
+          m10 += d1 * d0;
+          m11 += d1 * d1;
+          m20 += d2 * d0;
+          m21 += d2 * d1;
+          m22 += d2 * d2;
+        }
+      };
+      load(0, ba);
+      load(B, bb);
+      for (int t0 = 0; t0 < nmax; t0 += 3 * B) {
+        load(t0 + 2 * B, bc);
+        sum(t0, ba);
+        load(t0 + 3 * B, ba);
+        sum(t0 + B, bb);
+        load(t0 + 4 * B, bb);
+        sum(t0 + 2 * B, bc);
+      }
+    }
+  } else {
+    // a wave with a queued point (more than NL_CAP neighbours): per-lane walks, each lane at its own pace
+    const bool small = n <= NL_CAP;
+    const int32_t *row = small ? nullptr : reinterpret_cast<const int32_t *>(P.arena + P.big_off[w]);
+    auto at = [&](int t) { return small ? col[(size_t)t * 64] : P.pxyz[row[t]]; };
+    for (int t = 0; t < n; t++) {
+      const float4 v = at(t);
+      c0 += (double)v.x;
+      c1 += (double)v.y;
+      c2 += (double)v.z;
+    }
+    c0 /= (double)n;
+    c1 /= (double)n;
+    c2 /= (double)n;
+    for (int t = 0; t < n; t++) {
+      const float4 v = at(t);
+      const double d0 = (double)v.x - c0, d1 = (double)v.y - c1, d2 = (double)v.z - c2;
+      m00 += d0 * d0;
+      m10 += d1 * d0;
+      m11 += d1 * d1;
+      m20 += d2 * d0;
+      m21 += d2 * d1;
+      m22 += d2 * d2;
     }
   }
   double ev[3], Q[9];
