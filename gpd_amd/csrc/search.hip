@@ -1584,56 +1584,56 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
 #pragma unroll
       for (int i = 0; i < B; i++) v[i] = col[(size_t)min(t0 + i, NL_CAP - 1) * 64];
     };
-    float4 ba[B], bb[B], bc[B];
-    {
-      auto sum = [&](int t0, const float4 (&v)[B]) {
+    // neighbouring points have neighbourhoods of similar size: up to the shortest list of the wave (rounded down to whole
+    // rounds of three batches) no entry needs a mask — the masks are two v_cndmask per double, as many instructions as the
+    // sums themselves, and this kernel is ONE wave per SIMD: its time is its instruction count
+    int nmin = n;
 #pragma unroll
-        for (int i = 0; i < B; i++) {
-          const bool on = t0 + i < n;
-          c0 += on ? (double)v[i].x : 0.0;
-          c1 += on ? (double)v[i].y : 0.0;
-          c2 += on ? (double)v[i].z : 0.0;
-        }
-      };
-      load(0, ba);
-      load(B, bb);
-      for (int t0 = 0; t0 < nmax; t0 += 3 * B) {
-        load(t0 + 2 * B, bc);
-        sum(t0, ba);
-        load(t0 + 3 * B, ba);
-        sum(t0 + B, bb);
-        load(t0 + 4 * B, bb);
-        sum(t0 + 2 * B, bc);
+    for (int o = 32; o > 0; o >>= 1) nmin = min(nmin, __shfl_xor(nmin, o));
+    const int tfull = __builtin_amdgcn_readfirstlane(nmin) / (3 * B) * (3 * B);
+    float4 ba[B], bb[B], bc[B];
+    auto sum0 = [&](int t0, const float4 (&v)[B], bool masked) {
+#pragma unroll
+      for (int i = 0; i < B; i++) {
+        const bool on = !masked || t0 + i < n;
+        c0 += on ? (double)v[i].x : 0.0;
+        c1 += on ? (double)v[i].y : 0.0;
+        c2 += on ? (double)v[i].z : 0.0;
       }
-    }
+    };
+    auto sum1 = [&](int t0, const float4 (&v)[B], bool masked) {
+#pragma unroll
+      for (int i = 0; i < B; i++) {
+        const bool on = !masked || t0 + i < n;
+        const double d0 = on ? (double)v[i].x - c0 : 0.0, d1 = on ? (double)v[i].y - c1 : 0.0, d2 = on ? (double)v[i].z - c2 : 0.0;
+        m00 += d0 * d0;
+        m10 += d1 * d0;
+        m11 += d1 * d1;
+        m20 += d2 * d0;
+        m21 += d2 * d1;
+        m22 += d2 * d2;
+      }
+    };
+#define NL_ROUND(SUM, MASKED)    \
+  load(t0 + 2 * B, bc);          \
+  SUM(t0, ba, MASKED);           \
+  load(t0 + 3 * B, ba);          \
+  SUM(t0 + B, bb, MASKED);       \
+  load(t0 + 4 * B, bb);          \
+  SUM(t0 + 2 * B, bc, MASKED);
+    load(0, ba);
+    load(B, bb);
+    int t0 = 0;
+    for (; t0 < tfull; t0 += 3 * B) { NL_ROUND(sum0, false) }
+    for (; t0 < nmax; t0 += 3 * B) { NL_ROUND(sum0, true) }
     c0 /= (double)n;
     c1 /= (double)n;
     c2 /= (double)n;
-    {
-      auto sum = [&](int t0, const float4 (&v)[B]) {
-#pragma unroll
-        for (int i = 0; i < B; i++) {
-          const bool on = t0 + i < n;
-          const double d0 = on ? (double)v[i].x - c0 : 0.0, d1 = on ? (double)v[i].y - c1 : 0.0, d2 = on ? (double)v[i].z - c2 : 0.0;
-          m00 += d0 * d0;
-          m10 += d1 * d0;
-          m11 += d1 * d1;
-          m20 += d2 * d0;
-          m21 += d2 * d1;
-          m22 += d2 * d2;
-        }
-      };
-      load(0, ba);
-      load(B, bb);
-      for (int t0 = 0; t0 < nmax; t0 += 3 * B) {
-        load(t0 + 2 * B, bc);
-        sum(t0, ba);
-        load(t0 + 3 * B, ba);
-        sum(t0 + B, bb);
-        load(t0 + 4 * B, bb);
-        sum(t0 + 2 * B, bc);
-      }
-    }
+    load(0, ba);
+    load(B, bb);
+    for (t0 = 0; t0 < tfull; t0 += 3 * B) { NL_ROUND(sum1, false) }
+    for (; t0 < nmax; t0 += 3 * B) { NL_ROUND(sum1, true) }
+#undef NL_ROUND
   } else {
     // a wave with a queued point (more than NL_CAP neighbours): per-lane walks, each lane at its own pace
     const bool small = n <= NL_CAP;
