@@ -327,7 +327,12 @@ struct ImageState {
   uint8_t *d_images_hwc = nullptr;    // [n][60][60][C], only when the caller downloads pixels
   uint32_t *d_set_bits = nullptr;     // [sets][SETWORDS] shadow voxel bitsets
   int num_shadow_sets = 0, cap_shadow_sets = 0;
-  bool wide = false, cap_wide = false;  // the shadow kernels' wide voxel windows (images.hip Vox<WIDE>), picked from the image volume
+  bool wide = false;                  // the shadow kernels' wide voxel windows (images.hip Vox<WIDE>), picked from the image volume
+  bool huge = false;                  // ... or beyond those: the general shadow kernel, a set region of run-time size
+  int set_sd = 0, set_sr = 0;         // edge / radius (voxels) of the region shadow_set_kernel fills around a sample
+  size_t cap_setwords = 0;            // words per row of d_set_bits
+  int32_t *d_overflow2 = nullptr;     // [capacity + 1]: candidates the large shadow instantiation could not list, then their count
+  char *d_huge_scratch = nullptr;     // list rows of the general shadow kernel
   int channels = 0;
   int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
   int32_t *d_pts_overflow = nullptr;  // [capacity + 1]: candidates for the large points instantiation, then their count

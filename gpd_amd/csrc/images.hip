@@ -86,6 +86,8 @@ struct ImgConsts {
   double thr[3][kImg + 1];      // thr[a][k] = smallest x with floor((x/len[a])/(1/60)) >= k
   double inv_len[3];            // RN(1/len[a]) for the division by a constant below
   int true_div;                 // 1: the host self-check of div_len failed for these extents, divide for real
+  int set_sd, set_sr;           // edge / radius of the voxel region shadow_set_kernel fills around a sample: 86 / 43, 128 / 64 (WIDE) or,
+                                // for image volumes beyond those windows, whatever the geometry needs (images_reserve)
 };
 __constant__ ImgConsts c_img;
 
@@ -109,6 +111,7 @@ struct ImgParams {
   int32_t *pts_overflow_count;
   char *pts_scratch;            // fallback instantiation: PTS_SCRATCH_BYTES per listed candidate
   int exit_after;               // profiling aid (GPD_IMG_EXIT=k): leave the kernel after phase k (0: run to the end)
+  char *huge_scratch;           // shadow_image_any_kernel: HUGE_SCRATCH_BYTES per workgroup of its grid
 };
 
 struct Box {
@@ -1083,6 +1086,229 @@ __global__ __launch_bounds__(IMG_THREADS, SHC <= SH_CAP ? 4 : 2) void shadow_ima
 }
 
 // ---------------------------------------------------------------------------
+// shadow_image_any_kernel: the shadow channels of a candidate whose box the tuned kernels above cannot take — an image
+// volume beyond their voxel windows (the host then sends EVERY candidate here), or more in-box voxels than the large
+// instantiation lists (queued by it).  The reference has no size limit (hand_set.cpp:138, image_strategy.cpp:192-233);
+// this is its device counterpart without one that matters: window edges up to 256 voxels (0.77 m), 65535 voxels in
+// the box, a set region of run-time size.  Same arithmetic and the same order as shadow_image_body — the voxel list in
+// lexicographic order, per projection a counting sort by pixel and one lane per pixel running the mean in list order —
+// with the list, its cell keys and the segment table in a scratch row in global memory and none of the register tricks.
+// A persistent launch: workgroup b takes entries b, b + grid, ... of its list.
+// ---------------------------------------------------------------------------
+constexpr int HUGE_CAP = 65535;       // in-box voxels (segment starts are 16 bits wide in the pixel table)
+constexpr int HUGE_WIN = 256;         // window edge in voxels
+constexpr size_t HUGE_SCRATCH_BYTES = (size_t)HUGE_WIN * HUGE_WIN * sizeof(int32_t) + (size_t)(HUGE_CAP + 1) * (2 * sizeof(uint32_t) + sizeof(uint16_t)) + 64;
+struct __attribute__((aligned(16))) SmemAny {
+  __attribute__((aligned(16))) float raster0[kPix];
+  __attribute__((aligned(16))) uint32_t cells[kPix];
+  uint16_t nz[kPix];
+  double thr[3][kImg + 1];
+  double recip[128];
+  float red_f[4 * IMG_WAVES];
+  int red_i[IMG_WAVES];
+  int vorg[3], wdim[3];
+  int flag;
+};
+
+__device__ void shadow_image_any_body(const ImgParams &P, SmemAny &S, const int cand, char *scratch) {
+  const ImgConsts &K = c_img;
+  const int SD = K.set_sd, SR = K.set_sr;
+  const size_t SETWORDS = (size_t)(((long long)SD * SD * SD + 31) / 32);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int set_ord = P.meta[4 * cand + 2];
+  const int set_nb = P.meta[4 * cand + 3];
+  uint8_t *out = P.images + (size_t)cand * kPix * K.C;
+  int32_t *rowtab = reinterpret_cast<int32_t *>(scratch);                              // [wx * wy]: count, then start of a window row
+  uint32_t *lin = reinterpret_cast<uint32_t *>(rowtab + HUGE_WIN * HUGE_WIN);          // [n]: ix | iy << 8 | iz << 16, ascending = lexicographic
+  uint32_t *ckey = lin + (HUGE_CAP + 1);                                               // [n]: cell x | y << 6 | z << 12
+  uint16_t *place = reinterpret_cast<uint16_t *>(ckey + (HUGE_CAP + 1));               // [n]: segment table of the counting sort
+  Box B;
+  load_box(P.hands[P.cand_hand[cand]], B);
+  for (int i = tid; i < 3 * (kImg + 1); i += IMG_THREADS) (&S.thr[0][0])[i] = (&K.thr[0][0])[i];
+  for (int i = tid; i < 128; i += IMG_THREADS) S.recip[i] = i ? 1.0 / (double)i : 0.0;
+  if (tid == 0) {
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int k = 0; k < 8; k++) {
+      const double bx = (k & 1) ? B.hi[0] : B.lo[0];
+      const double by = (k & 2) ? B.hi[1] : B.lo[1];
+      const double bz = (k & 4) ? B.hi[2] : B.lo[2];
+      for (int a = 0; a < 3; a++) {
+        const double w = B.sample[a] + B.F[3 * a] * bx + B.F[3 * a + 1] * by + B.F[3 * a + 2] * bz;
+        lo[a] = fmin(lo[a], w);
+        hi[a] = fmax(hi[a], w);
+      }
+    }
+    int bad = 0;
+    for (int a = 0; a < 3; a++) {
+      const int v0 = (int)floor(lo[a] * K.voxel_mult) - 1, v1 = (int)floor(hi[a] * K.voxel_mult) + 1;
+      const int o = (int)floor(B.sample[a] * K.voxel_mult) - SR;
+      S.vorg[a] = v0;
+      S.wdim[a] = v1 - v0 + 1;
+      // (the window's one-voxel margins may stick out of the region: they hold no voxel of the box)
+      if (v1 - v0 + 1 > HUGE_WIN || v0 + 1 < o || v1 - 1 >= o + SD) bad = 1;
+    }
+    S.flag = bad;
+  }
+  __syncthreads();
+  if (S.flag) {  // beyond even this kernel (GPD_ERR_CAPACITY, flag 1): reported, never truncated
+    if (tid == 0) atomicOr(P.status, 1);
+    return;
+  }
+  const int x0 = S.vorg[0], y0 = S.vorg[1], z0 = S.vorg[2];
+  const int wx = S.wdim[0], wy = S.wdim[1], wz = S.wdim[2];
+  const int nrows = wx * wy;
+  const int ox = (int)floor(B.sample[0] * K.voxel_mult) - SR, oy = (int)floor(B.sample[1] * K.voxel_mult) - SR,
+            oz = (int)floor(B.sample[2] * K.voxel_mult) - SR;
+  // the set voxels of window row (ix, iy) that lie in the box, in ascending z: emit(iz) for each.  A row is a run of wz bits
+  // of the set region(s) — several cameras: the intersection of their voxel sets (hand_set.cpp:159-172) — and every set bit
+  // takes the oracle's exact f64 box test
+  auto walk_row = [&](int row, auto emit) {
+    const int ix = row / wy, iy = row - ix * wy;
+    const int sx = x0 + ix - ox, sy = y0 + iy - oy;
+    if (set_ord < 0 || (unsigned)sx >= (unsigned)SD || (unsigned)sy >= (unsigned)SD) return;
+    const int zlo = z0 - oz;  // region z of window z 0
+    const int za = zlo < 0 ? 0 : zlo, zb = zlo + wz < SD ? zlo + wz : SD;
+    if (za >= zb) return;
+    const long long rowbit = ((long long)sx * SD + sy) * SD;
+    for (long long w = (rowbit + za) >> 5; w <= (rowbit + zb - 1) >> 5; w++) {
+      uint32_t bits = ~0u;
+      for (int cb = 0; cb < set_nb; cb++) bits &= P.set_bits[((size_t)set_ord + cb) * SETWORDS + (size_t)w];
+      const long long first = w << 5;  // region bit of this word's bit 0
+      if (first < rowbit + za) bits &= ~0u << (int)(rowbit + za - first);
+      if (first + 32 > rowbit + zb) bits &= ~0u >> (int)(first + 32 - (rowbit + zb));
+      while (bits) {
+        const int t = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        const int iz = (int)(first + t - rowbit) - zlo;
+        double th[3];
+        to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
+        if (in_box(B, th)) emit(iz);
+      }
+    }
+  };
+  for (int row = tid; row < nrows; row += IMG_THREADS) {
+    int cnt = 0;
+    walk_row(row, [&](int) { cnt++; });
+    rowtab[row] = cnt;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // exclusive prefix over the rows in row order: a thread sums a run of consecutive rows
+  const int per = (nrows + IMG_THREADS - 1) / IMG_THREADS;
+  int cnt = 0;
+  for (int k = 0; k < per; k++) {
+    const int row = tid * per + k;
+    if (row < nrows) cnt += rowtab[row];
+  }
+  int n_sh;
+  int pos = block_excl_scan(S, cnt, &n_sh);
+  if (n_sh > HUGE_CAP) {
+    if (tid == 0) atomicOr(P.status, 4);
+    return;
+  }
+  for (int k = 0; k < per; k++) {
+    const int row = tid * per + k;
+    if (row < nrows) {
+      const int c = rowtab[row];
+      rowtab[row] = pos;
+      pos += c;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int row = tid; row < nrows; row += IMG_THREADS) {
+    int at = rowtab[row];
+    const int ix = row / wy, iy = row - ix * wy;
+    walk_row(row, [&](int iz) {
+      double th[3];
+      to_hand(B, (double)(ix + x0) * K.voxel, (double)(iy + y0) * K.voxel, (double)(iz + z0) * K.voxel, th);
+      lin[at] = (uint32_t)ix | ((uint32_t)iy << 8) | ((uint32_t)iz << 16);
+      ckey[at] = cells_of(S, B, th);
+      at++;
+    });
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int ns = n_sh;
+  for (int pr = 0; pr < 3; pr++) {
+    for (int c = tid; c < kPix; c += IMG_THREADS) S.cells[c] = 0u;
+    __syncthreads();
+    for (int k = tid; k < ns; k += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(ckey[k], pr)], 1u);
+    __syncthreads();
+    scan_cells(S);
+    for (int k = tid; k < ns; k += IMG_THREADS) {
+      const uint32_t old = atomicAdd(&S.cells[cell_of_key(ckey[k], pr)], 1u);
+      place[(old >> 16) + (old & 0xffffu)] = (uint16_t)k;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int da = depth_axis(pr);
+    const double Fd0 = da == 0 ? B.F[0] : (da == 1 ? B.F[1] : B.F[2]);
+    const double Fd1 = da == 0 ? B.F[3] : (da == 1 ? B.F[4] : B.F[5]);
+    const double Fd2 = da == 0 ? B.F[6] : (da == 1 ? B.F[7] : B.F[8]);
+    const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
+    float lmax = -FLT_MAX;
+    int lany = 0;
+    const int n_nz = list_nonempty_cells(S, S.nz);
+    for (int c = tid; c < kPix; c += IMG_THREADS) S.raster0[c] = 0.f;
+    __syncthreads();
+    for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
+      const int c = S.nz[qn];
+      const uint32_t w = S.cells[c];
+      const int cn = (int)(w & 0xffffu), start = (int)(w >> 16);
+      float v = 0.f, fc = 0.f;
+      // the segment holds list positions in arrival order: ascending position = ascending voxel (the std::set order of the oracle)
+      sort_u16(&place[start], cn);
+      for (int e = 0; e < cn; e++) {
+        const uint32_t lp = lin[place[start + e]];
+        const int ix = lp & 255, iy = (lp >> 8) & 255, iz = lp >> 16;
+        const double c0 = (double)(ix + x0) * K.voxel - B.sample[0], c1 = (double)(iy + y0) * K.voxel - B.sample[1],
+                     c2 = (double)(iz + z0) * K.voxel - B.sample[2];
+        const double td = Fd0 * c0 + Fd1 * c1 + Fd2 * c2;
+        const double d = div_len(td - offd, da);
+        fc = (float)((double)fc + 1.0);
+        v = (float)((double)v + (d - (double)v) * recip_count<128>(S.recip, fc));
+      }
+      lmax = fmaxf(lmax, v);
+      lany = 1;
+      S.raster0[c] = v;
+    }
+    __syncthreads();
+    lmax = wave_max_f32(lmax);
+    lany = __ballot(lany != 0) != 0ull;
+    if (lane == 0) {
+      S.red_f[tid >> 6] = lmax;
+      S.red_i[tid >> 6] = lany;
+    }
+    __syncthreads();
+    float gmax = -FLT_MAX;
+    int gany = 0;
+    for (int w = 0; w < IMG_WAVES; w++) {
+      gmax = fmaxf(gmax, S.red_f[w]);
+      gany |= S.red_i[w];
+    }
+    // minMaxLoc with mask -> max (0 if the mask is empty); image = max_img - image
+    const double mxd = gany ? (double)gmax : 0.0;
+    const float mxf = (float)mxd;
+    __syncthreads();  // red_f is rewritten by finalize_planes
+    for (int c = tid; c < kPix; c += IMG_THREADS) S.raster0[c] = ((S.cells[c] & 0xffffu) ? mxf : 0.0f) - S.raster0[c];
+    __syncthreads();
+    finalize_planes<1>(S, &S.raster0[0], nullptr, out + (size_t)(pr * K.per + 4) * kPix);
+  }
+}
+
+__global__ __launch_bounds__(IMG_THREADS) void shadow_image_any_kernel(ImgParams P) {
+  __shared__ SmemAny S;
+  char *scratch = P.huge_scratch + (size_t)blockIdx.x * HUGE_SCRATCH_BYTES;
+  const int count = P.cand_list ? *P.cand_count : P.num_cand;
+  for (int q = blockIdx.x; q < count; q += gridDim.x) {
+    __syncthreads();  // the previous candidate's LDS is dead
+    shadow_image_any_body(P, S, P.cand_list ? P.cand_list[q] : q, scratch);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // grasp_image_kernel: normals (3) and depth (1) channels per projection of one candidate
 // (createNormalsImage / createDepthImage, image_strategy.cpp:124-190).
 // ---------------------------------------------------------------------------
@@ -1500,13 +1726,16 @@ struct SetParams {
                                     // with different cameras run side by side)
 };
 
-template <bool WIDE>
+// MODE 0: the default region (86^3 bits, built in LDS, written out once); 1: WIDE (128^3 bits = 256 KB: straight into the
+// set's global row, which the host has cleared); 2: a region of run-time size (c_img.set_sd), also straight into global memory —
+// image volumes of any size the general shadow kernel below takes
+template <int MODE>
 __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
-  constexpr int SD = Vox<WIDE>::SD, SR = Vox<WIDE>::SR, SETWORDS = Vox<WIDE>::SETWORDS;
-  // default: the region's bitset is built in LDS and written out once; WIDE (128^3 bits = 256 KB): straight into the
-  // set's global row, which the host has cleared
-  __shared__ uint32_t lds_bits[WIDE ? 1 : SETWORDS];
+  constexpr bool WIDE = MODE != 0;
   const ImgConsts &K = c_img;
+  const int SD = MODE == 2 ? K.set_sd : Vox<MODE == 1>::SD, SR = MODE == 2 ? K.set_sr : Vox<MODE == 1>::SR;
+  const int SETWORDS = MODE == 2 ? (int)(((long long)SD * SD * SD + 31) / 32) : Vox<MODE == 1>::SETWORDS;
+  __shared__ uint32_t lds_bits[WIDE ? 1 : Vox<false>::SETWORDS];
   const int set = blockIdx.x;
   const int tid = threadIdx.x;
   const int slot_s = P.set_meta[8 * set + 0];
@@ -1620,7 +1849,7 @@ void image_cell_thresholds(double len, double *out) {
 }
 
 void images_free(ImageState &im) {
-  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_status, im.d_set_bits, im.d_overflow, im.d_pts_overflow, im.d_pts_scratch};
+  void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_status, im.d_set_bits, im.d_overflow, im.d_overflow2, im.d_pts_overflow, im.d_pts_scratch, im.d_huge_scratch};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (im.ev_fork) (void)hipEventDestroy(im.ev_fork);
@@ -1639,10 +1868,11 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
   }
   if (n > im.capacity) {
     note_alloc();
-    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_overflow, im.d_pts_overflow};
+    void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_overflow, im.d_overflow2, im.d_pts_overflow};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
     im.d_overflow = nullptr;
+    im.d_overflow2 = nullptr;
     im.d_pts_overflow = nullptr;
     im.d_images = nullptr;
     im.d_images_hwc = nullptr;
@@ -1650,6 +1880,7 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
     const int cap = n + n / 4;  // slack: the clouds of a batch differ a little
     HIP_RET(hipMalloc(&im.d_images, (size_t)cap * kPix * C));
     HIP_RET(hipMalloc(&im.d_overflow, (size_t)(cap + 1) * sizeof(int32_t)));  // list + its counter
+    HIP_RET(hipMalloc(&im.d_overflow2, (size_t)(cap + 1) * sizeof(int32_t)));  // ... of the large instantiation, for the general kernel
     HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)(cap + 1) * sizeof(int32_t)));
     im.capacity = cap;
   }
@@ -1663,18 +1894,41 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
     const double rx = std::fmax(p.hand_depth - p.init_bite, p.volume_depth);
     const double ry = 0.5 * (p.hand_outer_diameter - p.finger_width) + 0.5 * p.volume_width;
     const double reach = std::sqrt(rx * rx + ry * ry + p.volume_height * p.volume_height);
-    im.wide = std::ceil(diag / vox) + 3.0 > (double)Vox<false>::VD || std::ceil(reach / vox) + 1.0 > (double)(Vox<false>::SR - 1);
+    const double need_win = std::ceil(diag / vox) + 3.0, need_reach = std::ceil(reach / vox) + 1.0;
+    im.wide = need_win > (double)Vox<false>::VD || need_reach > (double)(Vox<false>::SR - 1);
+    // beyond the wide windows as well: the general shadow kernel with a set region of the size this geometry needs
+    // (the reference has no limit, hand_set.cpp:138; what is left of ours: 256 voxels = 0.77 m of window edge, 65535 voxels in a box)
+    im.huge = need_win > (double)Vox<true>::VD || need_reach > (double)(Vox<true>::SR - 1);
+    if (im.huge) {
+      if (need_reach + 2.0 > 640.0) {  // 1280^3 bits = 262 MB per hand set and camera: an image volume of metres is a mistake, not a gripper
+        set_error("images: an image volume with %.2f m of reach is beyond the shadow region this library allocates", reach);
+        return GPD_ERR_CAPACITY;
+      }
+      im.set_sr = (int)need_reach + 2;
+      im.set_sd = 2 * im.set_sr;
+    } else {
+      im.set_sr = im.wide ? Vox<true>::SR : Vox<false>::SR;
+      im.set_sd = im.wide ? Vox<true>::SD : Vox<false>::SD;
+    }
   }
-  if (C == 15 && (shadow_sets > im.cap_shadow_sets || (im.wide && !im.cap_wide))) {
+  const size_t setwords = (size_t)(((long long)im.set_sd * im.set_sd * im.set_sd + 31) / 32);
+  if (C == 15 && (shadow_sets > im.cap_shadow_sets || setwords > im.cap_setwords)) {
     note_alloc();
     if (im.d_set_bits) (void)hipFree(im.d_set_bits);
     im.d_set_bits = nullptr;
     im.cap_shadow_sets = 0;
     const int want = shadow_sets > im.cap_shadow_sets ? shadow_sets : im.cap_shadow_sets;
     const int cap = want + want / 4;
-    HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * (im.wide ? Vox<true>::SETWORDS : Vox<false>::SETWORDS) * sizeof(uint32_t)));
+    const size_t words = setwords > im.cap_setwords ? setwords : im.cap_setwords;
+    HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * words * sizeof(uint32_t)));
     im.cap_shadow_sets = cap;
-    im.cap_wide = im.wide;  // (a wide allocation also serves the default windows)
+    im.cap_setwords = words;  // (a larger row also serves the smaller regions)
+  }
+  if (C == 15 && (im.wide || im.huge) && !im.d_huge_scratch) {
+    // the general shadow kernel's list rows, one per workgroup of its persistent grid; the default geometry cannot reach it
+    // (its box holds fewer voxel cells than the large instantiation lists)
+    note_alloc();
+    HIP_RET(hipMalloc(&im.d_huge_scratch, (size_t)LGRID * HUGE_SCRATCH_BYTES));
   }
   return GPD_OK;
 }
@@ -1719,6 +1973,8 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
   k.len[1] = k.vol_width;
   k.len[2] = k.dbl_h;
   k.true_div = 0;
+  k.set_sd = im.set_sd;
+  k.set_sr = im.set_sr;
   {
     // thresholds and the div_len() self-check depend on the box extents only: computed once per
     // geometry (the self-check alone is ~2 ms of host time)
@@ -1877,11 +2133,15 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     sp.set_meta = pl.d_set_meta;
     sp.set_bits = im.d_set_bits;
     std::memcpy(sp.view_point, im.view_points, sizeof(sp.view_point));
-    if (im.wide) {
+    if (im.huge) {
+      const size_t setwords = (size_t)(((long long)im.set_sd * im.set_sd * im.set_sd + 31) / 32);
+      HIP_RET(hipMemsetAsync(im.d_set_bits, 0, (size_t)im.num_shadow_sets * setwords * sizeof(uint32_t), stream));
+      shadow_set_kernel<2><<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
+    } else if (im.wide) {
       HIP_RET(hipMemsetAsync(im.d_set_bits, 0, (size_t)im.num_shadow_sets * Vox<true>::SETWORDS * sizeof(uint32_t), stream));
-      shadow_set_kernel<true><<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
+      shadow_set_kernel<1><<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
     } else {
-      shadow_set_kernel<false><<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
+      shadow_set_kernel<0><<<im.num_shadow_sets, SET_THREADS, 0, stream>>>(sp);
     }
     HIP_RET(hipGetLastError());
   }
@@ -1899,10 +2159,29 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     ib.cand_count = im.d_overflow + im.capacity;
     ib.overflow_list = nullptr;
     ib.overflow_count = nullptr;
-    if (im.wide) {
+    if (im.huge) {
+      // an image volume beyond the windows of the tuned kernels: every candidate through the general one
+      ImgParams ia = ip;
+      ia.overflow_list = nullptr;
+      ia.overflow_count = nullptr;
+      ia.huge_scratch = im.d_huge_scratch;
+      shadow_image_any_kernel<<<LGRID, IMG_THREADS, 0, stream>>>(ia);
+    } else if (im.wide) {
+      // a wide box can hold more voxels than the large instantiation lists: it queues those for the general kernel
+      HIP_RET(hipMemsetAsync(im.d_overflow2 + im.capacity, 0, sizeof(int32_t), stream));
+      ib.overflow_list = im.d_overflow2;
+      ib.overflow_count = im.d_overflow2 + im.capacity;
       shadow_image_kernel<SH_CAP, true><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
       HIP_RET(hipGetLastError());
       shadow_image_kernel<SH_CAP_BIG, true><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
+      HIP_RET(hipGetLastError());
+      ImgParams ia = ip;
+      ia.cand_list = im.d_overflow2;
+      ia.cand_count = im.d_overflow2 + im.capacity;
+      ia.overflow_list = nullptr;
+      ia.overflow_count = nullptr;
+      ia.huge_scratch = im.d_huge_scratch;
+      shadow_image_any_kernel<<<LGRID, IMG_THREADS, 0, stream>>>(ia);
     } else {
       shadow_image_kernel<SH_CAP, false><<<8 * ((n + 7) / 8), IMG_THREADS, lds_pad, stream>>>(ip);
       HIP_RET(hipGetLastError());
@@ -1932,8 +2211,8 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
 
 // text of the capacity flags an image kernel left in d_status
 void images_status_text(int status, char *buf, size_t len) {
-  snprintf(buf, len, "images: kernel capacity exceeded (flags %d: 1 voxel AABB, 2 in-box points > %d, 4 shadow voxels > %d)", status,
-           PT_CAP_BIG, SH_CAP_BIG);
+  snprintf(buf, len, "images: kernel capacity exceeded (flags %d: 1 image box beyond %d voxels of window edge, 2 in-box points > %d, "
+           "4 shadow voxels in a box > %d)", status, HUGE_WIN, PT_CAP_BIG, HUGE_CAP);
 }
 
 }  // namespace gpd

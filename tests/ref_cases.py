@@ -72,6 +72,7 @@ VARIANTS = {
     "deep_hand": (15, dict(hand_depth=0.08), 1),
     "other_image_volume": (15, dict(volume_width=0.08, volume_depth=0.05, volume_height=0.03), 1),
     "wide_image_volume": (15, dict(volume_width=0.16), 1),  # beyond the default voxel windows of the shadow kernels (Vox<WIDE>)
+    "huge_image_volume": (15, dict(volume_width=0.16, volume_depth=0.10), 1),  # beyond the wide windows too: the general shadow kernel
     "friction_viable_aperture": (15, dict(friction_coeff=35.0, min_viable=2, min_aperture=0.02, max_aperture=0.07), 1),
     "tight_workspace": (15, dict(workspace_grasps=[-0.1, 0.1, -0.1, 0.12, -1.0, 1.0]), 1),
     "frame_radius": (15, dict(nn_radius_frames=0.02), 1),

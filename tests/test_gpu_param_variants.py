@@ -35,6 +35,7 @@ VARIANTS = {
     "small_hand": dict(hand_outer_diameter=0.09, hand_depth=0.045, hand_height=0.015, init_bite=0.008),
     "other_image_volume": dict(volume_width=0.08, volume_depth=0.05, volume_height=0.03),
     "wide_image_volume": dict(volume_width=0.16),  # box diagonal 0.176 m: the 64^3 / 128^3 voxel windows (images.hip Vox<WIDE>)
+    "huge_image_volume": dict(volume_width=0.16, volume_depth=0.10),  # box diagonal 0.193 m: beyond the 64-voxel windows, the general shadow kernel
     "friction_viable_aperture": dict(friction_coeff=35.0, min_viable=2, min_aperture=0.02, max_aperture=0.07),
     "tight_workspace": dict(workspace_grasps=[-0.1, 0.1, -0.1, 0.12, -1.0, 1.0]),
     "frame_radius": dict(nn_radius_frames=0.02),
@@ -73,14 +74,14 @@ def test_detect_matches_oracle_under_parameter_variant(oracle_mod, name):
 
 
 @pytest.mark.gpu
-def test_oversized_image_volume_is_refused_not_truncated(oracle_mod):
-    """An image volume whose box does not fit even the wide voxel window of the shadow kernel (64^3 voxels of 3 mm: box
-    diagonals up to ~0.18 m) must come back as GPD_ERR_CAPACITY — the kernel would otherwise lose shadow voxels without
-    a trace.  Volumes that fit the default (46^3) or the wide windows are computed and match the oracle
-    (`other_image_volume`, `wide_image_volume` above)."""
+def test_image_volume_beyond_every_window_is_refused_not_truncated(oracle_mod):
+    """The reference has no limit on the image volume (hand_set.cpp:138).  The tuned shadow kernels take boxes up to
+    ~0.18 m of diagonal, the general one (`huge_image_volume` above: 0.16 x 0.10 m, parity with the oracle and with the
+    reference's own code) windows of 256 voxels = 0.77 m; an image volume beyond THAT must come back as GPD_ERR_CAPACITY —
+    never as images that silently lost shadow voxels."""
     cl = synth.make_cloud(4242, 20000)
     si = synth.sample_indices(cl, 40)
-    gp = _set(api.default_params(15), volume_width=0.16, volume_depth=0.10)
+    gp = _set(api.default_params(15), volume_width=0.70, volume_depth=0.40)
     ctx = api.Context(gp)
     try:
         ctx.set_lenet_weights(_weights(15))
