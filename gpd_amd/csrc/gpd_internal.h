@@ -113,8 +113,10 @@ int cluster_run(ClusterState &s, const gpd_hand *hands, const double *scores, in
 // cameras of a cloud: the kernels carry "which cameras see this neighbourhood" as a 32-bit mask and the view points
 // as a kernel argument (768 bytes)
 constexpr int kMaxCams = 32;
-// largest neighbourhood the search handles: hand_eval_kernel keeps neighbour ranks in 16 bits
-constexpr int kNnCapMax = 65535;
+// largest neighbourhood the search lists per sample (the reference has no limit, hand_search.cpp:178; ours is a matter of
+// memory: 44 bytes per list entry and sample).  Beyond 65535 entries hand_eval_kernel walks the full list instead of its
+// LDS table, whose neighbour ranks are 16 bits wide.
+constexpr int kNnCapMax = (1 << 20) - 1;
 // scratch of Cloud::calculateNormals on the device (search.hip normals_run): per-point neighbour lists in one array
 struct NormalsScratch {
   int cap_points = 0;

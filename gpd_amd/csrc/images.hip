@@ -57,7 +57,7 @@ constexpr int SET_THREADS = 1024;  // shadow_set_kernel
 constexpr int IMG_WAVES = IMG_THREADS / 64;
 constexpr int PT_CAP = 1024;  // in-box points per candidate on the two-per-CU instantiation (mean ~380 on the 3 mm benchmark clouds; entry
                               // indices are packed into 11 bits of the segment words); fuller boxes go to the large instantiation
-constexpr int PT_CAP_BIG = 16384;  // fallback instantiation of the points kernel: storage in a global scratch row
+constexpr int PT_CAP_BIG = 32768;  // fallback instantiation of the points kernel: storage in a global scratch row (its segment table, 64 KB, is what fills the CU's LDS)
 constexpr int SH_CAP = 6144;      // in-box shadow voxels per candidate (two workgroups per CU)
 constexpr int SH_CAP_BIG = 12288;  // fallback instantiation, one workgroup per CU
 // Voxel windows of the shadow kernels.  Default geometry (image box diagonal 0.1233 m, every box of a hand set within

@@ -2258,7 +2258,7 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
     atomicAdd(&P.dbg[8], (unsigned long long)N);
     atomicAdd(&P.dbg[9], (unsigned long long)k);
   }
-  if (k <= HE_COMPACT) {
+  if (k <= HE_COMPACT && N <= 65535) {  // (the table's neighbour ranks are 16 bits wide: a longer list is walked in full)
     L.ct0 = s_t0;
     L.ct1 = s_t1;
     L.ce = s_e;
@@ -2397,6 +2397,17 @@ void search_free(SearchState &s) {
 static int search_reserve(SearchState &s, int S, int cap, int slots) {
   if (S <= s.capacity_samples && cap == s.nn_cap) return GPD_OK;
   const int newS = S > s.capacity_samples ? S + S / 8 : s.capacity_samples;  // slack: the clouds of a batch differ a little
+  {
+    // 44 bytes per list entry and sample (gathered rows, index scratch, height list): with the large lists of a dense
+    // scan that is what bounds a call, and it should say so rather than fail inside hipMalloc
+    size_t free_b = 0, total_b = 0;
+    const size_t want = (size_t)newS * (size_t)cap * 44u;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want > free_b + (size_t)s.capacity_samples * (size_t)s.nn_cap * 44u) {
+      set_error("search: %d samples with neighbourhood lists of %d entries need %.1f GB of device memory (%.1f GB free): pass fewer samples per call",
+                newS, cap, want / 1e9, free_b / 1e9);
+      return GPD_ERR_CAPACITY;
+    }
+  }
   note_alloc();
   search_free(s);
   HIP_RET(hipMalloc(&s.d_sample_idx, (size_t)newS * sizeof(int32_t)));

@@ -560,3 +560,42 @@ def test_normals_of_neighbourhoods_beyond_every_lds_capacity(oracle_mod):
         assert np.array_equal(got2, oracle_mod.estimate_normals(xyz, cam, vp, 0.02))
     finally:
         ctx.close()
+
+
+def test_neighbourhoods_beyond_65535_points(oracle_mod):
+    """hand_search.cpp:178 takes whatever radiusSearch returns.  Sixteen times the density of the 3 mm benchmark cloud:
+    0.11 m neighbourhoods of 70-100 thousand points — beyond the 16-bit neighbour ranks of hand_eval_kernel's LDS table
+    (it walks the full list then), global-memory lists of > 65535 entries, image boxes with ten to twenty thousand points
+    (the large points kernel, 32768 entries) — records, images and scores against the oracle."""
+    cl = synth.make_cloud(1234, 30000)
+    rng = np.random.RandomState(6)
+    parts = [cl["xyz"]] + [(cl["xyz"] + rng.uniform(-0.0013, 0.0013, cl["xyz"].shape)).astype(np.float32) for _ in range(15)]
+    xyz = np.concatenate(parts)
+    nrm = np.concatenate([cl["normals"]] * 16)
+    cam = np.ones((1, len(xyz)), np.int32)
+    obj = np.flatnonzero(cl["is_object"])
+    si = obj[np.random.RandomState(10).choice(len(obj), 6, replace=False)].astype(np.int32)
+    from scipy.spatial import cKDTree
+    t = cKDTree(xyz.astype(np.float64))
+    sizes = [len(x) for x in t.query_ball_point(xyz[si].astype(np.float64), 0.11)]
+    assert max(sizes) > 65535 + 2000, max(sizes)
+    w = _weights(15)
+    p = oracle_mod.default_params(15)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(xyz, nrm, cam, cl["view_points"])
+        hands, n_cand = ctx.detect(si)
+        ohands, on_cand, _ = oracle_mod.detect(p, xyz, nrm, cam, cl["view_points"], si, w)
+        assert n_cand == on_cand and n_cand > 6
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes()
+        fw = oracle_mod.filter_workspace(p, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(p, xyz, nrm, cam, cl["view_points"], fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
+    finally:
+        ctx.close()
