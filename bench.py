@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # f32 vector == f32-input MFMA peak
 LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk (ds_read_b32 rate; 256 B/clk for b64/b128) x 2.4 GHz (MI355X_MICROARCH.md §LDS)
 LENET_MFLOP = {15: 83.04, 12: 73.63, 3: 45.41, 1: 39.14}  # SURVEY.md §8d (+ the 1-channel strategy)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
-SQ_FILE = os.path.join(ROOT, "profiles", "r03_pmc_sq.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+SQ_FILE = os.path.join(ROOT, "profiles", "r04_pmc_sq.json")
 KERNEL_SOURCES = ("gpd_amd/csrc/lenet.hip", "gpd_amd/csrc/images.hip", "gpd_amd/csrc/search.hip")
 
 CONFIGS = {  # BASELINE.json configs[1..3]
@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the barrier / reductions")
     ap.add_argument("--live-pmc", dest="live_pmc", action="store_true", default=None,
                     help="measure roofline.traffic / pmc_traffic here (two rocprofv3 --pmc child runs of this file after the timed region, "
-                         "~20 s) instead of reading profiles/r03_traffic.json; default: on for the default line on one GPU, unless this "
+                         "~20 s) instead of reading profiles/r04_traffic.json; default: on for the default line on one GPU, unless this "
                          "process is itself being profiled")
     ap.add_argument("--no-live-pmc", dest="live_pmc", action="store_false")
     args = ap.parse_args()
@@ -566,10 +566,10 @@ def _fc1_tile(n):
 
 
 def _live_pmc_kernels():
-    """--live-pmc: the two PMC passes of profiles/collect_r03.sh run from inside this process, on this box — `rocprofv3 --pmc
+    """--live-pmc: the two PMC passes of profiles/collect_r04.sh run from inside this process, on this box — `rocprofv3 --pmc
     FETCH_SIZE` and `--pmc WRITE_SIZE` (counters only, their own runs) around a short child run of this file — and reduced as
     profiles/summarize.py --traffic does (KiB per launch; reads x2 per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
-    Returns the per-kernel dict of profiles/r03_traffic.json, or None when rocprofv3 is missing / a pass fails."""
+    Returns the per-kernel dict of profiles/r04_traffic.json, or None when rocprofv3 is missing / a pass fails."""
     import glob
     import shutil
     import sqlite3
@@ -612,8 +612,8 @@ def _live_pmc_kernels():
 
 
 def _pmc_traffic(n_images, channels=15, live=False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json, produced by
-    profiles/collect_r03.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_traffic.json, produced by
+    profiles/collect_r04.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
     on: when a kernel file has changed since, the numbers are stale and dropped.  live (--live-pmc): measured here and now
     instead (_live_pmc_kernels), the file's figures next to them."""
     if channels != 15 or n_images != 5000:
@@ -638,7 +638,7 @@ def _pmc_traffic(n_images, channels=15, live=False):
         return {"note": "no PMC traffic file"}
     if filed is None:
         return {"note": "%s was measured on other kernel sources: stale, not reported" % os.path.relpath(TRAFFIC_FILE, ROOT)}
-    return _traffic_totals(filed, n_images, "profiles/r03_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; "
+    return _traffic_totals(filed, n_images, "profiles/r04_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; "
                            "reads x2 per the gfx950 note; same kernel sources as this run, by SHA-1)")
 
 
@@ -661,13 +661,13 @@ def _traffic_totals(d, n_images, source):
 
 def _pmc_sq():
     """LDS-array utilisation of the image kernels from the committed SQ-counter pass (profiles/pmc_sq.sh ->
-    profiles/r03_pmc_sq.json), dropped like the traffic numbers when the kernel sources have changed since."""
+    profiles/r04_pmc_sq.json), dropped like the traffic numbers when the kernel sources have changed since."""
     if not os.path.exists(SQ_FILE):
         return None
     d = json.load(open(SQ_FILE))
     if d.get("source_hashes") != source_hashes():
         return None
-    out = {"source": "profiles/r03_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
+    out = {"source": "profiles/r04_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
            "peak": "256 B/clk/CU = %.1f TB/s at 2.4 GHz" % (LDS_PEAK_GBS * 2 / 1e3)}
     for k, v in d["kernels"].items():
         for name in ("shadow_image_kernel<6144", "grasp_image_kernel<false>", "shadow_set_kernel"):

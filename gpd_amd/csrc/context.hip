@@ -543,11 +543,11 @@ int gpd_hip_create(int device, const gpd_params *params, gpd_hip_ctx **out) {
       set_error("gpd_hip_create: hand_outer_diameter must exceed finger_width");
       return GPD_ERR_INVALID;
     }
-    // deepenHand's steps (finger_hand.cpp:116-121) are evaluated all at once from a 32-entry table
+    // deepenHand's steps (finger_hand.cpp:116-121) come from a 128-entry table (fingers up to init_bite + 0.64 m)
     int steps = 0;
-    for (double d = params->init_bite + 0.005; d <= params->hand_depth && steps <= 32; d += 0.005) steps++;
-    if (params->deepen_hand && steps > 32) {
-      set_error("gpd_hip_create: hand_depth %.3f needs more than 32 deepening steps of 5 mm from init_bite %.3f", params->hand_depth,
+    for (double d = params->init_bite + 0.005; d <= params->hand_depth && steps <= 128; d += 0.005) steps++;
+    if (params->deepen_hand && steps > 128) {
+      set_error("gpd_hip_create: hand_depth %.3f needs more than 128 deepening steps of 5 mm from init_bite %.3f", params->hand_depth,
                 params->init_bite);
       return GPD_ERR_CAPACITY;
     }

@@ -366,7 +366,7 @@ struct HostConsts {
   double rot[GPD_MAX_SLOTS][9];  // Ry(pi) * R_axis(angle) factors: see host_math.cpp
   double rot_binormal[9];        // AngleAxisd(pi, UnitY)
   double finger_spacing[32];     // 2 * num_finger_placements
-  double deepen_depths[32];
+  double deepen_depths[128];
   int num_deepen;
   double cos_friction;
   double nn_radius_hands, nn_radius_images;

@@ -49,7 +49,7 @@ void host_consts(const gpd_params &p, HostConsts &h) {
   }
   // finger_hand.cpp:116-121: for (d = min + 0.005; d <= max; d += 0.005)
   h.num_deepen = 0;
-  for (double d = p.init_bite + 0.005; d <= p.hand_depth && h.num_deepen < 32; d += 0.005) h.deepen_depths[h.num_deepen++] = d;
+  for (double d = p.init_bite + 0.005; d <= p.hand_depth && h.num_deepen < 128; d += 0.005) h.deepen_depths[h.num_deepen++] = d;
   h.cos_friction = std::cos(p.friction_coeff * M_PI / 180.0);  // antipodal.cpp:30
   // hand_search.cpp:10-17, image_generator.cpp:43-46
   h.nn_radius_hands = std::fmax(std::fmax(p.hand_outer_diameter - p.finger_width, p.hand_depth), p.hand_height / 2.0);

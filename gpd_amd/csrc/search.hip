@@ -1802,7 +1802,7 @@ struct HandConsts {
   // by 1 % — a superset; the exact comparisons decide
   uint32_t slot_lut[256];
   double lut_base, lut_inv;
-  double depths[32];
+  double depths[128];  // deepenHand's steps (finger_hand.cpp:116-121), evaluated 32 at a time
   int num_deepen;
   int nfp;  // num_finger_placements
   int slots;
@@ -2309,30 +2309,38 @@ __global__ __launch_bounds__(256) void hand_eval_kernel(HandParams P) {
         seen++;
       }
     if (K.deepen) {
-      // ---- pass 2: deepenHand (finger_hand.cpp:107-139) for all depths at once
-      unsigned m_any = 0, m_back = 0, m_blk = 0;
+      // ---- pass 2: deepenHand (finger_hand.cpp:107-139), 32 depths at once (the shipped geometry has ten; a longer
+      //      finger simply takes another round of the loop — the reference has no bound on hand_depth)
       const double sl = K.spacing[mid], sr = K.spacing[nfp + mid];
-      for_each_entry(L, [&](double t0, double t1, int, int) {
-        const bool blk = (t1 > sl && t1 < sl + K.fw) || (t1 > sr && t1 < sr + K.fw);
-        for (int j = 0; j < K.num_deepen; j++) {
-          const double d = K.depths[j];
-          if (t0 < d) {
-            m_any |= 1u << j;
-            if (t0 < d - K.hand_depth) m_back |= 1u << j;
-            if (blk) m_blk |= 1u << j;
+      bool deeper = true;
+      for (int j0 = 0; j0 < K.num_deepen && deeper; j0 += 32) {
+        const int nj = min(32, K.num_deepen - j0);
+        unsigned m_any = 0, m_back = 0, m_blk = 0;
+        for_each_entry(L, [&](double t0, double t1, int, int) {
+          const bool blk = (t1 > sl && t1 < sl + K.fw) || (t1 > sr && t1 < sr + K.fw);
+          for (int j = 0; j < nj; j++) {
+            const double d = K.depths[j0 + j];
+            if (t0 < d) {
+              m_any |= 1u << j;
+              if (t0 < d - K.hand_depth) m_back |= 1u << j;
+              if (blk) m_blk |= 1u << j;
+            }
           }
+        });
+        m_any = block_or(m_any, s_u);
+        m_back = block_or(m_back, s_u);
+        m_blk = block_or(m_blk, s_u);
+        for (int j = 0; j < nj; j++) {
+          const bool ok = (m_any >> j & 1u) && !(m_back >> j & 1u) && !(m_blk >> j & 1u);
+          if (!ok) {
+            deeper = false;
+            break;
+          }
+          top = K.depths[j0 + j];
+          bottom = K.depths[j0 + j] - K.hand_depth;
         }
-      });
-      m_any = block_or(m_any, s_u);
-      m_back = block_or(m_back, s_u);
-      m_blk = block_or(m_blk, s_u);
-      HTICK(2);
-      for (int j = 0; j < K.num_deepen; j++) {
-        const bool ok = (m_any >> j & 1u) && !(m_back >> j & 1u) && !(m_blk >> j & 1u);
-        if (!ok) break;
-        top = K.depths[j];
-        bottom = K.depths[j] - K.hand_depth;
       }
+      HTICK(2);
       hand = 1u << mid;
     }
     // ---- pass 3-5: closing region, width, antipodal label

@@ -36,6 +36,7 @@ VARIANTS = {
     "other_image_volume": dict(volume_width=0.08, volume_depth=0.05, volume_height=0.03),
     "wide_image_volume": dict(volume_width=0.16),  # box diagonal 0.176 m: the 64^3 / 128^3 voxel windows (images.hip Vox<WIDE>)
     "huge_image_volume": dict(volume_width=0.16, volume_depth=0.10),  # box diagonal 0.193 m: beyond the 64-voxel windows, the general shadow kernel
+    "long_fingers": dict(hand_depth=0.20),  # 38 deepening steps (two rounds of 32), 0.2 m hand neighbourhoods
     "friction_viable_aperture": dict(friction_coeff=35.0, min_viable=2, min_aperture=0.02, max_aperture=0.07),
     "tight_workspace": dict(workspace_grasps=[-0.1, 0.1, -0.1, 0.12, -1.0, 1.0]),
     "frame_radius": dict(nn_radius_frames=0.02),

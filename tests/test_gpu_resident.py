@@ -267,7 +267,7 @@ def test_detect_batch_reports_a_bad_cloud(ctx, cloud30k):
 
 def test_create_rejects_bad_parameters():
     for field, value in (("hand_axes", 3), ("volume_width", 0.0), ("hand_depth", -0.06), ("finger_width", float("nan")),
-                         ("hand_depth", 0.5)):
+                         ("hand_depth", 0.9)):  # 178 deepening steps: beyond the 128-entry table
         p = api.default_params(15)
         if field == "hand_axes":
             p.hand_axes[0] = value
