@@ -329,18 +329,13 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
                                                                 float *__restrict__ flat, int n) {
   // one array: reads one step past the image / the weights (operand prefetch of the last step)
   // land in the next region, never outside the allocation
-  __shared__ __attribute__((aligned(16))) float s_all[20 * 784 + 500 * 48 + 4 * 48 + 2 * 500];
+  __shared__ __attribute__((aligned(16))) float s_all[20 * 784 + 500 * 48 + 4 * 48];
   float *s_in = s_all, *s_w = s_all + 20 * 784;
-  // the rows of filters 48, 49 (the VALU tail) sit in LDS as well: fetched as scalar loads from global memory they shared
-  // the lgkm counter with the LDS operand reads — SMEM returns out of order, so every use of a weight waited for ALL the
-  // LDS reads in flight (A/B with the tail removed: 1.22 -> 1.09 ms; profiles/r04_conv2_ab.sh)
-  float *s_wx = s_all + 20 * 784 + 500 * 48 + 4 * 48;
   const int tid = threadIdx.x;
   for (int i = tid; i < 504 * 48; i += C2_THREADS) {
     const int k = i / 48, f = i - k * 48;
     s_w[i] = k < 500 ? wt[k * 50 + f] : 0.f;
   }
-  for (int i = tid; i < 2 * 500; i += C2_THREADS) s_wx[i] = w[(size_t)48 * 500 + i];
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int kq = lane >> 4, j = lane & 15;
@@ -398,7 +393,7 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
       const float *aw = s_w + kq * 48 + j;                            // MFMA A operand: W[k0 + kq][f = j]
       // filters 48, 49 on the VALU: lane = r * 32 + col is conv pixel (2rp + r, col), col < 24
       const float *xv = s_in + (2 * rp + (lane >> 5)) * 28 + min(lane & 31, 23);
-      const float *wf = s_wx;
+      const float *__restrict__ wf = w + (size_t)48 * 500;
       float t48 = 0.f, t49 = 0.f;
       // operands of step s+1 are requested before the nine MFMAs of step s
       float a_cur[3], b_cur[3], a_nxt[3], b_nxt[3], xc[4], xn[4];
