@@ -124,7 +124,7 @@ struct Box {
 // points kernel: in-box points cached once, one projection's normals (3 planes) + depth at a time.
 // BIG (the overflow fallback, up to PT_CAP_BIG in-box points): the point arrays live in a global
 // scratch row instead of LDS.
-constexpr size_t PTS_SCRATCH_BYTES = (size_t)PT_CAP_BIG * (3 * sizeof(double) + sizeof(float4));
+constexpr size_t PTS_SCRATCH_BYTES = (size_t)PT_CAP_BIG * (3 * sizeof(double) + sizeof(float4) + sizeof(uint32_t));  // + the in-box points' neighbour indices, 32 bits wide
 struct PointArrays {
   double t[3][PT_CAP];  // hand-frame coordinates of the in-box points
   float4 an[PT_CAP];    // |normal| in the hand frame (x, y, z) and, as bits in w, the cell key
@@ -1326,11 +1326,17 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
   // the point arrays: LDS, or this workgroup's row of the global scratch
   double *gt = nullptr;
   float4 *gan = nullptr;
+  uint32_t *gidx = nullptr;
   if constexpr (BIG) {
     char *row = P.pts_scratch + (size_t)blockIdx.x * PTS_SCRATCH_BYTES;
     gt = reinterpret_cast<double *>(row);
     gan = reinterpret_cast<float4 *>(row + (size_t)CAP * 3 * sizeof(double));
+    gidx = reinterpret_cast<uint32_t *>(row + (size_t)CAP * (3 * sizeof(double) + sizeof(float4)));
   }
+  auto IDX = [&](int e) -> int {
+    if constexpr (BIG) return (int)gidx[e];
+    else return (int)S.place[e];
+  };
   auto T = [&](int a, int e) -> double & {
     if constexpr (BIG) return gt[(size_t)a * CAP + e];
     else return S.p.t[a][e];
@@ -1399,15 +1405,20 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       const unsigned long long ballot = __ballot(in);
       if (in) {
         const int e = base + __popcll(ballot & ((1ull << lane) - 1ull));
-        if (e < CAP) S.place[e] = (uint16_t)(b0 + r * IMG_THREADS + tid);
+        if (e < CAP) {
+          if constexpr (BIG) gidx[e] = (uint32_t)(b0 + r * IMG_THREADS + tid);
+          else S.place[e] = (uint16_t)(b0 + r * IMG_THREADS + tid);
+        }
       }
     }
     n_before = run;
     __syncthreads();  // the counts are rewritten by the next block / the cell counters start here
   }
   const int n_box_all = n_before;
-  if (n_box_all > CAP) {
-    // more in-box points than this instantiation holds: queue the candidate for the large one
+  if (n_box_all > CAP || (!BIG && N > 65536)) {
+    // more in-box points than this instantiation holds — or a neighbourhood of more than 65536 points, whose neighbour
+    // indices do not fit the 16-bit segment table the small instantiation lists them in (the reference has no limit,
+    // hand_search.cpp:178; the large one keeps them 32 bits wide): queue the candidate for the large one
     // (nothing has been written yet), or report it when this already is the large one
     if (tid == 0) {
       if (!BIG && P.pts_overflow_list)
@@ -1425,7 +1436,7 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int e = e0 + q * IMG_THREADS + tid;
-      const int i = e < n_box_all ? (int)S.place[e] : 0;
+      const int i = e < n_box_all ? IDX(e) : 0;
 #pragma unroll
       for (int a = 0; a < 6; a++) v[q][a] = nn[a * P.cap + i];
     }

@@ -574,7 +574,7 @@ def test_neighbourhoods_beyond_65535_points(oracle_mod):
     nrm = np.concatenate([cl["normals"]] * 16)
     cam = np.ones((1, len(xyz)), np.int32)
     obj = np.flatnonzero(cl["is_object"])
-    si = obj[np.random.RandomState(10).choice(len(obj), 6, replace=False)].astype(np.int32)
+    si = obj[np.random.RandomState(10).choice(len(obj), 16, replace=False)].astype(np.int32)
     from scipy.spatial import cKDTree
     t = cKDTree(xyz.astype(np.float64))
     sizes = [len(x) for x in t.query_ball_point(xyz[si].astype(np.float64), 0.11)]
