@@ -92,7 +92,7 @@ def test_fuzz_normals_match_oracle(oracle_mod, seed):
         ctx.close()
 
 
-def _geometry(seed):
+def _geometry(seed, wide=False):
     """Every knob of the hand / image geometry and of the search at once, drawn as arbitrary doubles (the shipped cfg files
     hold round decimals): threshold tables, the correctly-rounded division by the box extents, the finger lookup table, the
     deepen steps and the voxel windows all depend on them."""
@@ -107,7 +107,66 @@ def _geometry(seed):
     if rng.rand() < 0.3:
         kw["min_aperture"], kw["max_aperture"] = rng.uniform(0.0, 0.03), rng.uniform(0.05, 0.1)
     axes = [int(a) for a in rng.permutation(3)[: rng.randint(1, 4)]]
+    if wide:
+        # beyond the tuned kernels' windows and tables (round 4: none of this is refused any more): image volumes up to a box
+        # diagonal of ~0.28 m (the general shadow kernel), fingers of up to 0.16 m (more than 32 deepening steps), and the
+        # approach-direction filter of the fused entry
+        kw["volume_width"] = rng.uniform(0.12, 0.22)
+        kw["volume_depth"] = rng.uniform(0.06, 0.16)
+        kw["hand_depth"] = rng.uniform(0.06, 0.20)
+        if rng.rand() < 0.6:
+            d = rng.randn(3)
+            kw["direction"] = [float(x) for x in d / np.linalg.norm(d)]
+            kw["thresh_rad"] = rng.uniform(0.8, 2.4)
     return kw, axes, rng
+
+
+def _set_all(p, kw, axes):
+    for k, v in kw.items():
+        if k == "direction":
+            p.filter_approach_direction = 1
+            for i, a in enumerate(v):
+                p.direction[i] = a
+        else:
+            setattr(p, k, v)
+    p.num_hand_axes = len(axes)
+    for i, a in enumerate(axes):
+        p.hand_axes[i] = a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_FUZZ_WIDE", "5"))))
+def test_fuzz_wide_geometry_matches_oracle(oracle_mod, seed):
+    """The same with geometries the round-3 kernels refused (GPD_ERR_CAPACITY): wide and deep image volumes, long fingers,
+    plus the device-side approach-direction filter.  GPD_FUZZ_WIDE=N widens the draw."""
+    kw, axes, rng = _geometry(1000 + seed, wide=True)
+    c = _case(seed + 11)
+    if c["C"] != 15:
+        c["C"] = 15  # the shadow channels are what the wide volumes stress
+    w = _weights(15)
+    gp, op = api.default_params(15), oracle_mod.default_params(15)
+    _set_all(gp, kw, axes)
+    _set_all(op, kw, axes)
+    obj = np.flatnonzero(c["obj"])
+    si = rng.choice(obj, size=min(60, len(obj)), replace=False).astype(np.int32)
+    ctx = api.Context(gp)
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(c["xyz"], c["normals"], c["cam"], c["vp"])
+        hands, n_cand = ctx.detect(si)
+        ohands, on_cand, _ = oracle_mod.detect(op, c["xyz"], c["normals"], c["cam"], c["vp"], si, w)
+        assert hands.shape == ohands.shape and n_cand == on_cand, (kw, axes)
+        a, b = hands.copy(), ohands.copy()
+        assert np.abs(a["score"] - b["score"]).max() <= 1e-4, (kw, axes)
+        a["score"] = 0
+        b["score"] = 0
+        assert a.tobytes() == b.tobytes(), (kw, axes)
+        fw = oracle_mod.filter_workspace(op, ohands.copy())
+        img, cand = ctx.images(fw)
+        oimg, ocand = oracle_mod.images(op, c["xyz"], c["normals"], c["cam"], c["vp"], fw)
+        assert np.array_equal(cand, ocand) and np.array_equal(img, oimg), (kw, axes)
+    finally:
+        ctx.close()
 
 
 @pytest.mark.gpu
