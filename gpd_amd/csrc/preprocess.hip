@@ -251,15 +251,26 @@ static bool spine_ops(std::vector<int8_t> &ops, size_t n, unsigned long long &C,
 // kept point).  rank[pos] = how many points were kept before this one, -1 for a dropped point.
 static int voxel_accept_host(const int4 *keys, int n, const int8_t *ops, int32_t *rank) {
   int sx[64], sy[64], sz[64];
+  // A kept point — on a raw scan nearly every one — matches NO spine voxel, and proving that by comparing with all ~35 of
+  // them was the walk's cost (8 ns per point).  A 1024-slot counting filter over the spine's voxels answers "certainly not on
+  // the spine" in one load; only a point whose slot is occupied walks the spine (round 4: 1.0 -> 0.35 ms per 120k points).
+  unsigned short filter[1024];
+  std::memset(filter, 0, sizeof(filter));
+  auto slot = [](int x, int y, int z) {
+    const unsigned h = (unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u;
+    return (h ^ (h >> 13)) & 1023u;
+  };
   int L = 0, m = 0;
   for (int i = 0; i < n; i++) {
     const int qx = keys[i].x, qy = keys[i].y, qz = keys[i].z;
+    const unsigned h = slot(qx, qy, qz);
     bool hit = false;
-    for (int d = L - 1; d >= 0; d--)  // the recent nodes sit at the bottom of the spine: most drops end here at once
-      if (sx[d] == qx && sy[d] == qy && sz[d] == qz) {
-        hit = true;
-        break;
-      }
+    if (filter[h])
+      for (int d = L - 1; d >= 0; d--)  // the recent nodes sit at the bottom of the spine: most drops end here at once
+        if (sx[d] == qx && sy[d] == qy && sz[d] == qz) {
+          hit = true;
+          break;
+        }
     if (hit) {
       rank[i] = -1;
       continue;
@@ -268,10 +279,12 @@ static int voxel_accept_host(const int4 *keys, int n, const int8_t *ops, int32_t
     sx[L] = qx;
     sy[L] = qy;
     sz[L] = qz;
+    filter[h]++;
     const int g = ops[m];
     m++;
     L++;
     if (g >= 0) {  // the node at depth g leaves the spine, the ones below move up
+      filter[slot(sx[g], sy[g], sz[g])]--;
       for (int d = g; d + 1 < L; d++) {
         sx[d] = sx[d + 1];
         sy[d] = sy[d + 1];
