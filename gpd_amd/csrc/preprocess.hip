@@ -253,7 +253,7 @@ static int voxel_accept_host(const int4 *keys, int n, const int8_t *ops, int32_t
   int sx[64], sy[64], sz[64];
   // A kept point — on a raw scan nearly every one — matches NO spine voxel, and proving that by comparing with all ~35 of
   // them was the walk's cost (8 ns per point).  A 1024-slot counting filter over the spine's voxels answers "certainly not on
-  // the spine" in one load; only a point whose slot is occupied walks the spine (round 4: 1.0 -> 0.35 ms per 120k points).
+  // the spine" in one load; only a point whose slot is occupied walks the spine (round 4: gpd_hip_preprocess_cloud on a raw 120k-point scan 1.42 -> 0.68 ms first to last device operation).
   unsigned short filter[1024];
   std::memset(filter, 0, sizeof(filter));
   auto slot = [](int x, int y, int z) {
