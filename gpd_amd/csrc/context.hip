@@ -253,6 +253,7 @@ static int lane_reserve(gpd_hip_ctx *ctx, Lane &L, int points, int cams, int sam
   const gpd_params &p = ctx->params;
   const int slots = p.num_hand_axes * p.num_orientations;
   int rc = cloud_reserve(L.cloud, points, cams);
+  if (!rc) rc = cloud_reserve_grid(L.cloud, 1 << 20);  // 2 cm cells of a scene up to ~8 m^3 (8 MB); a larger one grows the tables
   if (!rc && samples > 0) rc = search_reserve_samples(L.search, samples, slots);
   if (!rc && samples > 0) rc = plan_reserve(L.plan, L.search.capacity_samples, slots, cams, L.stream);
   if (rc || candidates <= 0) return rc;

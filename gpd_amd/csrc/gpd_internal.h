@@ -174,6 +174,7 @@ inline GridView grid_view(const Cloud &c) {
 int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
                  const double *view_points, hipStream_t stream, bool sync);
 int cloud_reserve(Cloud &c, int n, int num_cams);
+int cloud_reserve_grid(Cloud &c, int cells);
 void cloud_free(Cloud &c);
 int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream);
 

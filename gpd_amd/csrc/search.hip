@@ -186,6 +186,21 @@ int cloud_reserve(Cloud &c, int n, int num_cams) {
   return GPD_OK;
 }
 
+// The uniform grid's tables for scenes of up to `cells` cells of 2 cm (a 2 x 2 x 1 m scene has 500 000); a larger scene grows them.
+int cloud_reserve_grid(Cloud &c, int cells) {
+  if (cells <= c.g_cells_cap) return GPD_OK;
+  note_alloc();
+  if (c.g_start) (void)hipFree(c.g_start);
+  if (c.g_cursor) (void)hipFree(c.g_cursor);
+  c.g_start = nullptr;
+  c.g_cursor = nullptr;
+  c.g_cells_cap = 0;
+  HIP_RET(hipMalloc(&c.g_start, (size_t)(cells + 1) * sizeof(int32_t)));
+  HIP_RET(hipMalloc(&c.g_cursor, (size_t)cells * sizeof(int32_t)));
+  c.g_cells_cap = cells;
+  return GPD_OK;
+}
+
 // The caller's arrays are copied into a pinned staging buffer (one pass that also takes the bounds of the
 // uniform grid and rejects non-finite coordinates), so the three host-to-device copies are truly
 // asynchronous: with sync == false nothing here waits for the device and the upload of the next cloud
@@ -242,16 +257,8 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
   }
   const int cells = c.g_dim[0] * c.g_dim[1] * c.g_dim[2];
   if (cells > c.g_cells_cap) {
-    note_alloc();
-    if (c.g_start) (void)hipFree(c.g_start);
-    if (c.g_cursor) (void)hipFree(c.g_cursor);
-    c.g_start = nullptr;
-    c.g_cursor = nullptr;
-    c.g_cells_cap = 0;
-    const int want = cells + cells / 2;
-    HIP_RET(hipMalloc(&c.g_start, (size_t)(want + 1) * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&c.g_cursor, (size_t)want * sizeof(int32_t)));
-    c.g_cells_cap = want;
+    const int rc = cloud_reserve_grid(c, cells + cells / 2);
+    if (rc) return rc;
   }
   GridView g = grid_view(c);
   HIP_RET(hipMemsetAsync(c.g_cursor, 0, (size_t)cells * sizeof(int32_t), stream));

@@ -249,6 +249,50 @@ def test_detect_batch_multi_three_contexts_uneven_jobs(ctx, lenet15_real):
             o.close()
 
 
+def test_reserve_then_batch_allocates_nothing(lenet15_real, oracle_mod):
+    """gpd_hip_reserve sizes both lanes once; a batch within those sizes then books no buffer growth on any cloud (`allocs`),
+    its host timeline is ordered, and the results are those of the single-cloud entry.  Without the reservation the batch
+    entry sizes the lanes itself: the growths are booked on the first cloud only."""
+    clouds = [synth.make_cloud(900 + cid, 12000 + 900 * cid) for cid in range(5)]
+    samples = [synth.sample_indices(cl, 60 + 9 * cid) for cid, cl in enumerate(clouds)]
+    for reserve in (True, False):
+        c = api.Context(api.default_params(15))
+        try:
+            c.set_lenet_weights(lenet15_real)
+            if reserve:
+                c.reserve(max_points=max(len(cl["xyz"]) for cl in clouds), max_cams=1, max_samples=max(len(s) for s in samples))
+            got = c.detect_batch(clouds, samples, 0)
+            tl = c.last_batch_timeline
+            allocs = [a for _, a in tl]
+            if reserve:
+                assert sum(allocs) == 0, allocs
+            else:
+                assert allocs[0] > 0 and sum(allocs[1:]) == 0, allocs
+            for h, _ in tl:
+                assert 0 < h[0] <= h[2] and h[1] <= h[2] <= h[3] <= h[4], h
+            c.detect_batch(clouds, samples, 0)  # a second batch of the same sizes: nothing grows either way
+            assert sum(a for _, a in c.last_batch_timeline) == 0
+            p = oracle_mod.default_params(15)
+            for (hands, ns, nc, _), cl, si in zip(got, clouds, samples):
+                oh, on, _ = oracle_mod.detect(p, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, lenet15_real)
+                flat = oh.reshape(-1)
+                want = flat[np.flatnonzero(flat["valid"])]
+                assert nc == on and len(hands) == len(want)
+                a, b = hands.copy(), want.copy()
+                assert np.abs(a["score"] - b["score"]).max() <= 1e-4
+                a["score"] = 0
+                b["score"] = 0
+                assert a.tobytes() == b.tobytes()
+        finally:
+            c.close()
+    with pytest.raises(api.GpdHipError, match="bad argument"):
+        c2 = api.Context(api.default_params(15))
+        try:
+            c2.reserve(max_points=0)
+        finally:
+            c2.close()
+
+
 def test_detect_batch_reports_a_bad_cloud(ctx, cloud30k):
     cl = cloud30k
     si = synth.sample_indices(cl, 40)
