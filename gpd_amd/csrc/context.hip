@@ -45,7 +45,10 @@ void set_error(const char *fmt, ...) {
 }
 
 static thread_local int g_allocs = 0;
-void note_alloc() { g_allocs++; }
+void note_alloc(const char *where) {
+  g_allocs++;
+  if (prof_env("GPD_ALLOC_TRACE")) fprintf(stderr, "[alloc] %s\n", where);  // (profiling build only)
+}
 
 }  // namespace gpd
 
@@ -176,7 +179,7 @@ static void lane_free(Lane &L) {
 
 static int reserve_scores(Lane &L, int n) {
   if (n <= L.d_scores_cap) return GPD_OK;
-  note_alloc();
+  note_alloc(__func__);
   if (L.d_scores) (void)hipFree(L.d_scores);
   L.d_scores = nullptr;
   L.d_scores_cap = 0;
@@ -188,7 +191,7 @@ static int reserve_scores(Lane &L, int n) {
 
 static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
   if (records > L.d_out_cap) {
-    note_alloc();
+    note_alloc(__func__);
     if (L.d_out) (void)hipFree(L.d_out);
     L.d_out = nullptr;
     L.d_out_cap = 0;
@@ -198,7 +201,7 @@ static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
   }
   const size_t bytes = L.d_out_cap * sizeof(gpd_hand) + extra_bytes;
   if (bytes > L.h_out_bytes) {
-    note_alloc();
+    note_alloc(__func__);
     if (L.h_out) (void)hipHostFree(L.h_out);
     L.h_out = nullptr;
     L.h_out_bytes = 0;
@@ -212,7 +215,7 @@ static int reserve_out(Lane &L, size_t records, size_t extra_bytes) {
 // selections (num_selected > 0): the winners' ordinals + tie flag, and the job's own list of every scored candidate
 static int reserve_selection(Lane &L, int k, int n) {
   if (k + 1 > L.d_sel_cap) {
-    note_alloc();
+    note_alloc(__func__);
     if (L.d_sel) (void)hipFree(L.d_sel);
     L.d_sel = nullptr;
     L.d_sel_cap = 0;
@@ -221,7 +224,7 @@ static int reserve_selection(Lane &L, int k, int n) {
     L.d_sel_cap = cap;
   }
   if ((size_t)n > L.d_all_cap) {
-    note_alloc();
+    note_alloc(__func__);
     if (L.d_all) (void)hipFree(L.d_all);
     L.d_all = nullptr;
     L.d_all_cap = 0;

@@ -53,7 +53,7 @@ void set_error(const char *fmt, ...);
 // every growth of a device / pinned buffer (hipFree + hipMalloc: a device stall) is counted per host thread; the batch
 // entry reports the count per cloud (gpd_detect_job::allocs) so that a pass that was supposed to run on pre-sized lanes
 // can be seen to have done so
-void note_alloc();
+void note_alloc(const char *where);
 
 // roctx range around a stage of the path (host side: what the stage enqueues); `rocprofv3 --marker-trace --kernel-trace`
 // shows them over the kernel timeline (the reference times its stages with omp_get_wtime, grasp_detector.cpp:223-273)
@@ -181,6 +181,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
 // ---- Candidate search (search.hip) -----------------------------------------------
 struct SearchState {
   int num_samples = 0, capacity_samples = 0;
+  int min_samples = 0;                // sample capacity to keep across a change of the list capacity (search_force_capacity)
   int nn_cap = 0;                     // entries per neighbourhood list: 8192 / 16384 (LDS sorts) or up to kNnCapMax (global-memory sort)
   uint64_t cloud_generation = 0;
   int32_t *d_sample_idx = nullptr;    // [S]

@@ -1878,7 +1878,7 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
     HIP_RET(hipMalloc(&im.d_pts_scratch, (size_t)LGRID * PTS_SCRATCH_BYTES));
   }
   if (n > im.capacity) {
-    note_alloc();
+    note_alloc(__func__);
     void *ptrs[] = {im.d_images, im.d_images_hwc, im.d_overflow, im.d_overflow2, im.d_pts_overflow};
     for (void *q : ptrs)
       if (q) (void)hipFree(q);
@@ -1924,7 +1924,7 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
   }
   const size_t setwords = (size_t)(((long long)im.set_sd * im.set_sd * im.set_sd + 31) / 32);
   if (C == 15 && (shadow_sets > im.cap_shadow_sets || setwords > im.cap_setwords)) {
-    note_alloc();
+    note_alloc(__func__);
     if (im.d_set_bits) (void)hipFree(im.d_set_bits);
     im.d_set_bits = nullptr;
     im.cap_shadow_sets = 0;
@@ -1938,7 +1938,7 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
   if (C == 15 && (im.wide || im.huge) && !im.d_huge_scratch) {
     // the general shadow kernel's list rows, one per workgroup of its persistent grid; the default geometry cannot reach it
     // (its box holds fewer voxel cells than the large instantiation lists)
-    note_alloc();
+    note_alloc(__func__);
     HIP_RET(hipMalloc(&im.d_huge_scratch, (size_t)LGRID * HUGE_SCRATCH_BYTES));
   }
   return GPD_OK;

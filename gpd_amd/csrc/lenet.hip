@@ -706,7 +706,7 @@ __global__ __launch_bounds__(FC2_THREADS) void fc2_score_kernel(const float *__r
 hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   if (n <= s.capacity) return hipSuccess;
   const int num_cus = s.num_cus;
-  note_alloc();
+  note_alloc(__func__);
   lenet_scratch_free(s);
   s.num_cus = num_cus;
   n += n / 4;  // slack: the clouds of a batch differ a little, every growth stalls the device

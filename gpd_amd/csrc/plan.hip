@@ -347,7 +347,7 @@ void plan_free(Plan &pl) {
 // Tables for up to capS samples x slots hands and `cams` cameras (grow only; a growth stalls the device).
 int plan_reserve(Plan &pl, int want_samples, int slots, int cams, hipStream_t stream) {
   if (want_samples <= pl.cap_samples && slots <= pl.cap_slots && cams <= pl.cap_cams) return GPD_OK;
-  note_alloc();
+  note_alloc(__func__);
   const int capS = want_samples > pl.cap_samples ? want_samples : pl.cap_samples;
   const int capC = cams > pl.cap_cams ? cams : pl.cap_cams;
   const int capL = slots > pl.cap_slots ? slots : pl.cap_slots;

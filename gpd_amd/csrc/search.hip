@@ -162,7 +162,7 @@ void cloud_free(Cloud &c) {
 // once, ahead of the first cloud.
 int cloud_reserve(Cloud &c, int n, int num_cams) {
   if (n <= c.capacity && num_cams <= c.cap_cams) return GPD_OK;
-  note_alloc();
+  note_alloc(__func__);
   const uint64_t gen = c.generation;
   const int cap = n > c.capacity ? n + n / 4 : c.capacity;  // slack: clouds of a batch differ by a few points
   const int cams = num_cams > c.cap_cams ? num_cams : c.cap_cams;
@@ -189,7 +189,7 @@ int cloud_reserve(Cloud &c, int n, int num_cams) {
 // The uniform grid's tables for scenes of up to `cells` cells of 2 cm (a 2 x 2 x 1 m scene has 500 000); a larger scene grows them.
 int cloud_reserve_grid(Cloud &c, int cells) {
   if (cells <= c.g_cells_cap) return GPD_OK;
-  note_alloc();
+  note_alloc(__func__);
   if (c.g_start) (void)hipFree(c.g_start);
   if (c.g_cursor) (void)hipFree(c.g_cursor);
   c.g_start = nullptr;
@@ -1716,7 +1716,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
   NormalsScratch &s = c.normals;
   const int P = c.num_points;
   if (P > s.cap_points) {
-    note_alloc();
+    note_alloc(__func__);
     unsigned long long *arena = s.d_arena;
     const long long arena_cap = s.arena_cap;
     s.d_arena = nullptr;
@@ -1733,7 +1733,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     s.cap_points = cap;
   }
   if (!s.d_arena) {
-    note_alloc();
+    note_alloc(__func__);
     const long long want = 1ll << 20;  // 8 MB: a voxelised cloud needs none of it
     HIP_RET(hipMalloc(&s.d_arena, (size_t)want * sizeof(unsigned long long)));
     s.arena_cap = want;
@@ -1774,7 +1774,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     HIP_RET(hipStreamSynchronize(stream));
     if (!(h.status & 1)) break;
     // more / larger neighbourhoods beyond a wave's reach than the arena holds: grow it to what this run asked for
-    note_alloc();
+    note_alloc(__func__);
     (void)hipFree(s.d_arena);
     s.d_arena = nullptr;
     s.arena_cap = 0;
@@ -2412,7 +2412,8 @@ void search_free(SearchState &s) {
 
 static int search_reserve(SearchState &s, int S, int cap, int slots) {
   if (S <= s.capacity_samples && cap == s.nn_cap) return GPD_OK;
-  const int newS = S > s.capacity_samples ? S + S / 8 : s.capacity_samples;  // slack: the clouds of a batch differ a little
+  int newS = S > s.capacity_samples ? S + S / 8 : s.capacity_samples;  // slack: the clouds of a batch differ a little
+  if (newS < s.min_samples) newS = s.min_samples;  // (a list-capacity change keeps the sample capacity the lane was sized for)
   {
     // 44 bytes per list entry and sample (gathered rows, index scratch, height list): with the large lists of a dense
     // scan that is what bounds a call, and it should say so rather than fail inside hipMalloc
@@ -2424,7 +2425,7 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
       return GPD_ERR_CAPACITY;
     }
   }
-  note_alloc();
+  note_alloc(__func__);
   search_free(s);
   HIP_RET(hipMalloc(&s.d_sample_idx, (size_t)newS * sizeof(int32_t)));
   HIP_RET(hipMalloc(&s.d_sample_xyz, (size_t)newS * 3 * sizeof(double)));
@@ -2634,8 +2635,10 @@ int search_next_capacity(const SearchState &s, int worst) {
 }
 int search_force_capacity(SearchState &s, int cap) {
   if (cap == s.nn_cap) return GPD_OK;
+  const int keep = s.capacity_samples > s.min_samples ? s.capacity_samples : s.min_samples;
   search_free(s);
-  s.nn_cap = cap;  // search_reserve allocates on the next run (capacity_samples is 0 now)
+  s.nn_cap = cap;  // search_reserve allocates on the next run (capacity_samples is 0 now) ...
+  s.min_samples = keep;  // ... for at least as many samples as before: a lane sized by gpd_hip_reserve stays sized
   return GPD_OK;
 }
 
