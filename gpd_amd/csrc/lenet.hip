@@ -326,7 +326,7 @@ __host__ __device__ constexpr int c2_tap_off(int k) { return (k / 25) * 784 + ((
 
 __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__restrict__ pool1, const float *__restrict__ wt,
                                                                 const float *__restrict__ w, const float *__restrict__ bias,
-                                                                float *__restrict__ flat, int n) {
+                                                                float *__restrict__ flat, int n, int *__restrict__ queue) {
   // one array: reads one step past the image / the weights (operand prefetch of the last step)
   // land in the next region, never outside the allocation
   __shared__ __attribute__((aligned(16))) float s_all[20 * 784 + 500 * 48 + 4 * 48];
@@ -373,12 +373,21 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
     const float4 *fsrc = reinterpret_cast<const float4 *>(pool1 + (size_t)(IMG) * P1_IMG);         \
     C2_EACH(C2_FETCH1)                                                                             \
   }
-  if ((int)blockIdx.x < n) C2_FETCH(blockIdx.x)
-  for (int img = blockIdx.x; img < n; img += gridDim.x) {
-    __syncthreads();  // previous image fully consumed (and the weights are in place)
+  // The images are drawn from a counter of the launch (`queue`, zero at launch: the first gridDim.x images are the
+  // workgroups' own numbers, the counter hands out the rest), one ahead of the image being convolved.  A fixed deal
+  // (image b, b + G, ...) made the kernel as slow as its LAST-STARTED workgroup: in gpd_hip_detect_batch the other lane's
+  // kernels hold CUs when this one is launched, a 156 KB workgroup starts on such a CU only once it is empty, and with a
+  // fixed share it then finished that much later (conv2 1.51 -> 1.73 ms per 6077 images inside the batch, r04_batch_timeline.txt).
+  __shared__ int s_nxt;
+  int img = blockIdx.x;
+  if (img < n) C2_FETCH(img)
+  for (; img < n;) {
+    if (tid == 0) s_nxt = (int)gridDim.x + atomicAdd(queue, 1);
+    __syncthreads();  // previous image fully consumed (and the weights are in place); s_nxt is visible
     C2_EACH(C2_STAGE1)
+    const int nxt = s_nxt;
     __syncthreads();
-    if (img + (int)gridDim.x < n) C2_FETCH(img + gridDim.x)
+    if (nxt < n) C2_FETCH(nxt)
     {
       const int rp = wave;  // output rows 2rp, 2rp+1
       f32x4 acc[3][3];      // [pixel tile][filter tile]
@@ -504,6 +513,7 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
         }
       }
     }
+    img = nxt;
   }
 }
 
@@ -770,7 +780,10 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
-    conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m);
+    // conv2 draws its images from a counter (c1_stats[3], zero at launch)
+    if (hipMemsetAsync(s.c1_stats + 3, 0, sizeof(unsigned long long), stream) != hipSuccess) return hipGetLastError();
+    conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m,
+                                                                             reinterpret_cast<int *>(s.c1_stats + 3));
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[1], stream);
     switch (fc1_pick_nt(m)) {
       case 1: fc1_launch<1>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
