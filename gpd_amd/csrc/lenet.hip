@@ -72,35 +72,47 @@ __host__ __device__ inline void c1_pixel_of(int pc, int &py, int &px) {
   px = strip * 8 + (within - py * sw);
 }
 
-// chunks of [c0, c1) that touch image j (the number of releases its slot waits for)
-__device__ inline int c1_chunks_of_image(int j, int c0, int c1) {
-  const int lo = max(c0, (C1_PIX * j) / 64), hi = min(c1 - 1, (C1_PIX * j + C1_PIX - 1) / 64);
-  return hi >= lo ? hi - lo + 1 : 0;
-}
+// chunks of the workgroup that touch its j-th image (the number of releases its slot waits for): the pooled pixels of its
+// images are numbered through and cut into chunks of 64; the chunk that holds an image's last pixels always exists
+__device__ inline int c1_chunks_of_image(int j) { return (C1_PIX * j + C1_PIX - 1) / 64 - (C1_PIX * j) / 64 + 1; }
 
 template <int C>
 __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *__restrict__ images, const float *__restrict__ wp,
                                                                const float *__restrict__ bias, float *__restrict__ out, int n,
-                                                               unsigned long long *__restrict__ stats, int fault) {
+                                                               unsigned long long *__restrict__ stats, int fault, int *__restrict__ queue) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[2][C * kPix];
   __shared__ __attribute__((aligned(16))) float s_wa[16 * C * 28];  // filters 0..15: [f][c][25 taps + 3 pad]
   __shared__ __attribute__((aligned(16))) float s_wb[4 * C * 28];   // filters 16..19
   __shared__ int s_next;
-  __shared__ int s_slot_img[2];  // image held by the slot (published after its bytes), -1: none
+  __shared__ int s_slot_img[2];  // local sequence number of the image held by the slot (published after its bytes), -1: none
+  __shared__ int s_gid[2];       // ... and which image of the launch that is
   __shared__ int s_refs[2];      // chunks of this workgroup that still have to release the slot's image
   __shared__ int s_abort;        // a wave gave up waiting for a slot: the others of the workgroup leave too
+  __shared__ int s_last;         // the workgroup's last local sequence number; INT_MAX until the launch's queue ran dry
+  __shared__ int s_drawn;        // local sequence numbers that have drawn their image (the draws happen in this order)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int first = blockIdx.x, stride = gridDim.x;  // the workgroup's s-th image is first + s * stride
-  if (first >= n) return;
-  const int nimg = (n - first + stride - 1) / stride;
-  const int c0 = 0, c1 = (nimg * C1_PIX + 63) / 64;  // its chunks
-  const int img_first = 0, img_last = nimg - 1;      // (sequence numbers)
+  // The workgroup's images: its own number first, then whatever the launch's counter (`queue`, zero at launch) hands out —
+  // drawn one slot refill ahead, strictly in the order of the local sequence numbers, so that "the queue is dry" at number q
+  // means it is dry for every later one (two refills racing for the counter could otherwise leave a hole: a drawn image
+  // behind an empty number).  Round 2 dealt the images out (b, b + G, ...): neighbouring candidates have similar images, and
+  // with the zero skipping a fixed share made the slowest workgroup 13 % longer than the average; the first counter version
+  // drew at release time without the ordering and was withdrawn.  Inside gpd_hip_detect_batch a fixed share also made the
+  // kernel as slow as its last-started workgroup.
+  const int G = gridDim.x;
+  if ((int)blockIdx.x >= n) return;
+  if (tid == 0) {
+    const int g1 = G + atomicAdd(queue, 1);
+    s_gid[0] = blockIdx.x;
+    s_gid[1] = g1;
+    s_last = g1 < n ? INT_MAX : 0;
+    s_drawn = 2;
+  }
+  __syncthreads();
   for (int q = 0; q < 2; q++) {  // the first two images, by everybody
-    const int img = img_first + q;
-    if (img > img_last) break;
-    const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)(first + img * stride) * kPix * C);
-    uint4 *dst = reinterpret_cast<uint4 *>(s_img[img & 1]);
+    if (q > *(volatile int *)&s_last) break;
+    const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)s_gid[q] * kPix * C);
+    uint4 *dst = reinterpret_cast<uint4 *>(s_img[q & 1]);
     for (int i = tid; i < kPix * C / 16; i += C1_THREADS) dst[i] = src[i];
   }
   {  // padded weight table [20][C][28] (built once on the host side of the C-ABI): filters 0..15, then 16..19
@@ -110,13 +122,13 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     for (int i = tid; i < 4 * C * 7; i += C1_THREADS) db[i] = src[16 * C * 7 + i];
   }
   if (tid == 0) {
-    s_next = c0;
+    s_next = 0;
     s_abort = 0;
     s_slot_img[0] = s_slot_img[1] = -1;
     for (int q = 0; q < 2; q++)
-      if (img_first + q <= img_last) {
-        s_slot_img[(img_first + q) & 1] = img_first + q;
-        s_refs[(img_first + q) & 1] = c1_chunks_of_image(img_first + q, c0, c1);
+      if (q <= s_last) {
+        s_slot_img[q] = q;
+        s_refs[q] = c1_chunks_of_image(q);
       }
   }
   __syncthreads();
@@ -127,21 +139,34 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     int task = 0;
     if (lane == 0) task = atomicAdd(&s_next, 1);
     task = __builtin_amdgcn_readfirstlane(task);
-    if (task >= c1) break;
+    // the images this chunk reads (the second one only when the chunk straddles an image boundary).  Whether they exist is
+    // known at the latest when their slots would have been refilled: s_last turns from INT_MAX into the last number then.
+    const int ia = (64 * task) / C1_PIX, ib0 = (64 * task + 63) / C1_PIX;
+    if (ia > *(volatile int *)&s_last) break;  // (chunks are taken in ascending order: every later one is past the end too)
     n_tasks++;
-    // the images this chunk reads (the second one only when the chunk straddles an image boundary)
-    const int ia = (64 * task) / C1_PIX, ib = min((64 * task + 63) / C1_PIX, img_last);
     // (a slot is refilled within ~10 us of its release; a wait of ~0.5 s can only be a broken protocol.  The wave then
     //  raises the launch's error word — stats[2], which the host turns into GPD_ERR_HIP at its next synchronisation — and
     //  the workgroup's abort flag, and every wave of the workgroup leaves: the kernel ends, the context stays usable,
     //  the scores of this launch are not handed out.  It used to be a __builtin_trap(), which killed the HIP context.)
-    bool give_up = false;
-    for (int spins = 0; *(volatile int *)&s_slot_img[ia & 1] != ia || *(volatile int *)&s_slot_img[ib & 1] != ib; spins++) {
+    bool give_up = false, past_end = false;
+    int ib = ib0;
+    for (int spins = 0;; spins++) {
+      const int last = *(volatile int *)&s_last;
+      if (ia > last) {
+        past_end = true;
+        break;
+      }
+      ib = ib0 < last ? ib0 : last;
+      if (*(volatile int *)&s_slot_img[ia & 1] == ia && *(volatile int *)&s_slot_img[ib & 1] == ib) break;
       __builtin_amdgcn_s_sleep(4);
       if (*(volatile int *)&s_abort || spins > (1 << 22)) {
         give_up = true;
         break;
       }
+    }
+    if (past_end) {
+      n_tasks--;
+      break;
     }
     if (give_up) {
       if (lane == 0) {
@@ -154,12 +179,13 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     // pooled pixel of the lane: image, then strip-major pixel number -> (row, column).  Lanes past the last pixel of
     // the workgroup redo it and store nothing.
     const int g = task * 64 + lane;
-    const int gc = g < nimg * C1_PIX ? g : nimg * C1_PIX - 1;
+    const int npix = (ib + 1) * C1_PIX;  // pixels up to the end of the chunk's last image (ib < ib0: the workgroup's last one)
+    const int gc = g < npix ? g : npix - 1;
     const int q = gc >= C1_PIX * (ia + 1) ? ia + 1 : ia, pc = gc - q * C1_PIX;
     int py, px;
     c1_pixel_of(pc, py, px);
     // where the lane's pixel goes in pool1; -1: nothing to store
-    const int ooff = g < nimg * C1_PIX ? (first + q * stride) * P1_IMG + pc : -1;  // chunk order: see P1_PLANE
+    const int ooff = g < npix ? s_gid[q & 1] * P1_IMG + pc : -1;  // chunk order: see P1_PLANE
     const uint8_t *base = s_img[q & 1] + (2 * py) * kImg + 2 * px;
     f32x16 acc16[4];
     f32x4 acc4[4];
@@ -268,8 +294,32 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
     for (int r = 0; r < 2; r++) {
       if (!(refill >> r & 1)) continue;
       const int nxt = (r ? ib : ia) + 2;
-      if (nxt > img_last) continue;
-      const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)(first + nxt * stride) * kPix * C);
+      // the image for local number nxt: drawn when the numbers before it have drawn theirs
+      int gid = -1;
+      if (lane == 0) {
+        for (int spins = 0;; spins++) {
+          if (nxt > *(volatile int *)&s_last) break;  // the queue ran dry at an earlier number
+          if (*(volatile int *)&s_drawn == nxt) {
+            gid = G + atomicAdd(queue, 1);
+            if (gid >= n) {
+              gid = -1;
+              *(volatile int *)&s_last = nxt - 1;  // dry: this workgroup ends with nxt - 1 (waiting chunks see it and leave)
+            }
+            __threadfence_block();
+            *(volatile int *)&s_drawn = nxt + 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          if (*(volatile int *)&s_abort || spins > (1 << 22)) {  // the same watchdog as for the slots
+            *(volatile int *)&s_abort = 1;
+            if (stats) atomicMax(&stats[2], 1ull);
+            break;
+          }
+        }
+      }
+      gid = __builtin_amdgcn_readfirstlane(gid);
+      if (gid < 0) continue;
+      const uint4 *src = reinterpret_cast<const uint4 *>(images + (size_t)gid * kPix * C);
       uint4 *dst = reinterpret_cast<uint4 *>(s_img[nxt & 1]);
       constexpr int NV = kPix * C / 16;
       for (int i0 = 0; i0 < NV; i0 += 64 * 8) {  // eight loads in flight per lane
@@ -285,7 +335,8 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
           if (i < NV) dst[i] = v[u];
         }
       }
-      if (lane == 0) s_refs[nxt & 1] = c1_chunks_of_image(nxt, c0, c1);
+      if (lane == 0) s_gid[nxt & 1] = gid;
+      if (lane == 0) s_refs[nxt & 1] = c1_chunks_of_image(nxt);
       __threadfence_block();  // the bytes and the release count are in LDS before the slot is published
       // (fault: the test hook GPD_C1_FAULT=1 makes workgroup 0 "forget" to publish — the protocol bug the watchdog is for)
       if (lane == 0 && !(fault && blockIdx.x == 0)) *(volatile int *)&s_slot_img[nxt & 1] = nxt;
@@ -772,11 +823,13 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     // persistent conv1: one workgroup per CU, at least two images each
     const int fault = prof_env("GPD_C1_FAULT") != nullptr;  // test hook of the slot watchdog (tests/test_gpu_lenet_stress.py)
     const int c1_grid = m / 2 < 1 ? 1 : (m / 2 < num_cus ? m / 2 : num_cus);
+    int *queue = reinterpret_cast<int *>(s.c1_stats + 3);  // the launch's image counter (conv1, then conv2: zeroed before each)
+    if (hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream) != hipSuccess) return hipGetLastError();
     switch (w.channels) {
-      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
-      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
-      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
-      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault); break;
+      case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault, queue); break;
+      case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault, queue); break;
+      case 3: conv1_mfma_kernel<3><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault, queue); break;
+      case 1: conv1_mfma_kernel<1><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault, queue); break;
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
