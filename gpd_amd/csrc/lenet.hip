@@ -300,10 +300,13 @@ __global__ __launch_bounds__(C1_THREADS) void conv1_mfma_kernel(const uint8_t *_
         for (int spins = 0;; spins++) {
           if (nxt > *(volatile int *)&s_last) break;  // the queue ran dry at an earlier number
           if (*(volatile int *)&s_drawn == nxt) {
+            // (s_last is written before s_drawn: seeing the ticket, look at s_last once more — the number before may have found
+            //  the queue dry between the two reads above, and its s_last must not be overwritten by a later number's)
+            if (nxt > *(volatile int *)&s_last) break;
             gid = G + atomicAdd(queue, 1);
             if (gid >= n) {
               gid = -1;
-              *(volatile int *)&s_last = nxt - 1;  // dry: this workgroup ends with nxt - 1 (waiting chunks see it and leave)
+              atomicMin(&s_last, nxt - 1);  // dry: this workgroup ends with nxt - 1 (waiting chunks see it and leave)
             }
             __threadfence_block();
             *(volatile int *)&s_drawn = nxt + 1;
