@@ -338,6 +338,7 @@ struct ImageState {
   int32_t *d_overflow2 = nullptr;     // [capacity + 1]: candidates the large shadow instantiation could not list, then their count
   char *d_huge_scratch = nullptr;     // list rows of the general shadow kernel
   int channels = 0;
+  int slots = 0;                      // hand slots per set of the list (num_hand_axes * num_orientations)
   int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
   int32_t *d_pts_overflow = nullptr;  // [capacity + 1]: candidates for the large points instantiation, then their count
   char *d_pts_scratch = nullptr;      // point arrays of the large instantiation, one row per workgroup of its grid

@@ -1733,6 +1733,9 @@ struct SetParams {
   const double *frames;     // [S][12], sample first
   const int32_t *set_meta;  // [bitsets][8]: sample slot, N_images, lcg offset lo, hi, camera, -
   uint32_t *set_bits;       // [sets][Vox::SETWORDS]
+  const gpd_hand *hands;    // [S][slots] records of the search ...
+  const int32_t *hand_cand; // ... and which of them are candidates (>= 0): the default mode writes only the part of a set's
+  int slots;                //     region its candidates' boxes can touch
   double view_point[3 * kMaxCams];  // of the cloud (a kernel argument, not a device constant: clouds of a batch
                                     // with different cameras run side by side)
 };
@@ -1792,8 +1795,46 @@ __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
     state = K.stride_a * state + K.stride_c;  // advance by SET_THREADS * num_shadow draws
   }
   if (!WIDE) {
+    // Written out: only the rows (lines along z) inside the voxel bounding box of the set's candidate boxes, one voxel of margin
+    // around each — shadow_image_kernel reads the rows of a candidate's window and keeps the bits its box test passes, and no bit
+    // outside a box passes it, so whatever an earlier launch left in the rest of the row is never seen (129 MB of bitsets per
+    // 5000 candidates were written in full before: half of the image stage's excess HBM traffic).
+    __shared__ int s_bb[4];  // x0, x1, y0, y1 in region voxels
+    if (tid == 0) {
+      s_bb[0] = s_bb[2] = SD;
+      s_bb[1] = s_bb[3] = -1;
+    }
     __syncthreads();
-    for (int w = tid; w < SETWORDS; w += SET_THREADS) out[w] = lds_bits[w];
+    if (tid < P.slots && P.hand_cand[(size_t)slot_s * P.slots + tid] >= 0) {
+      const gpd_hand &H = P.hands[(size_t)slot_s * P.slots + tid];
+      const double lo[3] = {H.bottom, H.center - K.half_od, -1.0 * K.vol_height};
+      const double hi[3] = {H.bottom + K.vol_depth, H.center + K.half_od, K.vol_height};
+      double wmin[2] = {DBL_MAX, DBL_MAX}, wmax[2] = {-DBL_MAX, -DBL_MAX};
+      for (int k = 0; k < 8; k++) {
+        const double bx = (k & 1) ? hi[0] : lo[0], by = (k & 2) ? hi[1] : lo[1], bz = (k & 4) ? hi[2] : lo[2];
+        for (int a = 0; a < 2; a++) {
+          const double w = H.sample[a] + H.frame[3 * a] * bx + H.frame[3 * a + 1] * by + H.frame[3 * a + 2] * bz;
+          wmin[a] = fmin(wmin[a], w);
+          wmax[a] = fmax(wmax[a], w);
+        }
+      }
+      // the window shadow_image_kernel opens for this box: floor(min) - 1 .. floor(max) + 1, here relative to the region
+      atomicMin(&s_bb[0], (int)floor(wmin[0] * K.voxel_mult) - 1 - ox);
+      atomicMax(&s_bb[1], (int)floor(wmax[0] * K.voxel_mult) + 1 - ox);
+      atomicMin(&s_bb[2], (int)floor(wmin[1] * K.voxel_mult) - 1 - oy);
+      atomicMax(&s_bb[3], (int)floor(wmax[1] * K.voxel_mult) + 1 - oy);
+    }
+    __syncthreads();
+    const int x0 = max(s_bb[0], 0), x1 = min(s_bb[1], SD - 1), y0 = max(s_bb[2], 0), y1 = min(s_bb[3], SD - 1);
+    if (x1 >= x0 && y1 >= y0) {
+      const int wpr = (((y1 - y0 + 1) * SD + 31) >> 5) + 1;  // words one x-slab's rows can span
+      for (int idx = tid; idx < (x1 - x0 + 1) * wpr; idx += SET_THREADS) {
+        const int x = x0 + idx / wpr, k = idx - (idx / wpr) * wpr;
+        const int first = (x * SD + y0) * SD, last = (x * SD + y1 + 1) * SD - 1;  // the slab's bits
+        const int w = (first >> 5) + k;
+        if (w <= (last >> 5)) out[w] = lds_bits[w];
+      }
+    }
   }
 }
 
@@ -1953,6 +1994,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
   const int n = sm.num_candidates;
   im.num_candidates = n;
   im.channels = C;
+  im.slots = p.num_hand_axes * p.num_orientations;
   im.stat_sets = sm.live_sets;
   im.stat_sum_set_ni = sm.sum_set_ni;
   im.stat_sum_cand_ni = sm.sum_cand_ni;
@@ -2143,6 +2185,9 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     sp.frames = s.d_frames;
     sp.set_meta = pl.d_set_meta;
     sp.set_bits = im.d_set_bits;
+    sp.hands = s.d_hands;
+    sp.hand_cand = pl.d_hand_cand;
+    sp.slots = im.slots;
     std::memcpy(sp.view_point, im.view_points, sizeof(sp.view_point));
     if (im.huge) {
       const size_t setwords = (size_t)(((long long)im.set_sd * im.set_sd * im.set_sd + 31) / 32);
