@@ -36,8 +36,9 @@ def _case(seed):
     return dict(xyz=xyz, normals=nrm, cam=cam, vp=vp, kw=kw, C=C, obj=cl["is_object"], rng=rng)
 
 
+# GPD_FUZZ_DETECT / _WIDE / _GEOMETRY widen the seed ranges for a soak run (profiles/r04_soak.sh)
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_FUZZ_DETECT", "12"))))
 def test_fuzz_detect_matches_oracle(oracle_mod, seed):
     c = _case(seed)
     C = c["C"]
