@@ -509,11 +509,16 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
 #if !defined(C2_EXP) || C2_EXP != 3
           __builtin_amdgcn_sched_barrier(0);
 #endif
+          // the nine MFMAs at raised wave priority: the SIMD's other two waves are in their VALU tail / operand requests at
+          // any time, and the arbiter otherwise lets those instructions in between this wave's MFMAs (conv2 1.21 -> 1.19 ms;
+          // the same around conv1's and ip1's MFMA runs changes nothing: profiles/NOTES.md E)
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int ft = 0; ft < 3; ft++)
               acc[t][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ft], b_cur[t], acc[t][ft], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
 #if !defined(C2_EXP) || C2_EXP != 3
           __builtin_amdgcn_sched_barrier(0);
 #endif
