@@ -1408,11 +1408,11 @@ int gpd_hip_last_fallbacks(gpd_hip_ctx *ctx, long long out[4]) {
   const ImageState &im = L.images;
   int32_t v = 0;
   if (im.d_overflow && im.channels == 15 && im.num_candidates > 0) {
-    HIP_TRY(hipMemcpy(&v, im.d_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&v, im.d_status + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
     out[1] = v;
   }
   if (im.d_pts_overflow && im.num_candidates > 0) {
-    HIP_TRY(hipMemcpy(&v, im.d_pts_overflow + im.capacity, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&v, im.d_status + 3, sizeof(int32_t), hipMemcpyDeviceToHost));
     out[2] = v;
   }
   out[3] = im.num_candidates > 0 ? (im.num_candidates + 65535) / 65536 : 0;

@@ -335,14 +335,14 @@ struct ImageState {
   bool huge = false;                  // ... or beyond those: the general shadow kernel, a set region of run-time size
   int set_sd = 0, set_sr = 0;         // edge / radius (voxels) of the region shadow_set_kernel fills around a sample
   size_t cap_setwords = 0;            // words per row of d_set_bits
-  int32_t *d_overflow2 = nullptr;     // [capacity + 1]: candidates the large shadow instantiation could not list, then their count
+  int32_t *d_overflow2 = nullptr;     // [capacity]: candidates the large shadow instantiation could not list (count: d_status[2])
   char *d_huge_scratch = nullptr;     // list rows of the general shadow kernel
   int channels = 0;
   int slots = 0;                      // hand slots per set of the list (num_hand_axes * num_orientations)
-  int32_t *d_overflow = nullptr;      // [capacity + 1]: candidates for the large shadow instantiation, then their count
-  int32_t *d_pts_overflow = nullptr;  // [capacity + 1]: candidates for the large points instantiation, then their count
+  int32_t *d_overflow = nullptr;      // [capacity]: candidates for the large shadow instantiation (count: d_status[1])
+  int32_t *d_pts_overflow = nullptr;  // [capacity]: candidates for the large points instantiation (count: d_status[3])
   char *d_pts_scratch = nullptr;      // point arrays of the large instantiation, one row per workgroup of its grid
-  int32_t *d_status = nullptr;        // error flags from the kernels
+  int32_t *d_status = nullptr;        // [4]: error flags from the kernels, then the counters of the three overflow lists
   long long stat_sets = 0, stat_sum_set_ni = 0, stat_sum_cand_ni = 0;  // for the algorithmic byte count
   std::vector<unsigned char> consts;  // the constant block (image geometry) the candidate list was built with
   double view_points[3 * kMaxCams] = {0};  // of the cloud the list was built on (shadow_set_kernel argument)
@@ -356,7 +356,7 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets);
 // Sizes the image buffers for the plan's candidate list (summary already on the host) and launches the image kernels.
 int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream);
 // Re-launches them on the resident list.  Nothing waits for the device: capacity flags accumulate in im.d_status.
-int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream);
+int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream, bool counters_clean = false);
 void images_status_text(int status, char *buf, size_t len);
 hipError_t planar_to_hwc(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream);
 hipError_t hwc_to_planar(const uint8_t *src, uint8_t *dst, int n, int C, hipStream_t stream);

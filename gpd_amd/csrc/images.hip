@@ -1915,7 +1915,8 @@ void images_free(ImageState &im) {
 int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) {
   const int C = p.image_num_channels;
   if (!im.d_status) {
-    HIP_RET(hipMalloc(&im.d_status, sizeof(int32_t)));
+    HIP_RET(hipMalloc(&im.d_status, 4 * sizeof(int32_t)));  // [0] flags, [1..3] the counters of the three overflow lists: ONE memset per launch
+    HIP_RET(hipMemset(im.d_status, 0, 4 * sizeof(int32_t)));
     HIP_RET(hipMalloc(&im.d_pts_scratch, (size_t)LGRID * PTS_SCRATCH_BYTES));
   }
   if (n > im.capacity) {
@@ -1931,9 +1932,9 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
     im.capacity = 0;
     const int cap = n + n / 4;  // slack: the clouds of a batch differ a little
     HIP_RET(hipMalloc(&im.d_images, (size_t)cap * kPix * C));
-    HIP_RET(hipMalloc(&im.d_overflow, (size_t)(cap + 1) * sizeof(int32_t)));  // list + its counter
-    HIP_RET(hipMalloc(&im.d_overflow2, (size_t)(cap + 1) * sizeof(int32_t)));  // ... of the large instantiation, for the general kernel
-    HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)(cap + 1) * sizeof(int32_t)));
+    HIP_RET(hipMalloc(&im.d_overflow, (size_t)cap * sizeof(int32_t)));  // list (its counter: d_status[1])
+    HIP_RET(hipMalloc(&im.d_overflow2, (size_t)cap * sizeof(int32_t)));  // ... of the large instantiation, for the general kernel
+    HIP_RET(hipMalloc(&im.d_pts_overflow, (size_t)cap * sizeof(int32_t)));
     im.capacity = cap;
   }
   {
@@ -2004,7 +2005,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
     const int rc = images_reserve(p, im, n, im.num_shadow_sets);
     if (rc) return rc;
   }
-  HIP_RET(hipMemsetAsync(im.d_status, 0, sizeof(int32_t), stream));
+  HIP_RET(hipMemsetAsync(im.d_status, 0, 4 * sizeof(int32_t), stream));  // the flags and the overflow counters of this launch
   if (n == 0) return GPD_OK;
   ImgConsts k;
   std::memset(&k, 0, sizeof(k));
@@ -2082,7 +2083,7 @@ int images_run(const gpd_params &p, const Cloud &c, const SearchState &s, const 
   }
   const unsigned char *kb = reinterpret_cast<const unsigned char *>(&k);
   if (im.consts.size() != sizeof(k) || std::memcmp(im.consts.data(), kb, sizeof(k)) != 0) im.consts.assign(kb, kb + sizeof(k));
-  return images_launch(s, pl, im, stream);
+  return images_launch(s, pl, im, stream, /*counters_clean=*/true);
 }
 
 // c_img is ONE block per device, shared by every context of the process on that device.  Under the
@@ -2111,9 +2112,11 @@ static int load_img_consts(const std::vector<unsigned char> &want, hipStream_t s
 // Launches the image kernels over the candidate list resident on the device.  Nothing here waits for the
 // device: the large instantiations read the length of their queues on the device, capacity flags
 // accumulate in im.d_status (read by the caller with its results).
-int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream) {
+int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStream_t stream, bool counters_clean) {
   const int n = im.num_candidates;
   if (n <= 0) return GPD_OK;
+  // the three overflow counters of the launch (the flags in d_status[0] accumulate over re-launches)
+  if (!counters_clean) HIP_RET(hipMemsetAsync(im.d_status + 1, 0, 3 * sizeof(int32_t), stream));
   std::lock_guard<std::mutex> consts_lock(g_img_mutex);
   {
     const int rc = load_img_consts(im.consts, stream);
@@ -2160,15 +2163,14 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     HIP_RET(hipStreamWaitEvent(pts_stream, im.ev_fork, 0));
   }
   ip.pts_overflow_list = im.d_pts_overflow;
-  ip.pts_overflow_count = im.d_pts_overflow + im.capacity;
+  ip.pts_overflow_count = im.d_status + 3;
   ip.pts_scratch = nullptr;
-  HIP_RET(hipMemsetAsync(im.d_pts_overflow + im.capacity, 0, sizeof(int32_t), pts_stream));
   grasp_image_kernel<false><<<8 * ((n + 7) / 8), IMG_THREADS, lds_pad, pts_stream>>>(ip);
   HIP_RET(hipGetLastError());
   {
     ImgParams ib = ip;
     ib.cand_list = im.d_pts_overflow;
-    ib.cand_count = im.d_pts_overflow + im.capacity;
+    ib.cand_count = im.d_status + 3;
     ib.pts_overflow_list = nullptr;
     ib.pts_overflow_count = nullptr;
     ib.pts_scratch = im.d_pts_scratch;
@@ -2205,14 +2207,13 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
   ip.cand_count = nullptr;
   ip.num_cand = n;
   ip.overflow_list = im.d_overflow;
-  ip.overflow_count = im.d_overflow + im.capacity;
+  ip.overflow_count = im.d_status + 1;
   if (im.channels == 15) {
     // most boxes fit the two-per-CU instantiation; the few that do not are queued by it and
     // redone by the large one
-    HIP_RET(hipMemsetAsync(im.d_overflow + im.capacity, 0, sizeof(int32_t), stream));
     ImgParams ib = ip;
     ib.cand_list = im.d_overflow;
-    ib.cand_count = im.d_overflow + im.capacity;
+    ib.cand_count = im.d_status + 1;
     ib.overflow_list = nullptr;
     ib.overflow_count = nullptr;
     if (im.huge) {
@@ -2224,16 +2225,15 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
       shadow_image_any_kernel<<<LGRID, IMG_THREADS, 0, stream>>>(ia);
     } else if (im.wide) {
       // a wide box can hold more voxels than the large instantiation lists: it queues those for the general kernel
-      HIP_RET(hipMemsetAsync(im.d_overflow2 + im.capacity, 0, sizeof(int32_t), stream));
       ib.overflow_list = im.d_overflow2;
-      ib.overflow_count = im.d_overflow2 + im.capacity;
+      ib.overflow_count = im.d_status + 2;
       shadow_image_kernel<SH_CAP, true><<<8 * ((n + 7) / 8), IMG_THREADS, 0, stream>>>(ip);
       HIP_RET(hipGetLastError());
       shadow_image_kernel<SH_CAP_BIG, true><<<LGRID, IMG_THREADS, 0, stream>>>(ib);
       HIP_RET(hipGetLastError());
       ImgParams ia = ip;
       ia.cand_list = im.d_overflow2;
-      ia.cand_count = im.d_overflow2 + im.capacity;
+      ia.cand_count = im.d_status + 2;
       ia.overflow_list = nullptr;
       ia.overflow_count = nullptr;
       ia.huge_scratch = im.d_huge_scratch;

@@ -831,7 +831,7 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     // persistent conv1: one workgroup per CU, at least two images each
     const int fault = prof_env("GPD_C1_FAULT") != nullptr;  // test hook of the slot watchdog (tests/test_gpu_lenet_stress.py)
     const int c1_grid = m / 2 < 1 ? 1 : (m / 2 < num_cus ? m / 2 : num_cus);
-    int *queue = reinterpret_cast<int *>(s.c1_stats + 3);  // the launch's image counter (conv1, then conv2: zeroed before each)
+    int *queue = reinterpret_cast<int *>(s.c1_stats + 3);  // the image counters of the two conv launches (conv1's, conv2's): one memset for both
     if (hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream) != hipSuccess) return hipGetLastError();
     switch (w.channels) {
       case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault, queue); break;
@@ -841,10 +841,8 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
       default: return hipErrorInvalidValue;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[0], stream);
-    // conv2 draws its images from a counter (c1_stats[3], zero at launch)
-    if (hipMemsetAsync(s.c1_stats + 3, 0, sizeof(unsigned long long), stream) != hipSuccess) return hipGetLastError();
-    conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m,
-                                                                             reinterpret_cast<int *>(s.c1_stats + 3));
+    // conv2 draws its images from the second counter (zero since the memset above)
+    conv2_mfma_kernel<<<(m < num_cus ? m : num_cus), C2_THREADS, 0, stream>>>(s.pool1, w.c2wt, w.c2w, w.c2b, s.flat, m, queue + 1);
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[1], stream);
     switch (fc1_pick_nt(m)) {
       case 1: fc1_launch<1>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
