@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--batch-samples", type=int, default=2564, help="samples per cloud of the batch legs")
     ap.add_argument("--batch-clouds", type=int, default=None,
                     help="replay mode: clouds per rank and pass of the batch_end_to_end leg (default 24 on one GPU, 32 on several; 0 disables)")
-    ap.add_argument("--batch-passes", type=int, default=4, help="replay mode: timed passes of the batch_end_to_end leg (after one full untimed pass)")
+    ap.add_argument("--batch-passes", type=int, default=8, help="replay mode: timed passes of the batch_end_to_end leg (after one full untimed pass)")
     ap.add_argument("--cpu-samples", type=int, default=1500, help="samples of the CPU-baseline leg (0 disables)")
     ap.add_argument("--devices", default=None,
                     help="comma list: the HIP device of local rank r is devices[r %% len] (default: r).  `--devices 0,0` runs two ranks on ONE "
@@ -204,19 +204,22 @@ def main():
         t0 = time.perf_counter()
         n_cand = 0
         stage = np.zeros(3)
-        pass_s, pass_cand, pass_allocs, pass_host = [], [], [], []
+        pass_s, pass_cand, pass_allocs, pass_host, pass_rows = [], [], [], [], []
         for _ in range(passes):
             tp = time.perf_counter()
             nc_pass = 0
+            per_cloud = []
             for hands, ns, nc, ms in ctx.run_batch(prepared):
                 nc_pass += nc
                 stage += ms
+                per_cloud.append([round(float(x), 2) for x in ms])
             pass_s.append(time.perf_counter() - tp)
             pass_cand.append(nc_pass)
             n_cand += nc_pass
             tl = ctx.last_batch_timeline
             pass_allocs.append(sum(a for _, a in tl))
             pass_host.append(_host_split([h for h, _ in tl]))
+            pass_rows.append([[round(x, 2) for x in h] + [ms_c] for (h, _), ms_c in zip(tl, per_cloud)])
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -234,6 +237,10 @@ def main():
                             "cand_per_s_rank0": {"min": rates[0], "median": rates[len(rates) // 2], "max": rates[-1]},
                             "buffer_growths_in_timed_passes": int(sum(pass_allocs)),
                             "host_ms_slowest_pass": pass_host[slow], "host_ms_fastest_pass": pass_host[int(np.argmin(pass_s))],
+                            # a pass more than 5 % above the median: its clouds one by one, so that the stall can be placed
+                            # ([begin done, plan arrived, middle enqueued, results arrived, records copied] ms since entry,
+                            #  then the cloud's [search, images, LeNet] kernel ms)
+                            "outlier_pass_clouds": pass_rows[slow] if pass_s[slow] > 1.05 * sorted(pass_s)[len(pass_s) // 2] else None,
                             "note": "one pass = one gpd_hip_detect_batch call over the rank's clouds (pipeline filled and drained per call); "
                                     "host_ms: the calling thread's time enqueuing / copying vs blocked on the device (gpd_detect_job.host_ms)"},
                     kernel_ms_rank0={"search": float(stage[0]), "images": float(stage[1]), "lenet": float(stage[2]),
@@ -325,11 +332,18 @@ def main():
     assert launches == args.steps
     pairs_done, pairs_seen = ctx.conv1_stats(reset=True)
     live_frac = pairs_done / pairs_seen if pairs_seen else None
-    trained = _trained_magnitude_leg(ctx, hands_f, C, real) if (rank == 0 and args.gpus == 1 and C == 15 and args.cpu_samples > 0) else None
-
+    # (the batch leg runs BEFORE any leg that uses the host's cores: the oracle's OpenMP team and torch's intra-op threads keep
+    #  spinning for a while after their last parallel region, and a spinning team beside the HIP runtime's threads showed up as
+    #  one 30 ms stall in one of eight batch passes — r04_cold.sh on two boxes; 48 passes without those legs: none)
     batch = None
     if args.batch_clouds > 0 and C == 15 and not clutter:
         batch = batch_leg([rank + world * k for k in range(args.batch_clouds)], args.batch_passes, 1)
+    trained = None
+    if rank == 0 and args.gpus == 1 and C == 15 and args.cpu_samples > 0:
+        if batch is not None:  # the batch left its last cloud resident: the benchmark's cloud and its search state once more
+            ctx.upload_cloud(cloud["xyz"], cloud["normals"], cloud["cam_source"], cloud["view_points"])
+            ctx.search(si)
+        trained = _trained_magnitude_leg(ctx, hands_f, C, real)
 
     if rank == 0:
         value = total_cand * args.steps / elapsed
