@@ -52,6 +52,10 @@ class GpdHipError(RuntimeError):
     pass
 
 
+# gpd_hip_set_lenet_mode (include/gpd_hip.h)
+LENET_SPLIT, LENET_F32_CHAIN = 0, 1
+
+
 def bind_host_thread(device):
     """gpd_hip_bind_host_thread: the calling thread onto the CPUs of the device's NUMA node -> (node or -1, cpus)."""
     n = C.c_int(0)
@@ -63,12 +67,16 @@ EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_h
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
-           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters", "gpd_hip_reserve", "gpd_hip_bind_host_thread"]
+           "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters", "gpd_hip_reserve", "gpd_hip_bind_host_thread",
+           "gpd_hip_set_lenet_mode", "gpd_hip_lenet_debug", "gpd_hip_lenet_fast_tables"]
 
 
-def build():
-    """Compile libgpd_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+def build(prof=True):
+    """Compile libgpd_hip.so for gfx950 (hipcc cross-compiles without a GPU) and, with `prof`, the profiling build
+    libgpd_hip_prof.so (needs the roctx headers; the release library does not)."""
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+    if prof:
+        subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc"), "prof"])
 
 
 def lib():
@@ -108,6 +116,8 @@ def lib():
         L.gpd_hip_conv1_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.gpd_hip_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.gpd_hip_bind_host_thread.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.gpd_hip_set_lenet_mode.argtypes = [C.c_void_p, C.c_int]
+        L.gpd_hip_lenet_debug.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.gpd_hip_replay_times.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
         _LIB = L
     return _LIB
@@ -153,6 +163,17 @@ class Context:
         ch = self.params.image_num_channels
         assert arrs[0].size == 20 * ch * 25, "conv1 weights do not match image_num_channels"
         self._check(lib().gpd_hip_set_lenet_weights(self._h, ch, *[_ptr(a) for a in arrs]))
+
+    def set_lenet_mode(self, mode):
+        """LENET_SPLIT (default: int8 / bf16 matrix pipes on exactly split operands) or LENET_F32_CHAIN (the oracle's
+        k-ascending fmaf chains, bit-identical, 1/16 of the matrix rate)."""
+        self._check(lib().gpd_hip_set_lenet_mode(self._h, int(mode)))
+
+    def lenet_debug(self, which, n):
+        """Test hook: pool1 (0), the flattened pool2 as bf16 planes (1) or ip1 transposed (2) of the last score() pass."""
+        out = {0: np.zeros((n, 15680), np.float32), 1: np.zeros((3, n, 7200), np.uint16), 2: np.zeros((500, n), np.float32)}[which]
+        self._check(lib().gpd_hip_lenet_debug(self._h, int(which), int(n), _ptr(out)))
+        return out
 
     def score(self, images=None, n=None):
         """Classifier::classifyImages; images [n,60,60,C] u8, or None to score the device images."""

@@ -617,6 +617,7 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
                   &ctx->lenet.f1w, &ctx->lenet.f1b, &ctx->lenet.f2w, &ctx->lenet.f2b, &ctx->lenet.c1wp, &ctx->lenet.c2wt};
   for (float **p : ws)
     if (*p) (void)hipFree(*p);
+  lenet_fast_free(ctx->lenet.fast);
   for (auto &e : ctx->replay_events) (void)hipEventDestroy(e);
   if (ctx->pipe_stream) {
     (void)hipStreamSynchronize(ctx->pipe_stream);
@@ -674,13 +675,22 @@ int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1
                {&ctx->lenet.c2w, conv2_w, (size_t)50 * 500},          {&ctx->lenet.c2b, conv2_b, 50},
                {&ctx->lenet.f1w, ip1_w, (size_t)kFc1In * kFc1Out},    {&ctx->lenet.f1b, ip1_b, kFc1Out},
                {&ctx->lenet.f2w, ip2_w, (size_t)2 * kFc1Out},         {&ctx->lenet.f2b, ip2_b, 2}};
-  // conv1 drops input windows that are entirely zero; that is exact only for finite weights
-  // (inf * 0 would be NaN in the reference's dense GEMM)
-  for (size_t i = 0; i < (size_t)20 * channels * 25; i++)
-    if (!std::isfinite(conv1_w[i])) {
-      set_error("gpd_hip_set_lenet_weights: conv1 weight %zu is not finite", i);
-      return GPD_ERR_INVALID;
-    }
+  // the f32 chain's conv1 drops input windows that are entirely zero; that is exact only for finite weights
+  // (inf * 0 would be NaN in the reference's dense GEMM); the split path cuts conv1 / conv2 / ip1 weights into
+  // fixed-point digits / bf16 pieces, which are defined for finite numbers
+  {
+    struct {
+      const char *name;
+      const float *w;
+      size_t n;
+    } fin[] = {{"conv1", conv1_w, (size_t)20 * channels * 25}, {"conv2", conv2_w, (size_t)50 * 500}, {"ip1", ip1_w, (size_t)kFc1In * kFc1Out}};
+    for (auto &it : fin)
+      for (size_t i = 0; i < it.n; i++)
+        if (!std::isfinite(it.w[i])) {
+          set_error("gpd_hip_set_lenet_weights: %s weight %zu is not finite", it.name, i);
+          return GPD_ERR_INVALID;
+        }
+  }
   for (auto &L : ctx->lane)
     if (L.stream) HIP_TRY(hipStreamSynchronize(L.stream));  // no kernel still reads the old weights
   for (auto &it : items) {
@@ -710,7 +720,51 @@ int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1
       HIP_TRY(hipMemcpy(*it.dst, it.src->data(), it.src->size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
+  HIP_TRY(lenet_fast_prepare(ctx->lenet.fast, channels, conv1_w, conv2_w, ip1_w));
   ctx->lenet.channels = channels;
+  return GPD_OK;
+}
+
+int gpd_hip_set_lenet_mode(gpd_hip_ctx *ctx, int mode) {
+  if (!ctx || (mode != GPD_LENET_SPLIT && mode != GPD_LENET_F32_CHAIN)) {
+    set_error("gpd_hip_set_lenet_mode: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (auto &L : ctx->lane)
+    if (L.stream) HIP_TRY(hipStreamSynchronize(L.stream));  // the two modes lay pool1 out differently: no launch in flight
+  ctx->lenet.mode = mode;
+  return GPD_OK;
+}
+
+// test hook: the intermediate tensors of lane 0's last LeNet pass (which = 0: pool1 as f32 [n][15680], 1: the three bf16
+// planes of the flattened pool2 [3][n][7200] (split path), 2: fc1 transposed f32 [500][n])
+int gpd_hip_lenet_debug(gpd_hip_ctx *ctx, int which, int n, void *out) {
+  if (!ctx || !out || n < 1) {
+    set_error("gpd_hip_lenet_debug: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  Lane &L = ctx->lane[0];
+  LeNetScratch &s = L.lenet_scratch;
+  if (n > s.capacity) {
+    set_error("gpd_hip_lenet_debug: n = %d exceeds the scratch capacity %d", n, s.capacity);
+    return GPD_ERR_STATE;
+  }
+  HIP_TRY(hipStreamSynchronize(L.stream));
+  if (which == 0) {
+    HIP_TRY(hipMemcpy(out, s.pool1, (size_t)n * 15680 * sizeof(float), hipMemcpyDeviceToHost));
+  } else if (which == 1) {
+    for (int pc = 0; pc < 3; pc++)
+      HIP_TRY(hipMemcpy2D(static_cast<char *>(out) + (size_t)pc * n * 7200 * 2, 7200 * 2, s.xs + (size_t)pc * s.capacity * 7232, 7232 * 2, 7200 * 2, n,
+                          hipMemcpyDeviceToHost));
+  } else if (which == 2) {
+    HIP_TRY(hipMemcpy2D(out, (size_t)n * sizeof(float), s.fc1t, (size_t)s.capacity * sizeof(float), (size_t)n * sizeof(float), kFc1Out,
+                        hipMemcpyDeviceToHost));
+  } else {
+    set_error("gpd_hip_lenet_debug: which = %d", which);
+    return GPD_ERR_INVALID;
+  }
   return GPD_OK;
 }
 

@@ -22,8 +22,22 @@ constexpr int kFc1In = 7200;        // 50 * 12 * 12
 constexpr int kFc1Out = 500;
 
 // ---- LeNet (lenet.hip) ----------------------------------------------------
+// operand tables of the split path (lenet_fast.hip): conv1 as four int8 digit planes of 32-bit fixed-point weights, conv2 / ip1
+// as three bf16 pieces per weight, all in the kernels' MFMA fragment layouts
+struct LeNetFast {
+  uint4 *c1a = nullptr;            // conv1 A fragments [7 k-steps][5 row tiles][64 lanes] x 16 int8
+  double *c1corr = nullptr;        // [20] 128 * sum of the filter's fixed-point weights (the x - 128 shift of the inputs)
+  int *c1shift = nullptr;          // [20] fixed-point position s of the filter: value = integer * 2^-s
+  uint4 *c2b = nullptr;            // conv2 B fragments [2][2][3 pieces][16 k-steps][64 lanes] x 8 bf16
+  unsigned short *f1wt = nullptr;  // ip1 [3 pieces][512 units][7232 k] bf16
+};
+void lenet_fast_free(LeNetFast &f);
+hipError_t lenet_fast_prepare(LeNetFast &f, int channels, const float *c1w, const float *c2w, const float *f1w);
+
 struct LeNetWeights {
   int channels = 0;
+  int mode = GPD_LENET_SPLIT;  // gpd_hip_set_lenet_mode
+  LeNetFast fast;
   float *c1w = nullptr, *c1b = nullptr, *c2w = nullptr, *c2b = nullptr;
   float *c1wp = nullptr;  // conv1 weights padded to [20][C][28] (25 taps + 3 zeros): 16-byte rows for the LDS table
   float *c2wt = nullptr;  // conv2 weights k-major [K][F] for the implicit-GEMM A operand
@@ -32,8 +46,10 @@ struct LeNetWeights {
 
 struct LeNetScratch {
   int capacity = 0;        // images per chunk
-  float *pool1 = nullptr;  // [cap][20][784]: planes in conv1's chunk order (whole-line stores, lenet.hip P1_PLANE)
+  float *pool1 = nullptr;  // f32 chain: [cap][20][784], planes in conv1's chunk order (whole-line stores, lenet.hip P1_PLANE);
+                           // split path: [cap][784][20], pixel-major
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
+  unsigned short *xs = nullptr;  // split path: flat as three bf16 planes [3][cap][7232] (k >= 7200: zeros, written once at allocation)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)
   unsigned long long *c1_stats = nullptr;  // device: [0] (chunk, channel) pairs conv1 executed, [1] pairs it looked at — summed
@@ -44,6 +60,9 @@ struct LeNetScratch {
 // Scores n images (device pointer, planar u8 [n][C][3600]) into d_scores (device). Async on stream.
 hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *d_images, int n, float *d_scores,
                          hipStream_t stream, hipEvent_t *kernel_events = nullptr);
+// the split path's three matrix kernels (lenet_fast.hip); `queue`: two zeroed image counters (conv1's, conv2's)
+hipError_t lenet_forward_fast(const LeNetWeights &w, LeNetScratch &s, const uint8_t *img, int m, float *d_scores, hipStream_t stream,
+                              hipEvent_t *kernel_events, int *queue);
 hipError_t lenet_scratch_reserve(LeNetScratch &s, int n);
 // after the stream was synchronised: GPD_ERR_HIP (and the error word cleared) when a conv1 launch gave up on its slot protocol
 int lenet_check(LeNetScratch &s);

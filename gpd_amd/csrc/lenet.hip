@@ -782,6 +782,9 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   hipError_t e;
   if ((e = hipMalloc(&s.pool1, (size_t)n * P1_IMG * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
+  constexpr size_t kXld = 7232;  // lenet_fast.hip F2_XLD: 7200 + 32 zeros, which no kernel ever writes
+  if ((e = hipMalloc(&s.xs, (size_t)3 * n * kXld * sizeof(unsigned short))) != hipSuccess) return e;
+  if ((e = hipMemset(s.xs, 0, (size_t)3 * n * kXld * sizeof(unsigned short))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.c1_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
   if ((e = hipMemset(s.c1_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
@@ -805,6 +808,7 @@ int lenet_check(LeNetScratch &s) {
 void lenet_scratch_free(LeNetScratch &s) {
   if (s.pool1) (void)hipFree(s.pool1);
   if (s.flat) (void)hipFree(s.flat);
+  if (s.xs) (void)hipFree(s.xs);
   if (s.fc1t) (void)hipFree(s.fc1t);
   if (s.c1_stats) (void)hipFree(s.c1_stats);
   s = LeNetScratch();
@@ -828,11 +832,16 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
   for (int off = 0; off < n; off += kChunk) {
     const int m = (n - off < kChunk) ? (n - off) : kChunk;
     const uint8_t *img = d_images + (size_t)off * kPix * w.channels;
+    int *queue = reinterpret_cast<int *>(s.c1_stats + 3);  // the image counters of the two conv launches (conv1's, conv2's): one memset for both
+    if (hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream) != hipSuccess) return hipGetLastError();
+    if (w.mode == GPD_LENET_SPLIT) {
+      // the default: int8 / bf16 MFMA kernels on exactly split operands (lenet_fast.hip)
+      if ((e = lenet_forward_fast(w, s, img, m, d_scores + off, stream, kernel_events && off == 0 ? kernel_events : nullptr, queue)) != hipSuccess)
+        return e;
+    } else {
     // persistent conv1: one workgroup per CU, at least two images each
     const int fault = prof_env("GPD_C1_FAULT") != nullptr;  // test hook of the slot watchdog (tests/test_gpu_lenet_stress.py)
     const int c1_grid = m / 2 < 1 ? 1 : (m / 2 < num_cus ? m / 2 : num_cus);
-    int *queue = reinterpret_cast<int *>(s.c1_stats + 3);  // the image counters of the two conv launches (conv1's, conv2's): one memset for both
-    if (hipMemsetAsync(queue, 0, sizeof(unsigned long long), stream) != hipSuccess) return hipGetLastError();
     switch (w.channels) {
       case 15: conv1_mfma_kernel<15><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault, queue); break;
       case 12: conv1_mfma_kernel<12><<<c1_grid, C1_THREADS, 0, stream>>>(img, w.c1wp, w.c1b, s.pool1, m, s.c1_stats, fault, queue); break;
@@ -855,6 +864,7 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
       default: fc1_launch<8>(w.f1w, w.f1b, s.flat, s.fc1t, m, s.capacity, stream); break;
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[2], stream);
+    }
     fc2_score_kernel<<<(m + 31) / 32, FC2_THREADS, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
   }
   return hipGetLastError();

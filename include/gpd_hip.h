@@ -34,6 +34,17 @@ extern "C" {
 #define GPD_ERR_CAPACITY (-3)  /* a neighbourhood exceeded the LDS list capacity */
 #define GPD_ERR_STATE (-4)     /* call order violated (no cloud / no weights)    */
 
+/* How Classifier::classifyImages' dot products are summed (gpd_hip_set_lenet_mode):
+ *  GPD_LENET_SPLIT      (default) conv1 on the int8 matrix pipe — exact integer dot products of the u8 inputs with 32-bit
+ *                       fixed-point weights, one rounding — conv2 / ip1 on the bf16 matrix pipe with every f32 operand cut
+ *                       into three bf16 pieces (six exact piece products per term, f32 accumulation); ip2 as f32 chains.
+ *                       The reference's Eigen GEMM fixes no summation order (conv_layer.cpp:54, dense_layer.cpp:11); the
+ *                       scores are within 1e-4 of its plain-float path and closer to float64 than an f32 chain's.
+ *  GPD_LENET_F32_CHAIN  every dot product as ONE k-ascending f32 fmaf chain on the f32-input MFMA: bit-identical to
+ *                       oracle/gpd_oracle.cpp, 1/16 of the matrix rate.  The checker mode. */
+#define GPD_LENET_SPLIT 0
+#define GPD_LENET_F32_CHAIN 1
+
 /*
  * Parameters of the path.  Field names follow the reference's cfg keys:
  * hand geometry  — cfg/hand_geometry.cfg:8-12, candidate/hand_geometry.cpp:25-30
@@ -109,13 +120,17 @@ const char *gpd_hip_last_error(void);
  * conv1 [20][C*25] row-major, conv2 [50][500] row-major, ip1 column-major
  * 500 x 7200 over the pixel-major flatten (eigen_classifier.cpp:103-107,
  * dense_layer.cpp:7), ip2 column-major 2 x 500.  Copied to the device once.
- * The conv1 weights must be finite (GPD_ERR_INVALID otherwise): conv1 skips input
- * patches that are all zero, which is exact for finite weights only (0 * inf = NaN). */
+ * All conv1 / conv2 / ip1 weights must be finite (GPD_ERR_INVALID otherwise): the f32 chain's conv1 skips input
+ * patches that are all zero, which is exact for finite weights only (0 * inf = NaN), and the split
+ * path's fixed-point / bf16 pieces are defined for finite numbers. */
 int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels,
                               const float *conv1_w, const float *conv1_b,
                               const float *conv2_w, const float *conv2_b,
                               const float *ip1_w, const float *ip1_b,
                               const float *ip2_w, const float *ip2_b);
+
+/* GPD_LENET_SPLIT or GPD_LENET_F32_CHAIN (above) for every later scoring call of the context. */
+int gpd_hip_set_lenet_mode(gpd_hip_ctx *ctx, int mode);
 
 /* Replaces Classifier::classifyImages (net/classifier.h:70-71,
  * eigen_classifier.cpp:59-79).  images: n contiguous 60x60xC u8 HWC images
@@ -327,6 +342,13 @@ int gpd_hip_replay_kernel_ms(gpd_hip_ctx *ctx, float ms[4]);
  * executed / looked-at x the dense FLOP count = the FLOPs the matrix pipe really ran (bench.py's roofline.frac).
  * Measurement only: no reference counterpart. */
 int gpd_hip_conv1_stats(gpd_hip_ctx *ctx, unsigned long long pairs[2], int reset);
+/* test hook: intermediate tensors of the last gpd_hip_score pass (n images) — which = 0: pool1 f32 [n][15680] (layout of the
+ * mode), 1: the three bf16 planes of the flattened pool2 [3][n][7200] (GPD_LENET_SPLIT), 2: ip1 after ReLU, transposed f32 [500][n] */
+int gpd_hip_lenet_debug(gpd_hip_ctx *ctx, int which, int n, void *out);
+/* test hook, host only: the operand tables of the split path's conv kernels as uploaded — atab: conv1's int8 digit
+ * fragments [7][5][64][16], corr / shift [20], btab: conv2's bf16 fragments [2][2][3][16][64][8] */
+int gpd_hip_lenet_fast_tables(int channels, const float *conv1_w, const float *conv2_w, uint8_t *atab, double *corr, int *shift,
+                              unsigned short *btab);
 
 #ifdef __cplusplus
 }

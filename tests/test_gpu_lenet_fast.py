@@ -1,0 +1,202 @@
+"""The default LeNet path (GPD_LENET_SPLIT: conv1 on int8 MFMA with exact integer sums, conv2 / ip1 on bf16 MFMA with
+three-piece operands) through the C-ABI, stage by stage and end to end.
+
+  * pool1 is EXACT: bit-identical to an integer convolution with the fixed-point weights, rounded once (numpy int64);
+  * the flattened pool2 and ip1 against float64 references of the same inputs;
+  * scores: within 1e-4 of the reference's plain-float path on every 15-channel pin (BASELINE.json's bar, asserted against
+    what the reference's own code returned), and closer to the order-free long-double yardstick than the f32 chain is;
+  * every image's score is independent of the batch it is scored in (tile shapes, ragged tails, two passes);
+  * the f32-chain mode stays bit-identical to the oracle.
+"""
+import numpy as np
+import pytest
+
+import ref_cases as rcs
+from gpd_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(C, mode=None, weights=None):
+    from gpd_amd import api
+    ctx = api.Context(api.default_params(C))
+    ctx.set_lenet_weights(weights if weights is not None else rcs.weights(C, trained_magnitude=True))
+    if mode is not None:
+        ctx.set_lenet_mode(mode)
+    return ctx
+
+
+def _bf16_to_f64(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def _conv_valid(x, w):
+    F = w.shape[0]
+    H, W = x.shape[1] - 4, x.shape[2] - 4
+    out = np.zeros((F, H, W), np.int64 if x.dtype == np.int64 else np.float64)
+    for ky in range(5):
+        for kx in range(5):
+            out += np.einsum("fc,chw->fhw", w[:, :, ky, kx], x[:, ky:ky + H, kx:kx + W])
+    return out
+
+
+def _pool(h):
+    F, H, W = h.shape
+    return h.reshape(F, H // 2, 2, W // 2, 2).max(axis=(2, 4))
+
+
+def _pool1_exact(img_hwc, w, C):
+    """conv1 + pool1 as the split path defines it: integer dot products with round(w 2^s), one rounding, + bias"""
+    c1w = w["c1w"].reshape(20, C, 5, 5)
+    x = np.transpose(img_hwc, (2, 0, 1)).astype(np.int64)
+    out = np.zeros((20, 28, 28), np.float32)
+    for f in range(20):
+        mx = float(np.abs(c1w[f]).max())
+        s = 30 - int(np.frexp(mx)[1]) if mx > 0 else 0
+        Wi = np.rint(c1w[f].astype(np.float64) * 2.0 ** s).astype(np.int64)[None]
+        h = _pool(_conv_valid(x, Wi))[0]
+        out[f] = np.ldexp(h.astype(np.float32), -s).astype(np.float32) + w["c1b"][f]
+    return np.transpose(out, (1, 2, 0))  # [row][column][filter]
+
+
+@pytest.mark.parametrize("C", [15, 12, 3, 1])
+def test_stages_against_numpy(C):
+    from gpd_amd import api
+    rng = np.random.RandomState(100 + C)
+    w = synth.lenet_weights(C, seed=11, trained_magnitude=True)
+    n = 37
+    img = rng.randint(0, 256, (n, 60, 60, C)).astype(np.uint8)
+    img[rng.rand(n, 60, 60, C) < 0.6] = 0  # grasp images are mostly zeros
+    img[3] = 255
+    img[4] = 0
+    ctx = _ctx(C, api.LENET_SPLIT, w)
+    try:
+        sc = ctx.score(img)
+        pool1 = ctx.lenet_debug(0, n).reshape(n, 28, 28, 20)
+        xs = ctx.lenet_debug(1, n)
+        fc1t = ctx.lenet_debug(2, n)
+        # conv1: exact
+        for i in (0, 3, 4, 17, n - 1):
+            assert np.array_equal(pool1[i], _pool1_exact(img[i], w, C)), i
+        # conv2 + pool2: float64 on the device's own pool1; flat index = pixel * 50 + filter
+        flat = (_bf16_to_f64(xs[0]) + _bf16_to_f64(xs[1]) + _bf16_to_f64(xs[2]))  # [n][7200], exact sum of the pieces
+        c2w = w["c2w"].reshape(50, 20, 5, 5).astype(np.float64)
+        for i in (0, 3, 17, n - 1):
+            h = _conv_valid(np.transpose(pool1[i], (2, 0, 1)).astype(np.float64), c2w)
+            ref = (np.transpose(_pool(h), (1, 2, 0)) + w["c2b"].astype(np.float64)).reshape(-1)
+            scale = np.abs(ref).max()
+            assert np.abs(flat[i] - ref).max() <= scale * 2e-6, (i, np.abs(flat[i] - ref).max(), scale)
+        # the pieces are a split of an f32: the sum is an f32
+        assert np.array_equal(flat.astype(np.float32).astype(np.float64), flat)
+        # ip1 + ReLU on the device's own flat
+        y = np.maximum(flat @ w["f1w"].reshape(7200, 500).astype(np.float64) + w["f1b"].astype(np.float64), 0.0)
+        scale = np.abs(y).max()
+        assert np.abs(fc1t.T - y).max() <= scale * 1e-5, (np.abs(fc1t.T - y).max(), scale)
+        # ip2 on the device's own ip1
+        f2 = w["f2w"].astype(np.float64)
+        ref = (fc1t.T.astype(np.float64) @ f2[1::2] + w["f2b"][1]) - (fc1t.T.astype(np.float64) @ f2[0::2] + w["f2b"][0])
+        assert np.abs(sc - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    finally:
+        ctx.close()
+
+
+def test_scores_on_every_reference_pin():
+    """All 15-channel pins: |split - reference plain float| <= 1e-4 (the bar), split is at least as close to the long-double
+    yardstick as the f32 chain, and the chain mode reproduces the pins' fma scores bit for bit."""
+    from gpd_amd import api
+    ctx = _ctx(15)
+    try:
+        worst_split = worst_chain = 0.0
+        total = 0
+        for name in sorted(rcs.VARIANTS):
+            pin = rcs.load_pin(name)
+            assert pin is not None
+            if "images" not in pin or pin["images"].shape[-1] != 15 or "scores_plain_trained" not in pin:
+                continue
+            img = pin["images"]
+            ctx.set_lenet_mode(api.LENET_SPLIT)
+            s = ctx.score(img)
+            ctx.set_lenet_mode(api.LENET_F32_CHAIN)
+            c = ctx.score(img)
+            assert np.array_equal(c, pin["scores_fma_trained"]), name
+            assert np.abs(s - pin["scores_plain_trained"]).max() <= 1e-4, name
+            assert np.abs(s - pin["scores_ld_trained"]).max() <= 1e-4, name
+            worst_split = max(worst_split, float(np.abs(s - pin["scores_ld_trained"]).max()))
+            worst_chain = max(worst_chain, float(np.abs(c - pin["scores_ld_trained"]).max()))
+            total += len(img)
+        assert total >= 100
+        print("pins: %d images, max |split - long double| = %.3g, max |f32 chain - long double| = %.3g" % (total, worst_split, worst_chain))
+        assert worst_split <= worst_chain
+    finally:
+        ctx.close()
+
+
+def test_score_is_independent_of_the_batch():
+    """Tile shapes of ip1 (16 .. 80 images), ragged tails, one image, two persistent rounds of the conv kernels: an image's
+    score does not depend on its neighbours."""
+    from gpd_amd import api
+    rng = np.random.RandomState(4)
+    base = rng.randint(0, 256, (700, 60, 60, 15)).astype(np.uint8)
+    base[rng.rand(*base.shape) < 0.65] = 0
+    ctx = _ctx(15, api.LENET_SPLIT)
+    try:
+        ref = ctx.score(base)
+        assert np.isfinite(ref).all() and len(np.unique(ref)) > 600
+        for n in (1, 2, 15, 16, 17, 255, 256, 257, 511, 699):
+            idx = rng.permutation(700)[:n]
+            assert np.array_equal(ctx.score(base[idx]), ref[idx]), n
+        big = np.concatenate([base] * 9)[:5500]  # > 5120: two rounds of ip1 tiles
+        got = ctx.score(big)
+        assert np.array_equal(got, np.concatenate([ref] * 9)[:5500])
+        assert len(ctx.score(np.zeros((0, 60, 60, 15), np.uint8))) == 0
+    finally:
+        ctx.close()
+
+
+def test_modes_switch_back_and_forth(oracle_mod):
+    from gpd_amd import api
+    rng = np.random.RandomState(8)
+    img = rng.randint(0, 256, (90, 60, 60, 15)).astype(np.uint8)
+    img[rng.rand(*img.shape) < 0.7] = 0
+    w = rcs.weights(15, trained_magnitude=True)
+    want = oracle_mod.lenet(img, w)
+    ctx = _ctx(15, None, w)
+    try:
+        a = ctx.score(img)  # the default is the split path
+        ctx.set_lenet_mode(api.LENET_F32_CHAIN)
+        assert np.array_equal(ctx.score(img), want)
+        ctx.set_lenet_mode(api.LENET_SPLIT)
+        assert np.array_equal(ctx.score(img), a)
+        assert np.abs(a - want).max() <= 1e-4 and not np.array_equal(a, want)
+        with pytest.raises(api.GpdHipError):
+            ctx.set_lenet_mode(7)
+    finally:
+        ctx.close()
+
+
+def test_split_path_through_the_fused_entries(oracle_mod, cloud30k):
+    """detect / detect_select / detect_batch with the default mode: candidates, records and images as ever; scores within
+    1e-4 of the oracle's chain; the selection is the selection of the device's own scores."""
+    from gpd_amd import api
+    w = rcs.weights(15, trained_magnitude=True)
+    si = synth.sample_indices(cloud30k, 300)
+    p = oracle_mod.default_params(15)
+    oh, on, _ = oracle_mod.detect(p, cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"], cloud30k["view_points"], si, w)
+    ctx = _ctx(15, None, w)
+    try:
+        ctx.upload_cloud(cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"], cloud30k["view_points"])
+        hands, n = ctx.detect(si)
+        v = oh["valid"].astype(bool)
+        assert n == on and np.array_equal(hands["valid"], oh["valid"])
+        err = np.abs(hands["score"][v] - oh["score"][v]).max()
+        assert err <= 1e-4, err
+        allc, ns, nc = ctx.detect_select(si, 0)
+        assert nc == on and np.array_equal(np.sort(allc["score"]), np.sort(hands["score"][v]))
+        best, _, _ = ctx.detect_select(si, 50)
+        order = np.argsort(-allc["score"].astype(np.float64), kind="stable")[:50]
+        assert np.array_equal(np.sort(best["score"])[::-1], allc["score"][order])
+        res = ctx.detect_batch([cloud30k, cloud30k], [si, si[:100]], 0)
+        assert res[0][2] == on and np.array_equal(np.sort(res[0][0]["score"]), np.sort(allc["score"]))
+        assert np.array_equal(res[1][0]["score"], ctx.detect_select(si[:100], 0)[0]["score"])
+    finally:
+        ctx.close()
