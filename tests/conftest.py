@@ -24,7 +24,8 @@ def lenet15_real():
     import numpy as np
     from gpd_amd import synth
     real = dict(np.load(os.path.join(ROOT, "tests", "golden", "lenet15_params.npz")))
-    return synth.lenet_weights(15, real=real)
+    # ip1 / 128: logits of the size a trained LeNet produces (|score| < 20), where "within 1e-4" can be decided for the split path
+    return synth.lenet_weights(15, real=real, trained_magnitude=True)
 
 
 @pytest.fixture(scope="session")

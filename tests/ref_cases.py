@@ -131,3 +131,20 @@ def records_equal(a, b, where=None):
 def load_pin(name):
     path = os.path.join(GOLD, "ref_pin_%s.npz" % name)
     return dict(np.load(path)) if os.path.exists(path) else None
+
+
+def assert_scores(ctx, img, want, tol=1e-4, rel=0.0):
+    """Classifier::classifyImages in both modes of the library: the f32-chain mode reproduces `want` (the oracle's k-ascending
+    fmaf chains) bit for bit; the default split mode (int8 / bf16 matrix pipes on exactly split operands) is within `tol`
+    absolute (BASELINE.json's 1e-4 at trained-net magnitudes) or `rel` of the largest |score| (weight sets that drive the
+    logits to ~1000, where one f32 ulp is 6e-5).  Returns the split-mode scores; the context is left in split mode."""
+    from gpd_amd import api
+    ctx.set_lenet_mode(api.LENET_F32_CHAIN)
+    got = ctx.score(img)
+    assert np.array_equal(got, want), float(np.abs(got - want).max()) if len(want) else 0.0
+    ctx.set_lenet_mode(api.LENET_SPLIT)
+    got = ctx.score(img)
+    if len(want):
+        bound = max(tol, rel * float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= bound, (float(np.abs(got - want).max()), bound)
+    return got

@@ -50,7 +50,10 @@ def test_hip_reproduces_golden(C):
         img, cand = ctx.images(hands)
         assert np.array_equal(cand, d["cand_index"])
         assert np.array_equal(img, d["images"])
-        assert np.abs(ctx.score(img) - d["scores"]).max() <= 1e-4
+        # the golden scores were made with the benchmark's synthetic ip1 (|score| ~ 1000, one f32 ulp = 6e-5): bit for bit in the
+        # f32-chain mode, relative for the default split mode
+        import ref_cases
+        ref_cases.assert_scores(ctx, img, d["scores"], rel=2e-5)
     finally:
         ctx.close()
 

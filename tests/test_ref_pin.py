@@ -201,6 +201,7 @@ def test_hip_matches_reference_pin(name):
     ctx = api.Context(p)
     try:
         ctx.set_lenet_weights(rcs.weights(C))
+        ctx.set_lenet_mode(api.LENET_F32_CHAIN)  # the pins' `scores_fma*` are the k-ascending fma definition: the checker mode
         ctx.upload_cloud(cl["xyz"], cl["normals"], cam, vp)
         hands = ctx.search(si)
         dh, n_cand = ctx.detect(si)  # fused route: valid = flag after filterGraspsWorkspace, scores written back
@@ -214,6 +215,14 @@ def test_hip_matches_reference_pin(name):
         assert n_cand == len(pin["cand"])
         if C == 15:
             assert np.array_equal(dh.reshape(-1)[pin["cand"]]["score"], pin["scores_fma"])
+            # the default mode (int8 / bf16 matrix pipes, exactly split operands): north_star's bar against what the
+            # reference's own code returned with its plain float products, and against the long-double yardstick
+            ctx.set_lenet_mode(api.LENET_SPLIT)
+            sp = ctx.score(img)
+            assert np.abs(sp - pin["scores_plain_trained"]).max() <= 1e-4 and np.abs(sp - pin["scores_ld_trained"]).max() <= 1e-4
+            d2, n2 = ctx.detect(si)
+            assert n2 == n_cand and np.array_equal(d2["valid"], dh["valid"])
+            assert np.array_equal(d2.reshape(-1)[pin["cand"]]["score"], sp)
     finally:
         ctx.close()
 
@@ -276,6 +285,7 @@ def test_hip_config1_end_to_end_matches_reference_detectGrasps():
     ctx = api.Context(api.default_params(15))
     try:
         ctx.set_lenet_weights(rcs.weights(15))
+        ctx.set_lenet_mode(api.LENET_F32_CHAIN)  # the reference's scores under the fma definition, bit for bit (the default mode: test_host_cli.py)
         vox = ctx.preprocess_cloud(xyz, voxel_size=0.003)[0]
         ctx.upload_cloud(vox, np.zeros_like(vox))
         nrm = ctx.estimate_normals(0.03)
@@ -301,6 +311,7 @@ def test_hip_direction_filter_and_clustering_match_reference_detectGrasps(oracle
     ctx = api.Context(api.default_params(15))
     try:
         ctx.set_lenet_weights(rcs.weights(15, trained_magnitude=True))
+        ctx.set_lenet_mode(api.LENET_F32_CHAIN)  # the reference's scores under the fma definition, bit for bit
         ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
         hands = ctx.search(si)
         hands["valid"] = ctx.detect(si)[0]["valid"]  # the flags after filterGraspsWorkspace, from the fused entry
@@ -337,6 +348,7 @@ def test_hip_fused_direction_filter_matches_reference_detectGrasps(oracle_mod):
         ctx = api.Context(p)
         try:
             ctx.set_lenet_weights(w)
+            ctx.set_lenet_mode(api.LENET_F32_CHAIN)  # scores compared bit for bit with the oracle's / the reference's
             ctx.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
             hands, n_cand = ctx.detect(si)
             oh, on, _ = oracle_mod.detect(po, cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"], si, w)
@@ -347,6 +359,7 @@ def test_hip_fused_direction_filter_matches_reference_detectGrasps(oracle_mod):
                 plain, n_plain = api.Context(api.default_params(15)), None
                 try:
                     plain.set_lenet_weights(w)
+                    plain.set_lenet_mode(api.LENET_F32_CHAIN)
                     plain.upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
                     assert plain.detect(si)[0].tobytes() == hands.tobytes()
                 finally:
