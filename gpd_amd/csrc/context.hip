@@ -756,7 +756,7 @@ int gpd_hip_lenet_debug(gpd_hip_ctx *ctx, int which, int n, void *out) {
     HIP_TRY(hipMemcpy(out, s.pool1, (size_t)n * 15680 * sizeof(float), hipMemcpyDeviceToHost));
   } else if (which == 1) {
     for (int pc = 0; pc < 3; pc++)
-      HIP_TRY(hipMemcpy2D(static_cast<char *>(out) + (size_t)pc * n * 7200 * 2, 7200 * 2, s.xs + (size_t)pc * s.capacity * 7232, 7232 * 2, 7200 * 2, n,
+      HIP_TRY(hipMemcpy2D(static_cast<char *>(out) + (size_t)pc * n * 7200 * 2, 7200 * 2, s.xs + (size_t)pc * s.capacity * kLenetXld, kLenetXld * 2, 7200 * 2, n,
                           hipMemcpyDeviceToHost));
   } else if (which == 2) {
     HIP_TRY(hipMemcpy2D(out, (size_t)n * sizeof(float), s.fc1t, (size_t)s.capacity * sizeof(float), (size_t)n * sizeof(float), kFc1Out,

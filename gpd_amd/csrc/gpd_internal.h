@@ -20,6 +20,7 @@ constexpr int kImg = 60;            // image_size (eigen_classifier.cpp:12)
 constexpr int kPix = kImg * kImg;   // 3600
 constexpr int kFc1In = 7200;        // 50 * 12 * 12
 constexpr int kFc1Out = 500;
+constexpr int kLenetXld = 7296;     // row length of the split path's flat bf16 planes: 7200 + 96 zeros = 4 K quarters x 57 steps of 32 (lenet_fast.hip)
 
 // ---- LeNet (lenet.hip) ----------------------------------------------------
 // operand tables of the split path (lenet_fast.hip): conv1 as four int8 digit planes of 32-bit fixed-point weights, conv2 / ip1
@@ -29,7 +30,7 @@ struct LeNetFast {
   double *c1corr = nullptr;        // [20] 128 * sum of the filter's fixed-point weights (the x - 128 shift of the inputs)
   int *c1shift = nullptr;          // [20] fixed-point position s of the filter: value = integer * 2^-s
   uint4 *c2b = nullptr;            // conv2 B fragments [2][2][3 pieces][16 k-steps][64 lanes] x 8 bf16
-  unsigned short *f1wt = nullptr;  // ip1 [3 pieces][512 units][7232 k] bf16
+  unsigned short *f1wt = nullptr;  // ip1 [3 pieces][512 units][7296 k] bf16
 };
 void lenet_fast_free(LeNetFast &f);
 hipError_t lenet_fast_prepare(LeNetFast &f, int channels, const float *c1w, const float *c2w, const float *f1w);
@@ -49,8 +50,9 @@ struct LeNetScratch {
   float *pool1 = nullptr;  // f32 chain: [cap][20][784], planes in conv1's chunk order (whole-line stores, lenet.hip P1_PLANE);
                            // split path: [cap][784][20], pixel-major
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
-  unsigned short *xs = nullptr;  // split path: flat as three bf16 planes [3][cap][7232] (k >= 7200: zeros, written once at allocation)
+  unsigned short *xs = nullptr;  // split path: flat as three bf16 planes [3][cap][7296] (k >= 7200: zeros, written once at allocation)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
+  float *fc1p = nullptr;   // split path: ip1's partial sums over the four K quarters [4][500][cap]
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)
   unsigned long long *c1_stats = nullptr;  // device: [0] (chunk, channel) pairs conv1 executed, [1] pairs it looked at — summed
                                            // over its launches since the last gpd_hip_conv1_stats(reset); [2] != 0: a launch gave up

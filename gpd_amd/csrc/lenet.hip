@@ -778,14 +778,15 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   note_alloc(__func__);
   lenet_scratch_free(s);
   s.num_cus = num_cus;
-  n += n / 4;  // slack: the clouds of a batch differ a little, every growth stalls the device
+  n = (n + n / 4 + 3) & ~3;  // slack: the clouds of a batch differ a little, every growth stalls the device; a multiple of 4: the row length of the transposed ip1 buffers (16-byte accesses)
   hipError_t e;
   if ((e = hipMalloc(&s.pool1, (size_t)n * P1_IMG * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
-  constexpr size_t kXld = 7232;  // lenet_fast.hip F2_XLD: 7200 + 32 zeros, which no kernel ever writes
+  constexpr size_t kXld = kLenetXld;  // 7200 + 96 zeros, which no kernel ever writes
   if ((e = hipMalloc(&s.xs, (size_t)3 * n * kXld * sizeof(unsigned short))) != hipSuccess) return e;
   if ((e = hipMemset(s.xs, 0, (size_t)3 * n * kXld * sizeof(unsigned short))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
+  if ((e = hipMalloc(&s.fc1p, (size_t)4 * n * kFc1Out * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.c1_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
   if ((e = hipMemset(s.c1_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
   s.capacity = n;
@@ -810,6 +811,7 @@ void lenet_scratch_free(LeNetScratch &s) {
   if (s.flat) (void)hipFree(s.flat);
   if (s.xs) (void)hipFree(s.xs);
   if (s.fc1t) (void)hipFree(s.fc1t);
+  if (s.fc1p) (void)hipFree(s.fc1p);
   if (s.c1_stats) (void)hipFree(s.c1_stats);
   s = LeNetScratch();
 }

@@ -91,6 +91,10 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
   const int j = lane & 15, q = lane >> 4;
   int img = blockIdx.x;
   if (img >= n) return;
+  // waves w and w + 4 share a SIMD (MI355X_MICROARCH.md: a workgroup's waves go to the SIMDs cyclically): the first keeps a
+  // higher priority for the whole launch, so its MFMA run always has the matrix pipe and the other wave's run falls into ITS
+  // epilogue — complementary phases instead of lockstep
+  if (wave < F1_WAVES / 2) __builtin_amdgcn_s_setprio(2);
   // the weight fragments: resident for the whole launch
   i32x4 A[F1_KS][F1_MT];
 #pragma unroll
@@ -145,6 +149,27 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
     __syncthreads();  // the pixel-major image is complete, the raw region is free, s_nxt is visible
     const int nxt = s_nxt;
     const uint4 *nsrc = reinterpret_cast<const uint4 *>(images + (size_t)(nxt < n ? nxt : img) * RAW);
+    // A wave's tiles are wave, wave + 8, ...  Per tile: 35 MFMAs back to back (a VALU instruction of the SAME wave between two
+    // MFMAs costs matrix-pipe time — interleaving this wave's epilogue with its own MFMAs by sched_group_barrier measured
+    // 0.48 ms against 0.40 — an instruction of the SIMD's OTHER wave costs nothing), then the requests for the next tile's pixel
+    // fragments (their registers are free now; the data arrives during the epilogue), then the epilogue.  The two waves of a SIMD
+    // run at different priorities (see kernel head): with equal priorities they fall into lockstep — both in their MFMA runs,
+    // sharing the pipe, then both in their epilogues with the pipe idle.
+    auto tile_addr = [&](int t, const uint8_t *&pa, const uint8_t *&pb, const uint8_t *&pc) {
+      const int tc = t < F1_TILES ? t : F1_TILES - 1;  // past the end: any valid address (the fragments are not used)
+      const int trow = tc / 7, tcol = tc - 7 * trow;
+      const uint8_t *base = s_hwc + ((2 * trow) * F1_PITCH + 8 * tcol) * 16 + lane_off;
+      pa = base + kyg * F1_ROWB;
+      pb = base + 4 * F1_ROWB + q * 16;
+      pc = base + 4 * F1_ROWB + 4 * 16;
+    };
+    i32x4 B[F1_KS];
+    {
+      const uint8_t *pa, *pb, *pc;
+      tile_addr(wave, pa, pb, pc);
+#pragma unroll
+      for (int ks = 0; ks < F1_KS; ks++) B[ks] = *reinterpret_cast<const i32x4 *>(ks < 5 ? pa + ks * 16 : ks == 5 ? pb : pc);
+    }
     int it = 0;
     for (int t = wave; t < F1_TILES; t += F1_WAVES, it++) {
       // one 16-byte piece of the next image per thread and tile: requested now, stored after the tile
@@ -152,16 +177,6 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
       const bool has_piece = nxt < n && piece < NV;
       uint4 stage = make_uint4(0, 0, 0, 0);
       if (has_piece) stage = nsrc[piece];
-      const int trow = t / 7, tcol = t - 7 * trow;
-      const uint8_t *base = s_hwc + ((2 * trow) * F1_PITCH + 8 * tcol) * 16 + lane_off;
-      const uint8_t *pa = base + kyg * F1_ROWB;
-      const uint8_t *pb = base + 4 * F1_ROWB + q * 16;
-      const uint8_t *pc = base + 4 * F1_ROWB + 4 * 16;
-      i32x4 B[F1_KS];
-#pragma unroll
-      for (int ks = 0; ks < 5; ks++) B[ks] = *reinterpret_cast<const i32x4 *>(pa + ks * 16);
-      B[5] = *reinterpret_cast<const i32x4 *>(pb);
-      B[6] = *reinterpret_cast<const i32x4 *>(pc);
       i32x4 acc[F1_MT];
 #pragma unroll
       for (int mt = 0; mt < F1_MT; mt++) acc[mt] = i32x4{0, 0, 0, 0};
@@ -170,19 +185,27 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
       for (int ks = 0; ks < F1_KS; ks++)
 #pragma unroll
         for (int mt = 0; mt < F1_MT; mt++) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks][mt], B[ks], acc[mt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);  // the 35 MFMAs stay one run: the SIMD's other wave has its epilogue meanwhile
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const uint8_t *pa, *pb, *pc;
+        tile_addr(t + F1_WAVES, pa, pb, pc);
+#pragma unroll
+        for (int ks = 0; ks < F1_KS; ks++) B[ks] = *reinterpret_cast<const i32x4 *>(ks < 5 ? pa + ks * 16 : ks == 5 ? pb : pc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       // epilogue: exact sum of the digit planes (f64), pool over the quad, one rounding.  The quad's four lanes end up with the
-      // same pooled sums: lane p finishes tile p (filter 4 p + q), and every lane tile 4 (filter 16 + q, stored by p = 0)
-      double s[F1_MT];
+      // same pooled sums: lane p finishes row tile p (filter 4 p + q), and every lane row tile 4 (filter 16 + q, stored by p = 0)
+      double sm[F1_MT];
 #pragma unroll
       for (int mt = 0; mt < F1_MT; mt++) {
         const int hi = (int)((unsigned)acc[mt][3] << 8) + acc[mt][2];  // |.| < 2^31: the top digit is within +-64
         const int lo = (int)((unsigned)acc[mt][1] << 8) + acc[mt][0];
-        s[mt] = dpp_quad_max(__builtin_fma((double)hi, 65536.0, (double)lo));
+        sm[mt] = dpp_quad_max(__builtin_fma((double)hi, 65536.0, (double)lo));
       }
-      const double s_own = p == 0 ? s[0] : p == 1 ? s[1] : p == 2 ? s[2] : s[3];
+      const double s_own = p == 0 ? sm[0] : p == 1 ? sm[1] : p == 2 ? sm[2] : sm[3];
       const float v_own = ldexpf((float)(s_own + k_corr_own), -k_shift_own) + k_bias_own;
-      const float v_4 = ldexpf((float)(s[4] + k_corr_4), -k_shift_4) + k_bias_4;
+      const float v_4 = ldexpf((float)(sm[4] + k_corr_4), -k_shift_4) + k_bias_4;
+      const int trow = t / 7, tcol = t - 7 * trow;
       float *dst = pool1 + ((size_t)img * 784 + trow * 28 + 4 * tcol + w) * 20;
       dst[4 * p + q] = v_own;
       if (p == 0) dst[16 + q] = v_4;
@@ -248,9 +271,11 @@ __host__ __device__ inline Bf3 bf16_split3(float a) {
 //   v_mfma_f32_16x16x32_bf16: A (pixels): lane (pixel m = l & 15, k group g = l >> 4) holds 8 k = two 4-channel groups of
 //   8 bytes; B (weights): lane (filter l & 15, k group g); D: lane (filter l & 15), register r = pixel 4 (l >> 4) + r — a tile
 //   is 8 x 2 conv pixels = four pool windows, pixel m = 4 window + position, so the pool is a max over the lane's registers.
-// Four waves per workgroup, ONE per SIMD, 512 registers each: wave (np, half) keeps the three bf16 planes of 32 filters
-// (2 column tiles x 3 pieces x 16 k-steps x 4 VGPRs = 384 registers) for the whole launch and walks the 18 pixel tiles of its
-// half of the image; the activations of a k-step (3 pieces x 2 reads of 8 bytes) feed 12 MFMAs.
+// Eight waves per workgroup, two per SIMD: wave (nt, half) keeps the three bf16 planes of 16 filters (3 pieces x 16 k-steps
+// x 4 VGPRs = 192 registers) for the whole launch and walks the 18 pixel tiles of its half of the image; the activations of a
+// k-step (3 pieces x 2 reads of 8 bytes) feed 6 MFMAs on two alternating accumulators.  (Round 5's first version ran four
+// waves with 32 filters each in 512 registers, one per SIMD: every stall of the single wave idled the SIMD's matrix pipe,
+// MfmaUtil 63 %.)
 // LDS: the image as bf16 pieces [row 28][piece 3][column 28][channel 20] (94 080 B) + the next image's raw f32 rows (62 720 B),
 // which arrive one 16-byte piece per thread and tile and are split between two barriers.
 // The 128 four-channel k-slots of the 16 k-steps hold the 125 (tap, channel group) pairs so that the two lane groups of a
@@ -258,12 +283,12 @@ __host__ __device__ inline Bf3 bf16_split3(float a) {
 //   entry e = ks + 16 h: e < 25: ky = e / 5, cg = e % 5, kx = g       e in 25..29: cg = e - 25, kx = 4, ky = g
 //                        e = 30: ky = kx = 4, cg = g                  e = 31: ky = kx = 4, cg = 4 (lane group 0 only)
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int F2_THREADS = 256;
+constexpr int F2_THREADS = 512;
 constexpr int F2_PP = 28 * 40;         // bytes of one piece row: 28 pixels x 20 bf16
 constexpr int F2_RS = 3 * F2_PP;       // bytes of one image row (three pieces)
 constexpr int F2_IMG = 28 * F2_RS;     // 94080
 constexpr int F2_RAW = 784 * 20 * 4;   // 62720
-constexpr int F2_XLD = 7232;           // row length of the flat bf16 planes: 7200 + 32 zeros (ip1 walks K in steps of 64)
+constexpr int F2_XLD = kLenetXld;      // row length of the flat bf16 planes: 7200 + 96 zeros (ip1 walks four K quarters in steps of 32)
 
 // (tap = ky * 5 + kx, channel group) of k-slot entry e for lane group g; tap -1: empty
 __host__ __device__ constexpr int f2_slot_tap(int e, int g) {
@@ -279,20 +304,16 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
   __shared__ int s_nxt;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int np = wave & 1, half = wave >> 1;
+  const int nt = wave & 3, half = wave >> 2;
   const int j = lane & 15, q = lane >> 4;
   int img = blockIdx.x;
   if (img >= n) return;
-  // the weight fragments of the wave's 32 filters: [column tile][piece][k-step]
-  bf16x8 W[2][3][16];
+  // the weight fragments of the wave's 16 filters: [piece][k-step]
+  bf16x8 W[3][16];
 #pragma unroll
-  for (int nt = 0; nt < 2; nt++)
+  for (int pc = 0; pc < 3; pc++)
 #pragma unroll
-    for (int pc = 0; pc < 3; pc++)
-#pragma unroll
-      for (int ks = 0; ks < 16; ks++) {
-        W[nt][pc][ks] = as_bf16x8(btab[(((np * 2 + nt) * 3 + pc) * 16 + ks) * 64 + lane]);
-      }
+    for (int ks = 0; ks < 16; ks++) W[pc][ks] = as_bf16x8(btab[((nt * 3 + pc) * 16 + ks) * 64 + lane]);
   {  // the first image, by everybody
     const uint4 *src = reinterpret_cast<const uint4 *>(pool1 + (size_t)img * (784 * 20));
     uint4 *dst = reinterpret_cast<uint4 *>(s_raw);
@@ -318,7 +339,8 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
   // the four address patterns of the k-slot table (see above): + 40 g (columns), + g rows, + 8 g (channel groups), none
   const int off_x = lane_off + 40 * q, off_y = lane_off + q * F2_RS + 4 * 40, off_z = lane_off + 4 * F2_RS + 4 * 40 + 8 * q,
             off_w = lane_off + 4 * F2_RS + 4 * 40 + 32;
-  const float k_bias0 = (32 * np + j) < 50 ? bias[32 * np + j] : 0.f, k_bias1 = (32 * np + 16 + j) < 50 ? bias[32 * np + 16 + j] : 0.f;
+  const int f_own = 16 * nt + j;  // the lane's filter (50..63: padding)
+  const float k_bias = f_own < 50 ? bias[f_own] : 0.f;
   for (;;) {
     if (tid == 0) s_nxt = (int)gridDim.x + atomicAdd(queue, 1);
     __syncthreads();  // the pieces are complete, the raw region is free, s_nxt is visible
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
         }
         return as_bf16x8(make_uint4(v[0].x, v[0].y, v[1].x, v[1].y));
       };
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // two chains (even / odd terms), added at the end
       bf16x8 a_buf[2][3];  // the fragments of k-step ks live in a_buf[ks & 1]: the next step's are requested before this step's MFMAs
 #pragma unroll
       for (int pc = 0; pc < 3; pc++) a_buf[0][pc] = frag(0, pc);
@@ -359,26 +381,22 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
 #pragma unroll
           for (int pc = 0; pc < 3; pc++) a_buf[(ks + 1) & 1][pc] = frag(ks + 1, pc);
         }
-        // small terms first; the two column tiles alternate so that dependent MFMAs are two issues apart
 #pragma unroll
         for (int term = 0; term < 6; term++) {
-          // (activation piece, weight piece): l*h, h*l, m*m, m*h, h*m, h*h
+          // (activation piece, weight piece): l*h, h*l, m*m, m*h, h*m, h*h — small terms first
           const int pa = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
           const int pw = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
-#pragma unroll
-          for (int nt = 0; nt < 2; nt++)
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_buf[ks & 1][pa], W[nt][pw][ks], acc[nt], 0, 0, 0);
+          acc[term & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_buf[ks & 1][pa], W[pw][ks], acc[term & 1], 0, 0, 0);
         }
       }
       // pool over the lane's four registers, bias, split for ip1, store: flat index = pixel * 50 + filter (eigen_classifier.cpp:103-107)
       const int prow = rp, pcol = 4 * xt + q;
-#pragma unroll
-      for (int nt = 0; nt < 2; nt++) {
-        const int f = 32 * np + 16 * nt + j;
-        const float v = fmaxf(fmaxf(acc[nt][0], acc[nt][1]), fmaxf(acc[nt][2], acc[nt][3])) + (nt ? k_bias1 : k_bias0);
-        if (f < 50) {
+      {
+        const f32x4 t = acc[0] + acc[1];
+        const float v = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])) + k_bias;
+        if (f_own < 50) {
           const Bf3 sp = bf16_split3(v);
-          unsigned short *o = xs + (size_t)img * F2_XLD + (prow * 12 + pcol) * 50 + f;
+          unsigned short *o = xs + (size_t)img * F2_XLD + (prow * 12 + pcol) * 50 + f_own;
           o[0] = sp.h;
           o[xs_plane] = sp.m;
           o[2 * xs_plane] = sp.l;
@@ -395,51 +413,60 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ip1 on the bf16 matrix pipe: D[image][unit] = sum_k X[image][k] W[k][unit], six piece products per k.
-//   X: three bf16 planes [n][7232] written by conv2 (k = pixel * 50 + filter, then 32 zeros), W: three bf16 planes
-//   [512][7232], unit-major (k contiguous), built once at gpd_hip_set_lenet_weights.
+//   X: three bf16 planes [n][7296] written by conv2 (k = pixel * 50 + filter, then 96 zeros), W: three bf16 planes
+//   [512][7296], unit-major (k contiguous), built once at gpd_hip_set_lenet_weights.
 //   A (images): lane (row l & 15, k group l >> 4) = 16 contiguous bytes; B (units) likewise; D: lane (unit l & 15),
-//   register r = image 4 (l >> 4) + r  ->  a float4 of the transposed output per lane.
-// Workgroup tile 128 units x 16 NT images (NT picked per launch to fill the CUs in whole rounds), four waves, one per SIMD:
-// wave w owns units 32 w .. 32 w + 31 x all images (2 NT accumulators).  K in steps of 64: two LDS buffers of
-// 3 x (16 NT + 128) rows x 128 bytes, rows XOR-swizzled by (row >> 1) & 7 in 16-byte chunks so that every ds_read_b128 of a
-// fragment is bank-conflict free; global -> registers one step ahead, registers -> LDS while the other buffer is multiplied.
+//   register r = image 4 (l >> 4) + r.
+// The GEMM is small against the chip (5000 x 512 x 7200) and its operands are fat (six bytes per element): with one
+// 80 x 128 tile per CU the first version moved 2.3 GB through L2 for 0.11 ms of MFMA work (0.29 ms, MfmaUtil 30 %).  Now
+// K is cut into four quarters: a workgroup owns a 32 NT x 256 tile of ONE quarter (NT <= 5: 160 x 256 x 1824 at n = 5000,
+// 256 workgroups) and writes partial sums; ip2's kernel adds the four quarters in order (deterministic, and the same for
+// every batch size), + bias, ReLU.  Tile traffic halves (1.15 GB), and workgroup L runs on XCD L % 8 = (unit half, quarter):
+// every XCD's L2 holds ITS 2.8 MB slice of W for the whole launch.
+// Eight waves, two per SIMD, as 2 (images) x 4 (units): a wave owns 16 NT images x 64 units = 4 NT accumulators.  K in steps
+// of 32: two LDS buffers of 3 x (32 NT + 256) rows x 64 bytes, the four 16-byte chunks of a row XOR-swizzled by
+// (4 - (row >> 2)) & 3: every ds_read_b128 of a fragment is bank-conflict free.  global -> registers one step ahead,
+// registers -> LDS while the other buffer is multiplied.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int F3_THREADS = 256, F3_BU = 128, F3_BK = 64, F3_STEPS = F2_XLD / F3_BK;  // 113
-static_assert(F2_XLD % F3_BK == 0, "K steps");
+constexpr int F3_THREADS = 512, F3_BN = 256, F3_BK = 32, F3_KQ = 4;
+constexpr int F3_KLEN = F2_XLD / F3_KQ, F3_STEPS = F3_KLEN / F3_BK;  // 1824, 57
+static_assert(F2_XLD % (F3_KQ * F3_BK) == 0 && F2_XLD >= kFc1In, "K quarters");
 
 template <int NT>
 __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned short *__restrict__ xs, size_t xs_plane,
                                                              const unsigned short *__restrict__ wt, size_t wt_plane,
-                                                             const float *__restrict__ bias, float *__restrict__ out_t, int n, int ld_out) {
-  constexpr int BM = 16 * NT;
-  constexpr int XB = BM * 128, WB = F3_BU * 128;  // bytes of one piece's tile
+                                                             float *__restrict__ out_p, size_t out_plane, int n, int ld_out) {
+  constexpr int BM = 32 * NT;
+  constexpr int XB = BM * 64, WB = F3_BN * 64;  // bytes of one piece's tile
   constexpr int STAGE = 3 * (XB + WB);
   __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];
   static_assert(2 * STAGE <= 160 * 1024, "LDS");
   const int tid = threadIdx.x;
   const int L = blockIdx.x;
-  const int xcd = L & 7, slot = L >> 3;
-  const int u0 = (slot & 3) * F3_BU;
-  const int m0 = ((slot >> 2) * 8 + xcd) * BM;
+  const int xcd = L & 7;
+  const int ut = xcd & 1, kq = xcd >> 1;
+  const int m0 = (L >> 3) * BM;
   if (m0 >= n) return;
+  const int u0 = ut * F3_BN, k_base = kq * F3_KLEN;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 2, wu = wave & 3;
   const int g = lane >> 4, j = lane & 15;
-  // loader roles: a 16-byte chunk per thread and load, 8 consecutive lanes cover one row's 128 bytes; thread -> (row tid >> 3
-  // + 32 i, chunk tid & 7): the row's swizzle (row >> 1) & 7 does not depend on i
-  constexpr int W_PT = F3_BU / 32, X_PT = (BM + 31) / 32;  // loads per piece
-  const int lrow = tid >> 3, lch = tid & 7;
-  const unsigned short *wsrc = wt + (size_t)(u0 + lrow) * F2_XLD + lch * 8;
-  const int ldst = lrow * 128 + ((lch ^ ((lrow >> 1) & 7)) << 4);
+  // loader roles: a 16-byte chunk per thread and load, 4 consecutive lanes cover one row's 64 bytes; thread -> (row tid >> 2
+  // + 128 i, chunk tid & 3): the row's swizzle does not depend on i
+  constexpr int W_PT = F3_BN / 128, X_PT = (BM + 127) / 128;  // loads per piece
+  const int lrow = tid >> 2, lch = tid & 3;
+  const unsigned short *wsrc = wt + (size_t)(u0 + lrow) * F2_XLD + k_base + lch * 8;
+  const int ldst = lrow * 64 + ((lch ^ ((4 - (lrow >> 2)) & 3)) << 4);
   const unsigned short *xsrc[X_PT];
 #pragma unroll
-  for (int i = 0; i < X_PT; i++) xsrc[i] = xs + (size_t)min(m0 + lrow + 32 * i, n - 1) * F2_XLD + lch * 8;
+  for (int i = 0; i < X_PT; i++) xsrc[i] = xs + (size_t)min(m0 + lrow + 128 * i, n - 1) * F2_XLD + k_base + lch * 8;
   u32x4 rw[3 * W_PT], rx[3 * X_PT];
   auto fetch = [&](int step, u32x4(&w2)[3 * W_PT], u32x4(&x2)[3 * X_PT]) {
     const int k0 = step * F3_BK;
 #pragma unroll
     for (int pc = 0; pc < 3; pc++) {
 #pragma unroll
-      for (int i = 0; i < W_PT; i++) w2[pc * W_PT + i] = *reinterpret_cast<const u32x4 *>(wsrc + pc * wt_plane + (size_t)i * 32 * F2_XLD + k0);
+      for (int i = 0; i < W_PT; i++) w2[pc * W_PT + i] = *reinterpret_cast<const u32x4 *>(wsrc + pc * wt_plane + (size_t)i * 128 * F2_XLD + k0);
 #pragma unroll
       for (int i = 0; i < X_PT; i++) x2[pc * X_PT + i] = *reinterpret_cast<const u32x4 *>(xsrc[i] + pc * xs_plane + k0);
     }
@@ -449,47 +476,39 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
 #pragma unroll
     for (int pc = 0; pc < 3; pc++) {
 #pragma unroll
-      for (int i = 0; i < W_PT; i++) *reinterpret_cast<u32x4 *>(b + 3 * XB + pc * WB + i * 32 * 128) = w2[pc * W_PT + i];
+      for (int i = 0; i < W_PT; i++) *reinterpret_cast<u32x4 *>(b + 3 * XB + pc * WB + i * 128 * 64) = w2[pc * W_PT + i];
 #pragma unroll
       for (int i = 0; i < X_PT; i++)
-        if (lrow + 32 * i < BM) *reinterpret_cast<u32x4 *>(b + pc * XB + i * 32 * 128) = x2[pc * X_PT + i];
+        if (lrow + 128 * i < BM) *reinterpret_cast<u32x4 *>(b + pc * XB + i * 128 * 64) = x2[pc * X_PT + i];
     }
   };
-  f32x4 acc[NT][2];
+  f32x4 acc[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; t++)
 #pragma unroll
-    for (int ut = 0; ut < 2; ut++) acc[t][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // fragment addresses inside a piece's tile: row * 128 + ((4 kk + g) ^ ((row >> 1) & 7)) * 16; row & 15 = j for both operands
-  const int sw = (j >> 1) & 7;
-  const int xrow = j * 128, wrow = (32 * wave + j) * 128;
+    for (int c = 0; c < 4; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment addresses inside a piece's tile: row * 64 + ((g ^ swizzle(row)) << 4); row & 15 = j for both operands
+  const int foff = j * 64 + ((g ^ ((4 - (j >> 2)) & 3)) << 4);
+  const int xoff = (wm * 16 * NT) * 64 + foff, woff = (wu * 64) * 64 + foff;
   auto compute = [&](int buf) {
     const uint8_t *b = smem + buf * STAGE;
+    bf16x8 wb[3][4];
 #pragma unroll
-    for (int kk = 0; kk < 2; kk++) {
-      const int coff = ((4 * kk + g) ^ sw) << 4;
-      bf16x8 xa[NT][3], wb[2][3];
+    for (int pc = 0; pc < 3; pc++)
 #pragma unroll
-      for (int pc = 0; pc < 3; pc++) {
+      for (int c = 0; c < 4; c++) wb[pc][c] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + 3 * XB + pc * WB + woff + c * 16 * 64));
+    // by image piece, small terms first: l*h; m*m, m*h; h*l, h*m, h*h
 #pragma unroll
-        for (int ut = 0; ut < 2; ut++) {
-          wb[ut][pc] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + 3 * XB + pc * WB + wrow + ut * 16 * 128 + coff));
-        }
+    for (int pa = 2; pa >= 0; pa--) {
+      bf16x8 xa[NT];
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-          xa[t][pc] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + pc * XB + xrow + t * 16 * 128 + coff));
-        }
-      }
+      for (int t = 0; t < NT; t++) xa[t] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + pa * XB + xoff + t * 16 * 64));
 #pragma unroll
-      for (int term = 0; term < 6; term++) {
-        // (image piece, weight piece): l*h, h*l, m*m, m*h, h*m, h*h — small terms first
-        const int pa = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
-        const int pw = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+      for (int pw = 2 - pa; pw >= 0; pw--)
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
-          for (int ut = 0; ut < 2; ut++) acc[t][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t][pa], wb[ut][pw], acc[t][ut], 0, 0, 0);
-      }
+          for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t], wb[pw][c], acc[t][c], 0, 0, 0);
     }
   };
   fetch(0, rw, rx);
@@ -504,20 +523,39 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
     compute(t & 1);
     __syncthreads();
   }
-  // bias, ReLU (eigen_classifier.cpp:113), transposed store for ip2: a lane holds four consecutive images of one unit
+  // the quarter's partial sums, transposed for ip2: a lane holds four consecutive images of one unit
+  float *outq = out_p + kq * out_plane;
 #pragma unroll
-  for (int ut = 0; ut < 2; ut++) {
-    const int u = u0 + 32 * wave + 16 * ut + j;
+  for (int c = 0; c < 4; c++) {
+    const int u = u0 + 64 * wu + 16 * c + j;
     if (u >= kFc1Out) continue;
-    const float bu = bias[u];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const int m = m0 + 16 * t + 4 * g;
-      float *o = out_t + (size_t)u * ld_out + m;
+      const int m = m0 + 16 * NT * wm + 16 * t + 4 * g;
+      float *o = outq + (size_t)u * ld_out + m;
 #pragma unroll
       for (int r = 0; r < 4; r++)
-        if (m + r < n) o[r] = fmaxf(acc[t][ut][r] + bu, 0.f);
+        if (m + r < n) o[r] = acc[t][c][r];
     }
+  }
+}
+
+// ip1's epilogue: unit u of image m = relu(q0 + q1 + q2 + q3 + bias) over the four K quarters in this order (eigen_classifier.cpp:113),
+// transposed [500][ld] for ip2 (lenet.hip fc2_score_kernel).  Four images per thread.
+__global__ __launch_bounds__(256) void fc1_combine_kernel(const float *__restrict__ fc1p, size_t plane, const float *__restrict__ b1,
+                                                          float *__restrict__ fc1t, int n, int ld) {
+  const int m = 4 * (blockIdx.x * 256 + threadIdx.x), u = blockIdx.y;
+  if (m >= n) return;
+  const float *q = fc1p + (size_t)u * ld + m;
+  float *o = fc1t + (size_t)u * ld + m;
+  const float bu = b1[u];
+  if (m + 3 < n && (ld & 3) == 0) {
+    const float4 a = *reinterpret_cast<const float4 *>(q), b = *reinterpret_cast<const float4 *>(q + plane),
+                 c = *reinterpret_cast<const float4 *>(q + 2 * plane), d = *reinterpret_cast<const float4 *>(q + 3 * plane);
+    *reinterpret_cast<float4 *>(o) = make_float4(fmaxf(((a.x + b.x) + c.x) + d.x + bu, 0.f), fmaxf(((a.y + b.y) + c.y) + d.y + bu, 0.f),
+                                                 fmaxf(((a.z + b.z) + c.z) + d.z + bu, 0.f), fmaxf(((a.w + b.w) + c.w) + d.w + bu, 0.f));
+  } else {
+    for (int r = 0; r < 4 && m + r < n; r++) o[r] = fmaxf(((q[r] + q[plane + r]) + q[2 * plane + r]) + q[3 * plane + r] + bu, 0.f);
   }
 }
 
@@ -660,16 +698,15 @@ hipError_t lenet_fast_prepare(LeNetFast &f, int channels, const float *c1w, cons
 
 template <int NT>
 static void fc1f_launch(const LeNetWeights &w, LeNetScratch &s, int n, hipStream_t stream) {
-  const int m_tiles = (n + 16 * NT - 1) / (16 * NT);
-  const int groups = (m_tiles + 7) / 8;
+  const int m_tiles = (n + 32 * NT - 1) / (32 * NT);
   const size_t xs_plane = (size_t)s.capacity * F2_XLD, wt_plane = (size_t)512 * F2_XLD;
-  fc1_bf16_kernel<NT><<<groups * 4 * 8, F3_THREADS, 0, stream>>>(s.xs, xs_plane, w.fast.f1wt, wt_plane, w.f1b, s.fc1t, n, s.capacity);
+  fc1_bf16_kernel<NT><<<m_tiles * 8, F3_THREADS, 0, stream>>>(s.xs, xs_plane, w.fast.f1wt, wt_plane, s.fc1p, (size_t)kFc1Out * s.capacity, n, s.capacity);
 }
-// image-tile height: the smallest multiple of 16 (at most 80: two LDS buffers) whose tiles fill the chip's 64 workgroup
-// columns (256 CUs / 4 unit tiles) in r whole rounds, r as small as possible
+// image-tile height 32 NT: the smallest (at most 160: two LDS buffers) whose tiles (8 workgroups each: 2 unit halves x 4 K
+// quarters) fill the chip's 256 CUs in r whole rounds, r as small as possible
 static int fc1f_pick_nt(int n) {
   for (int r = 1;; r++) {
-    const int nt = (n + 64 * r * 16 - 1) / (64 * r * 16);
+    const int nt = (n + 32 * r * 32 - 1) / (32 * r * 32);
     if (nt <= 5) return nt < 1 ? 1 : nt;
   }
 }
@@ -695,6 +732,7 @@ hipError_t lenet_forward_fast(const LeNetWeights &w, LeNetScratch &s, const uint
     case 4: fc1f_launch<4>(w, s, m, stream); break;
     default: fc1f_launch<5>(w, s, m, stream); break;
   }
+  fc1_combine_kernel<<<dim3((m + 1023) / 1024, kFc1Out), 256, 0, stream>>>(s.fc1p, (size_t)kFc1Out * s.capacity, w.f1b, s.fc1t, m, s.capacity);
   if (kernel_events) (void)hipEventRecord(kernel_events[2], stream);
   return hipGetLastError();
 }
