@@ -36,11 +36,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3      # f32 vector == f32-input MFMA peak
+BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense; 16x16x32 measured 2075, 32x32x16 2382)
+I8_PEAK_TOPS = 5000.0        # dense int8 MFMA (= the fp8 rate; 16x16x64 measured 3944, 32x32x32 4404)
 LDS_PEAK_GBS = 256 * 128 * 2.4  # 256 CUs x 128 B/clk (ds_read_b32 rate; 256 B/clk for b64/b128) x 2.4 GHz (MI355X_MICROARCH.md §LDS)
 LENET_MFLOP = {15: 83.04, 12: 73.63, 3: 45.41, 1: 39.14}  # SURVEY.md §8d (+ the 1-channel strategy)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
-SQ_FILE = os.path.join(ROOT, "profiles", "r04_pmc_sq.json")
-KERNEL_SOURCES = ("gpd_amd/csrc/lenet.hip", "gpd_amd/csrc/images.hip", "gpd_amd/csrc/search.hip")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+SQ_FILE = os.path.join(ROOT, "profiles", "r05_pmc_sq.json")
+KERNEL_SOURCES = ("gpd_amd/csrc/lenet.hip", "gpd_amd/csrc/lenet_fast.hip", "gpd_amd/csrc/images.hip", "gpd_amd/csrc/search.hip")
+DTYPE = ("f64 geometry / u8 images / LeNet f32-equivalent by exact operand splitting: conv1 int8 digit planes of 32-bit fixed-point "
+         "weights (i32 accumulate, exact), conv2 + ip1 three bf16 pieces per operand (six exact products per term, f32 accumulate), ip2 f32")
+
+
+def lenet_mfma_work(C):
+    """What the split path's three matrix kernels EXECUTE per image (padding included) and what that is algorithmically
+    (gpd_amd/csrc/lenet_fast.hip): conv1 196 tiles x 35 v_mfma_i32_16x16x64_i8 (20 filters x 4 digits = 80 rows, 7 k-steps of 4 taps x
+    16 channels for 25 taps x C channels); conv2 36 tiles x 4 column tiles x 96 v_mfma_f32_16x16x32_bf16 (50 -> 64 filters, 500 ->
+    512 k, six piece products); ip1 512 units x 7296 k x six piece products."""
+    return {
+        "conv1_i8_kernel": dict(pipe="i8", executed=196 * 35 * 32768.0, algorithmic_split=2.0 * 20 * 25 * C * 56 * 56 * 4,
+                                algorithmic=2.0 * 20 * 25 * C * 56 * 56),
+        "conv2_bf16_kernel": dict(pipe="bf16", executed=36 * 4 * 96 * 16384.0, algorithmic_split=2.0 * 50 * 500 * 24 * 24 * 6,
+                                  algorithmic=2.0 * 50 * 500 * 24 * 24),
+        "fc1_bf16_kernel": dict(pipe="bf16", executed=2.0 * 512 * 7296 * 6, algorithmic_split=2.0 * 500 * 7200 * 6, algorithmic=2.0 * 500 * 7200),
+    }
 
 CONFIGS = {  # BASELINE.json configs[1..3]
     "2": dict(points=30000, candidates=5000, channels=15, clutter=False),
@@ -81,7 +99,7 @@ def main():
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the barrier / reductions")
     ap.add_argument("--live-pmc", dest="live_pmc", action="store_true", default=None,
                     help="measure roofline.traffic / pmc_traffic here (two rocprofv3 --pmc child runs of this file after the timed region, "
-                         "~20 s) instead of reading profiles/r04_traffic.json; default: on for the default line on one GPU, unless this "
+                         "~20 s) instead of reading profiles/r05_traffic.json; default: on for the default line on one GPU, unless this "
                          "process is itself being profiled")
     ap.add_argument("--no-live-pmc", dest="live_pmc", action="store_false")
     args = ap.parse_args()
@@ -155,7 +173,9 @@ def main():
     gold = os.path.join(ROOT, "tests", "golden", "lenet%d_params.npz" % C)
     if os.path.exists(gold):
         real = dict(np.load(gold))
-    w = synth.lenet_weights(C, real=real)
+    # the headline is timed on the trained-magnitude weight set (the synthetic ip1 / 128: |score| < 20, the range in which
+    # BASELINE's "within 1e-4" can be decided — same FLOPs, same kernels)
+    w = synth.lenet_weights(C, real=real, trained_magnitude=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -258,7 +278,7 @@ def main():
                 "metric": "15-ch grasp candidates generated+scored/sec, end to end over a batch of clouds (configs[4])",
                 "value": leg["cand_per_s"], "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": leg["wall_s"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "f64 geometry / f32 LeNet / u8 images", "data": "synthetic",
+                "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                 "config": {"workload": "%d synthetic 30k-point clouds x %d samples (~%d candidates each), 15-channel, cloud i -> rank i mod %d; "
                                        "per cloud: host buffers in, upload, grid, search, filter, images, LeNet, scored candidates out"
                            % (args.clouds, args.batch_samples, leg["candidates"] // max(1, leg["clouds"]), world),
@@ -322,8 +342,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.replay(3)
-    img_ms, net_ms, launches, _ = ctx.replay_times()
-    kernel_ms = ctx.replay_kernel_ms()              # conv1, conv2, ip1, ip2 summed over the timed steps
+    img_ms, net_ms, launches, timed_scores = ctx.replay_times(n_scores=n_cand)  # the scores of the last timed step come back with the times
+    kernel_ms = ctx.replay_kernel_ms()              # conv1, conv2, ip1 (+ its combine pass), ip2 summed over the timed steps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -343,7 +363,7 @@ def main():
         if batch is not None:  # the batch left its last cloud resident: the benchmark's cloud and its search state once more
             ctx.upload_cloud(cloud["xyz"], cloud["normals"], cloud["cam_source"], cloud["view_points"])
             ctx.search(si)
-        trained = _trained_magnitude_leg(ctx, hands_f, C, real)
+        trained = _score_accuracy_leg(ctx, hands_f, C, w, timed_scores)
 
     if rank == 0:
         value = total_cand * args.steps / elapsed
@@ -363,38 +383,47 @@ def main():
                               "img_per_s": n_cand / net_s},
         }
         # per-kernel LeNet durations (HIP events between the kernels on the context's stream)
-        kflops = {"conv1_mfma_kernel": 2.0 * 20 * 25 * C * 56 * 56, "conv2_mfma_kernel": 2.0 * 50 * 500 * 24 * 24,
-                  "fc1_mfma_kernel": 2.0 * 500 * 7200, "fc2_score_kernel": 2.0 * 2 * 500}
+        work = lenet_mfma_work(C)
+        kflops = {k: v["algorithmic"] for k, v in work.items()}
+        kflops["fc2_score_kernel"] = 2.0 * 2 * 500
         for (name, fl), ms_sum in zip(kflops.items(), kernel_ms):
             k_s = ms_sum / 1e3 / args.steps
             kernels[name] = {"ms": k_s * 1e3, "algorithmic_flops": fl * n_cand,
                              "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None,
                              "frac_f32": fl * n_cand / k_s / 1e12 / F32_PEAK_TFLOPS if k_s > 0 else None}
+            if name in work and k_s > 0:
+                wk = work[name]
+                peak = I8_PEAK_TOPS if wk["pipe"] == "i8" else BF16_PEAK_TFLOPS
+                kernels[name].update({"pipe": wk["pipe"], "executed_ops": wk["executed"] * n_cand, "executed_Tops": wk["executed"] * n_cand / k_s / 1e12,
+                                      "frac_pipe": wk["executed"] * n_cand / k_s / 1e12 / peak,
+                                      "useful_share_of_executed": wk["algorithmic_split"] / wk["executed"]})
         traffic = _pmc_traffic(n_cand, C, live=args.live_pmc and args.gpus == 1)
         sq = _pmc_sq()
         if sq:
             # the image kernels are latency / LDS bound, not HBM bound: their LDS roofline is the share of
             # the chip's LDS-array cycles that moved data (peak 256 B/clk/CU, MI355X_MICROARCH.md §LDS)
             kernels["grasp_image_kernel"]["lds_roofline"] = sq
-        dom = max(kflops, key=lambda k: kernels[k]["ms"])
+        dom = max(work, key=lambda k: kernels[k]["ms"])
         if kernels[dom]["ms"] >= img_s * 1e3 / 3.0:
-            # the dominant single kernel of the step (conv1 + pool1 at 15 channels): f32 MFMA bound.  conv1 drops the
-            # (64-pixel chunk, channel) pairs whose input patches are all zero (exact: the products are zeros), so the
-            # FLOPs it EXECUTES are the dense count x the live-pair fraction the kernel counts itself (gpd_hip_conv1_stats,
-            # over exactly the timed launches).  `frac` is that executed rate over the peak — a utilisation, <= 1, the
-            # number to hold against MfmaUtil; the dense-equivalent figure (SURVEY 8d's algorithmic FLOPs / time) rides along.
-            dense = kernels[dom]["achieved_TFLOPs"]
-            lf = live_frac if (dom == "conv1_mfma_kernel" and live_frac is not None) else 1.0
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": dense * lf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": dense * lf / F32_PEAK_TFLOPS,
-                        "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
-                        "flops_per_launch": kernels[dom]["algorithmic_flops"], "launch_ms": kernels[dom]["ms"],
-                        "live_pair_fraction": lf, "executed_flops_per_launch": kernels[dom]["algorithmic_flops"] * lf,
-                        "achieved_dense_equivalent": dense, "frac_dense_equivalent": dense / F32_PEAK_TFLOPS,
-                        "note": "achieved = executed FLOPs (dense 2*20*25*C*56*56 per image x live (chunk, channel) pair fraction, counted "
-                                "by the kernel over the timed launches) / HIP-event time of the kernel; *_dense_equivalent = all algorithmic "
-                                "FLOPs / the same time (can pass 1.0 of peak: skipped work is not work)"}
-            kernels[dom]["frac_executed"] = roofline["frac"]
+            # the dominant single kernel of the step.  Since round 5 the LeNet runs on the int8 / bf16 matrix pipes with exactly
+            # split operands: `achieved` = the MFMA operations the kernel EXECUTES per launch (instruction count x operations per
+            # instruction: padding included, nothing skipped) / its HIP-event time, against the dense peak of ITS pipe — a
+            # utilisation, the number to hold against MfmaUtil.  The f32-equivalent rate (SURVEY 8d's algorithmic FLOPs / the same
+            # time) rides along, against the 157.3 TFLOP/s f32 peak the previous rounds' f32-input MFMA kernels were priced on.
+            kd, wk = kernels[dom], work[dom]
+            peak = I8_PEAK_TOPS if wk["pipe"] == "i8" else BF16_PEAK_TFLOPS
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": kd["executed_Tops"], "peak": peak,
+                        "unit": "TOP/s" if wk["pipe"] == "i8" else "TFLOP/s", "frac": kd["executed_Tops"] / peak,
+                        "pipe": wk["pipe"], "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
+                        "ops_per_launch": kd["executed_ops"], "launch_ms": kd["ms"],
+                        "algorithmic_flops_per_launch": kd["algorithmic_flops"],
+                        "f32_equivalent": {"achieved_TFLOPs": kd["achieved_TFLOPs"], "frac_of_f32_peak": kd["frac_f32"],
+                                           "note": "SURVEY 8d's f32 FLOPs of the layer / the same time, against the 157.3 TFLOP/s f32-input MFMA "
+                                                   "peak (the pipe of rounds 1-4: conv2 there ran at 0.77 of it)"},
+                        "useful_share_of_executed": wk["algorithmic_split"] / wk["executed"],
+                        "note": "achieved = executed MFMA operations per launch (tiles x instructions x ops per instruction, lenet_mfma_work) / "
+                                "HIP-event time of the kernel; useful_share_of_executed = algorithmic FLOPs x the split factor (4 digit planes / 6 "
+                                "piece products) over the executed ones (the rest is tile padding: 50 -> 64 filters, 25 -> 28 tap slots, ...)"}
         else:
             roofline = {"kernel": "image stage (shadow_set + shadow_image + grasp_image kernels)", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}
@@ -409,7 +438,7 @@ def main():
             "metric": "15-ch grasp candidates scored/sec (imagegen+LeNet) at 1/2/4/8 MI355X" if C == 15 else "%d-ch grasp candidates scored/sec (imagegen+LeNet)" % C,
             "value": value, "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 geometry / f32 LeNet / u8 images", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": "single %dk-point synthetic %scloud per GPU (seed 1234+rank), first %d valid candidates, %d-channel LeNet"
                        % (points // 1000, "clutter " if clutter else "", n_cand, C), "points": points, "candidates_per_gpu": n_cand,
                        "samples": int(n_samples), "channels": C, "sharding": "one cloud per GPU, no collective"},
@@ -427,7 +456,7 @@ def main():
         if numa is not None:
             out["host_binding_rank0"] = numa
         if trained is not None:
-            out["scores_trained_magnitude"] = trained
+            out["scores_timed_list"] = trained
         if batch is not None:
             batch["note"] = ("gpd_hip_detect_batch, %d clouds per rank and pass x %d samples, %d timed passes after one full untimed pass, two clouds "
                              "in flight per context: upload + grid + search + filter + images + LeNet + scored candidates back to the host"
@@ -541,49 +570,48 @@ def _lenet_f64(images, w):
         return (z[:, 1] - z[:, 0]).numpy()
 
 
-def _trained_magnitude_leg(ctx, hands_f, C, real, n=256):
-    """BASELINE's "scores within 1e-4 of the Eigen path" decided where it can be: the benchmark's synthetic ip1 drives the
-    logits to |score| ~ 1000 (one float32 ulp = 6e-5: no two float32 summation orders agree to 1e-4 there), so a second
-    weight set — the same ip1 / 128, logits of the size a trained LeNet produces — scores a sample of the benchmark's own
-    images: HIP against the oracle's k-ascending fma chains (bit-identical by construction) and both against float64."""
+def _score_accuracy_leg(ctx, hands_f, C, w, timed_scores):
+    """BASELINE's "scores within 1e-4 of the Eigen path" on ALL candidates of the timed list, with the weights the headline is
+    timed on (trained-net magnitudes, |score| < 20): the scores the timed region produced (default mode: int8 / bf16 matrix pipes
+    on exactly split operands) against the oracle's k-ascending f32 fma chains — the definition the reference's plain-float path
+    shares up to summation order (tests/test_ref_pin.py asserts |chain - reference plain float| on the pins) — and both against
+    float64 (torch, CPU); then the library's f32-chain mode, which must reproduce the oracle bit for bit."""
     import oracle
-    from gpd_amd import synth
-    sub = hands_f.copy()
-    flat = sub.reshape(-1)
-    keep = np.flatnonzero(flat["valid"])
-    keep = keep[:: max(1, len(keep) // n)][:n]
-    flat["valid"] = 0
-    flat["valid"][keep] = 1
-    imgs, _ = ctx.images(sub, download=True)
-    out = {}
-    for tag, tm in (("trained_magnitude", True), ("benchmark_weights", False)):
-        w = synth.lenet_weights(C, real=real, trained_magnitude=tm)
-        ctx.set_lenet_weights(w)
-        hip = ctx.score(imgs)
-        orc = oracle.lenet(imgs, w)
-        f64 = _lenet_f64(imgs, w)
-        out[tag] = {"images": int(len(imgs)), "max_abs_score": float(np.abs(f64).max()), "max_abs_hip_minus_oracle": float(np.abs(hip - orc).max()),
-                    "max_abs_oracle_minus_float64": float(np.abs(orc - f64).max()), "max_abs_hip_minus_float64": float(np.abs(hip - f64).max())}
-    out["note"] = ("the absolute 1e-4 bar of BASELINE.json is met at trained-net magnitudes; at the benchmark's synthetic magnitudes it is "
-                   "a relative 8e-6 (tests/test_lenet_reorder.py)")
-    return out
+    from gpd_amd import api
+    imgs, _ = ctx.images(hands_f, download=True)
+    assert len(imgs) == len(timed_scores)
+    orc = oracle.lenet(imgs, w)
+    f64 = _lenet_f64(imgs, w)
+    ctx.set_lenet_mode(api.LENET_F32_CHAIN)
+    chain = ctx.score(imgs)
+    ctx.set_lenet_mode(api.LENET_SPLIT)
+    again = ctx.score(imgs)
+    return {"images": int(len(imgs)), "weights": "trained magnitude (synthetic ip1 / 128): the set the headline is timed on",
+            "max_abs_score": float(np.abs(f64).max()),
+            "max_abs_hip_minus_oracle_chain": float(np.abs(timed_scores - orc).max()),
+            "max_abs_hip_minus_float64": float(np.abs(timed_scores - f64).max()),
+            "max_abs_oracle_chain_minus_float64": float(np.abs(orc - f64).max()),
+            "f32_chain_mode_bit_identical_to_oracle": bool(np.array_equal(chain, orc)),
+            "timed_scores_reproduced_by_gpd_hip_score": bool(np.array_equal(again, timed_scores)),
+            "within_1e-4": bool(np.abs(timed_scores - orc).max() <= 1e-4 and np.abs(timed_scores - f64).max() <= 1e-4),
+            "note": "hip = the scores of the last timed step (gpd_hip_replay), all candidates of the timed list"}
 
 
 def _fc1_tile(n):
-    """lenet.hip fc1_pick_nt: the m-tile width (in 16s) ip1 runs with for n images."""
+    """lenet_fast.hip fc1f_pick_nt: ip1's image-tile height (in 32s) for n images."""
     r = 1
     while True:
-        nt = -(-n // (64 * r * 16))
-        if nt <= 8:
+        nt = -(-n // (32 * r * 32))
+        if nt <= 5:
             return max(nt, 1)
         r += 1
 
 
 def _live_pmc_kernels():
-    """--live-pmc: the two PMC passes of profiles/collect_r04.sh run from inside this process, on this box — `rocprofv3 --pmc
+    """--live-pmc: the two PMC passes of profiles/collect_r05.sh run from inside this process, on this box — `rocprofv3 --pmc
     FETCH_SIZE` and `--pmc WRITE_SIZE` (counters only, their own runs) around a short child run of this file — and reduced as
     profiles/summarize.py --traffic does (KiB per launch; reads x2 per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
-    Returns the per-kernel dict of profiles/r04_traffic.json, or None when rocprofv3 is missing / a pass fails."""
+    Returns the per-kernel dict of profiles/r05_traffic.json, or None when rocprofv3 is missing / a pass fails."""
     import glob
     import shutil
     import sqlite3
@@ -626,8 +654,8 @@ def _live_pmc_kernels():
 
 
 def _pmc_traffic(n_images, channels=15, live=False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_traffic.json, produced by
-    profiles/collect_r04.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r05_traffic.json, produced by
+    profiles/collect_r05.sh on the default workload).  The file carries the SHA-1 of the kernel sources it was measured
     on: when a kernel file has changed since, the numbers are stale and dropped.  live (--live-pmc): measured here and now
     instead (_live_pmc_kernels), the file's figures next to them."""
     if channels != 15 or n_images != 5000:
@@ -652,36 +680,36 @@ def _pmc_traffic(n_images, channels=15, live=False):
         return {"note": "no PMC traffic file"}
     if filed is None:
         return {"note": "%s was measured on other kernel sources: stale, not reported" % os.path.relpath(TRAFFIC_FILE, ROOT)}
-    return _traffic_totals(filed, n_images, "profiles/r04_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; "
+    return _traffic_totals(filed, n_images, "profiles/r05_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of the default workload; "
                            "reads x2 per the gfx950 note; same kernel sources as this run, by SHA-1)")
 
 
 def _traffic_totals(d, n_images, source):
     out = {"source": source}
-    fc1 = "fc1_mfma_kernel<%d>" % _fc1_tile(n_images)
+    fc1 = "fc1_bf16_kernel<%d>" % _fc1_tile(n_images)
 
     def total(names):
         vals = [v["hbm_bytes_per_launch"] for k, v in d.items() if any(s in k for s in names)]
         return float(sum(vals)) if vals else None
 
     out["image"] = total(("grasp_image_kernel<false>", "shadow_image_kernel<6144", "shadow_set_kernel"))
-    out["lenet"] = total(("conv1_mfma", "conv2_mfma", fc1, "fc2_score"))
-    out["conv1_mfma"] = total(("conv1_mfma",))
-    out["conv2_mfma"] = total(("conv2_mfma",))
-    out["fc1_mfma"] = total((fc1,))
+    out["lenet"] = total(("conv1_i8", "conv2_bf16", fc1, "fc1_combine", "fc2_score"))
+    out["conv1_i8"] = total(("conv1_i8",))
+    out["conv2_bf16"] = total(("conv2_bf16",))
+    out["fc1_bf16"] = total((fc1, "fc1_combine"))
     out["search"] = total(("neighbourhood_kernel<false>", "hand_eval_kernel", "plan_kernel", "centre_kernel"))
     return {k: v for k, v in out.items() if v is not None}
 
 
 def _pmc_sq():
     """LDS-array utilisation of the image kernels from the committed SQ-counter pass (profiles/pmc_sq.sh ->
-    profiles/r04_pmc_sq.json), dropped like the traffic numbers when the kernel sources have changed since."""
+    profiles/r05_pmc_sq.json), dropped like the traffic numbers when the kernel sources have changed since."""
     if not os.path.exists(SQ_FILE):
         return None
     d = json.load(open(SQ_FILE))
     if d.get("source_hashes") != source_hashes():
         return None
-    out = {"source": "profiles/r04_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
+    out = {"source": "profiles/r05_pmc_sq.json: SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs); bank-conflict cycles as a share of it",
            "peak": "256 B/clk/CU = %.1f TB/s at 2.4 GHz" % (LDS_PEAK_GBS * 2 / 1e3)}
     for k, v in d["kernels"].items():
         for name in ("shadow_image_kernel<6144", "grasp_image_kernel<false>", "shadow_set_kernel"):

@@ -30,7 +30,7 @@ for p in ("p1", "p2"):
         dur[k] = v
 lines = []
 for k, v in sorted(d.items(), key=lambda kv: -dur.get(kv[0], 0)):
-    if dur.get(k, 0) < 1e5 or "mfma" in k:
+    if dur.get(k, 0) < 1e5 or "mfma" in k or "conv1_i8" in k or "_bf16_kernel" in k:
         continue
     g = v.get("GRBM_GUI_ACTIVE", 0) / 8.0
     simd_quads = g * 1024 / 4.0

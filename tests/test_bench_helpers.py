@@ -14,10 +14,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_fc1_tile_rule_matches_the_kernel_launcher():
-    # lenet.hip fc1_pick_nt: smallest multiple of 16 (<= 128) whose m-tiles fill 64 workgroup columns in whole rounds
-    assert [bench._fc1_tile(n) for n in (1, 37, 1024, 1025, 5000, 6077, 8192, 10000, 16384, 50000)] == [1, 1, 1, 2, 5, 6, 8, 5, 8, 7]
-    src = open(os.path.join(ROOT, "gpd_amd", "csrc", "lenet.hip")).read()
-    assert "(n + 64 * r * 16 - 1) / (64 * r * 16)" in src  # the rule restated above is the one in the launcher
+    # lenet_fast.hip fc1f_pick_nt: image tiles of 32 NT rows (NT <= 5), 8 workgroups each, filling 256 CUs in whole rounds
+    assert [bench._fc1_tile(n) for n in (1, 37, 1024, 1025, 5000, 6077, 8192, 10000, 16384, 50000)] == [1, 1, 1, 2, 5, 3, 4, 5, 4, 5]
+    src = open(os.path.join(ROOT, "gpd_amd", "csrc", "lenet_fast.hip")).read()
+    assert "(n + 32 * r * 32 - 1) / (32 * r * 32)" in src  # the rule restated above is the one in the launcher
+
+
+def test_executed_mfma_work_matches_the_kernels_constants():
+    """bench.py prices the split path's kernels by the MFMA operations they execute: the tile / step counts it multiplies
+    are the kernels' own constants."""
+    src = open(os.path.join(ROOT, "gpd_amd", "csrc", "lenet_fast.hip")).read()
+    for needle in ("F1_TILES = 28 * 7", "F1_KS = 7, F1_MT = 5", "for (int tt = 0; tt < 18; tt++)", "for (int ks = 0; ks < 16; ks++)", "kLenetXld"):
+        assert needle in src, needle
+    w = bench.lenet_mfma_work(15)
+    assert w["conv1_i8_kernel"]["executed"] == 196 * 7 * 5 * 16 * 16 * 64 * 2
+    assert w["conv2_bf16_kernel"]["executed"] == 2 * 18 * 4 * 16 * 6 * 16 * 16 * 32 * 2  # halves x tiles x column tiles x k-steps x pieces
+    assert w["fc1_bf16_kernel"]["executed"] == 2.0 * 512 * 7296 * 6
+    for v in w.values():
+        assert 0.7 < v["algorithmic_split"] / v["executed"] <= 1.0
 
 
 def test_bench_launches_itself_for_several_gpus(tmp_path):
@@ -44,25 +58,25 @@ def test_bench_launches_itself_for_several_gpus(tmp_path):
 
 def test_pmc_numbers_are_dropped_when_a_kernel_source_changes(tmp_path, monkeypatch):
     good = {"source_hashes": bench.source_hashes(),
-            "kernels": {"void gpd::conv1_mfma_kernel<15>(x)": {"hbm_bytes_per_launch": 8e8},
-                        "void gpd::fc1_mfma_kernel<5>(x)": {"hbm_bytes_per_launch": 2.7e8},
-                        "void gpd::fc1_mfma_kernel<6>(x)": {"hbm_bytes_per_launch": 3.0e8}}}
+            "kernels": {"void gpd::conv1_i8_kernel<15>(x)": {"hbm_bytes_per_launch": 8e8},
+                        "void gpd::fc1_bf16_kernel<5>(x)": {"hbm_bytes_per_launch": 2.7e8},
+                        "void gpd::fc1_bf16_kernel<3>(x)": {"hbm_bytes_per_launch": 3.0e8}}}
     f = tmp_path / "traffic.json"
     f.write_text(json.dumps(good))
     monkeypatch.setattr(bench, "TRAFFIC_FILE", str(f))
     t = bench._pmc_traffic(5000)
-    assert t["conv1_mfma"] == 8e8 and t["fc1_mfma"] == 2.7e8      # the ip1 instantiation this n runs with
+    assert t["conv1_i8"] == 8e8 and t["fc1_bf16"] == 2.7e8      # the ip1 instantiation this n runs with
     assert "default workload" in bench._pmc_traffic(6077)["note"] and "default workload" in bench._pmc_traffic(5000, 12)["note"]
     good["source_hashes"]["gpd_amd/csrc/lenet.hip"] = "0" * 40
     f.write_text(json.dumps(good))
     t = bench._pmc_traffic(5000)
-    assert "conv1_mfma" not in t and "stale" in t["note"]
+    assert "conv1_i8" not in t and "stale" in t["note"]
 
 
 def test_committed_profiles_belong_to_the_committed_kernels():
-    """profiles/r03_traffic.json / r03_pmc_sq.json are only reported while the kernel sources are the ones they were
-    measured on; a commit that changes a kernel has to re-collect them (profiles/collect_r03.sh, profiles/pmc_sq.sh)."""
-    for name in ("r03_traffic.json", "r03_pmc_sq.json"):
+    """profiles/r05_traffic.json / r05_pmc_sq.json are only reported while the kernel sources are the ones they were
+    measured on; a commit that changes a kernel has to re-collect them (profiles/collect_r05.sh, profiles/pmc_sq.sh)."""
+    for name in ("r05_traffic.json", "r05_pmc_sq.json"):
         if not os.path.exists(os.path.join(ROOT, "profiles", name)):
             pytest.skip(name + " not collected yet")
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -76,7 +90,7 @@ def test_traffic_totals_take_every_kernel_of_a_stage():
     """The per-stage totals pick their kernels by name: with the committed profile every kernel of the image stage, of
     LeNet and of the search must be found (the shadow image kernel once dropped out of `image` when it gained a second
     template argument: 505 instead of 623 MB), and a live measurement reports the committed figures next to its own."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_traffic.json")
     if not os.path.exists(path):
         pytest.skip("no committed traffic profile")
     d = json.load(open(path))["kernels"]
@@ -89,7 +103,7 @@ def test_traffic_totals_take_every_kernel_of_a_stage():
 
     img = one("grasp_image_kernel<false>") + one("shadow_image_kernel<6144") + one("shadow_set_kernel")
     assert t["image"] == pytest.approx(img) and one("shadow_image_kernel<6144") > 5e7
-    assert t["lenet"] == pytest.approx(one("conv1_mfma") + one("conv2_mfma") + one("fc1_mfma_kernel<5>") + one("fc2_score"))
+    assert t["lenet"] == pytest.approx(one("conv1_i8") + one("conv2_bf16") + one("fc1_bf16_kernel<5>") + one("fc1_combine") + one("fc2_score"))
     assert t["search"] == pytest.approx(one("neighbourhood_kernel<false>") + one("hand_eval_kernel") + one("plan_kernel") + one("centre_kernel"))
 
 
@@ -105,12 +119,12 @@ def test_live_pmc_falls_back_to_the_committed_profile(monkeypatch):
         raise RuntimeError("no counters")
     monkeypatch.setattr(bench, "_live_pmc_kernels", boom)
     assert bench._pmc_traffic(5000, live=True) == b
-    fake = {"void gpd::conv1_mfma_kernel<15>(x)": {"hbm_bytes_per_launch": 7e8}}
+    fake = {"void gpd::conv1_i8_kernel<15>(x)": {"hbm_bytes_per_launch": 7e8}}
     monkeypatch.setattr(bench, "_live_pmc_kernels", lambda: fake)
     c = bench._pmc_traffic(5000, live=True)
-    assert c["conv1_mfma"] == 7e8 and c["source"].startswith("live")
-    if "conv1_mfma" in b:
-        assert c["committed_file"]["conv1_mfma"] == b["conv1_mfma"]
+    assert c["conv1_i8"] == 7e8 and c["source"].startswith("live")
+    if "conv1_i8" in b:
+        assert c["committed_file"]["conv1_i8"] == b["conv1_i8"]
 
 
 def test_batch_mode_cloud_assignment():
