@@ -108,11 +108,11 @@ def main():
         # 127.0.0.1), same arguments; rank 0 of the children prints the ONE line
         sys.exit(_self_launch(args.gpus))
     if args.live_pmc is None:
-        # the headline line measures its HBM traffic itself; not under a profiler (rocprofv3 around this process: the
-        # collection scripts), not for the side configs, not on several GPUs
-        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
-        args.live_pmc = (args.gpus == 1 and args.config is None and args.mode == "replay" and args.points is None and args.candidates is None
-                         and args.channels is None and not args.clutter and not profiled and not os.environ.get("GPD_BENCH_DRYRUN"))
+        # Off by default since round 5: the two TCC counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE around a child run)
+        # took the GPU node down twice in a row on 2026-09-25 (the pool's known weakness: PMC collection can crash nodes) — a
+        # bench line must not be able to do that.  --live-pmc switches them on; without them `traffic` comes from the committed,
+        # source-stamped profile when there is one, else it is null.
+        args.live_pmc = False
     if args.batch_clouds is None:
         args.batch_clouds = 24 if args.gpus == 1 else 32
     if args.steps is None:
