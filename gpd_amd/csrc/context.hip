@@ -249,12 +249,17 @@ static int lane_reserve(gpd_hip_ctx *ctx, Lane &L, int points, int cams, int sam
 constexpr int kLeNetChunk = 65536;                // lenet_forward's images per pass (lenet.hip)
 constexpr size_t kReserveBudget = 16ull << 30;   // candidate-sized buffers of a lane when the caller names no bound
 
-// the most candidates `samples` samples can give (every slot a valid hand), cut to what kReserveBudget holds
-static int candidate_bound(const gpd_params &p, int samples) {
+// the most candidates `samples` samples can give (every slot a valid hand), cut to what `budget` bytes hold: per candidate
+// its image, the LeNet scratch of both scoring modes (pool1, the f32 and the three-plane bf16 flatten, ip1 and its four K
+// quarters), score and records; per (hand set, camera) a shadow voxel bitset of the 86^3-bit default window (wider image
+// volumes take more: images_reserve grows them on demand)
+static int candidate_bound(const gpd_params &p, int samples, int cams = 1, size_t budget = kReserveBudget) {
   const long long upper = (long long)samples * p.num_hand_axes * p.num_orientations;
-  const size_t per = (size_t)kPix * p.image_num_channels + (20 * 784 + kFc1In + kFc1Out + 1) * sizeof(float) + 2 * sizeof(gpd_hand);
-  const long long fit = (long long)(kReserveBudget / per);
-  return (int)std::min(upper, fit);
+  const size_t per = (size_t)kPix * p.image_num_channels + (20 * 784 + kFc1In + 5 * kFc1Out + 1) * sizeof(float) + 3 * (size_t)kLenetXld * 2 +
+                     2 * sizeof(gpd_hand);
+  const size_t bitsets = p.image_num_channels == 15 ? (size_t)std::max(samples, 1) * std::max(cams, 1) * ((86 * 86 * 86 + 31) / 32 * 4) : 0;
+  const long long fit = budget > bitsets ? (long long)((budget - bitsets) / per) : 0;
+  return (int)std::max(1ll, std::min(upper, fit));
 }
 
 static int lane_reserve(gpd_hip_ctx *ctx, Lane &L, int points, int cams, int samples, int candidates, int selected) {
@@ -637,7 +642,7 @@ int gpd_hip_reserve(gpd_hip_ctx *ctx, int max_points, int max_cams, int max_samp
     return GPD_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(ctx->device));
-  const int cand = max_candidates > 0 ? max_candidates : candidate_bound(ctx->params, max_samples);
+  const int cand = max_candidates > 0 ? max_candidates : candidate_bound(ctx->params, max_samples, max_cams);
   for (int l = 0; l < kLanes; l++) {
     int rc = lane_init(ctx->lane[l]);
     if (rc) return rc;
@@ -1138,12 +1143,31 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
       return GPD_ERR_INVALID;
     }
     const int before = g_allocs;
-    for (int l = 0; l < kLanes && l < num_jobs; l++) {
+    // Best effort: the bound samples x slots is an UPPER bound — sized against what the device has free right now
+    // (half of it over the lanes in use, the set bitsets counted), and when the allocation still fails (several contexts
+    // on one GPU, a fragmented heap) the batch goes on: the buffers then grow on demand to the real candidate counts, as
+    // before round 4 — a failed pre-size is a slower first pass, not a failed batch.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+      (void)hipGetLastError();
+      free_b = 2 * kReserveBudget;
+    }
+    const int lanes_used = std::min(kLanes, num_jobs);
+    const size_t budget = std::min(kReserveBudget, free_b / 2 / (size_t)std::max(lanes_used, 1));
+    for (int l = 0; l < lanes_used; l++) {
       Lane &L = ctx->lane[l];
-      const int cand = candidate_bound(ctx->params, maxS);
+      if (L.search.nn_cap > 16384) {  // lists beyond the LDS sizes, left by a dense cloud of an earlier call: not pre-sized for a whole batch
+        const int rcf = search_force_capacity(L.search, 8192);
+        if (rcf) return rcf;
+      }
+      const int cand = candidate_bound(ctx->params, maxS, maxC, budget);
       int rc = GPD_OK;
       if (!all_selected) rc = lane_reserve(ctx, L, maxP, maxC, maxS, cand, 0);
       if (!rc && maxSel > 0) rc = lane_reserve(ctx, L, maxP, maxC, maxS, cand, maxSel);
+      if (rc == GPD_ERR_HIP) {
+        (void)hipGetLastError();  // out of memory: clear it, the jobs size their buffers themselves
+        break;
+      }
       if (rc) return rc;
     }
     if (num_jobs > 0) jobs[0].allocs = g_allocs - before;  // the pre-sizing is booked on the first cloud

@@ -203,6 +203,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
 struct SearchState {
   int num_samples = 0, capacity_samples = 0;
   int min_samples = 0;                // sample capacity to keep across a change of the list capacity (search_force_capacity)
+  uint64_t seen_generation = 0;       // Cloud::generation of the last run: lists beyond the LDS capacities shrink back on a new cloud
   int nn_cap = 0;                     // entries per neighbourhood list: 8192 / 16384 (LDS sorts) or up to kNnCapMax (global-memory sort)
   uint64_t cloud_generation = 0;
   int32_t *d_sample_idx = nullptr;    // [S]

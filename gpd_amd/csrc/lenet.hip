@@ -474,21 +474,11 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
           const int s1 = sI + 1 < 25 ? sI + 1 : 0;
           const int bump = sI + 1 < 25 ? 0 : 4 * 784;
           const float *x1 = xin + offp[s1] + bump;
-#if !defined(C2_EXP) || C2_EXP != 2  // (C2_EXP: timing experiments of profiles/r04_conv2_ab.sh, wrong results)
 #pragma unroll
           for (int q = 0; q < 3; q++) {
             a_nxt[q] = aw[(sI + 1) * 4 * 48 + 16 * q];
             b_nxt[q] = x1[8 * q];
           }
-#else
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            a_nxt[q] = a_cur[q];
-            b_nxt[q] = b_cur[q];
-          }
-          (void)x1;
-#endif
-#if !defined(C2_EXP) || (C2_EXP != 1 && C2_EXP != 2)
 #pragma unroll
           for (int i = 0; i < 4; i++) xn[i] = xv[c2_tap_off(4 * s1 + i) + bump];
           // ---- filters 48, 49: four taps of this step, k ascending
@@ -502,13 +492,7 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
           t49 = __builtin_fmaf(wb.z, xc[2], t49);
           t48 = __builtin_fmaf(wa.w, xc[3], t48);
           t49 = __builtin_fmaf(wb.w, xc[3], t49);
-#else
-#pragma unroll
-          for (int i = 0; i < 4; i++) xn[i] = xc[i];
-#endif
-#if !defined(C2_EXP) || C2_EXP != 3
           __builtin_amdgcn_sched_barrier(0);
-#endif
           // the nine MFMAs at raised wave priority: the SIMD's other two waves are in their VALU tail / operand requests at
           // any time, and the arbiter otherwise lets those instructions in between this wave's MFMAs (conv2 1.21 -> 1.19 ms;
           // the same around conv1's and ip1's MFMA runs changes nothing: profiles/NOTES.md E)
@@ -519,9 +503,7 @@ __global__ __launch_bounds__(C2_THREADS) void conv2_mfma_kernel(const float *__r
             for (int ft = 0; ft < 3; ft++)
               acc[t][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[ft], b_cur[t], acc[t][ft], 0, 0, 0);
           __builtin_amdgcn_s_setprio(0);
-#if !defined(C2_EXP) || C2_EXP != 3
           __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
           for (int q = 0; q < 3; q++) {
             a_cur[q] = a_nxt[q];

@@ -1286,7 +1286,8 @@ struct NormalsParams {
   float r2;
   float reach;
   int32_t *count;                  // [P] by cell-order position
-  float4 *lists;                   // [P / 64][NL_CAP][64] neighbour coordinates in FLANN order, transposed per block of 64 points
+  int w0, w1;                      // the tile of this pass: cell-order positions [w0, w1), w0 a multiple of 64
+  float4 *lists;                   // [(w1 - w0) / 64][NL_CAP][64] neighbour coordinates in FLANN order, transposed per block of 64 points
   int32_t *big;                    // [0] number of queued points, [1 ..] their cell-order positions
   long long *big_off;              // [P] slice of a queued point in the arena (8-byte units)
   unsigned long long *arena;       // sort space + sorted indices of the queued points
@@ -1431,14 +1432,8 @@ __device__ __forceinline__ void normals_sort_store(const NormalsParams &P, const
   double key[K];
 #pragma unroll
   for (int r = 0; r < K; r++) key[r] = __longlong_as_double((long long)(lane * K + r < n ? keys[lane * K + r] : NL_PAD_KEY));
-#ifndef NL_SKIP_SORT  // (timing experiments only: profiles/r04_normals_ab.sh)
   wave_sort_regs<K>(key, lane);
-#endif
-#ifdef NL_SKIP_STORE
-  if (key[0] == 12345.0) P.count[w] = 0;
-  return;
-#endif
-  float4 *col = P.lists + (size_t)(w >> 6) * NL_CAP * 64 + (w & 63);
+  float4 *col = P.lists + (size_t)((w - P.w0) >> 6) * NL_CAP * 64 + (w & 63);
 #pragma unroll
   for (int r0 = 0; r0 < K; r0 += 4) {  // four gathers in flight, then their four stores
     const int e = lane * K + r0;
@@ -1461,8 +1456,8 @@ __global__ __launch_bounds__(64 * NL_WAVES) void normals_list_kernel(NormalsPara
   // per-lane values they became exec-mask regions with a vmcnt(0) at every join: the loads of a column batch were waited
   // for one by one)
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int w = blockIdx.x * NL_WAVES + wv;
-  if (w >= P.num_points) return;
+  const int w = P.w0 + blockIdx.x * NL_WAVES + wv;
+  if (w >= P.w1) return;
   unsigned long long *keys = s_keys[wv];
   const float4 q4 = P.grid.p[w];
   const float qx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(q4.x))),
@@ -1567,8 +1562,8 @@ __global__ __launch_bounds__(256) void normals_list_big_kernel(NormalsParams P) 
 }
 
 __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
-  if (w >= P.num_points) return;
+  const int w = P.w0 + blockIdx.x * 64 + threadIdx.x;
+  if (w >= P.w1) return;
   if (*P.status & 1) return;  // the arena was too small: this run is repeated
   const int n = P.count[w];
   const float4 q = P.grid.p[w];
@@ -1577,7 +1572,7 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
   // centroid: three sequential sums in neighbour order; covariance entries 00, 10, 11, 20, 21, 22 about it: six more
   double c0 = 0.0, c1 = 0.0, c2 = 0.0;
   double m00 = 0.0, m10 = 0.0, m11 = 0.0, m20 = 0.0, m21 = 0.0, m22 = 0.0;
-  const float4 *col = P.lists + (size_t)(w >> 6) * NL_CAP * 64 + (w & 63);  // this point's column of its block's transposed lists
+  const float4 *col = P.lists + (size_t)((w - P.w0) >> 6) * NL_CAP * 64 + (w & 63);  // this point's column of its block's transposed lists
   int nmax = n;  // the longest list of this wave: the loop below is uniform, shorter lists are masked out arithmetically
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
@@ -1712,6 +1707,8 @@ void normals_free(NormalsScratch &s) {
 // Host wrapper: normals of the uploaded cloud, result to the host and into the context's device copy.  Nothing waits
 // for the device between the three kernels; the arena of the large neighbourhoods grows when a cloud needs more (the
 // status word comes back with the result, and the run is repeated once with the size the first one asked for).
+constexpr int kNormalsTile = 65536;  // points per pass of the normals kernels (a multiple of 64): their transposed lists are 1 GB
+
 int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream) {
   NormalsScratch &s = c.normals;
   const int P = c.num_points;
@@ -1725,7 +1722,11 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     s.arena_cap = arena_cap;
     const int cap = P + P / 4;
     HIP_RET(hipMalloc(&s.d_count, (size_t)cap * sizeof(int32_t)));
-    HIP_RET(hipMalloc(&s.d_lists, ((size_t)cap + 63) / 64 * 64 * NL_CAP * sizeof(float4)));  // 16 KB of address space per point; a point touches 16 B per neighbour
+    // the transposed lists take 16 KB per point (1024 entries of 16 bytes; a point touches 16 B per neighbour): a tile of at
+    // most kNormalsTile points at a time shares ONE such array (1 GB), whatever the size of the cloud — sized per point of
+    // the whole cloud it was 10 GB for a 500k-point raw scan
+    const size_t tile_pts = std::min<size_t>(((size_t)cap + 63) / 64 * 64, kNormalsTile);
+    HIP_RET(hipMalloc(&s.d_lists, tile_pts * NL_CAP * sizeof(float4)));
     HIP_RET(hipMalloc(&s.d_big, ((size_t)cap + 1) * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_big_off, (size_t)cap * sizeof(long long)));
     HIP_RET(hipMalloc(&s.d_ctl, 4 * sizeof(unsigned long long)));  // [0] arena top, [1] status
@@ -1758,20 +1759,38 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     unsigned long long top, status;
   } h = {0, 0};
   int32_t queued = 0;
+  const int tiles = (P + kNormalsTile - 1) / kNormalsTile;
+  std::vector<int32_t> tile_queued((size_t)tiles, 0);
   for (int attempt = 0; attempt < 2; attempt++) {
     np.arena = s.d_arena;
     np.arena_cap = s.arena_cap;
-    HIP_RET(hipMemsetAsync(s.d_ctl, 0, 2 * sizeof(unsigned long long), stream));
-    HIP_RET(hipMemsetAsync(s.d_big, 0, sizeof(int32_t), stream));
     HIP_RET(hipMemsetAsync(s.d_out, 0, (size_t)P * 3 * sizeof(float), stream));
-    normals_list_kernel<<<(P + NL_WAVES - 1) / NL_WAVES, 64 * NL_WAVES, 0, stream>>>(np);
-    normals_list_big_kernel<<<256, 256, 0, stream>>>(np);
-    normals_finish_kernel<<<(P + 63) / 64, 64, 0, stream>>>(np);
-    HIP_RET(hipGetLastError());
-    HIP_RET(hipMemcpyAsync(&h, s.d_ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipMemcpyAsync(&queued, s.d_big, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipMemcpyAsync(normals_out, s.d_out, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipStreamSynchronize(stream));
+    unsigned long long top_max = 0, status_any = 0;
+    queued = 0;
+    for (int t = 0; t < tiles; t++) {
+      // one tile of points: its lists, the queue of its large neighbourhoods and their arena slices, its sums — the lists array
+      // and the arena are the next tile's again
+      np.w0 = t * kNormalsTile;
+      np.w1 = std::min(P, np.w0 + kNormalsTile);
+      const int tp = np.w1 - np.w0;
+      HIP_RET(hipMemsetAsync(s.d_ctl, 0, 2 * sizeof(unsigned long long), stream));
+      HIP_RET(hipMemsetAsync(s.d_big, 0, sizeof(int32_t), stream));
+      normals_list_kernel<<<(tp + NL_WAVES - 1) / NL_WAVES, 64 * NL_WAVES, 0, stream>>>(np);
+      normals_list_big_kernel<<<256, 256, 0, stream>>>(np);
+      normals_finish_kernel<<<(tp + 63) / 64, 64, 0, stream>>>(np);
+      HIP_RET(hipGetLastError());
+      if (tiles > 1 || t == tiles - 1) {
+        HIP_RET(hipMemcpyAsync(&h, s.d_ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIP_RET(hipMemcpyAsync(&tile_queued[(size_t)t], s.d_big, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        if (t == tiles - 1) HIP_RET(hipMemcpyAsync(normals_out, s.d_out, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_RET(hipStreamSynchronize(stream));  // (several tiles: the control words are the next tile's)
+        top_max = std::max(top_max, h.top);
+        status_any |= h.status;
+        queued += tile_queued[(size_t)t];
+      }
+    }
+    h.top = top_max;
+    h.status = status_any;
     if (!(h.status & 1)) break;
     // more / larger neighbourhoods beyond a wave's reach than the arena holds: grow it to what this run asked for
     note_alloc(__func__);
@@ -2413,7 +2432,10 @@ void search_free(SearchState &s) {
 static int search_reserve(SearchState &s, int S, int cap, int slots) {
   if (S <= s.capacity_samples && cap == s.nn_cap) return GPD_OK;
   int newS = S > s.capacity_samples ? S + S / 8 : s.capacity_samples;  // slack: the clouds of a batch differ a little
-  if (newS < s.min_samples) newS = s.min_samples;  // (a list-capacity change keeps the sample capacity the lane was sized for)
+  // (a list-capacity change keeps the sample capacity the lane was sized for — while the lists are the LDS-sorted sizes: the
+  //  global-memory lists of a dense scan cost 44 bytes per entry and sample, up to 46 MB per sample at 2^20 entries, and are
+  //  sized for the call at hand only: 2884 reserved samples x 200k entries would be 25 GB)
+  if (newS < s.min_samples && cap <= 16384) newS = s.min_samples;
   {
     // 44 bytes per list entry and sample (gathered rows, index scratch, height list): with the large lists of a dense
     // scan that is what bounds a call, and it should say so rather than fail inside hipMalloc
@@ -2426,7 +2448,9 @@ static int search_reserve(SearchState &s, int S, int cap, int slots) {
     }
   }
   note_alloc(__func__);
+  const uint64_t seen = s.seen_generation;
   search_free(s);
+  s.seen_generation = seen;  // (search_free resets the whole state; the cloud the lists belong to is still the same)
   HIP_RET(hipMalloc(&s.d_sample_idx, (size_t)newS * sizeof(int32_t)));
   HIP_RET(hipMalloc(&s.d_sample_xyz, (size_t)newS * 3 * sizeof(double)));
   HIP_RET(hipMalloc(&s.d_counts, (size_t)newS * 8 * sizeof(int32_t)));
@@ -2539,6 +2563,15 @@ static int search_join(SearchState &s, hipStream_t stream) {
 static int neighbourhoods(const gpd_params &p, const Cloud &c, SearchState &s, const HostConsts &hc, const int32_t *sample_idx,
                           const double *sample_xyz, int S, int slots, int *cap_out, hipStream_t stream, bool sync_counts = true,
                           bool want_height_list = true) {
+  // a new cloud starts from the LDS-sorted list size again: the large lists one dense cloud needed are not carried into the
+  // next one (they come back through the retry below if it needs them too)
+  if (s.seen_generation != c.generation) {
+    s.seen_generation = c.generation;
+    if (s.nn_cap > 16384) {
+      const int rcf = search_force_capacity(s, 8192);
+      if (rcf) return rcf;
+    }
+  }
   int cap = s.nn_cap ? s.nn_cap : 8192;
   int rc = search_reserve(s, S, cap, slots);
   if (rc) return rc;
@@ -2636,7 +2669,9 @@ int search_next_capacity(const SearchState &s, int worst) {
 int search_force_capacity(SearchState &s, int cap) {
   if (cap == s.nn_cap) return GPD_OK;
   const int keep = s.capacity_samples > s.min_samples ? s.capacity_samples : s.min_samples;
+  const uint64_t seen = s.seen_generation;
   search_free(s);
+  s.seen_generation = seen;
   s.nn_cap = cap;  // search_reserve allocates on the next run (capacity_samples is 0 now) ...
   s.min_samples = keep;  // ... for at least as many samples as before: a lane sized by gpd_hip_reserve stays sized
   return GPD_OK;

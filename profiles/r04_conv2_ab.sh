@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5: the C2_EXP switches this script compiled with were removed from the shipped sources — the experiment is closed, its
+#  results are in the .txt beside this file; a new one of the kind: profiles/mkpatched.sh NAME FILE 'sed-script')
 # What bounds conv2_mfma_kernel (MfmaUtil 74 %, 117 of the 155 TFLOP/s the pipe sustains)?  Timing-only builds (wrong
 # results): 1 = without the VALU tail of filters 48, 49; 2 = additionally without the LDS operand reads in the loop (the
 # operands of step 0 reused: what the MFMA issue structure alone takes); 3 = without the sched_barriers.

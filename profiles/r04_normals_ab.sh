@@ -1,4 +1,6 @@
 #!/bin/bash
+# (round 5: the NL_SKIP_SORT / NL_SKIP_STORE switches this script compiled with were removed from the shipped sources — the experiment is closed, its
+#  results are in the .txt beside this file; a new one of the kind: profiles/mkpatched.sh NAME FILE 'sed-script')
 # where the time of normals_list_kernel goes: the shipped kernel against builds without the sort / without the gather + store
 # (wrong results, timing only).  gpurun -- bash profiles/r04_normals_ab.sh
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

@@ -615,3 +615,49 @@ def test_neighbourhoods_beyond_65535_points(oracle_mod):
         assert np.array_equal(cand, ocand) and np.array_equal(img, oimg)
     finally:
         ctx.close()
+
+
+def test_normals_of_a_cloud_beyond_one_tile_of_points(oracle_mod):
+    """The normals kernels work through a cloud in tiles of 65536 points that share one lists array (search.hip kNormalsTile):
+    a 150k-point cloud takes three passes, the last one ragged — normals bit for bit against the oracle, then a small cloud on
+    the same context."""
+    cl = synth.make_cloud(31, 150000)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.upload_cloud(cl["xyz"], np.zeros_like(cl["xyz"]), cl["cam_source"], cl["view_points"])
+        got = ctx.estimate_normals(0.01)
+        want = oracle_mod.estimate_normals(cl["xyz"], cl["cam_source"], cl["view_points"], 0.01)
+        assert np.array_equal(got, want)
+        small = synth.make_cloud(32, 5000)
+        ctx.upload_cloud(small["xyz"], np.zeros_like(small["xyz"]), small["cam_source"], small["view_points"])
+        assert np.array_equal(ctx.estimate_normals(0.03), oracle_mod.estimate_normals(small["xyz"], small["cam_source"], small["view_points"], 0.03))
+    finally:
+        ctx.close()
+
+
+def test_batch_after_a_dense_cloud_and_with_little_memory_to_presize(oracle_mod, cloud30k):
+    """(1) the large neighbourhood lists one dense cloud needed are not carried into the next cloud / the next batch
+    (they were: 44 bytes x list capacity x the lane's reserved samples); (2) a batch whose up-front sizing does not fit goes on
+    with on-demand growth."""
+    w = _weights(15)
+    rng = np.random.RandomState(3)
+    d = rng.randn(30000, 3)
+    blob = (d / np.linalg.norm(d, axis=1, keepdims=True) * (0.04 * rng.rand(30000, 1) ** (1.0 / 3.0))).astype(np.float32) + np.float32(0.5)
+    nb = blob / np.maximum(np.linalg.norm(blob - 0.5, axis=1, keepdims=True), 1e-6)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        ctx.upload_cloud(blob, nb.astype(np.float32))
+        ctx.search(np.arange(4, dtype=np.int32))  # neighbourhoods of ~30000 points: the global-memory lists
+        assert ctx.fallbacks()["neighbourhood_list_capacity"] > 16384
+        si = synth.sample_indices(cloud30k, 400)
+        res = ctx.detect_batch([cloud30k, cloud30k], [si, si[:50]], 0)
+        assert ctx.fallbacks()["neighbourhood_list_capacity"] == 8192
+        p = oracle_mod.default_params(15)
+        oh, on, _ = oracle_mod.detect(p, cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"], cloud30k["view_points"], si, w)
+        assert res[0][2] == on
+        got = np.sort(res[0][0]["score"])
+        want = np.sort(oh["score"][oh["valid"].astype(bool)])
+        assert np.abs(got - want).max() <= 1e-4
+    finally:
+        ctx.close()
