@@ -45,6 +45,7 @@ class DetectJob(C.Structure):
         ("num_points", C.c_int32), ("num_cams", C.c_int32), ("num_samples", C.c_int32), ("num_selected", C.c_int32),
         ("hands_capacity", C.c_int32), ("num_sets", C.c_int32), ("num_candidates", C.c_int32), ("num_hands", C.c_int32),
         ("status", C.c_int32), ("stage_ms", C.c_float * 3), ("host_ms", C.c_float * 5), ("allocs", C.c_int32),
+        ("reserved_", C.c_int32), ("lcg_base", C.c_uint64), ("lcg_draws", C.c_uint64),
     ]
 
 
@@ -68,7 +69,7 @@ EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_h
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
            "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
            "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters", "gpd_hip_reserve", "gpd_hip_bind_host_thread",
-           "gpd_hip_set_lenet_mode", "gpd_hip_lenet_debug", "gpd_hip_lenet_fast_tables"]
+           "gpd_hip_set_lenet_mode", "gpd_hip_lenet_debug", "gpd_hip_lenet_fast_tables", "gpd_hip_detect_sharded"]
 
 
 def build(prof=True):
@@ -103,6 +104,7 @@ def lib():
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gpd_hip_detect_batch.argtypes = [C.c_void_p, C.POINTER(DetectJob), C.c_int]
         L.gpd_hip_detect_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(DetectJob), C.c_int]
+        L.gpd_hip_detect_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(DetectJob)]
         L.gpd_hip_last_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
@@ -307,6 +309,21 @@ class Context:
         self._check(lib().gpd_hip_detect_batch_multi(arr, len(ctxs), jobs, len(clouds)))
         return [(k[5][: j.num_hands], j.num_sets, j.num_candidates, [float(x) for x in j.stage_ms])
                 for j, k in zip(jobs, keep)]
+
+    def detect_sharded(self, others, cloud, samples, split=None):
+        """gpd_hip_detect_sharded: ONE cloud, its samples cut into len(others) + 1 contiguous ranges (at the indices `split`, default
+        equal shares), range g on context g.  -> (hands of all ranges concatenated, per-shard (n_sets, n_candidates, lcg_base,
+        lcg_draws))."""
+        ctxs = [self] + list(others)
+        G = len(ctxs)
+        si = np.ascontiguousarray(samples, np.int32)
+        cuts = [0] + (list(split) if split is not None else [len(si) * g // G for g in range(1, G)]) + [len(si)]
+        parts = [si[cuts[g]:cuts[g + 1]] for g in range(G)]
+        jobs, keep = self._jobs([cloud] * G, parts, 0)
+        arr = (C.c_void_p * G)(*[c._h for c in ctxs])
+        self._check(lib().gpd_hip_detect_sharded(arr, G, jobs))
+        hands = np.concatenate([k[5][: j.num_hands] for j, k in zip(jobs, keep)])
+        return hands, [(j.num_sets, j.num_candidates, int(j.lcg_base), int(j.lcg_draws)) for j in jobs]
 
     def stage_ms(self):
         ms = np.zeros(3, np.float32)

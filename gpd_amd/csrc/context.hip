@@ -118,6 +118,8 @@ struct Job {
   double t_plan_ms = 0.0;  // host clock when the plan summary had arrived (job_middle past its wait)
   double copy_ms = 0.0;    // job_end: handing the records over (after the wait)
   int chunks = 0;          // > 0: the records leave the device in this many copies, an event behind each
+  unsigned long long lcg_base = 0;   // in: shadow draws of the cloud's sample ranges before this one (gpd_hip_detect_sharded)
+  unsigned long long lcg_draws = 0;  // out: shadow draws of this job's hand sets
 };
 
 }  // namespace
@@ -309,7 +311,9 @@ static int job_begin(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   return GPD_OK;
 }
 
-static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
+// the middle step in two halves: wait for the plan summary (the only mid-pipeline wait; a list-capacity retry happens here), then
+// enqueue images + LeNet + gather.  gpd_hip_detect_sharded puts the host-side scan of the shards' draw totals between the two.
+static int job_wait_plan(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   if (!J.live) return GPD_OK;
   J.live = false;  // set again once everything is enqueued
   HIP_TRY(hipEventSynchronize(L.ev_plan));  // not the stream: in a batch the next cloud's search is already queued behind
@@ -328,6 +332,14 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
     J.live = false;
     HIP_TRY(hipStreamSynchronize(L.stream));
   }
+  J.lcg_draws = L.plan.h_summary->total_draws;
+  J.live = true;
+  return GPD_OK;
+}
+
+static int job_enqueue(gpd_hip_ctx *ctx, Lane &L, Job &J) {
+  if (!J.live) return GPD_OK;
+  J.live = false;
   const PlanSummary sm = *L.plan.h_summary;
   static const bool plan_timing = prof_env("GPD_PLAN_TIMING") != nullptr;
   if (plan_timing)
@@ -352,6 +364,7 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   (void)hipEventElapsedTime(&L.stage_ms[0], L.ev[0], L.ev[1]);  // here: the next job on this lane records them again
   HIP_TRY(hipEventRecord(L.ev[4], L.stream));
   L.images.side_stream = !ctx->in_batch;
+  L.images.lcg_base = J.lcg_base;
   int rc;
   {
     StageRange r("gpd:images (shadow sets, shadow channels, normals + depth channels)");
@@ -419,6 +432,11 @@ static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
   HIP_TRY(hipEventRecord(L.ev_done, L.stream));
   J.live = true;
   return GPD_OK;
+}
+
+static int job_middle(gpd_hip_ctx *ctx, Lane &L, Job &J) {
+  const int rc = job_wait_plan(ctx, L, J);
+  return rc ? rc : job_enqueue(ctx, L, J);
 }
 
 static bool score_greater(const std::pair<float, int32_t> &a, const std::pair<float, int32_t> &b) { return a.first > b.first; }
@@ -987,6 +1005,7 @@ int gpd_hip_images(gpd_hip_ctx *ctx, const gpd_hand *hands, int num_sets, uint8_
               L.plan.h_summary->mismatch_set);
     return GPD_ERR_STATE;
   }
+  L.images.lcg_base = 0;  // gpd_hip_images: the cloud's stream of shadow draws from its start
   rc = images_run(ctx->params, L.cloud, s, L.plan, L.images, L.stream);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(L.ev[1], L.stream));
@@ -1200,6 +1219,7 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     J[i].num_selected = j.num_selected;
     J[i].hands = j.hands;
     J[i].capacity = j.hands_capacity;
+    J[i].lcg_base = j.lcg_base;
     rc = job_begin(ctx, L, J[i]);
     j.allocs += g_allocs - allocs0;
     j.host_ms[0] = (float)(now_ms() - t_entry);
@@ -1214,6 +1234,7 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     jobs[i].num_sets = J[i].num_sets;
     jobs[i].num_candidates = J[i].num_candidates;
     jobs[i].num_hands = J[i].num_hands;
+    jobs[i].lcg_draws = J[i].lcg_draws;
     for (int k = 0; k < 3; k++) jobs[i].stage_ms[k] = L.stage_ms[k];
   };
   // cloud i+1's upload + search are enqueued (other lane's buffers) before the host waits for cloud i's plan;
@@ -1331,6 +1352,115 @@ int gpd_hip_detect_batch_multi(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect
       set_error("context %d: %s", c, texts[(size_t)c].c_str());
       return rcs[(size_t)c];
     }
+  return GPD_OK;
+}
+
+// ONE cloud, its samples cut into contiguous ranges, one range per context (sample-range sharding with the cloud
+// replicated; BASELINE configs[3] across GPUs).  The reference draws every shadow point of a cloud from ONE LCG stream
+// (hand_set.cpp:268-283), hand set after hand set, so range g has to start where the ranges before it stopped:
+//   phase 1  every context uploads the cloud and searches + plans its range; the plan summary carries the range's draw total
+//   host     exclusive scan of the G totals (G numbers: still no collective)
+//   phase 2  images + LeNet + records with lcg_base = the draws before the range
+// The concatenated results are byte for byte those of one gpd_hip_detect_select over all samples (tests/test_gpu_resident.py).
+int gpd_hip_detect_sharded(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect_job *shards) {
+  if (!ctxs || num_ctx < 1 || !shards) {
+    set_error("gpd_hip_detect_sharded: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  for (int c = 0; c < num_ctx; c++) {
+    if (!ctxs[c]) {
+      set_error("gpd_hip_detect_sharded: context %d is null", c);
+      return GPD_ERR_INVALID;
+    }
+    for (int d = 0; d < c; d++)
+      if (ctxs[d] == ctxs[c]) {
+        set_error("gpd_hip_detect_sharded: context %d is listed twice (a context serves one thread)", c);
+        return GPD_ERR_INVALID;
+      }
+    const gpd_detect_job &j = shards[c];
+    if (!j.xyz || !j.normals || !j.cam_source || !j.view_points || (j.num_samples > 0 && (!j.sample_indices || !j.hands)) || j.num_points < 1 ||
+        j.num_cams < 1 || j.num_samples < 0 || j.hands_capacity < 0 || j.num_selected != 0) {
+      set_error("gpd_hip_detect_sharded: shard %d: bad argument (selectGrasps over a sharded cloud is the caller's: num_selected must be 0)", c);
+      return GPD_ERR_INVALID;
+    }
+    if (!ctxs[c]->lenet.channels) {
+      set_error("gpd_hip_detect_sharded: context %d: LeNet weights not set", c);
+      return GPD_ERR_STATE;
+    }
+  }
+  std::vector<Job> J((size_t)num_ctx);
+  std::vector<int> rcs((size_t)num_ctx, GPD_OK);
+  std::vector<std::string> texts((size_t)num_ctx);
+  auto run = [&](auto &&body) {
+    std::vector<std::thread> threads;
+    for (int c = 0; c < num_ctx; c++)
+      threads.emplace_back([&, c]() {
+        if (rcs[(size_t)c]) return;
+        (void)gpd_hip_bind_host_thread(ctxs[c]->device, nullptr);
+        int rc = hipSetDevice(ctxs[c]->device) == hipSuccess ? GPD_OK : GPD_ERR_HIP;
+        if (!rc) rc = body(c);
+        if (rc) {
+          rcs[(size_t)c] = rc;
+          texts[(size_t)c] = g_err;  // the error text is per thread
+          (void)hipStreamSynchronize(ctxs[c]->lane[0].stream);
+        }
+      });
+    for (auto &t : threads) t.join();
+  };
+  run([&](int c) -> int {
+    gpd_hip_ctx *ctx = ctxs[c];
+    gpd_detect_job &j = shards[c];
+    j.status = GPD_OK;
+    j.num_sets = j.num_candidates = j.num_hands = 0;
+    int rc = lane_init(ctx->lane[0]);
+    if (rc) return rc;
+    Lane &L = ctx->lane[0];
+    rc = check_samples(ctx, L, "gpd_hip_detect_sharded", j.sample_indices, nullptr, j.num_samples, j.num_points);
+    if (!rc) rc = cloud_upload(L.cloud, j.xyz, j.normals, j.num_points, j.cam_source, j.num_cams, j.view_points, L.stream, /*sync=*/false);
+    if (rc) return rc;
+    Job &jb = J[(size_t)c];
+    jb.sample_idx = j.sample_indices;
+    jb.S = j.num_samples;
+    jb.mode = 1;
+    jb.num_selected = 0;
+    jb.hands = j.hands;
+    jb.capacity = j.hands_capacity;
+    rc = job_begin(ctx, L, jb);
+    if (!rc) rc = job_wait_plan(ctx, L, jb);
+    return rc;
+  });
+  unsigned long long base = 0;
+  for (int c = 0; c < num_ctx; c++) {
+    J[(size_t)c].lcg_base = shards[c].lcg_base = base;
+    shards[c].lcg_draws = J[(size_t)c].lcg_draws;
+    base += J[(size_t)c].lcg_draws;
+  }
+  run([&](int c) -> int {
+    gpd_hip_ctx *ctx = ctxs[c];
+    Lane &L = ctx->lane[0];
+    Job &jb = J[(size_t)c];
+    int rc = job_enqueue(ctx, L, jb);
+    if (!rc) rc = job_end(ctx, L, jb);
+    if (rc) return rc;
+    shards[c].num_sets = jb.num_sets;
+    shards[c].num_candidates = jb.num_candidates;
+    shards[c].num_hands = jb.num_hands;
+    for (int k = 0; k < 3; k++) shards[c].stage_ms[k] = L.stage_ms[k];
+    return GPD_OK;
+  });
+  for (int c = 0; c < num_ctx; c++)
+    if (rcs[(size_t)c]) {
+      shards[c].status = rcs[(size_t)c];
+      set_error("context %d: %s", c, texts[(size_t)c].c_str());
+      return rcs[(size_t)c];
+    }
+  // a record's set_index counts the hand sets of the whole cloud: the sets of the ranges before are added
+  int sets_before = 0;
+  for (int c = 0; c < num_ctx; c++) {
+    if (sets_before)
+      for (int i = 0; i < shards[c].num_hands; i++) shards[c].hands[i].set_index += sets_before;
+    sets_before += shards[c].num_sets;
+  }
   return GPD_OK;
 }
 

@@ -292,6 +292,7 @@ struct PlanSummary {  // copied to the host once per call (pinned)
                              // not have), -1: none
   int32_t pad_[2];
   long long sum_set_ni, sum_cand_ni;  // for the algorithmic byte count of SURVEY §8d
+  unsigned long long total_draws;     // shadow LCG draws of all hand sets of the call (the next sample range's lcg_base)
 };
 struct PlanPart {  // what one workgroup of plan_kernel publishes for the workgroups after it (64 bytes)
   int32_t sum[3];   // hand sets, candidates, shadow bitsets of its samples
@@ -347,6 +348,7 @@ int select_topk_capacity();
 
 // ---- Grasp images (images.hip) ---------------------------------------------------
 struct ImageState {
+  unsigned long long lcg_base = 0;    // shadow draws consumed before this list's first hand set (a sample range of a sharded cloud)
   int num_candidates = 0;
   int capacity = 0;                   // images
   uint8_t *d_images = nullptr;        // planar [n][C][60][60]

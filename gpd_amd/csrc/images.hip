@@ -1736,6 +1736,7 @@ struct SetParams {
   const gpd_hand *hands;    // [S][slots] records of the search ...
   const int32_t *hand_cand; // ... and which of them are candidates (>= 0): the default mode writes only the part of a set's
   int slots;                //     region its candidates' boxes can touch
+  unsigned long long lcg_base;  // draws consumed before this call's first hand set (gpd_hip_detect_sharded; else 0)
   double view_point[3 * kMaxCams];  // of the cloud (a kernel argument, not a device constant: clouds of a batch
                                     // with different cameras run side by side)
 };
@@ -1754,8 +1755,10 @@ __global__ __launch_bounds__(SET_THREADS) void shadow_set_kernel(SetParams P) {
   const int tid = threadIdx.x;
   const int slot_s = P.set_meta[8 * set + 0];
   const int N = P.set_meta[8 * set + 1];
+  // position in the cloud's ONE stream of shadow draws (hand_set.cpp:268-283): the plan's offset among this call's hand sets
+  // + the draws of the sample ranges before it, when the cloud's samples are sharded over several contexts
   const unsigned long long off =
-      ((unsigned long long)(uint32_t)P.set_meta[8 * set + 3] << 32) | (uint32_t)P.set_meta[8 * set + 2];
+      P.lcg_base + (((unsigned long long)(uint32_t)P.set_meta[8 * set + 3] << 32) | (uint32_t)P.set_meta[8 * set + 2]);
   const int cam = P.set_meta[8 * set + 4];
   const float *nn = P.nn + (size_t)slot_s * 6 * P.cap;
   uint32_t *out = P.set_bits + (size_t)set * SETWORDS;
@@ -2190,6 +2193,7 @@ int images_launch(const SearchState &s, const Plan &pl, ImageState &im, hipStrea
     sp.hands = s.d_hands;
     sp.hand_cand = pl.d_hand_cand;
     sp.slots = im.slots;
+    sp.lcg_base = im.lcg_base;
     std::memcpy(sp.view_point, im.view_points, sizeof(sp.view_point));
     if (im.huge) {
       const size_t setwords = (size_t)(((long long)im.set_sd * im.set_sd * im.set_sd + 31) / 32);

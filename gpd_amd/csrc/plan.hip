@@ -320,6 +320,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_kernel(PlanParams P) {
     sm.num_sets = carry.a + total.a;
     sm.num_candidates = carry.b + total.b;
     sm.num_shadow_sets = carry.c + total.c;
+    sm.total_draws = carry.d + total.d;
     sm.worst_found = t_worst;
     sm.live_sets = (int)t_live;
     sm.mismatch_set = t_mis != 0x7fffffff ? t_mis : -1;

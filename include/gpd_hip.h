@@ -271,6 +271,12 @@ typedef struct gpd_detect_job {
   float host_ms[5];
   int32_t allocs;              /* out: buffer growths (hipFree + hipMalloc = a device stall) booked on this cloud;
                                   0 everywhere but the first cloud of a batch whose lanes were not yet sized */
+  int32_t reserved_;
+  /* The cloud's ONE stream of shadow draws (HandSet::fastrand, hand_set.cpp:263-283) when its samples are cut into ranges:
+   * lcg_base (in) = draws of the sample ranges before this job's (0: the job starts the cloud's stream — every ordinary
+   * call), lcg_draws (out) = draws of this job's hand sets.  gpd_hip_detect_sharded fills lcg_base itself. */
+  uint64_t lcg_base;
+  uint64_t lcg_draws;
 } gpd_detect_job;
 
 /* detect_grasps over a batch of independent clouds (src/detect_grasps.cpp:20-86 called once per
@@ -289,6 +295,15 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs);
  * Every context must carry the LeNet weights.  Results are those of gpd_hip_detect_batch on any one context
  * (the shadow LCG restarts per cloud, so they do not depend on the sharding).  Returns the first error. */
 int gpd_hip_detect_batch_multi(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect_job *jobs, int num_jobs);
+
+/* ONE cloud over several contexts ("sample-range sharding with the cloud replicated"; BASELINE configs[3] across
+ * GPUs): shards[g] is the job of ctxs[g] — the same cloud arrays, a CONTIGUOUS range of the cloud's samples (range g before
+ * range g + 1 in the caller's sample order), its own output buffer, num_selected = 0.  The reference draws all shadow points of a
+ * cloud from one LCG stream, hand set after hand set (hand_set.cpp:268-283): phase 1 searches every range and takes its draw
+ * total, the totals are scanned on the host (num_ctx numbers — still no collective), phase 2 generates and scores the images
+ * with lcg_base = the draws of the ranges before.  The concatenated records are byte for byte those of ONE
+ * gpd_hip_detect_select(num_selected = 0) over all samples, whatever the split.  Every context must carry the LeNet weights. */
+int gpd_hip_detect_sharded(gpd_hip_ctx *const *ctxs, int num_ctx, gpd_detect_job *shards);
 
 /* Binds the CALLING host thread to the CPUs of the NUMA node `device` hangs off (sysfs numa_node / cpulist, within the
  * process's allowed set): the thread that feeds a GPU — staging copies, launches, result copies — should run on that

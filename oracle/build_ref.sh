@@ -22,7 +22,8 @@ set -u
 HERE=$(cd "$(dirname "$0")" && pwd)
 ROOT=$(dirname "$HERE")
 REF=${REF:-/root/reference}
-OUT=$HERE/_ref
+OUT=${OUT:-$HERE/_ref}   # (profiles/thirdparty_sensitivity.py builds perturbed variants into oracle/_ref/perturb<N> with EXTRA=-DGPD_SHIM_PERTURB=<N>)
+EXTRA=${EXTRA:-}
 WHAT=${1:-all}
 skip() { echo "oracle/build_ref.sh: SKIPPED — $1"; exit 0; }
 [ -d "$REF/src/gpd" ] || skip "no reference tree at $REF (prebuilt oracle/_ref, if any, is used as it is)"
@@ -35,7 +36,7 @@ descriptor/image_1_channels_strategy descriptor/image_3_channels_strategy descri
 descriptor/image_15_channels_strategy descriptor/image_generator descriptor/image_geometry clustering grasp_detector"
 
 tier_a() {
-  local CXXFLAGS="-std=gnu++14 -O2 -mavx2 -mfma -ffp-contract=off -fPIC -w -include omp.h -I$HERE/shim -I$REF/include"
+  local CXXFLAGS="-std=gnu++14 -O2 -mavx2 -mfma -ffp-contract=off -fPIC -w -include omp.h -I$HERE/shim -I$REF/include $EXTRA"
   local objs="" pids="" fail=0
   for f in $TUS; do
     local o="$OUT/obj/$(echo $f | tr / _).o" extra=""

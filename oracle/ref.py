@@ -14,7 +14,7 @@ import numpy as np
 from .oracle import HAND_DTYPE, Params, _p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "_ref", "libgpd_ref.so")
+_PATH = os.environ.get("GPD_REF_LIB") or os.path.join(_HERE, "_ref", "libgpd_ref.so")  # (GPD_REF_LIB: a perturbed build of profiles/thirdparty_sensitivity.py)
 _LIB = None
 
 

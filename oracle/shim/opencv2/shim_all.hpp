@@ -76,7 +76,11 @@ inline int depthSize(int depth) {
   }
 }
 inline uchar saturate_u8(float v) {  // saturate_cast<uchar>(float): cvRound (round half to even) then clamp
+#if defined(GPD_SHIM_PERTURB) && GPD_SHIM_PERTURB == 4
+  long r = (long)std::floor((double)v + 0.5);  // sensitivity study: cvRound as some builds without SSE2 / lrint compute it
+#else
   long r = std::lrintf(v);
+#endif
   return (uchar)std::min(255L, std::max(0L, r));
 }
 }  // namespace shim
@@ -369,7 +373,11 @@ inline void normalize(const Mat &src, Mat &dst, double a = 1, double b = 0, int 
     }
   if (src.total() == 0) smin = smax = 0;
   const double dmin = std::min(a, b), dmax = std::max(a, b);
+#if defined(GPD_SHIM_PERTURB) && GPD_SHIM_PERTURB == 5
+  const double scale = smax - smin > DBL_EPSILON ? (dmax - dmin) / (smax - smin) : 0;  // sensitivity study: one division instead of reciprocal * range
+#else
   const double scale = (dmax - dmin) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
+#endif
   const double shift = dmin - smin * scale;
   src.convertTo(dst, dtype < 0 ? src.depth() : CV_MAT_DEPTH(dtype), scale, shift);
 }

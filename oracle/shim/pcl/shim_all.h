@@ -206,7 +206,15 @@ class KdTreeFLANN {
       d2 = d2 + dz * dz;
       if (d2 < radius2) hits.push_back(std::make_pair(d2, (int)i));
     }
+#if defined(GPD_SHIM_PERTURB) && GPD_SHIM_PERTURB == 1
+    // sensitivity study (profiles/thirdparty_sensitivity.py): neighbours at EQUAL distance in the opposite order — what FLANN
+    // returns for ties depends on its tree walk, which this subset does not restate
+    std::sort(hits.begin(), hits.end(), [](const std::pair<float, int> &x, const std::pair<float, int> &y) {
+      return x.first < y.first || (x.first == y.first && x.second > y.second);
+    });
+#else
     std::sort(hits.begin(), hits.end());
+#endif
     if (max_nn > 0 && hits.size() > max_nn) hits.resize(max_nn);
     k_indices.resize(hits.size());
     k_sqr_distances.resize(hits.size());

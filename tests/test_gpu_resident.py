@@ -321,3 +321,52 @@ def test_create_rejects_bad_parameters():
             setattr(p, field, value)
         with pytest.raises(api.GpdHipError):
             api.Context(p)
+
+
+def test_one_cloud_sharded_by_sample_range_equals_the_single_call(cloud30k, lenet15_real):
+    """gpd_hip_detect_sharded: the samples of ONE cloud cut into contiguous ranges over 2 and 3 contexts (here on one device).
+    The reference draws a cloud's shadow points from one LCG stream, set after set (hand_set.cpp:268-283); the ranges' draw totals
+    are scanned on the host and every range starts its stream where the ones before it stopped — so the concatenated records,
+    scores included (they see every image byte, shadow channels included), are byte for byte those of the single-context call,
+    for even, uneven and empty shares; without the scan they are not."""
+    si = synth.sample_indices(cloud30k, 700)
+    one = api.Context(api.default_params(15))
+    others = [api.Context(api.default_params(15)) for _ in range(2)]
+    try:
+        for c in [one] + others:
+            c.set_lenet_weights(lenet15_real)
+        one.upload_cloud(cloud30k["xyz"], cloud30k["normals"], cloud30k["cam_source"], cloud30k["view_points"])
+        want, ns, nc = one.detect_select(si, 0)
+        assert nc > 1200
+        for ctxs, split in (((one, others[0]), None), ((one, others[0]), [123]), ((one, others[0], others[1]), None),
+                            ((others[1], one, others[0]), [1, 650]), ((one, others[0], others[1]), [0, 700])):
+            got, info = ctxs[0].detect_sharded(ctxs[1:], cloud30k, si, split)
+            assert sum(i[1] for i in info) == nc and sum(i[0] for i in info) == ns
+            assert info[0][2] == 0 and all(info[g][2] == sum(i[3] for i in info[:g]) for g in range(len(info)))
+            assert got.tobytes() == want.tobytes(), (len(ctxs), split)
+        # the scan matters: the second half on its own (its stream restarted) scores differently
+        half = len(si) // 2
+        alone, _, _ = others[0].detect_batch([cloud30k], [si[half:]], 0)[0][:3]
+        tail = want[len(want) - len(alone):]
+        assert len(alone) > 500 and np.array_equal(alone["position"], tail["position"]) and not np.array_equal(alone["score"], tail["score"])
+    finally:
+        one.close()
+        for c in others:
+            c.close()
+
+
+def test_sharded_dense_cloud(lenet15_real):
+    """BASELINE configs[3] across contexts: a 300k-point clutter cloud, 1500 samples, three ranges."""
+    cl = synth.make_cloud(1234, 300000, clutter=True)
+    si = synth.sample_indices(cl, 1500)
+    ctxs = [api.Context(api.default_params(15)) for _ in range(3)]
+    try:
+        for c in ctxs:
+            c.set_lenet_weights(lenet15_real)
+        ctxs[0].upload_cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+        want, ns, nc = ctxs[0].detect_select(si, 0)
+        got, info = ctxs[0].detect_sharded(ctxs[1:], cl, si)
+        assert nc > 2000 and sum(i[1] for i in info) == nc and got.tobytes() == want.tobytes()
+    finally:
+        for c in ctxs:
+            c.close()
