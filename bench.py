@@ -358,6 +358,9 @@ def main():
     batch = None
     if args.batch_clouds > 0 and C == 15 and not clutter:
         batch = batch_leg([rank + world * k for k in range(args.batch_clouds)], args.batch_passes, 1)
+    batch_raw = None
+    if args.batch_clouds > 0 and C == 15 and not clutter and args.config is None and args.gpus == 1:
+        batch_raw = _raw_batch_leg(ctx, api, synth, max(args.batch_clouds // 2, 2), max(args.batch_passes // 2, 3), args.batch_samples)
     trained = None
     if rank == 0 and args.gpus == 1 and C == 15 and args.cpu_samples > 0:
         if batch is not None:  # the batch left its last cloud resident: the benchmark's cloud and its search state once more
@@ -462,6 +465,8 @@ def main():
                              "in flight per context: upload + grid + search + filter + images + LeNet + scored candidates back to the host"
                              % (args.batch_clouds, args.batch_samples, args.batch_passes))
             out["batch_end_to_end"] = batch
+        if batch_raw is not None:
+            out["batch_raw_end_to_end"] = batch_raw
         raw = None
         if args.config is None and C == 15 and not clutter:  # the widened row before the path, on the default line only
             raw, out["preprocess"] = _preprocess_leg(ctx)
@@ -476,6 +481,35 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _raw_batch_leg(ctx, api, synth, n_clouds, passes, n_samples):
+    """gpd_hip_detect_batch on RAW scans (gpd_detect_job.raw): 120k-point synthetic scans (the cloud of the `preprocess` leg, one
+    seed per cloud: points on the 3 mm lattice, which the reference's voxeliser keeps nearly all of) through workspace cut +
+    voxeliser (0.003) + normals (0.03) + search at 2564 sample coordinates + images + LeNet, scored candidates back on the host;
+    one untimed pass, then `passes` timed ones.  Not part of `value`."""
+    scans, samples = [], []
+    for k in range(n_clouds):
+        cl = synth.make_cloud(3000 + k, PRE_POINTS)
+        scans.append(dict(xyz=cl["xyz"], cam_source=cl["cam_source"], view_points=cl["view_points"]))
+        samples.append(cl["xyz"][synth.sample_indices(cl, n_samples)].astype(np.float64))
+    jobs, keep = ctx.raw_batch(scans, samples, np.array(PRE_WORKSPACE), PRE_VOXEL, 0.03)
+    L = api.lib()
+    ctx._check(L.gpd_hip_detect_batch(ctx._h, jobs, len(jobs)))
+    times, cands = [], []
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        ctx._check(L.gpd_hip_detect_batch(ctx._h, jobs, len(jobs)))
+        times.append(time.perf_counter() - t0)
+        cands.append(sum(j.num_candidates for j in jobs))
+    order = sorted(times)
+    return {"clouds_per_pass": n_clouds, "raw_points_per_cloud": int(len(scans[0]["xyz"])), "points_after_preprocessing": [int(j.num_points_processed) for j in jobs][:4],
+            "samples_per_cloud": n_samples, "passes": passes, "wall_ms_per_pass": [t * 1e3 for t in times],
+            "ms_per_cloud": {"min": order[0] * 1e3 / n_clouds, "median": order[len(order) // 2] * 1e3 / n_clouds, "max": order[-1] * 1e3 / n_clouds},
+            "cand_per_s_median": cands[0] / order[len(order) // 2], "buffer_growths_in_timed_passes": int(sum(j.allocs for j in jobs)),
+            "kernel_ms_last_cloud": {"search": float(jobs[-1].stage_ms[0]), "images": float(jobs[-1].stage_ms[1]), "lenet": float(jobs[-1].stage_ms[2])},
+            "note": "CandidatesGenerator::preprocessPointCloud inside the batch entry: the voxelised cloud never leaves the device, the voxeliser's "
+                    "sequential chain of cloud i + 1 runs on the calling host thread beside cloud i's image / LeNet kernels"}
 
 
 def _host_split(tl):

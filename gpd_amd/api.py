@@ -46,6 +46,8 @@ class DetectJob(C.Structure):
         ("hands_capacity", C.c_int32), ("num_sets", C.c_int32), ("num_candidates", C.c_int32), ("num_hands", C.c_int32),
         ("status", C.c_int32), ("stage_ms", C.c_float * 3), ("host_ms", C.c_float * 5), ("allocs", C.c_int32),
         ("reserved_", C.c_int32), ("lcg_base", C.c_uint64), ("lcg_draws", C.c_uint64),
+        ("raw", C.c_int32), ("voxel_size", C.c_float), ("workspace", C.c_void_p), ("normals_radius", C.c_double), ("sample_xyz", C.c_void_p),
+        ("num_points_processed", C.c_int32), ("reserved2_", C.c_int32),
     ]
 
 
@@ -273,6 +275,28 @@ class Context:
             j.sample_indices, j.hands = _ptr(si), _ptr(hands)
             j.num_points, j.num_cams, j.num_samples = P, cam.shape[0], len(si)
             j.num_selected, j.hands_capacity = int(num_selected), cap
+        return jobs, keep
+
+    def raw_batch(self, scans, samples_xyz, workspace=None, voxel_size=0.003, normals_radius=0.03, num_selected=0):
+        """The job array of gpd_hip_detect_batch for RAW scans (dicts with xyz, cam_source, view_points): preprocessPointCloud
+        (workspace cut, voxeliser, normals) on the device, search at the given sample coordinates (one f64 [S, 3] array per scan)."""
+        jobs = (DetectJob * len(scans))()
+        keep = []
+        ws = None if workspace is None else np.ascontiguousarray(workspace, np.float64)
+        for j, cl, sm in zip(jobs, scans, samples_xyz):
+            xyz = np.ascontiguousarray(cl["xyz"], np.float32)
+            P = len(xyz)
+            cam = np.ascontiguousarray(cl["cam_source"], np.int32).reshape(-1, P)
+            vp = np.ascontiguousarray(cl["view_points"], np.float64).reshape(-1, 3)
+            sm = np.ascontiguousarray(sm, np.float64).reshape(-1, 3)
+            cap = len(sm) * self.n_slots if num_selected == 0 else min(num_selected, len(sm) * self.n_slots)
+            hands = np.empty(max(cap, 1), HAND_DTYPE)
+            keep.append((xyz, None, cam, vp, sm, hands, ws))
+            j.xyz, j.cam_source, j.view_points, j.hands = _ptr(xyz), _ptr(cam), _ptr(vp), _ptr(hands)
+            j.sample_xyz, j.workspace = _ptr(sm), _ptr(ws)
+            j.num_points, j.num_cams, j.num_samples = P, cam.shape[0], len(sm)
+            j.num_selected, j.hands_capacity = int(num_selected), cap
+            j.raw, j.voxel_size, j.normals_radius = 1, float(voxel_size), float(normals_radius)
         return jobs, keep
 
     def batch(self, clouds, samples, num_selected=0):

@@ -82,6 +82,7 @@ struct Lane {
   hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr};  // a large record list leaves in four copies: the host copies one on while the next travels
   float stage_ms[3] = {0.f, 0.f, 0.f};
   Cloud cloud;
+  PreState pre;      // raw scans of gpd_hip_detect_batch: workspace cut + voxeliser of the cloud this lane works on
   SearchState search;
   Plan plan;
   ImageState images;
@@ -165,6 +166,10 @@ static int lane_init(Lane &L, hipStream_t shared = nullptr) {
 static void lane_free(Lane &L) {
   if (L.stream) (void)hipStreamSynchronize(L.stream);
   lenet_scratch_free(L.lenet_scratch);
+  preprocess_free(L.pre);
+  for (auto &e : L.pre.ev)
+    if (e) (void)hipEventDestroy(e);
+  if (L.pre.ev_keys) (void)hipEventDestroy(L.pre.ev_keys);
   cloud_free(L.cloud);
   search_free(L.search);
   plan_free(L.plan);
@@ -636,6 +641,7 @@ void gpd_hip_destroy(gpd_hip_ctx *ctx) {
   cluster_free(ctx->cluster);
   for (auto &e : ctx->pre.ev)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->pre.ev_keys) (void)hipEventDestroy(ctx->pre.ev_keys);
   float **ws[] = {&ctx->lenet.c1w, &ctx->lenet.c1b, &ctx->lenet.c2w, &ctx->lenet.c2b,
                   &ctx->lenet.f1w, &ctx->lenet.f1b, &ctx->lenet.f2w, &ctx->lenet.f2b, &ctx->lenet.c1wp, &ctx->lenet.c2wt};
   for (float **p : ws)
@@ -1131,8 +1137,10 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     j.stage_ms[0] = j.stage_ms[1] = j.stage_ms[2] = 0.f;
     j.allocs = 0;
     for (float &t : j.host_ms) t = 0.f;
-    if (!j.xyz || !j.normals || j.num_points <= 0 || !j.cam_source || j.num_cams < 1 || !j.view_points || !j.sample_indices ||
-        j.num_samples < 0 || !j.hands || j.hands_capacity < 0 || j.num_selected < 0) {
+    const bool samples_ok = j.raw ? (j.sample_xyz != nullptr || j.num_samples == 0) : j.sample_indices != nullptr;
+    if (!j.xyz || (!j.raw && !j.normals) || j.num_points <= 0 || !j.cam_source || j.num_cams < 1 || !j.view_points || !samples_ok ||
+        j.num_samples < 0 || !j.hands || j.hands_capacity < 0 || j.num_selected < 0 ||
+        (j.raw && !(j.normals_radius > 0.0 && std::isfinite(j.normals_radius) && std::isfinite(j.voxel_size)))) {
       set_error("gpd_hip_detect_batch: job %d has a bad argument", i);
       return GPD_ERR_INVALID;
     }
@@ -1206,8 +1214,52 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
       std::memcpy(first_text, g_err, sizeof(g_err));
     }
   };
+  std::vector<char> raw_pending((size_t)num_jobs, 0);
+  // a RAW scan's first half: upload, workspace cut, voxel keys, the keys on their way to the host — nothing waits
+  auto begin_raw = [&](int i) {
+    gpd_detect_job &j = jobs[i];
+    Lane &L = ctx->lane[i % kLanes];
+    const int allocs0 = g_allocs;
+    j.num_points_processed = 0;
+    int rc = check_samples(ctx, L, "gpd_hip_detect_batch", nullptr, j.sample_xyz, j.num_samples, j.num_points);
+    if (!rc) rc = preprocess_begin(L.pre, j.xyz, j.cam_source, j.num_points, j.num_cams, j.workspace, j.voxel_size, L.stream);
+    j.allocs += g_allocs - allocs0;
+    if (rc) return fail(i, rc);
+    raw_pending[(size_t)i] = 1;
+  };
+  // ... and its second half, called once the previous cloud's image / LeNet kernels are in the queue: the voxeliser's sequential
+  // chain on this host core (beside those kernels), the gather, the cloud built from the device arrays, the normals, the search
+  auto begin_raw_finish = [&](int i) {
+    if (!raw_pending[(size_t)i]) return;
+    raw_pending[(size_t)i] = 0;
+    gpd_detect_job &j = jobs[i];
+    Lane &L = ctx->lane[i % kLanes];
+    const int allocs0 = g_allocs;
+    int rc = preprocess_finish(L.pre, L.stream);
+    if (!rc && L.pre.M < 1) {
+      set_error("gpd_hip_detect_batch: cloud %d: no point is left after the workspace cut", i);
+      rc = GPD_ERR_INVALID;
+    }
+    if (!rc) rc = cloud_from_device(L.cloud, L.pre.d_out_xyz, L.pre.d_out_cam, L.pre.M, j.num_cams, j.view_points, L.stream);
+    if (!rc) rc = normals_run(L.cloud, j.normals_radius, nullptr, L.stream);
+    if (rc) return fail(i, rc);
+    j.num_points_processed = L.pre.M;
+    J[i].sample_idx = nullptr;
+    J[i].sample_xyz = j.sample_xyz;
+    J[i].S = j.num_samples;
+    J[i].mode = 1;
+    J[i].num_selected = j.num_selected;
+    J[i].hands = j.hands;
+    J[i].capacity = j.hands_capacity;
+    J[i].lcg_base = j.lcg_base;
+    rc = job_begin(ctx, L, J[i]);
+    j.allocs += g_allocs - allocs0;
+    j.host_ms[0] = (float)(now_ms() - t_entry);
+    if (rc) fail(i, rc);
+  };
   auto begin = [&](int i) {
     gpd_detect_job &j = jobs[i];
+    if (j.raw) return begin_raw(i);
     Lane &L = ctx->lane[i % kLanes];
     const int allocs0 = g_allocs;
     int rc = check_samples(ctx, L, "gpd_hip_detect_batch", j.sample_indices, nullptr, j.num_samples, j.num_points);
@@ -1242,7 +1294,10 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
   // (stream order keeps cloud i+1's search behind the image / LeNet kernels of cloud i-1, whose buffers it reuses; of
   //  the pinned host buffers, begin touches the cloud / summary staging only, which job i-1 is done with since its
   //  own middle step)
-  if (num_jobs > 0) begin(0);
+  if (num_jobs > 0) {
+    begin(0);
+    begin_raw_finish(0);
+  }
   for (int i = 0; i < num_jobs; i++) {
     if (i + 1 < num_jobs) begin(i + 1);
     if (jobs[i].status == GPD_OK) {
@@ -1253,6 +1308,7 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
       jobs[i].host_ms[2] = (float)(now_ms() - t_entry);
       if (rc) fail(i, rc);
     }
+    if (i + 1 < num_jobs) begin_raw_finish(i + 1);  // (a raw scan: its host-side chain runs beside cloud i's image / LeNet kernels)
     if (i >= 1) end(i - 1);
   }
   if (num_jobs > 0) end(num_jobs - 1);

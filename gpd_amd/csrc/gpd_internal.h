@@ -107,11 +107,20 @@ struct PreState {
           *d_out_src = nullptr;
   int4 *d_keys = nullptr;
   void *d_meta = nullptr;
-  std::vector<char> h_keys;     // host route of the voxeliser's chain: the voxel keys of the points inside the workspace ...
-  std::vector<int32_t> h_rank;  // ... and what the walk decided (rank among the kept points, -1: dropped)
+  char *h_pin = nullptr;        // pinned host side of the voxeliser's chain: the voxel keys of every point (16 B), what the walk
+                                // decided (rank among the kept points, -1: dropped; 4 B), the counters
   hipEvent_t ev[2] = {nullptr, nullptr};
+  hipEvent_t ev_keys = nullptr; // the keys and counters have arrived in h_pin
+  int n = 0, num_cams = 0, M = 0;  // the call in flight between preprocess_begin and preprocess_finish; M: points it left on the device
+  float cell = 0.f;
 };
 void preprocess_free(PreState &s);
+// the two halves of preprocess_run (gpd_hip_detect_batch on raw scans puts other clouds' work between them): begin enqueues the
+// upload, the workspace cut, the voxel keys and their way back to pinned memory; finish waits for them, walks the voxeliser's
+// chain on the host and gathers the kept points: s.M of them in s.d_out_xyz [M][3] / s.d_out_cam [cams][M] on the device
+int preprocess_begin(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
+                     hipStream_t stream);
+int preprocess_finish(PreState &s, hipStream_t stream);
 // workspace: 6 doubles or nullptr; cell <= 0: no voxeliser.  src_out (may be nullptr): input index of every output point.
 // ms (may be nullptr): device time of the kernels.
 int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
@@ -195,6 +204,8 @@ inline GridView grid_view(const Cloud &c) {
 int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const int32_t *cam_source, int num_cams,
                  const double *view_points, hipStream_t stream, bool sync);
 int cloud_reserve(Cloud &c, int n, int num_cams);
+// the cloud from device arrays (the preprocessing kernels' output): d_xyz [n][3], d_cam [cams][n]; normals zero until normals_run
+int cloud_from_device(Cloud &c, const float *d_xyz, const int32_t *d_cam, int n, int num_cams, const double *view_points, hipStream_t stream);
 int cloud_reserve_grid(Cloud &c, int cells);
 void cloud_free(Cloud &c);
 int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream);

@@ -300,20 +300,52 @@ void preprocess_free(PreState &s) {
   void *dev[] = {s.d_xyz, s.d_cam, s.d_block_count, s.d_block_off, s.d_block_lo, s.d_src, s.d_keys, s.d_rank, s.d_out_xyz, s.d_out_cam, s.d_out_src, s.d_meta};
   for (void *p : dev)
     if (p) (void)hipFree(p);
-  hipEvent_t e0 = s.ev[0], e1 = s.ev[1];  // the events outlive a re-allocation
+  if (s.h_pin) (void)hipHostFree(s.h_pin);
+  hipEvent_t e0 = s.ev[0], e1 = s.ev[1], e2 = s.ev_keys;  // the events outlive a re-allocation
   s = PreState();
   s.ev[0] = e0;
   s.ev[1] = e1;
+  s.ev_keys = e2;
 }
 
-int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
-                   float *xyz_out, int32_t *cam_out, int32_t *src_out, int *num_out, float *ms, hipStream_t stream) {
-  *num_out = 0;
-  if (ms) *ms = 0.f;
+static int pre_check(const PreMeta &hm) {
+  // a refused cloud (non-finite coordinate, voxel index beyond int32) stops: no ranks exist for it, and voxel_emit_kernel
+  // must not run on the ranks an earlier call left in d_rank
+  if (hm.bad & 1) {
+    set_error("preprocess_cloud: the cloud holds non-finite coordinates (remove NaN/Inf points first)");
+    return GPD_ERR_INVALID;
+  }
+  if (hm.bad & 6) {
+    set_error("preprocess_cloud: %s", (hm.bad & 2) ? "a voxel index does not fit 32 bits (voxel size too small for the cloud's extent)"
+                                                   : "more points than the voxeliser's tree walk supports");
+    return GPD_ERR_CAPACITY;
+  }
+  return GPD_OK;
+}
+
+// the spine table up to n kept points (it only ever grows)
+static std::vector<int8_t> g_ops;
+static unsigned long long g_ops_C = 0ull, g_ops_R = 0ull;
+static int g_ops_L = 0;
+static std::mutex g_ops_mutex;
+
+// Phase 1, nothing waits: the scan to the device, the workspace cut, the voxel keys, and the keys + the counters on their way
+// back into pinned memory (all n slots: how many are inside the workspace is only known on the device).  gpd_hip_detect_batch
+// enqueues this for cloud i + 1 BEFORE it waits for anything of cloud i.
+int preprocess_begin(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
+                     hipStream_t stream) {
+  s.n = n;
+  s.num_cams = num_cams;
+  s.cell = cell;
+  s.M = 0;
   if (n == 0) return GPD_OK;
   if (n > s.capacity || num_cams > s.cap_cams) {
     const int cap = n > s.capacity ? n + n / 4 : s.capacity, cams = num_cams > s.cap_cams ? num_cams : s.cap_cams;
+    note_alloc(__func__);
     preprocess_free(s);
+    s.n = n;
+    s.num_cams = num_cams;
+    s.cell = cell;
     const int blocks = (cap + PP_THREADS - 1) / PP_THREADS;
     HIP_RET(hipMalloc(&s.d_xyz, (size_t)cap * 3 * sizeof(float)));
     HIP_RET(hipMalloc(&s.d_cam, (size_t)cap * (cams > 0 ? cams : 1) * sizeof(int32_t)));
@@ -327,11 +359,14 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
     HIP_RET(hipMalloc(&s.d_out_cam, (size_t)cap * (cams > 0 ? cams : 1) * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_out_src, (size_t)cap * sizeof(int32_t)));
     HIP_RET(hipMalloc(&s.d_meta, sizeof(PreMeta)));
+    // pinned: [keys 16 B x cap][ranks 4 B x cap][PreMeta][bounds 6 floats]
+    HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&s.h_pin), (size_t)cap * 20 + 256, 0));
     s.capacity = cap;
     s.cap_cams = cams;
   }
   if (!s.ev[0])
     for (auto &e : s.ev) HIP_RET(hipEventCreate(&e));
+  if (!s.ev_keys) HIP_RET(hipEventCreateWithFlags(&s.ev_keys, hipEventDisableTiming));
   Workspace W;
   W.active = workspace != nullptr;
   for (int a = 0; a < 6; a++) W.w[a] = workspace ? workspace[a] : 0.0;
@@ -344,76 +379,80 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
   ws_count_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, n, W, s.d_block_count, s.d_block_lo, meta);
   ws_scan_kernel<<<1, 1024, 0, stream>>>(s.d_block_count, s.d_block_lo, blocks, s.d_block_off, meta);
   ws_scatter_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, n, W, s.d_block_off, cell, meta, s.d_src, s.d_keys);
+  HIP_RET(hipGetLastError());
+  char *hp = s.h_pin;
+  HIP_RET(hipMemcpyAsync(hp + (size_t)s.capacity * 20, s.d_meta, sizeof(PreMeta), hipMemcpyDeviceToHost, stream));
   if (cell > 0.f) {
-    // the spine table up to n kept points (it only ever grows; the device copy is refreshed when it did or was re-allocated)
-    static std::vector<int8_t> ops;
-    static unsigned long long ops_C = 0ull, ops_R = 0ull;
-    static int ops_L = 0;
-    static std::mutex ops_mutex;
     {
-      std::lock_guard<std::mutex> lock(ops_mutex);
-      if (!spine_ops(ops, (size_t)n, ops_C, ops_R, ops_L)) {
+      std::lock_guard<std::mutex> lock(g_ops_mutex);
+      if (!spine_ops(g_ops, (size_t)n, g_ops_C, g_ops_R, g_ops_L)) {
         set_error("preprocess_cloud: more points than the voxeliser's tree walk supports");
         return GPD_ERR_CAPACITY;
       }
     }
-    {
-      // keys to the host (16 bytes per point inside the workspace), the walk, the ranks back (4 bytes per point)
-      PreMeta hm;
-      HIP_RET(hipMemcpyAsync(&hm, s.d_meta, sizeof(hm), hipMemcpyDeviceToHost, stream));
-      HIP_RET(hipStreamSynchronize(stream));
-      // a refused cloud (non-finite coordinate, voxel index beyond int32) stops here: no ranks exist for it, and
-      // voxel_emit_kernel must not run on the ranks an earlier call left in d_rank
-      if (hm.bad & 1) {
-        set_error("preprocess_cloud: the cloud holds non-finite coordinates (remove NaN/Inf points first)");
-        return GPD_ERR_INVALID;
+    HIP_RET(hipMemcpyAsync(hp, s.d_keys, (size_t)n * sizeof(int4), hipMemcpyDeviceToHost, stream));
+  }
+  HIP_RET(hipEventRecord(s.ev_keys, stream));
+  return GPD_OK;
+}
+
+// Phase 2: waits for the keys, walks the spine on this host core (the strictly sequential chain of the voxeliser's keep / drop
+// decisions), sends the ranks and gathers the kept voxels.  On return s.M points lie on the device: s.d_out_xyz [M][3],
+// s.d_out_cam [cams][M], s.d_out_src [M] (input index; without a voxeliser: s.d_src), enqueued on `stream`.
+int preprocess_finish(PreState &s, hipStream_t stream) {
+  s.M = 0;
+  const int n = s.n;
+  if (n == 0) return GPD_OK;
+  HIP_RET(hipEventSynchronize(s.ev_keys));
+  char *hp = s.h_pin;
+  const PreMeta hm = *reinterpret_cast<const PreMeta *>(hp + (size_t)s.capacity * 20);
+  int rc = pre_check(hm);
+  if (rc) return rc;
+  PreMeta *meta = static_cast<PreMeta *>(s.d_meta);
+  const int blocks = (n + PP_THREADS - 1) / PP_THREADS;
+  const int kept = hm.kept;
+  if (s.cell > 0.f) {
+    int m = 0;
+    if (kept > 0) {
+      int32_t *rank = reinterpret_cast<int32_t *>(hp + (size_t)s.capacity * 16);
+      {
+        std::lock_guard<std::mutex> lock(g_ops_mutex);  // `g_ops` may grow under another context's call
+        m = voxel_accept_host(reinterpret_cast<const int4 *>(hp), kept, g_ops.data(), rank);
       }
-      if (hm.bad & 6) {
-        set_error("preprocess_cloud: %s", (hm.bad & 2) ? "a voxel index does not fit 32 bits (voxel size too small for the cloud's extent)"
-                                                       : "more points than the voxeliser's tree walk supports");
-        return GPD_ERR_CAPACITY;
-      }
-      const int kept = hm.kept;
-      if (kept > 0) {
-        s.h_keys.resize((size_t)kept * sizeof(int4));
-        s.h_rank.resize((size_t)kept);
-        HIP_RET(hipMemcpyAsync(s.h_keys.data(), s.d_keys, (size_t)kept * sizeof(int4), hipMemcpyDeviceToHost, stream));
-        HIP_RET(hipStreamSynchronize(stream));
-        int m;
-        {
-          std::lock_guard<std::mutex> lock(ops_mutex);  // `ops` may grow under another context's call
-          m = voxel_accept_host(reinterpret_cast<const int4 *>(s.h_keys.data()), kept, ops.data(), s.h_rank.data());
-        }
-        HIP_RET(hipMemcpyAsync(s.d_rank, s.h_rank.data(), (size_t)kept * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_RET(hipMemcpyAsync(reinterpret_cast<char *>(s.d_meta) + offsetof(PreMeta, voxels), &m, sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_RET(hipStreamSynchronize(stream));  // m and h_rank are read by the copies
-      }
+      int32_t *hm_voxels = reinterpret_cast<int32_t *>(hp + (size_t)s.capacity * 20 + 64);
+      *hm_voxels = m;
+      HIP_RET(hipMemcpyAsync(s.d_rank, rank, (size_t)kept * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      HIP_RET(hipMemcpyAsync(reinterpret_cast<char *>(s.d_meta) + offsetof(PreMeta, voxels), hm_voxels, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+      voxel_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_keys, s.d_rank, meta, s.cell, s.d_cam, n, s.num_cams, s.d_out_xyz, s.d_out_cam, s.d_out_src);
     }
-    voxel_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_keys, s.d_rank, meta, cell, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam, s.d_out_src);
+    s.M = m;
   } else {
-    ws_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, s.d_src, meta, s.d_cam, n, num_cams, s.d_out_xyz, s.d_out_cam);
+    if (kept > 0) ws_emit_kernel<<<blocks, PP_THREADS, 0, stream>>>(s.d_xyz, s.d_src, meta, s.d_cam, n, s.num_cams, s.d_out_xyz, s.d_out_cam);
+    s.M = kept;
   }
   HIP_RET(hipGetLastError());
   HIP_RET(hipEventRecord(s.ev[1], stream));
-  PreMeta h;
-  HIP_RET(hipMemcpyAsync(&h, s.d_meta, sizeof(h), hipMemcpyDeviceToHost, stream));
-  HIP_RET(hipStreamSynchronize(stream));
-  if (h.bad & 1) {
-    set_error("preprocess_cloud: the cloud holds non-finite coordinates (remove NaN/Inf points first)");
-    return GPD_ERR_INVALID;
+  return GPD_OK;
+}
+
+int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
+                   float *xyz_out, int32_t *cam_out, int32_t *src_out, int *num_out, float *ms, hipStream_t stream) {
+  *num_out = 0;
+  if (ms) *ms = 0.f;
+  if (n == 0) return GPD_OK;
+  int rc = preprocess_begin(s, xyz, cam_source, n, num_cams, workspace, cell, stream);
+  if (!rc) rc = preprocess_finish(s, stream);
+  if (rc) {
+    (void)hipStreamSynchronize(stream);
+    return rc;
   }
-  if (h.bad & 6) {
-    set_error("preprocess_cloud: %s", (h.bad & 2) ? "a voxel index does not fit 32 bits (voxel size too small for the cloud's extent)"
-                                                  : "more points than the voxeliser's tree walk supports");
-    return GPD_ERR_CAPACITY;
-  }
-  const int M = cell > 0.f ? h.voxels : h.kept;
+  const int M = s.M;
   if (M > 0) {
     HIP_RET(hipMemcpyAsync(xyz_out, s.d_out_xyz, (size_t)M * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
     if (num_cams > 0) HIP_RET(hipMemcpyAsync(cam_out, s.d_out_cam, (size_t)M * num_cams * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     if (src_out) HIP_RET(hipMemcpyAsync(src_out, cell > 0.f ? s.d_out_src : s.d_src, (size_t)M * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_RET(hipStreamSynchronize(stream));
   }
+  HIP_RET(hipStreamSynchronize(stream));
   if (ms) HIP_RET(hipEventElapsedTime(ms, s.ev[0], s.ev[1]));
   *num_out = M;
   return GPD_OK;

@@ -174,8 +174,8 @@ int cloud_reserve(Cloud &c, int n, int num_cams) {
   float4 **quads[] = {&c.g_p, &c.pxyz, &c.pnrm};
   for (float4 **p : quads) HIP_RET(hipMalloc(p, (size_t)cap * sizeof(float4)));
   HIP_RET(hipMalloc(&c.cam_source, (size_t)cap * cams * sizeof(int32_t)));
-  HIP_RET(hipMalloc(&c.staging, (size_t)cap * 6 * sizeof(float)));
-  HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&c.h_pin), (size_t)cap * (6 * sizeof(float) + cams * sizeof(int32_t)), 0));
+  HIP_RET(hipMalloc(&c.staging, ((size_t)cap * 6 + 8) * sizeof(float)));  // + 8: the bounds of a cloud handed over on the device
+  HIP_RET(hipHostMalloc(reinterpret_cast<void **>(&c.h_pin), (size_t)cap * (6 * sizeof(float) + cams * sizeof(int32_t)) + 32, 0));
   c.capacity = cap;
   c.cap_cams = cams;
   if (cells_cap > 0) {  // the grid tables keep their size across a growth of the point buffers
@@ -267,6 +267,89 @@ int cloud_upload(Cloud &c, const float *xyz, const float *normals, int n, const 
   grid_scatter_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor, c.g_p);
   HIP_RET(hipGetLastError());
   if (sync) HIP_RET(hipStreamSynchronize(stream));
+  return GPD_OK;
+}
+
+// min / max of n points [n][3] on the device -> out[6] (one workgroup: the clouds handed over on the device are the voxelised ones)
+__global__ __launch_bounds__(1024) void bounds_kernel(const float *__restrict__ xyz, int n, float *__restrict__ out) {
+  __shared__ float s_lo[16][3], s_hi[16][3];
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = threadIdx.x; i < n; i += 1024)
+    for (int a = 0; a < 3; a++) {
+      const float v = xyz[3 * (size_t)i + a];
+      lo[a] = fminf(lo[a], v);
+      hi[a] = fmaxf(hi[a], v);
+    }
+  for (int a = 0; a < 3; a++)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int a = 0; a < 3; a++) {
+      s_lo[threadIdx.x >> 6][a] = lo[a];
+      s_hi[threadIdx.x >> 6][a] = hi[a];
+    }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float l = FLT_MAX, h = -FLT_MAX;
+    for (int w = 0; w < 16; w++) {
+      l = fminf(l, s_lo[w][threadIdx.x]);
+      h = fmaxf(h, s_hi[w][threadIdx.x]);
+    }
+    out[threadIdx.x] = l;
+    out[3 + threadIdx.x] = h;
+  }
+}
+
+// The cloud from arrays that are ALREADY on the device (the output of the preprocessing kernels: finite by construction):
+// d_xyz [n][3], d_cam [cams][n]; normals zero until normals_run fills them.  One small wait: the bounds of the grid.
+int cloud_from_device(Cloud &c, const float *d_xyz, const int32_t *d_cam, int n, int num_cams, const double *view_points, hipStream_t stream) {
+  if (num_cams > kMaxCams || num_cams < 1 || n < 1) {
+    set_error("cloud_from_device: bad argument");
+    return GPD_ERR_INVALID;
+  }
+  {
+    const int rc = cloud_reserve(c, n, num_cams);
+    if (rc) return rc;
+  }
+  c.num_points = n;
+  c.num_cams = num_cams;
+  c.generation++;
+  std::memcpy(c.view_points, view_points, sizeof(double) * 3 * num_cams);
+  HIP_RET(hipMemcpyAsync(c.staging, d_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  HIP_RET(hipMemsetAsync(c.staging + (size_t)n * 3, 0, (size_t)n * 3 * sizeof(float), stream));
+  HIP_RET(hipMemcpyAsync(c.cam_source, d_cam, (size_t)n * num_cams * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  float *hb = reinterpret_cast<float *>(c.h_pin);  // the pinned staging is free: nothing of this cloud came through it
+  bounds_kernel<<<1, 1024, 0, stream>>>(c.staging, n, c.staging + (size_t)c.capacity * 6);
+  HIP_RET(hipMemcpyAsync(hb, c.staging + (size_t)c.capacity * 6, 6 * sizeof(float), hipMemcpyDeviceToHost, stream));
+  split_soa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(c.staging, c.staging + (size_t)n * 3, c.cam_source, n, c.px, c.py, c.pz, c.nx,
+                                                         c.ny, c.nz, c.pxyz, c.pnrm);
+  HIP_RET(hipGetLastError());
+  HIP_RET(hipStreamSynchronize(stream));
+  const float *lo = hb, *hi = hb + 3;
+  c.g_cell = 0.02f;
+  for (;;) {  // at most 256 cells per axis
+    bool ok = true;
+    for (int a = 0; a < 3; a++) {
+      c.g_lo[a] = lo[a];
+      c.g_dim[a] = (int)std::floor((hi[a] - lo[a]) / c.g_cell) + 1;
+      if (c.g_dim[a] > 256 || c.g_dim[a] < 1) ok = false;
+    }
+    if (ok) break;
+    c.g_cell *= 2.f;
+  }
+  const int cells = c.g_dim[0] * c.g_dim[1] * c.g_dim[2];
+  if (cells > c.g_cells_cap) {
+    const int rc = cloud_reserve_grid(c, cells + cells / 2);
+    if (rc) return rc;
+  }
+  GridView g = grid_view(c);
+  HIP_RET(hipMemsetAsync(c.g_cursor, 0, (size_t)cells * sizeof(int32_t), stream));
+  grid_count_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor);
+  grid_scan_kernel<<<1, 1024, 0, stream>>>(c.g_cursor, c.g_start, c.g_cursor, cells);
+  grid_scatter_kernel<<<(n + 255) / 256, 256, 0, stream>>>(g, c.px, c.py, c.pz, n, c.g_cursor, c.g_p);
+  HIP_RET(hipGetLastError());
   return GPD_OK;
 }
 
@@ -1782,7 +1865,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
       if (tiles > 1 || t == tiles - 1) {
         HIP_RET(hipMemcpyAsync(&h, s.d_ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_RET(hipMemcpyAsync(&tile_queued[(size_t)t], s.d_big, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        if (t == tiles - 1) HIP_RET(hipMemcpyAsync(normals_out, s.d_out, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        if (t == tiles - 1 && normals_out) HIP_RET(hipMemcpyAsync(normals_out, s.d_out, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_RET(hipStreamSynchronize(stream));  // (several tiles: the control words are the next tile's)
         top_max = std::max(top_max, h.top);
         status_any |= h.status;

@@ -277,6 +277,21 @@ typedef struct gpd_detect_job {
    * call), lcg_draws (out) = draws of this job's hand sets.  gpd_hip_detect_sharded fills lcg_base itself. */
   uint64_t lcg_base;
   uint64_t lcg_draws;
+  /* RAW scans (round 5): raw != 0 -> xyz / cam_source are the cloud as detect_grasps reads it from the sensor or the PCD, and
+   * the job runs CandidatesGenerator::preprocessPointCloud (candidates_generator.cpp:14-37) on the device first:
+   * Cloud::filterWorkspace with `workspace` (6 doubles xmin xmax ymin ymax zmin zmax; NULL: none), Cloud::voxelizeCloud
+   * (voxel_size; <= 0: none), Cloud::calculateNormals(normals_radius, towards the cameras that see each point).  `normals` and
+   * `sample_indices` are ignored (indices into the preprocessed cloud do not exist yet): the search runs at `sample_xyz`
+   * (num_samples x 3 doubles, the `samples` route of the reference: cloud.h setSamples, hand_search.cpp:160-165).  The voxelised
+   * cloud never leaves the device; the voxeliser's sequential keep / drop chain runs on the calling host thread while the
+   * previous cloud's image / LeNet kernels run.  num_points_processed (out): points after preprocessing. */
+  int32_t raw;
+  float voxel_size;
+  const double *workspace;
+  double normals_radius;
+  const double *sample_xyz;
+  int32_t num_points_processed;
+  int32_t reserved2_;
 } gpd_detect_job;
 
 /* detect_grasps over a batch of independent clouds (src/detect_grasps.cpp:20-86 called once per

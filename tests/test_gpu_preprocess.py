@@ -146,3 +146,89 @@ def test_config1_preprocessing_on_the_device(ctx, oracle_mod):
     n = ctx.estimate_normals(0.03)
     ov, _ = oracle_mod.voxelize(xyz, 0.003)
     assert np.array_equal(n, oracle_mod.estimate_normals(ov))
+
+
+def _stepwise(ctx, scan, samples_xyz, ws, cell, radius):
+    """the raw scan through the single calls: preprocess_cloud -> upload -> estimate_normals -> upload -> detect by coordinates"""
+    vox, cam, _, _ = ctx.preprocess_cloud(scan["xyz"], scan["cam_source"], ws, cell)
+    ctx.upload_cloud(vox, np.zeros_like(vox), cam, scan["view_points"])
+    nrm = ctx.estimate_normals(radius)
+    ctx.upload_cloud(vox, nrm, cam, scan["view_points"])
+    hands, n_cand = ctx.detect_samples(samples_xyz)
+    flat = hands.reshape(-1)
+    return flat[flat["valid"].astype(bool)], len(vox), n_cand
+
+
+def test_raw_scans_through_the_batch_entry(oracle_mod):
+    """gpd_detect_job.raw: workspace cut + voxeliser + normals inside gpd_hip_detect_batch, the voxelised cloud never leaving
+    the device — five raw scans (two cameras, different sizes, one without a workspace) against the same scans through the single
+    calls, byte for byte; then the stepwise route itself against the oracle on one of them."""
+    rng = np.random.RandomState(12)
+    scans, samples, wss = [], [], []
+    for k, n in enumerate((60000, 90000, 40000, 120000, 75000)):
+        cl = synth.make_cloud(500 + k, 30000)
+        # a raw scan: every lattice point four times, moved by up to 1 mm (the voxeliser's input), shuffled
+        parts = [(cl["xyz"] + rng.uniform(-1e-3, 1e-3, cl["xyz"].shape)).astype(np.float32) for _ in range(max(1, n // 30000))]
+        xyz = np.concatenate(parts)[:n]
+        perm = rng.permutation(len(xyz))
+        xyz = np.ascontiguousarray(xyz[perm])
+        cam = np.ones((2, len(xyz)), np.int32)
+        cam[1] = rng.rand(len(xyz)) < 0.5
+        cam[0, cam[1] == 1] = rng.rand(int(cam[1].sum())) < 0.5
+        cam[0, (cam[0] == 0) & (cam[1] == 0)] = 1
+        vp = np.array([[0.0, 0.0, 0.0], [0.25, -0.1, 0.05]])
+        scans.append(dict(xyz=xyz, cam_source=cam, view_points=vp))
+        obj = np.flatnonzero(cl["is_object"])
+        samples.append(cl["xyz"][rng.choice(obj, 150, replace=False)].astype(np.float64))
+        wss.append(None if k == 2 else np.array([-0.4, 0.4, -0.4, 0.4, -1.0, 1.0]))
+    w = synth.lenet_weights(15, real=dict(np.load(os.path.join(GOLD, "lenet15_params.npz"))), trained_magnitude=True)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        want = [_stepwise(ctx, sc, sm, ws, 0.003, 0.03) for sc, sm, ws in zip(scans, samples, wss)]
+        assert all(x[2] > 100 for x in want)
+        for ws_batch, idx in ((wss[0], [0, 1, 3, 4]), (None, [2])):
+            jobs, keep = ctx.raw_batch([scans[i] for i in idx], [samples[i] for i in idx], ws_batch, 0.003, 0.03)
+            ctx._check(api.lib().gpd_hip_detect_batch(ctx._h, jobs, len(jobs)))
+            for j, k, i in zip(jobs, keep, idx):
+                hands = k[5][: j.num_hands]
+                assert j.status == 0 and j.num_points_processed == want[i][1] and j.num_candidates == want[i][2]
+                assert hands.tobytes() == want[i][0].tobytes(), i
+        # the stepwise route against the oracle (scan 2: no workspace)
+        sc, sm = scans[2], samples[2]
+        vox, src = oracle_mod.voxelize(sc["xyz"], 0.003)
+        cam = (sc["cam_source"][:, src] == 1).astype(np.int32)
+        nrm = oracle_mod.estimate_normals(vox, cam, sc["view_points"], 0.03)
+        p = oracle_mod.default_params(15)
+        oh, on, _ = oracle_mod.detect(p, vox, nrm, cam, sc["view_points"], None, w, samples_xyz=sm) if "samples_xyz" in oracle_mod.detect.__code__.co_varnames else (None, None, None)
+        if oh is not None:
+            v = oh.reshape(-1)[oh.reshape(-1)["valid"].astype(bool)]
+            assert on == want[2][2] and np.array_equal(v["position"], want[2][0]["position"]) and np.abs(v["score"] - want[2][0]["score"]).max() <= 1e-4
+    finally:
+        ctx.close()
+
+
+def test_raw_krylon_through_the_batch_entry_matches_the_reference():
+    """configs[0]'s cloud as a raw job: tutorials/krylon.pcd's points, voxeliser 0.003, normals 0.03, the pin's samples by coordinates,
+    selectGrasps(50) — against what the reference's own detectGrasps returned (pin krylon_e2e_hands)."""
+    import ref_cases as rcs
+    pin = rcs.load_pin("extras")
+    H = api.HAND_DTYPE
+    rh = pin["krylon_e2e_hands"].view(H).reshape(-1)
+    xyz = np.load(os.path.join(GOLD, "krylon_xyz.npz"))["xyz"].astype(np.float32)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(rcs.weights(15))
+        ctx.set_lenet_mode(api.LENET_F32_CHAIN)  # the reference's scores under the fma definition, bit for bit
+        vox = ctx.preprocess_cloud(xyz, voxel_size=0.003)[0]
+        sm = vox[pin["krylon_e2e_samples"]].astype(np.float64)
+        scan = dict(xyz=xyz, cam_source=np.ones((1, len(xyz)), np.int32), view_points=np.zeros((1, 3)))
+        jobs, keep = ctx.raw_batch([scan, scan], [sm, sm[:40]], None, 0.003, 0.03, num_selected=50)
+        ctx._check(api.lib().gpd_hip_detect_batch(ctx._h, jobs, 2))
+        sel = keep[0][5][: jobs[0].num_hands]
+        sel = sel[np.argsort(-sel["score"].astype(np.float64), kind="stable")]
+        assert jobs[0].num_points_processed == len(vox) == 3366 and len(sel) == len(rh)
+        assert np.array_equal(sel["score"], rh["score"]) and np.array_equal(sel["position"], rh["position"]) and np.array_equal(sel["frame"], rh["frame"])
+        assert jobs[1].status == 0 and jobs[1].num_hands > 0
+    finally:
+        ctx.close()
