@@ -594,14 +594,19 @@ def _lenet_f64(images, w):
     import torch.nn.functional as Fn
     C = images.shape[3]
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+    c1w, c1b, c2w, c2b = d(w["c1w"].reshape(20, C, 5, 5)), d(w["c1b"]), d(w["c2w"].reshape(50, 20, 5, 5)), d(w["c2b"])
+    f1w, f1b, f2w, f2b = d(w["f1w"].reshape(7200, 500).T.copy()), d(w["f1b"]), d(w["f2w"].reshape(500, 2).T.copy()), d(w["f2b"])
+    out = np.zeros(len(images), np.float64)
     with torch.no_grad():
-        x = d(images.transpose(0, 3, 1, 2).astype(np.float64))
-        h = Fn.max_pool2d(Fn.conv2d(x, d(w["c1w"].reshape(20, C, 5, 5)), d(w["c1b"])), 2)
-        h = Fn.max_pool2d(Fn.conv2d(h, d(w["c2w"].reshape(50, 20, 5, 5)), d(w["c2b"])), 2)
-        flat = h.permute(0, 2, 3, 1).reshape(len(h), 7200)  # pixel-major, channel-minor (eigen_classifier.cpp:103-107)
-        y = torch.relu(Fn.linear(flat, d(w["f1w"].reshape(7200, 500).T.copy()), d(w["f1b"])))
-        z = Fn.linear(y, d(w["f2w"].reshape(500, 2).T.copy()), d(w["f2b"]))
-        return (z[:, 1] - z[:, 0]).numpy()
+        for i0 in range(0, len(images), 500):  # 500 images at a time: 0.6 GB of float64 activations, whatever the list's length
+            x = d(images[i0:i0 + 500].transpose(0, 3, 1, 2).astype(np.float64))
+            h = Fn.max_pool2d(Fn.conv2d(x, c1w, c1b), 2)
+            h = Fn.max_pool2d(Fn.conv2d(h, c2w, c2b), 2)
+            flat = h.permute(0, 2, 3, 1).reshape(len(h), 7200)  # pixel-major, channel-minor (eigen_classifier.cpp:103-107)
+            y = torch.relu(Fn.linear(flat, f1w, f1b))
+            z = Fn.linear(y, f2w, f2b)
+            out[i0:i0 + 500] = (z[:, 1] - z[:, 0]).numpy()
+    return out
 
 
 def _score_accuracy_leg(ctx, hands_f, C, w, timed_scores):
@@ -612,7 +617,15 @@ def _score_accuracy_leg(ctx, hands_f, C, w, timed_scores):
     float64 (torch, CPU); then the library's f32-chain mode, which must reproduce the oracle bit for bit."""
     import oracle
     from gpd_amd import api
-    imgs, _ = ctx.images(hands_f, download=True)
+    # at most the first 5000 candidates of the list (config 4's 50 000 images would be 2.7 GB of pixels on the host and a minute of
+    # CPU LeNet: the leg must stay small beside the measurement — round 5 lost three GPU boxes to the unbounded version of this leg)
+    sub = hands_f.copy()
+    flat = sub.reshape(-1)
+    keep = np.flatnonzero(flat["valid"])
+    if len(keep) > 5000:
+        flat["valid"][keep[5000:]] = 0
+        timed_scores = timed_scores[:5000]
+    imgs, _ = ctx.images(sub, download=True)
     assert len(imgs) == len(timed_scores)
     orc = oracle.lenet(imgs, w)
     f64 = _lenet_f64(imgs, w)
