@@ -656,6 +656,7 @@ static double nnRadiusImages(const gpd_params &P) {  // image_generator.cpp:43-4
 // ---------------------------------------------------------------------------
 // Shadow — hand_set.cpp:118-283 (15 channels only).
 // ---------------------------------------------------------------------------
+static uint64_t g_lcg_base = 0, g_lcg_draws = 0;  // gpd_oracle_set_lcg_base / gpd_oracle_last_lcg_draws (below)
 struct Lcg {  // hand_set.cpp:263-266 ("fastrand"); jump() = n steps at once
   uint32_t s;
   int next() {
@@ -1260,7 +1261,9 @@ int gpd_oracle_images(const gpd_params *P, const float *xyz, const float *normal
     float q[3] = {(float)h0.sample[0], (float)h0.sample[1], (float)h0.sample[2]};
     radiusSearch(g, q, radius, nbrs[k]);
   }
-  std::vector<uint64_t> lcg_off(live.size() + 1, 0);
+  // (g_lcg_base: the draws consumed before this call's first hand set — 0 for a whole cloud, as the reference's seed_ = 0 of a
+  //  fresh process; a sample RANGE of a cloud continues the one stream of hand_set.cpp:268-283 where the ranges before it stopped)
+  std::vector<uint64_t> lcg_off(live.size() + 1, g_lcg_base);
   const int num_shadow = (int)std::floor(radius / 0.003);  // as calculateShadow evaluates it
   if (C == 15)
     for (size_t k = 0; k < live.size(); k++) {
@@ -1275,6 +1278,7 @@ int gpd_oracle_images(const gpd_params *P, const float *xyz, const float *normal
       }
       lcg_off[k + 1] = lcg_off[k] + d;
     }
+  g_lcg_draws = lcg_off.back() - g_lcg_base;
   if (images) {
 #pragma omp parallel for schedule(dynamic, 2)
     for (int k = 0; k < (int)live.size(); k++) {
@@ -1462,6 +1466,11 @@ int gpd_oracle_num_threads() {
   return 1;
 #endif
 }
+// sample-range sharding of ONE cloud: the shadow draws consumed before the next gpd_oracle_images call's first hand
+// set, and the draws its hand sets consumed (tests/test_multi_gpu_gloo.py: two ranks, a host-side scan of the totals)
+void gpd_oracle_set_lcg_base(uint64_t base) { g_lcg_base = base; }
+uint64_t gpd_oracle_last_lcg_draws(void) { return g_lcg_draws; }
+
 void gpd_oracle_set_num_threads(int n) {
 #ifdef _OPENMP
   omp_set_num_threads(n);

@@ -134,6 +134,19 @@ def filter_workspace(params, hands):
     return hands
 
 
+def set_lcg_base(base):
+    """Shadow draws consumed before the next images() call's first hand set (0: a whole cloud, the default; a later sample range
+    of a sharded cloud: the draws of the ranges before it).  Stays set until changed."""
+    lib().gpd_oracle_set_lcg_base(C.c_uint64(int(base)))
+
+
+def last_lcg_draws():
+    """Shadow draws the hand sets of the last images() call consumed."""
+    L = lib()
+    L.gpd_oracle_last_lcg_draws.restype = C.c_uint64
+    return int(L.gpd_oracle_last_lcg_draws())
+
+
 def images(params, xyz, normals, cam_source, view_points, hands, want_images=True):
     """ImageGenerator::createImages -> (images[n,60,60,C] u8, cand_index[n])."""
     xyz = np.ascontiguousarray(xyz, np.float32)
