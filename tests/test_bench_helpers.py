@@ -132,3 +132,17 @@ def test_batch_mode_cloud_assignment():
         seen = sorted(c for r in range(world) for c in gdist.clouds_of_rank(256, r, world))
         assert seen == list(range(256))
         assert all(len(gdist.clouds_of_rank(256, r, world)) == 256 // world for r in range(world))
+
+
+def test_float64_reference_of_the_score_leg_is_chunk_independent(lenet15_real, oracle_mod):
+    """bench._lenet_f64 walks the list 500 images at a time (bounded host memory): a list that straddles two chunk
+    boundaries gives what each image gives alone (to float64 summation order), and agrees with the oracle's f32 chain to f32 summation noise."""
+    rng = np.random.RandomState(5)
+    imgs = (rng.randint(0, 256, (1003, 60, 60, 15)) * (rng.rand(1003, 60, 60, 15) < 0.2)).astype(np.uint8)
+    got = bench._lenet_f64(imgs, lenet15_real)
+    assert got.shape == (1003,) and got.dtype == np.float64
+    for i in (0, 499, 500, 999, 1000, 1002):
+        assert abs(got[i] - bench._lenet_f64(imgs[i:i + 1], lenet15_real)[0]) < 1e-12  # torch's f64 GEMM order moves with the batch size
+    chain = oracle_mod.lenet(imgs, lenet15_real)
+    assert np.abs(got - chain).max() < 1e-4
+    assert bench._lenet_f64(imgs[:0], lenet15_real).shape == (0,)
