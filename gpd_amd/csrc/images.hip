@@ -776,6 +776,11 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
 #pragma unroll
   for (int k = 0; k < RPT; k++) mask[k] = 0ull;
   if (set_ord >= 0) {
+    // INVARIANT of the bitset rows: shadow_set_kernel<0> writes exactly the union of the windows floor(min) - 1 .. floor(max) + 1
+    // that its candidates' boxes open (the same arithmetic as S.vorg above); the fixed VDIM x VDIM walk below can leave that
+    // union, and what it reads there is zero (images_reserve clears a new allocation) or voxels of an earlier launch's set.
+    // Neither can be kept: a bit survives only the exact f64 box test of its voxel, and no voxel outside
+    // [floor(min), floor(max)] lies in the box.  A reader that counts or uses bits BEFORE that test must clamp to the union.
     const uint32_t *sb = P.set_bits + (size_t)set_ord * SETWORDS;
     const int ox = (int)floor(B.sample[0] * K.voxel_mult) - SR, oy = (int)floor(B.sample[1] * K.voxel_mult) - SR,
               oz = (int)floor(B.sample[2] * K.voxel_mult) - SR;
@@ -1977,6 +1982,9 @@ int images_reserve(const gpd_params &p, ImageState &im, int n, int shadow_sets) 
     const int cap = want + want / 4;
     const size_t words = setwords > im.cap_setwords ? setwords : im.cap_setwords;
     HIP_RET(hipMalloc(&im.d_set_bits, (size_t)cap * words * sizeof(uint32_t)));
+    // defined contents from the first launch on: shadow_set_kernel<0> writes only the rows its candidates' windows cover, and
+    // the words around them keep what is there (zero, or an earlier launch's voxels — see the reader's note in shadow_image_kernel)
+    HIP_RET(hipMemset(im.d_set_bits, 0, (size_t)cap * words * sizeof(uint32_t)));
     im.cap_shadow_sets = cap;
     im.cap_setwords = words;  // (a larger row also serves the smaller regions)
   }
