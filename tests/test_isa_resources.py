@@ -1,0 +1,66 @@
+"""Static resources of the gfx950 kernels, read from the code objects the build leaves in gpd_amd/csrc/*.o (no GPU):
+what DESIGN.md says about registers, LDS and scratch is what the compiler produced, and profiles/r05_isa_stats.txt is the
+listing of the sources as committed."""
+import importlib.util
+import io
+import os
+from contextlib import redirect_stdout
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def isa():
+    from gpd_amd import api
+    api.lib()  # builds the library (and with it the objects) when it is missing
+    spec = importlib.util.spec_from_file_location("isa_stats", os.path.join(ROOT, "profiles", "isa_stats.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(os.path.join(mod.CSRC, "lenet_fast.o")):
+        pytest.skip("no objects beside the library (prebuilt .so only)")
+    return mod, {r["kernel"]: r for r in mod.collect()}
+
+
+def test_scoring_kernels_keep_everything_in_registers(isa):
+    _, k = isa
+    names = [n for n in k if k[n]["unit"] in ("lenet", "lenet_fast")]
+    assert len(names) >= 25
+    for n in names:
+        r = k[n]
+        assert r["scratch"] == 0 and r["vgpr_spills"] == 0 and r["sgpr_spills"] == 0 and not r["dynamic_stack"], (n, r)
+        assert r["vgpr"] + r["agpr"] <= 256, n  # two waves per SIMD at 512 threads: half of the 512 registers each
+        assert r["lds"] <= 160 * 1024, n
+
+
+def test_split_kernels_hold_the_matrix_instructions_the_bench_prices(isa):
+    """bench.lenet_mfma_work multiplies tiles x instructions x operations per instruction: the instruction counts per
+    tile / k-step are the ones in the code objects (nothing unrolled twice, nothing dropped)."""
+    _, k = isa
+    for C in (15, 12, 3, 1):
+        assert k["gpd::conv1_i8_kernel<%d>" % C]["matrix"] == {"v_mfma_i32_16x16x64_i8": 7 * 5}  # F1_KS x F1_MT per tile
+    assert k["gpd::conv2_bf16_kernel"]["matrix"] == {"v_mfma_f32_16x16x32_bf16": 16 * 6}  # k-steps x piece products per pixel tile and wave
+    for nt in (1, 2, 3, 4, 5):
+        assert k["gpd::fc1_bf16_kernel<%d>" % nt]["matrix"] == {"v_mfma_f32_16x16x32_bf16": nt * 4 * 6}  # m-tiles x n-tiles x pieces per BK
+    # LDS budgets of DESIGN.md section 4
+    assert k["gpd::conv2_bf16_kernel"]["lds"] == 94080 + 62720 + 4
+    assert k["gpd::conv1_i8_kernel<15>"]["lds"] <= 124 * 1024
+    assert k["gpd::fc1_bf16_kernel<5>"]["lds"] == 159744
+
+
+def test_default_geometry_kernels_do_not_touch_scratch(isa):
+    _, k = isa
+    for n in ("gpd::neighbourhood_kernel<false>", "gpd::neighbourhood_kernel<true>", "gpd::hand_eval_kernel", "gpd::plan_kernel",
+              "gpd::shadow_set_kernel<0>", "gpd::shadow_image_kernel<6144, false>", "gpd::shadow_image_kernel<12288, false>",
+              "gpd::grasp_image_kernel<false>", "gpd::normals_list_kernel", "gpd::normals_finish_kernel", "gpd::cluster_kernel"):
+        assert k[n]["scratch"] == 0 and k[n]["vgpr_spills"] == 0, (n, k[n])
+
+
+def test_committed_listing_is_of_the_committed_sources(isa):
+    mod, _ = isa
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        mod.main()
+    want = open(os.path.join(ROOT, "profiles", "r05_isa_stats.txt")).read()
+    assert buf.getvalue() == want, "kernels changed: python profiles/isa_stats.py > profiles/r05_isa_stats.txt"
