@@ -47,6 +47,10 @@ class HipClassifier : public Classifier {
   std::vector<float> classifyImages(const std::vector<std::unique_ptr<Image>> &image_list) override;
   int getBatchSize() const override { return batch_size_; }
   bool ok() const { return ctx_ != nullptr && loaded_; }
+  // Arithmetic of the scoring kernels (gpd_hip_set_lenet_mode): 0 = operands split exactly over the int8 / bf16 matrix
+  // pipes (default: within 1e-4 of EigenClassifier's plain-float result, closer to float64 than it), 1 = the f32 chain
+  // in the reference's own operation order.  GraspDetector sets it from the cfg key `hip_lenet_mode`.
+  bool setScoringMode(int mode);
   // raw float32 parameter file -> vector (EigenClassifier::readBinaryFileIntoVector, :185-204)
   static std::vector<float> readBinaryFileIntoVector(const std::string &location);
   // The parameters as read from the files (conv1 w, b, conv2 w, b, ip1 w, b, ip2 w, b): GraspDetector loads the

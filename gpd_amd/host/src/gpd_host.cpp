@@ -525,6 +525,15 @@ HipClassifier::~HipClassifier() {
   if (ctx_) gpd_hip_destroy(ctx_);
 }
 
+bool HipClassifier::setScoringMode(int mode) {
+  if (!ok()) return false;
+  if (gpd_hip_set_lenet_mode(ctx_, mode) != GPD_OK) {
+    printf("ERROR: %s\n", gpd_hip_last_error());
+    return false;
+  }
+  return true;
+}
+
 std::vector<float> HipClassifier::classifyImages(const std::vector<std::unique_ptr<Image>> &image_list) {
   std::vector<float> out(image_list.size(), 0.f);
   if (!ok()) return out;
@@ -682,6 +691,20 @@ GraspDetector::GraspDetector(const std::string &config_filename) {
                                          hc->parameter(5).data(), hc->parameter(6).data(), hc->parameter(7).data()) == GPD_OK) {
       has_classifier_ = true;
       fused_classifier_ = true;
+      // hip_lenet_mode (not a reference key): 0 = split operands on the int8 / bf16 matrix pipes (default), 1 = the f32
+      // chain in EigenClassifier's operation order; both the fused path's context and the plugin's own take it
+      const int mode = config_file.getValueOfKey<int>("hip_lenet_mode", 0);
+      if (mode != 0) {
+        bool set = gpd_hip_set_lenet_mode(ctx_, mode) == GPD_OK;
+        if (!set) printf("ERROR: hip_lenet_mode = %d: %s\n", mode, gpd_hip_last_error());
+        set = set && hc->setScoringMode(mode);
+        if (!set) {
+          has_classifier_ = fused_classifier_ = false;
+          classifier_.reset();
+        } else {
+          printf("hip_lenet_mode: %d\n", mode);
+        }
+      }
     } else {
       printf("ERROR: %s\n", gpd_hip_last_error());
       classifier_.reset();
