@@ -60,6 +60,42 @@ def lenet_mfma_work(C):
         "fc1_bf16_kernel": dict(pipe="bf16", executed=2.0 * 512 * 7296 * 6, algorithmic_split=2.0 * 500 * 7200 * 6, algorithmic=2.0 * 500 * 7200),
     }
 
+def lenet_kernel_entry(k_s, fl, n_cand, wk):
+    """One LeNet kernel's entry of `kernels`: k_s = seconds per launch (HIP events), fl = SURVEY 8d's f32 FLOPs per image,
+    wk = the kernel's entry of lenet_mfma_work (None: no matrix instructions, ip2)."""
+    e = {"ms": k_s * 1e3, "algorithmic_flops": fl * n_cand,
+         "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None,
+         "frac_f32": fl * n_cand / k_s / 1e12 / F32_PEAK_TFLOPS if k_s > 0 else None}
+    if wk is not None and k_s > 0:
+        peak = I8_PEAK_TOPS if wk["pipe"] == "i8" else BF16_PEAK_TFLOPS
+        e.update({"pipe": wk["pipe"], "executed_ops": wk["executed"] * n_cand, "executed_Tops": wk["executed"] * n_cand / k_s / 1e12,
+                  "frac_pipe": wk["executed"] * n_cand / k_s / 1e12 / peak,
+                  "useful_share_of_executed": wk["algorithmic_split"] / wk["executed"]})
+    return e
+
+
+def lenet_roofline(dom, kd, wk, traffic_bytes):
+    """The `roofline` object for the dominant LeNet kernel `dom`: kd = its entry of `kernels` (ms, executed_*, algorithmic_flops,
+    achieved_TFLOPs, frac_f32), wk = its entry of lenet_mfma_work, traffic_bytes = HBM bytes per launch from a counter pass or None."""
+    peak = I8_PEAK_TOPS if wk["pipe"] == "i8" else BF16_PEAK_TFLOPS
+    return {"kernel": dom, "bound": "mfma", "achieved": kd["executed_Tops"], "peak": peak,
+            "unit": "TOP/s" if wk["pipe"] == "i8" else "TFLOP/s", "frac": kd["executed_Tops"] / peak,
+            "pipe": wk["pipe"], "traffic": traffic_bytes,
+            "ops_per_launch": kd["executed_ops"], "launch_ms": kd["ms"],
+            "algorithmic_flops_per_launch": kd["algorithmic_flops"],
+            "f32_equivalent": {"achieved_TFLOPs": kd["achieved_TFLOPs"], "frac_of_f32_peak": kd["frac_f32"],
+                               "frac_of_pipe_peak": kd["achieved_TFLOPs"] / peak,
+                               "ceiling_frac_of_pipe_peak": wk["algorithmic"] / wk["executed"],
+                               "note": "SURVEY 8d's f32 FLOPs of the layer / the same time, against the 157.3 TFLOP/s f32-input MFMA "
+                                       "peak (the pipe of rounds 1-4: conv2 there ran at 0.77 of it) and against the peak of the pipe "
+                                       "it runs on now; ceiling = algorithmic / executed operations: what frac_of_pipe_peak would be "
+                                       "with the pipe 100 % busy (an exact f32 product costs 4 int8 / 6 bf16 instructions' worth)"},
+            "useful_share_of_executed": wk["algorithmic_split"] / wk["executed"],
+            "note": "achieved = executed MFMA operations per launch (tiles x instructions x ops per instruction, lenet_mfma_work) / "
+                    "HIP-event time of the kernel; useful_share_of_executed = algorithmic FLOPs x the split factor (4 digit planes / 6 "
+                    "piece products) over the executed ones (the rest is tile padding: 50 -> 64 filters, 25 -> 28 tap slots, ...)"}
+
+
 CONFIGS = {  # BASELINE.json configs[1..3]
     "2": dict(points=30000, candidates=5000, channels=15, clutter=False),
     "3a": dict(points=30000, candidates=5000, channels=3, clutter=False),
@@ -390,16 +426,7 @@ def main():
         kflops = {k: v["algorithmic"] for k, v in work.items()}
         kflops["fc2_score_kernel"] = 2.0 * 2 * 500
         for (name, fl), ms_sum in zip(kflops.items(), kernel_ms):
-            k_s = ms_sum / 1e3 / args.steps
-            kernels[name] = {"ms": k_s * 1e3, "algorithmic_flops": fl * n_cand,
-                             "achieved_TFLOPs": fl * n_cand / k_s / 1e12 if k_s > 0 else None,
-                             "frac_f32": fl * n_cand / k_s / 1e12 / F32_PEAK_TFLOPS if k_s > 0 else None}
-            if name in work and k_s > 0:
-                wk = work[name]
-                peak = I8_PEAK_TOPS if wk["pipe"] == "i8" else BF16_PEAK_TFLOPS
-                kernels[name].update({"pipe": wk["pipe"], "executed_ops": wk["executed"] * n_cand, "executed_Tops": wk["executed"] * n_cand / k_s / 1e12,
-                                      "frac_pipe": wk["executed"] * n_cand / k_s / 1e12 / peak,
-                                      "useful_share_of_executed": wk["algorithmic_split"] / wk["executed"]})
+            kernels[name] = lenet_kernel_entry(ms_sum / 1e3 / args.steps, fl, n_cand, work.get(name))
         traffic = _pmc_traffic(n_cand, C, live=args.live_pmc and args.gpus == 1)
         sq = _pmc_sq()
         if sq:
@@ -413,20 +440,7 @@ def main():
             # instruction: padding included, nothing skipped) / its HIP-event time, against the dense peak of ITS pipe — a
             # utilisation, the number to hold against MfmaUtil.  The f32-equivalent rate (SURVEY 8d's algorithmic FLOPs / the same
             # time) rides along, against the 157.3 TFLOP/s f32 peak the previous rounds' f32-input MFMA kernels were priced on.
-            kd, wk = kernels[dom], work[dom]
-            peak = I8_PEAK_TOPS if wk["pipe"] == "i8" else BF16_PEAK_TFLOPS
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": kd["executed_Tops"], "peak": peak,
-                        "unit": "TOP/s" if wk["pipe"] == "i8" else "TFLOP/s", "frac": kd["executed_Tops"] / peak,
-                        "pipe": wk["pipe"], "traffic": traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")),
-                        "ops_per_launch": kd["executed_ops"], "launch_ms": kd["ms"],
-                        "algorithmic_flops_per_launch": kd["algorithmic_flops"],
-                        "f32_equivalent": {"achieved_TFLOPs": kd["achieved_TFLOPs"], "frac_of_f32_peak": kd["frac_f32"],
-                                           "note": "SURVEY 8d's f32 FLOPs of the layer / the same time, against the 157.3 TFLOP/s f32-input MFMA "
-                                                   "peak (the pipe of rounds 1-4: conv2 there ran at 0.77 of it)"},
-                        "useful_share_of_executed": wk["algorithmic_split"] / wk["executed"],
-                        "note": "achieved = executed MFMA operations per launch (tiles x instructions x ops per instruction, lenet_mfma_work) / "
-                                "HIP-event time of the kernel; useful_share_of_executed = algorithmic FLOPs x the split factor (4 digit planes / 6 "
-                                "piece products) over the executed ones (the rest is tile padding: 50 -> 64 filters, 25 -> 28 tap slots, ...)"}
+            roofline = lenet_roofline(dom, kernels[dom], work[dom], traffic.get(dom.replace("_kernel", ""), traffic.get("lenet")))
         else:
             roofline = {"kernel": "image stage (shadow_set + shadow_image + grasp_image kernels)", "bound": "hbm", "achieved": img_gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": img_gbs / HBM_PEAK_GBS, "traffic": traffic.get("image")}

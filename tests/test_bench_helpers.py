@@ -146,3 +146,29 @@ def test_float64_reference_of_the_score_leg_is_chunk_independent(lenet15_real, o
     chain = oracle_mod.lenet(imgs, lenet15_real)
     assert np.abs(got - chain).max() < 1e-4
     assert bench._lenet_f64(imgs[:0], lenet15_real).shape == (0,)
+
+
+def test_roofline_object_reproduces_the_committed_line():
+    """lenet_kernel_entry / lenet_roofline (the functions bench.py's main builds `kernels` and `roofline` with) fed the launch
+    time of the committed round-5 line give that line's numbers, and the f32-equivalent block carries both peaks."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    rf, n = line["roofline"], line["config"]["candidates_per_gpu"]
+    dom = rf["kernel"]
+    work = bench.lenet_mfma_work(15)
+    kd = bench.lenet_kernel_entry(rf["launch_ms"] / 1e3, work[dom]["algorithmic"], n, work[dom])
+    for k in ("ms", "algorithmic_flops", "achieved_TFLOPs", "frac_f32", "executed_ops", "executed_Tops", "frac_pipe"):
+        assert kd[k] == pytest.approx(line["kernels"][dom][k], rel=1e-12), k
+    got = bench.lenet_roofline(dom, kd, work[dom], None)
+    for k in ("kernel", "bound", "peak", "unit", "pipe", "traffic"):
+        assert got[k] == rf[k], k
+    for k in ("achieved", "frac", "ops_per_launch", "launch_ms", "algorithmic_flops_per_launch", "useful_share_of_executed"):
+        assert got[k] == pytest.approx(rf[k], rel=1e-12), k
+    fe = got["f32_equivalent"]
+    assert fe["achieved_TFLOPs"] == pytest.approx(rf["f32_equivalent"]["achieved_TFLOPs"], rel=1e-12)
+    assert fe["frac_of_f32_peak"] == pytest.approx(fe["achieved_TFLOPs"] / 157.3, rel=1e-12)
+    assert fe["frac_of_pipe_peak"] == pytest.approx(fe["achieved_TFLOPs"] / got["peak"], rel=1e-12)
+    assert fe["frac_of_pipe_peak"] / fe["ceiling_frac_of_pipe_peak"] == pytest.approx(got["frac"], rel=1e-12)  # = the pipe's utilisation
+    # ip2 has no matrix instructions: a plain entry
+    e = bench.lenet_kernel_entry(25e-6, 2000.0, n, None)
+    assert "pipe" not in e and e["achieved_TFLOPs"] == pytest.approx(2000.0 * n / 25e-6 / 1e12)
+    json.dumps(got)
