@@ -623,6 +623,9 @@ def _lenet_f64(images, w):
     return out
 
 
+ACCURACY_LEG_MAX = 5000  # candidates the score-accuracy leg looks at (the whole timed list of every configuration but configs[3])
+
+
 def _score_accuracy_leg(ctx, hands_f, C, w, timed_scores):
     """BASELINE's "scores within 1e-4 of the Eigen path" on ALL candidates of the timed list, with the weights the headline is
     timed on (trained-net magnitudes, |score| < 20): the scores the timed region produced (default mode: int8 / bf16 matrix pipes
@@ -636,9 +639,9 @@ def _score_accuracy_leg(ctx, hands_f, C, w, timed_scores):
     sub = hands_f.copy()
     flat = sub.reshape(-1)
     keep = np.flatnonzero(flat["valid"])
-    if len(keep) > 5000:
-        flat["valid"][keep[5000:]] = 0
-        timed_scores = timed_scores[:5000]
+    if len(keep) > ACCURACY_LEG_MAX:
+        flat["valid"][keep[ACCURACY_LEG_MAX:]] = 0
+        timed_scores = timed_scores[:ACCURACY_LEG_MAX]
     imgs, _ = ctx.images(sub, download=True)
     assert len(imgs) == len(timed_scores)
     orc = oracle.lenet(imgs, w)
