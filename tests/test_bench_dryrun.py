@@ -123,3 +123,12 @@ def test_two_ranks_under_the_drivers_launcher(oracle_mod):
     assert abs(d["value"] - 2 * 160 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]  # both ranks' candidates / max time
     assert "cpu_baseline" not in d and "scores_timed_list" not in d and "batch_raw_end_to_end" not in d
     assert d["batch_end_to_end"]["clouds"] == 8 and "host_binding_rank0" in d  # 2 ranks x 2 clouds x 2 passes
+
+
+def test_smoke_entry_runs_against_the_stand_in(oracle_mod):
+    """__graft_entry__.smoke() (the driver's round-end check on cuda:0) executed against the stand-in: its own bookkeeping holds."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gpd_amd import api; import fake_context; api.Context = fake_context.FakeContext\n"
+            "import __graft_entry__ as g; g.smoke()\n" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert p.returncode == 0 and "smoke ok: 60 candidates" in p.stdout, p.stdout[-500:] + p.stderr[-2000:]

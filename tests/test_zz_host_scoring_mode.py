@@ -33,3 +33,10 @@ def test_scoring_mode_key_is_documented():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert "hip_lenet_mode" in open(os.path.join(root, "INTEGRATION.md")).read()
     assert "hip_lenet_mode" in open(os.path.join(root, "gpd_amd", "host", "src", "gpd_host.cpp")).read()
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke():
+    """the driver's smoke() as a test of the GPU suite"""
+    import __graft_entry__ as g
+    g.smoke()
