@@ -110,7 +110,7 @@ struct ImgParams {
   int32_t *pts_overflow_list;   // points kernel: candidates with more than PT_CAP in-box points
   int32_t *pts_overflow_count;
   char *pts_scratch;            // fallback instantiation: PTS_SCRATCH_BYTES per listed candidate
-  int exit_after;               // profiling aid (GPD_IMG_EXIT=k): leave the kernel after phase k (0: run to the end)
+  int exit_after;               // read by the instrumented build only (profiles/img_exits.patch: leave the kernel after phase k)
   char *huge_scratch;           // shadow_image_any_kernel: HUGE_SCRATCH_BYTES per workgroup of its grid
 };
 
@@ -669,14 +669,6 @@ __device__ inline void sort_u16_regs(uint16_t *p, int n) {
   for (int q = 0; q < N; q++)
     if (q < n) p[q] = (uint16_t)k[q];
 }
-// profiling build only (make EXTRA=-DGPD_IMG_EXITS, profiles/img_phases.sh): the early returns cost the shipped kernels
-// 11-24 spilled registers
-#ifdef GPD_IMG_EXITS
-#define EXIT_AT(k) \
-  if (P.exit_after == (k)) return
-#else
-#define EXIT_AT(k)
-#endif
 #define TICK(k)                                                     \
   do {                                                              \
     if (P.dbg && tid == 0) {                                        \
@@ -917,7 +909,6 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
   }
   __syncthreads();
   TICK(0);
-  EXIT_AT(1);
   int cnt = 0;
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
@@ -978,7 +969,6 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
   }
   __syncthreads();
   TICK(1);
-  EXIT_AT(2);
   auto cell_of_entry = [&](int k, int pr) {
     const uint32_t v = S.lin[k];
     return cell_of_key(((v >> LB) & 0xfffu) | ((uint32_t)S.cz[k] << 12), pr);
@@ -995,7 +985,6 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     }
     __syncthreads();
     TICK(2);
-    if (pr == 0) EXIT_AT(3);
     const int da = depth_axis(pr);
     // column `da` of F and the matching offset, selected without indexing the register-resident box
     const double Fd0 = da == 0 ? B.F[0] : (da == 1 ? B.F[1] : B.F[2]);
@@ -1008,7 +997,6 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     for (int c = tid; c < kPix / 4; c += IMG_THREADS) reinterpret_cast<float4 *>(S.raster0)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     TICK(9);
-    if (pr == 0) EXIT_AT(4);
     for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
       const int c = S.nz[qn];
       const uint32_t w = S.cells[c];
@@ -1032,7 +1020,6 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     }
     __syncthreads();
     TICK(10);
-    if (pr == 0) EXIT_AT(5);
     lmax = wave_max_f32(lmax);
     lany = __ballot(lany != 0) != 0ull;
     if (lane == 0) {  // (red_f / red_i were last read before the barrier above)
@@ -1064,8 +1051,6 @@ __device__ __forceinline__ void shadow_image_body(const ImgParams &P, SmemShadow
     TICK(3);
     finalize_planes<1>(S, &S.raster0[0], nullptr, out + (size_t)(pr * K.per + 4) * kPix);
     TICK(4);
-    if (pr == 0) EXIT_AT(6);
-    if (pr == 1) EXIT_AT(7);
   }
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }
@@ -1472,16 +1457,13 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     atomicAdd(&P.dbg[31], (unsigned long long)n_box_all);
   }
   TICK(5);
-  EXIT_AT(11);
   for (int c = tid; c < kPix / 4; c += IMG_THREADS) reinterpret_cast<uint4 *>(S.cells)[c] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   for (int pr = 0; pr < K.nproj; pr++) {
     // (the cell counters are zero: cleared above, then by the copy-out of the previous projection)
     for (int e = tid; e < nb; e += IMG_THREADS) atomicAdd(&S.cells[cell_of_key(__float_as_uint(AN(e).w), pr)], 1u);
     __syncthreads();
-    if (pr == 0) EXIT_AT(31);
     scan_cells(S);
-    if (pr == 0) EXIT_AT(32);
     for (int e = tid; e < nb; e += IMG_THREADS) {
       const uint32_t key = __float_as_uint(AN(e).w);
       const uint32_t old = atomicAdd(&S.cells[cell_of_key(key, pr)], 1u);
@@ -1489,14 +1471,12 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     }
     __syncthreads();
     TICK(6);
-    if (pr == 0) EXIT_AT(12);
     // the pixel owner walks its segment in neighbour order
     const int da = depth_axis(pr);
     const double offd = da == 0 ? B.off[0] : (da == 1 ? B.off[1] : B.off[2]);
     uint16_t *nz = S.nzlist;
     const int n_nz = list_nonempty_cells(S, nz);
     TICK(11);
-    if (pr == 0) EXIT_AT(13);
     for (int qn = tid; qn < n_nz; qn += IMG_THREADS) {
       const int c = nz[qn];
       const uint32_t w = S.cells[c];
@@ -1530,7 +1510,6 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
     TICK(13);
     __syncthreads();
     TICK(7);
-    if (pr == 0) EXIT_AT(14);
     // ---- the four planes of the projection at once.  `cells` is now an index raster: bit 31 set <-> the pixel holds
     //      points, low bits = its slot in nzv (float4: the three normal values and the depth value); every other word has
     //      bit 31 clear (segment starts are < 2^15) and stands for the empty pixel, slot 0 = zeros.  A group of four pixels
@@ -1581,7 +1560,6 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       }
     }
     __syncthreads();
-    if (pr == 0) EXIT_AT(21);
     const int n_live = S.counter;
     float d[GPT][4][4];  // the thread's live groups alist[tid + k * IMG_THREADS]: [plane][pixel]
     float mn0 = FLT_MAX, mx0 = -FLT_MAX, mn1 = FLT_MAX, mx1 = -FLT_MAX;
@@ -1622,7 +1600,6 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
         }
       }
     }
-    if (pr == 0) EXIT_AT(22);
     // createNormalsImage: the three planes are normalised as ONE 3-channel image; createDepthImage on its own
     // (image_strategy.cpp:144-153, 178-187; Image1ChannelsStrategy is the depth plane alone)
     if (64 * (tid >> 6) < n_live) {  // (a wave without a live group holds the initial values in every lane)
@@ -1662,7 +1639,6 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       fb[q] = (float)shift;
       bg[q] = to_byte(0.f, fs[q], fb[q]) * 0x01010101u;  // four background pixels: the value 0 through the same arithmetic
     }
-    if (pr == 0) EXIT_AT(23);
     // The bytes are staged in LDS — the index raster is dead after the barrier above: 4 planes x 900 dwords in MEMORY order
     // (image row = 59 - cell row, image_strategy.cpp:128-129) — and leave as 16-byte stores, 15 per wave instead of 56
     // four-byte ones (the store phase was issue bound: 36 of the 158 us a projection costs, profiles/img_phases.sh).
@@ -1699,11 +1675,8 @@ __device__ __forceinline__ void grasp_image_body(const ImgParams &P, SmemPts<BIG
       const int ch = K.C == 1 ? 0 : pr * K.per + pl;
       *reinterpret_cast<uint4 *>(out + (size_t)ch * kPix + 16 * j) = v;
     }
-    if (pr == 0) EXIT_AT(24);
     __syncthreads();
     TICK(8);
-    if (pr == 0) EXIT_AT(15);
-    if (pr == 1) EXIT_AT(16);
   }
   if (tid == 0 && S.flag) atomicOr(P.status, S.flag);
 }

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Cumulative cost of the image kernels' phases, each kernel alone on the chip, on the instrumented build
-# (make EXTRA=-DGPD_IMG_EXITS -> ab/libgpd_hip_exits.so; its early returns cost registers, so the absolute times are
-# 10-20 % above the shipped kernels': read the differences).  GPD_IMG_EXIT=k leaves both kernels after phase k —
+# (EXTRA=-DGPD_IMG_EXITS profiles/mkpatched.sh exits images.hip @profiles/img_exits.patch -> ab/libgpd_hip_exits.so: the early
+# returns live in that patch, not in the shipped source; they cost registers, so the absolute times are 10-20 % above the shipped
+# kernels': read the differences).  GPD_IMG_EXIT=k leaves both kernels after phase k —
 # shadow: 1 extract, 2 list, 3 count/place, 4 non-empty list, 5 walks, 6 first projection done, 7 second;
 # points: 11 collect, 12 count/place, 13 non-empty list, 14 walks, 21 live groups listed, 22 live groups dilated,
 # 23 min/max + scale, 15 first projection done, 16 second; 0 = whole kernel.
