@@ -74,3 +74,19 @@ def test_release_library_reads_no_environment_and_links_no_profiler():
     pout = subprocess.run(["nm", "-D", "--defined-only", prof], capture_output=True, text=True, check=True).stdout
     for n in _declared():
         assert n in pout
+
+
+def test_shipped_sources_carry_no_experiment_switches():
+    """The only conditional compilation in gpd_amd/csrc: the profiling build (GPD_PROFILING: roctx ranges, measurement switches read
+    from the environment) and the host / device halves of the bf16 helpers that both sides of lenet_fast.hip use.  Timing experiments
+    are built from patched copies (profiles/mkpatched.sh), not from switches in the product's sources."""
+    allowed = {"GPD_PROFILING", "__HIP_DEVICE_COMPILE__"}
+    d = os.path.join(ROOT, "gpd_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        for i, line in enumerate(open(os.path.join(d, f)), 1):
+            m = re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b(.*)", line)
+            if m:
+                names = set(re.findall(r"[A-Za-z_][A-Za-z_0-9]*", m.group(2))) - {"defined"}
+                assert names <= allowed, "%s:%d: %s" % (f, i, line.strip())
