@@ -369,7 +369,8 @@ int gpd_hip_replay_kernel_ms(gpd_hip_ctx *ctx, float ms[4]);
 
 /* conv1's zero skipping, counted by the kernel itself: pairs[0] = (64-pixel chunk, channel) pairs it executed,
  * pairs[1] = pairs it looked at, summed over the launches on the context's first lane since the last reset.
- * executed / looked-at x the dense FLOP count = the FLOPs the matrix pipe really ran (bench.py's roofline.frac).
+ * executed / looked-at x the dense FLOP count = the FLOPs the matrix pipe really ran (rounds 1-4: bench.py's roofline.frac).
+ * GPD_LENET_F32_CHAIN only — the split conv1 executes every tile and counts nothing (both numbers stay 0).
  * Measurement only: no reference counterpart. */
 int gpd_hip_conv1_stats(gpd_hip_ctx *ctx, unsigned long long pairs[2], int reset);
 /* test hook: intermediate tensors of the last gpd_hip_score pass (n images) — which = 0: pool1 f32 [n][15680] (layout of the
