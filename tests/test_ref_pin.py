@@ -480,3 +480,75 @@ def test_oracle_matches_live_reference_on_random_geometry(oracle_mod, seed):
     finally:
         det.close()
         rc.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_ROWS", "3"))))
+def test_oracle_matches_live_reference_on_random_preprocessing_and_selection(oracle_mod, seed):
+    """The rows either side of the path (SURVEY 8f) against the reference's own code on random inputs: Cloud::filterWorkspace,
+    Cloud::voxelizeCloud (std::set under its non-ordering comparator) on scans OFF the voxel lattice, Cloud::calculateNormals with
+    1-3 cameras, samples by coordinates, selectGrasps and Clustering::findClusters on random score lists (ties included),
+    HandSearch::reevaluateHypotheses against another cloud.  GPD_REF_FUZZ_ROWS=N widens the draw."""
+    ref = _live()
+    rng = np.random.RandomState(91000 + seed)
+    # a raw scan: lattice points moved by up to half a voxel, some duplicated, some outside the workspace
+    cl = synth.make_cloud(5000 + seed, int(rng.randint(3000, 9000)), clutter=bool(rng.randint(2)))
+    xyz = cl["xyz"] + rng.uniform(-0.0015, 0.0015, cl["xyz"].shape).astype(np.float32)
+    xyz = np.concatenate([xyz, xyz[rng.randint(0, len(xyz), len(xyz) // 7)]]).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    ncam = 1 + seed % 3
+    cam, vp = rcs._cams(ncam, len(xyz), seed) if ncam > 1 else (np.ones((1, len(xyz)), np.int32), np.asarray(cl["view_points"], np.float64).reshape(1, 3))
+    lo, hi = xyz.min(0), xyz.max(0)
+    ws = np.array([lo[0] + 0.02, hi[0] - 0.03, lo[1] - 1.0, hi[1] - 0.01, lo[2] - 1.0, hi[2] + 1.0], np.float64)
+    cell = float(rng.choice([0.003, 0.003, 0.005, 0.0025]))
+    radius = float(rng.choice([0.03, 0.02, 0.04]))
+    rc = ref.Cloud(xyz, None, cam, vp)
+    try:
+        rc.filter_workspace(ws)
+        cut, _ = rc.get()
+        keep = (xyz[:, 0] > ws[0]) & (xyz[:, 0] < ws[1]) & (xyz[:, 1] > ws[2]) & (xyz[:, 1] < ws[3]) & (xyz[:, 2] > ws[4]) & (xyz[:, 2] < ws[5])
+        assert np.array_equal(cut, xyz[keep]), "workspace cut"
+        rc.voxelize(cell)
+        vox, _ = rc.get()
+        ovox, osrc = oracle_mod.voxelize(xyz[keep], cell)
+        assert len(vox) < keep.sum() and np.array_equal(vox, ovox), "voxeliser"
+        rc.calculate_normals(radius)
+        _, nrm = rc.get()
+        ocam = cam[:, keep][:, osrc]
+        onrm = oracle_mod.estimate_normals(ovox, ocam, vp, radius)
+        assert np.array_equal(nrm.astype(np.float32), onrm), "normals"
+    finally:
+        rc.close()
+    # candidates of a synthetic cloud for the rows after the path
+    p = rcs.set_params(oracle_mod.default_params(15), num_orientations=int(rng.randint(4, 9)), hand_axes=[int(rng.choice([0, 1, 2]))])
+    si = synth.sample_indices(cl, 40, seed=seed)
+    nsel = int(rng.randint(5, 40))
+    det = ref.Detector(p, num_selected=nsel)
+    rc = ref.Cloud(cl["xyz"], cl["normals"], cl["cam_source"], cl["view_points"])
+    gt = synth.make_cloud(6000 + seed, 5000)
+    rc_gt = ref.Cloud(gt["xyz"], gt["normals"], gt["cam_source"], gt["view_points"])
+    try:
+        sm = cl["xyz"][si].astype(np.float64) + rng.normal(0, 0.002, (len(si), 3))
+        rc.set_samples(sm)
+        rh = det.generate(rc, len(sm))
+        oh = oracle_mod.search_xyz(p, cl["xyz"], cl["normals"], sm)
+        assert oh.shape == rh.shape and np.array_equal(oh["valid"], rh["valid"]) and rcs.records_equal(oh, rh, rh["valid"].astype(bool)) == [], "samples by coordinates"
+        flat = rh.reshape(-1)
+        flat = flat[flat["valid"].astype(bool)]
+        assert len(flat) > 10
+        for scores in (rng.normal(0, 3, len(flat)).astype(np.float32), np.round(rng.normal(0, 2, len(flat))).astype(np.float32),
+                       np.zeros(len(flat), np.float32)):
+            assert np.array_equal(det.select(scores), oracle_mod.select(scores, nsel)), "selectGrasps"
+            for rm in (False, True):
+                mi = int(rng.randint(1, 4))
+                c, cs = det.find_clusters(flat, scores.astype(np.float64), mi, rm)
+                oc, ocs, _ = oracle_mod.find_clusters(flat, scores.astype(np.float64), mi, rm)
+                assert len(c) == len(oc) and np.array_equal(cs, ocs) and rcs.records_equal(oc, c, np.ones(len(c), bool)) == [], "findClusters"
+        for cloud_h, c in ((rc_gt, gt), (rc, cl)):
+            lab, hh = det.reevaluate(cloud_h, flat)
+            olab, ohh = oracle_mod.reevaluate(p, c["xyz"], c["normals"], flat)
+            assert np.array_equal(lab, olab) and np.array_equal(hh["half_antipodal"], ohh["half_antipodal"]) and \
+                np.array_equal(hh["full_antipodal"], ohh["full_antipodal"]), "reevaluateHypotheses"
+    finally:
+        det.close()
+        rc.close()
+        rc_gt.close()
