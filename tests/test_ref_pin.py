@@ -138,8 +138,8 @@ def _oracle_e2e(oracle_mod, samples, num_selected, min_inliers):
     scores = sel["score"].astype(np.float64)
     if min_inliers > 0:
         c, cs, _ = oracle_mod.find_clusters(sel, scores, min_inliers, False)
-        if len(c) > 3:
-            sel, scores = c, cs
+        # three clusters or fewer: the selected grasps are ADDED to them (grasp_detector.cpp:288-294), not put in their place
+        sel, scores = (c, cs) if len(c) > 3 else (np.concatenate([c, sel]), np.concatenate([cs, scores]))
     order = np.argsort(-scores, kind="stable")
     return sel[order], scores[order]
 
@@ -552,3 +552,57 @@ def test_oracle_matches_live_reference_on_random_preprocessing_and_selection(ora
         det.close()
         rc.close()
         rc_gt.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_E2E", "2"))))
+def test_oracle_matches_live_reference_detectGrasps_on_random_scans(oracle_mod, seed):
+    """configs[0]'s sequence on random inputs: a raw scan off the voxel lattice through the reference's own Cloud preprocessing
+    (workspace, voxeliser, normals) and GraspDetector::detectGrasps (candidates, both filters, images, classifier, selectGrasps,
+    clusters, sort) against the oracle's stages glued as grasp_detector.cpp:192-328 glues them.  GPD_REF_FUZZ_E2E=N widens the draw."""
+    ref = _live()
+    rng = np.random.RandomState(93000 + seed)
+    cl = synth.make_cloud(8000 + seed, int(rng.randint(5000, 9000)), clutter=bool(rng.randint(2)))
+    xyz = (cl["xyz"] + rng.uniform(-0.0012, 0.0012, cl["xyz"].shape)).astype(np.float32)
+    nsel, min_inliers = int(rng.randint(10, 120)), int(rng.choice([0, 0, 1, 2]))
+    use_dir = bool(rng.rand() < 0.4)
+    kw = dict(num_orientations=int(rng.randint(4, 9)))
+    if use_dir:
+        kw.update(direction=[0.0, 0.0, -1.0], thresh_rad=float(rng.uniform(0.8, 1.6)))
+    p = rcs.set_params(oracle_mod.default_params(15), **kw)
+    w = rcs.weights(15, trained_magnitude=True)
+    cfg = dict(num_selected=nsel, min_inliers=min_inliers)
+    if use_dir:
+        cfg.update(filter_approach_direction=1, direction=tuple(kw["direction"]), thresh_rad=kw["thresh_rad"])
+    det = ref.Detector(p, weights=w, **cfg)
+    vp = np.asarray(cl["view_points"], np.float64).reshape(1, 3)
+    rc = ref.Cloud(xyz, None, np.ones((1, len(xyz)), np.int32), vp)
+    try:
+        rc.filter_workspace([-1.0, 1.0, -1.0, 1.0, -1.0, 1.0])
+        rc.voxelize(0.003)
+        rc.calculate_normals(0.03)
+        n = rc.size()
+        samples = np.random.RandomState(seed).permutation(n)[:60].astype(np.int32)
+        rc.set_sample_indices(samples)
+        ref.reset_shadow_seed()
+        ref.set_product_mode(1)
+        rh = det.detect(rc, 4096)
+    finally:
+        ref.set_product_mode(0)
+        det.close()
+        rc.close()
+    vox, src = oracle_mod.voxelize(xyz, 0.003)
+    assert len(vox) == n
+    nrm = oracle_mod.estimate_normals(vox, np.ones((1, len(vox)), np.int32), vp, 0.03)
+    hands, _, _ = oracle_mod.detect(p, vox, nrm, np.ones((1, len(vox)), np.int32), vp, samples, w)
+    flat = hands.reshape(-1)
+    flat = flat[flat["valid"].astype(bool)]
+    keep = oracle_mod.select(flat["score"], nsel)
+    sel = flat[keep]
+    scores = sel["score"].astype(np.float64)
+    if min_inliers > 0:
+        c, cs, _ = oracle_mod.find_clusters(sel, scores, min_inliers, False)
+        # three clusters or fewer: the selected grasps are ADDED to them (grasp_detector.cpp:288-294), not put in their place
+        sel, scores = (c, cs) if len(c) > 3 else (np.concatenate([c, sel]), np.concatenate([cs, scores]))
+    assert len(sel) == len(rh) and len(rh) > 0, (len(sel), len(rh), cfg, kw)
+    key = lambda a, s_: sorted(zip(np.asarray(s_, np.float32).tolist(), map(tuple, a["position"].tolist()), map(tuple, a["frame"].tolist())))
+    assert key(sel, scores) == key(rh, rh["score"]), (cfg, kw)
