@@ -834,6 +834,75 @@ def _cpu_normals_ms():
     return (time.perf_counter() - t0) * 1e3
 
 
+REF_LIVE_SAMPLES = 24  # samples of the in-run timing of the reference's own sources (~90 ms per candidate on one core: ~6 s)
+
+
+def _reference_sources_live(cloud, w, C, si_bench):
+    """oracle/_ref/libgpd_ref.so — the reference's OWN translation units (unmodified, through the test-only Eigen / PCL / OpenCV
+    interface subsets, one thread: its OpenMP loops are racy) — timed HERE, on this host, on the first
+    REF_LIVE_SAMPLES samples of the benchmark's own list: ImageGenerator::createImages + Classifier::classifyImages per candidate,
+    as `value` counts.  None when the library is not in the tree (it is built where /root/reference exists and travels with the
+    snapshot, like the product's own .so files).  Runs in a child process with a time limit: whatever happens inside the
+    reference's code cannot take the line with it."""
+    import subprocess
+    import tempfile
+    from oracle import ref
+    if not ref.available():
+        return None
+    with tempfile.TemporaryDirectory(prefix="gpd_reflive_") as tmp:
+        path = os.path.join(tmp, "in.npz")
+        np.savez(path, C=np.array(C), si=np.ascontiguousarray(si_bench[:REF_LIVE_SAMPLES], np.int32), xyz=cloud["xyz"], normals=cloud["normals"],
+                 cam_source=cloud["cam_source"], view_points=cloud["view_points"], **{"w_" + k: np.asarray(v) for k, v in w.items()})
+        code = "import sys; sys.path.insert(0, %r); import bench; bench._reference_sources_child(%r)" % (ROOT, path)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    for line in r.stdout.splitlines():
+        if line.startswith("@@REF "):
+            return json.loads(line[6:])
+    raise RuntimeError("child rc %s: %s" % (r.returncode, r.stderr[-300:]))
+
+
+def _reference_sources_child(path):
+    """the child of _reference_sources_live: prints one '@@REF {json}' line"""
+    import time
+    import oracle
+    from oracle import ref
+    d = np.load(path)
+    C = int(d["C"])
+    w = {k[2:]: d[k] for k in d.files if k.startswith("w_")}
+    p = oracle.default_params(C)
+    si = d["si"]
+    det = ref.Detector(p, weights=w)
+    rc = ref.Cloud(d["xyz"], d["normals"], d["cam_source"], d["view_points"])
+    try:
+        rc.set_sample_indices(si)
+        t0 = time.perf_counter()
+        det.generate(rc, len(si))
+        t_search = time.perf_counter() - t0
+        valid = det.filter_workspace()
+        n_valid = int(valid.sum())
+        if n_valid == 0:
+            print("@@REF null")
+            return
+        t0 = time.perf_counter()
+        img, _ = det.images(rc, n_valid + 16)
+        t_img = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        det.classify(img)
+        t_cls = time.perf_counter() - t0
+    finally:
+        det.close()
+        rc.close()
+    out = {"kind": "reference", "value": n_valid / (t_img + t_cls), "unit": "candidates/s", "cores": 1,
+           "sample": "measured in this run on this host: the first %d samples of the benchmark's list -> %d candidates; the reference's "
+                     "ImageGenerator::createImages %.2f s + Classifier::classifyImages %.2f s (generateGraspCandidates %.2f s not counted, "
+                     "as in `value`); its own translation units through the test-only Eigen / PCL / OpenCV subsets (plain loops: the "
+                     "reference on the real libraries is faster per core), one thread" % (len(si), n_valid, t_img, t_cls, t_search),
+           "ms_per_candidate": {"images": t_img / n_valid * 1e3, "classify": t_cls / n_valid * 1e3}}
+    sys.stdout.flush()
+    print("@@REF " + json.dumps(out))
+    sys.stdout.flush()
+
+
 def _cpu_baseline(cloud, w, C, si_bench, n_cand_bench, n_samples):
     """The OpenMP oracle on the benchmark's OWN candidate list — the same cloud, the same samples, the first n_cand_bench valid
     hands — when `--cpu-samples` allows it (the default does: ~2 s on a 128-core host), else on the first n_samples samples."""
@@ -850,10 +919,20 @@ def _cpu_baseline(cloud, w, C, si_bench, n_cand_bench, n_samples):
     t = float(times[1] + times[2])
     ref_file = os.path.join(ROOT, "profiles", "r04_ref_cpu_baseline.json")
     ref_own = json.load(open(ref_file)) if os.path.exists(ref_file) else None
+    ref_block = ref_own and dict(ref_own, note="NOT measured in this run: the reference's own translation units (through the test-only "
+                                 "Eigen / PCL / OpenCV subsets, one thread) were not here (oracle/_ref is built where /root/reference exists and "
+                                 "travels with the tree); timed in the build container on this workload's list by profiles/ref_cpu_baseline.py "
+                                 "and committed as profiles/r04_ref_cpu_baseline.json")
+    try:
+        live = _reference_sources_live(cloud, w, C, si_bench)
+    except Exception as e:  # the checker's checker must not cost the line
+        live = None
+        if ref_block is not None:
+            ref_block["live_attempt_failed"] = repr(e)[:200]
+    if live is not None:
+        ref_block = dict(live, committed_full_list=ref_own and {k: ref_own[k] for k in ("value", "sample", "host") if k in ref_own})
     return {"value": n_cand / t, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "reference_sources": ref_own and dict(ref_own, note="NOT measured in this run: the reference's own translation units (through the test-only "
-                                                  "Eigen / PCL / OpenCV subsets, one thread) exist in the build container only; timed there on this "
-                                                  "workload's list by profiles/ref_cpu_baseline.py and committed as profiles/r04_ref_cpu_baseline.json"),
+            "reference_sources": ref_block,
             "sample": "%d samples -> %s%d candidates of the same cloud%s; images %.2fs + LeNet %.2fs (search %.2fs not counted); "
                       "OpenMP CPU restatement (oracle/), not the reference binary"
                       % (n_samples, "the first " if same_list else "", n_cand, " = the list `value` is measured on" if same_list else "", times[1], times[2], times[0])}

@@ -60,6 +60,15 @@ def test_default_line_assembles(oracle_mod):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "candidates/s" and c["cores"] >= 1 and _finite(c["value"]) and c["value"] > 0 and "samples" in c["sample"]
     assert _finite(c["preprocess_ms"]) and _finite(c["normals_ms"])
+    # the reference's own sources beside it: timed in the run where oracle/_ref is in the tree (the build container; the GPU box
+    # when the snapshot carries it), else the committed figure
+    rs = c["reference_sources"]
+    from oracle import ref
+    if ref.available():
+        assert rs["kind"] == "reference" and rs["cores"] == 1 and 0 < rs["value"] < 1000 and "measured in this run" in rs["sample"]
+        assert rs["committed_full_list"]["value"] > 0
+    else:
+        assert "NOT measured in this run" in rs["note"]
     # the batch legs (two clouds per pass here): gpd_hip_detect_batch through the binding's own job arrays
     b = d["batch_end_to_end"]
     assert b["clouds"] == 4 and b["passes"]["n"] == 2 and b["passes"]["clouds_per_pass"] == 2 and b["candidates"] > 0
@@ -132,3 +141,13 @@ def test_smoke_entry_runs_against_the_stand_in(oracle_mod):
             "import __graft_entry__ as g; g.smoke()\n" % (ROOT, os.path.join(ROOT, "tests")))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert p.returncode == 0 and "smoke ok: 60 candidates" in p.stdout, p.stdout[-500:] + p.stderr[-2000:]
+
+
+def test_a_failing_reference_timing_does_not_cost_the_line(oracle_mod):
+    """cpu_baseline.reference_sources is timed in a child process: a reference library that cannot even be loaded (here: a file
+    that is not one) leaves the line intact, the committed figure in its place and the failure on record."""
+    d = _run("--points", "6000", "--candidates", "120", "--steps", "1", "--warmup", "0", "--batch-clouds", "0", "--cpu-samples", "16",
+             GPD_REF_LIB="/bin/true")
+    rs = d["cpu_baseline"]["reference_sources"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert "live_attempt_failed" in rs and "NOT measured in this run" in rs["note"] and rs["value"] > 0
