@@ -20,7 +20,8 @@ rank i mod N, every cloud uploaded, searched, imaged, scored and its candidates 
 (gpd_hip_detect_batch); a step = one pass over the rank's clouds; value = candidates of all ranks / time.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel), "kernels"
-(both stages), "cpu_baseline" (the CPU oracle on a bounded sample, all host cores).
+(both stages), "cpu_baseline" (the CPU oracle on a bounded sample, all host cores — and, where oracle/_ref is in the
+tree, the reference's own sources timed on a few samples of the same list, one core, in a child process).
 """
 import argparse
 import hashlib
