@@ -606,3 +606,34 @@ def test_oracle_matches_live_reference_detectGrasps_on_random_scans(oracle_mod, 
     assert len(sel) == len(rh) and len(rh) > 0, (len(sel), len(rh), cfg, kw)
     key = lambda a, s_: sorted(zip(np.asarray(s_, np.float32).tolist(), map(tuple, a["position"].tolist()), map(tuple, a["frame"].tolist())))
     assert key(sel, scores) == key(rh, rh["score"]), (cfg, kw)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_CAMERAS", "2"))))
+def test_oracle_matches_live_reference_on_camera_rigs(oracle_mod, seed):
+    """15-channel images under rigs of 4-12 cameras (one sees nothing, one only a side): the per-camera shadow sets and their
+    intersection (hand_set.cpp:118-233), the reference's ONE LCG stream over cameras and hand sets, 1-3 hand axes.
+    GPD_REF_FUZZ_CAMERAS=N widens the draw."""
+    ref = _live()
+    rng = np.random.RandomState(95000 + seed)
+    ncam = int(rng.randint(4, 13))
+    cl = synth.make_cloud(9000 + seed, int(rng.randint(4000, 9000)), clutter=bool(rng.randint(2)))
+    cam, vp = rcs._cams(ncam, len(cl["xyz"]), seed)
+    axes = [int(a) for a in rng.permutation(3)[: rng.randint(1, 4)]]
+    p = rcs.set_params(oracle_mod.default_params(15), hand_axes=axes, num_orientations=int(rng.randint(2, 9)))
+    si = synth.sample_indices(cl, 16, seed=seed)
+    det = ref.Detector(p)
+    rc = ref.Cloud(cl["xyz"], cl["normals"], cam, vp)
+    try:
+        rc.set_sample_indices(si)
+        rh = det.generate(rc, len(si))
+        oh = oracle_mod.search(p, cl["xyz"], cl["normals"], si)
+        assert oh.shape == rh.shape and np.array_equal(oh["valid"], rh["valid"]) and rcs.records_equal(oh, rh, rh["valid"].astype(bool)) == []
+        rv = det.filter_workspace()
+        ohf = oracle_mod.filter_workspace(p, oh.copy())
+        assert np.array_equal(rv, ohf["valid"])
+        rimg, rcand = det.images(rc, int(rv.sum()) + 1)
+        oimg, ocand = oracle_mod.images(p, cl["xyz"], cl["normals"], cam, vp, ohf)
+        assert len(rcand) > 0 and np.array_equal(rcand, ocand) and np.array_equal(rimg, oimg), (ncam, axes)
+    finally:
+        det.close()
+        rc.close()
