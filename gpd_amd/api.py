@@ -47,7 +47,7 @@ class DetectJob(C.Structure):
         ("status", C.c_int32), ("stage_ms", C.c_float * 3), ("host_ms", C.c_float * 5), ("allocs", C.c_int32),
         ("reserved_", C.c_int32), ("lcg_base", C.c_uint64), ("lcg_draws", C.c_uint64),
         ("raw", C.c_int32), ("voxel_size", C.c_float), ("workspace", C.c_void_p), ("normals_radius", C.c_double), ("sample_xyz", C.c_void_p),
-        ("num_points_processed", C.c_int32), ("reserved2_", C.c_int32),
+        ("num_points_processed", C.c_int32), ("num_samples_processed", C.c_int32),
     ]
 
 

@@ -722,6 +722,9 @@ int gpd_hip_set_lenet_weights(gpd_hip_ctx *ctx, int channels, const float *conv1
   }
   for (auto &L : ctx->lane)
     if (L.stream) HIP_TRY(hipStreamSynchronize(L.stream));  // no kernel still reads the old weights
+  // from here until every upload has succeeded the context holds NO weights: an update that fails half way (out of memory in
+  // lenet_fast_prepare, say) leaves scoring calls refused with "LeNet weights not set" instead of launching on freed tables
+  ctx->lenet.channels = 0;
   for (auto &it : items) {
     if (*it.dst) (void)hipFree(*it.dst);
     *it.dst = nullptr;
@@ -1215,14 +1218,29 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     }
   };
   std::vector<char> raw_pending((size_t)num_jobs, 0);
+  // a raw scan's samples after Cloud::filterWorkspace (cloud.cpp:225-237): the reference cuts `samples_` with the cloud
+  std::vector<std::vector<double>> raw_samples((size_t)num_jobs);
   // a RAW scan's first half: upload, workspace cut, voxel keys, the keys on their way to the host — nothing waits
   auto begin_raw = [&](int i) {
     gpd_detect_job &j = jobs[i];
     Lane &L = ctx->lane[i % kLanes];
     const int allocs0 = g_allocs;
     j.num_points_processed = 0;
+    j.num_samples_processed = 0;
     int rc = check_samples(ctx, L, "gpd_hip_detect_batch", nullptr, j.sample_xyz, j.num_samples, j.num_points);
-    if (!rc) rc = preprocess_begin(L.pre, j.xyz, j.cam_source, j.num_points, j.num_cams, j.workspace, j.voxel_size, L.stream);
+    if (!rc && j.workspace) {
+      // strict double comparisons on both sides, sample by sample, order kept (cloud.cpp:229-233): a sample outside the cut would
+      // still find neighbours, produce hand sets and shift every later set's shadow LCG offset away from the reference's
+      const double *w = j.workspace;
+      std::vector<double> &keep = raw_samples[(size_t)i];
+      keep.reserve((size_t)j.num_samples * 3);
+      for (int k = 0; k < j.num_samples; k++) {
+        const double *q = j.sample_xyz + 3 * (size_t)k;
+        if (q[0] > w[0] && q[0] < w[1] && q[1] > w[2] && q[1] < w[3] && q[2] > w[4] && q[2] < w[5]) keep.insert(keep.end(), q, q + 3);
+      }
+    }
+    // Cloud::removeNans (candidates_generator.cpp:17) is part of preprocessPointCloud: non-finite points are dropped here
+    if (!rc) rc = preprocess_begin(L.pre, j.xyz, j.cam_source, j.num_points, j.num_cams, j.workspace, j.voxel_size, L.stream, /*drop_nonfinite=*/true);
     j.allocs += g_allocs - allocs0;
     if (rc) return fail(i, rc);
     raw_pending[(size_t)i] = 1;
@@ -1245,8 +1263,9 @@ int gpd_hip_detect_batch(gpd_hip_ctx *ctx, gpd_detect_job *jobs, int num_jobs) {
     if (rc) return fail(i, rc);
     j.num_points_processed = L.pre.M;
     J[i].sample_idx = nullptr;
-    J[i].sample_xyz = j.sample_xyz;
-    J[i].S = j.num_samples;
+    J[i].sample_xyz = j.workspace ? raw_samples[(size_t)i].data() : j.sample_xyz;
+    J[i].S = j.workspace ? (int)(raw_samples[(size_t)i].size() / 3) : j.num_samples;
+    j.num_samples_processed = J[i].S;
     J[i].mode = 1;
     J[i].num_selected = j.num_selected;
     J[i].hands = j.hands;

@@ -117,9 +117,10 @@ struct PreState {
 void preprocess_free(PreState &s);
 // the two halves of preprocess_run (gpd_hip_detect_batch on raw scans puts other clouds' work between them): begin enqueues the
 // upload, the workspace cut, the voxel keys and their way back to pinned memory; finish waits for them, walks the voxeliser's
-// chain on the host and gathers the kept points: s.M of them in s.d_out_xyz [M][3] / s.d_out_cam [cams][M] on the device
+// chain on the host and gathers the kept points: s.M of them in s.d_out_xyz [M][3] / s.d_out_cam [cams][M] on the device.
+// drop_nonfinite: Cloud::removeNans first (cloud.cpp:154-164: a NaN / Inf point is dropped); without it such a cloud is refused
 int preprocess_begin(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
-                     hipStream_t stream);
+                     hipStream_t stream, bool drop_nonfinite);
 int preprocess_finish(PreState &s, hipStream_t stream);
 // workspace: 6 doubles or nullptr; cell <= 0: no voxeliser.  src_out (may be nullptr): input index of every output point.
 // ms (may be nullptr): device time of the kernels.

@@ -48,6 +48,7 @@ constexpr int PP_THREADS = 256;
 struct Workspace {
   double w[6];
   int active;
+  int drop_nonfinite;  // raw scans (Cloud::removeNans, cloud.cpp:154-164): a point with a NaN / Inf coordinate is dropped, not refused
 };
 struct PreMeta {      // device-side results the host reads once
   float lo[3];        // minimum of the points inside the workspace (pcl::getMinMax3D, cloud.cpp:290)
@@ -58,6 +59,7 @@ struct PreMeta {      // device-side results the host reads once
 
 __device__ inline bool inside_ws(const Workspace &W, float x, float y, float z) {
   // float coordinates against double bounds, strict on both sides (cloud.cpp:246-247)
+  if (W.drop_nonfinite && !(isfinite(x) && isfinite(y) && isfinite(z))) return false;
   return !W.active || ((double)x > W.w[0] && (double)x < W.w[1] && (double)y > W.w[2] && (double)y < W.w[3] && (double)z > W.w[4] &&
                        (double)z < W.w[5]);
 }
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(PP_THREADS) void ws_count_kernel(const float *__res
   bool keep = false;
   if (i < n) {
     const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
-    if (!(isfinite(px) && isfinite(py) && isfinite(pz))) atomicOr(&meta->bad, 1);
+    if (!W.drop_nonfinite && !(isfinite(px) && isfinite(py) && isfinite(pz))) atomicOr(&meta->bad, 1);
     keep = inside_ws(W, px, py, pz);
     if (keep) {
       x = px;
@@ -333,7 +335,7 @@ static std::mutex g_ops_mutex;
 // back into pinned memory (all n slots: how many are inside the workspace is only known on the device).  gpd_hip_detect_batch
 // enqueues this for cloud i + 1 BEFORE it waits for anything of cloud i.
 int preprocess_begin(PreState &s, const float *xyz, const int32_t *cam_source, int n, int num_cams, const double *workspace, float cell,
-                     hipStream_t stream) {
+                     hipStream_t stream, bool drop_nonfinite) {
   s.n = n;
   s.num_cams = num_cams;
   s.cell = cell;
@@ -369,6 +371,7 @@ int preprocess_begin(PreState &s, const float *xyz, const int32_t *cam_source, i
   if (!s.ev_keys) HIP_RET(hipEventCreateWithFlags(&s.ev_keys, hipEventDisableTiming));
   Workspace W;
   W.active = workspace != nullptr;
+  W.drop_nonfinite = drop_nonfinite ? 1 : 0;
   for (int a = 0; a < 6; a++) W.w[a] = workspace ? workspace[a] : 0.0;
   PreMeta *meta = static_cast<PreMeta *>(s.d_meta);
   const int blocks = (n + PP_THREADS - 1) / PP_THREADS;
@@ -440,7 +443,7 @@ int preprocess_run(PreState &s, const float *xyz, const int32_t *cam_source, int
   *num_out = 0;
   if (ms) *ms = 0.f;
   if (n == 0) return GPD_OK;
-  int rc = preprocess_begin(s, xyz, cam_source, n, num_cams, workspace, cell, stream);
+  int rc = preprocess_begin(s, xyz, cam_source, n, num_cams, workspace, cell, stream, /*drop_nonfinite=*/false);
   if (!rc) rc = preprocess_finish(s, stream);
   if (rc) {
     (void)hipStreamSynchronize(stream);

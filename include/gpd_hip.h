@@ -251,7 +251,10 @@ int gpd_hip_detect_select(gpd_hip_ctx *ctx, const int32_t *sample_indices, int n
  * reference counterpart: the reference allocates per call. */
 int gpd_hip_reserve(gpd_hip_ctx *ctx, int max_points, int max_cams, int max_samples, int max_candidates, int max_selected);
 
-/* One independent cloud of a batch: the arguments of gpd_hip_upload_cloud + gpd_hip_detect_select. */
+/* One independent cloud of a batch: the arguments of gpd_hip_upload_cloud + gpd_hip_detect_select.
+ * ZERO the struct (memset / `gpd_detect_job j = {0}`) before filling it: fields added in later rounds (lcg_base, raw, voxel_size,
+ * workspace, normals_radius, sample_xyz) are INPUTS, and an uninitialised `raw` or `lcg_base` selects the raw-scan route or
+ * offsets the cloud's shadow stream — wrong images, not an error. */
 typedef struct gpd_detect_job {
   const float *xyz;            /* in */
   const float *normals;
@@ -284,14 +287,18 @@ typedef struct gpd_detect_job {
    * `sample_indices` are ignored (indices into the preprocessed cloud do not exist yet): the search runs at `sample_xyz`
    * (num_samples x 3 doubles, the `samples` route of the reference: cloud.h setSamples, hand_search.cpp:160-165).  The voxelised
    * cloud never leaves the device; the voxeliser's sequential keep / drop chain runs on the calling host thread while the
-   * previous cloud's image / LeNet kernels run.  num_points_processed (out): points after preprocessing. */
+   * previous cloud's image / LeNet kernels run.  num_points_processed (out): points after preprocessing.
+   * As in the reference, the preprocessing starts with Cloud::removeNans (a point with a NaN / Inf coordinate is dropped — the rows
+   * an organised sensor scan carries for missing depth) and Cloud::filterWorkspace cuts the SAMPLES too (cloud.cpp:225-237: strict
+   * double comparisons, order kept): the search runs at the samples inside `workspace` only, num_samples_processed (out) says how
+   * many those were, and the job's records are those of that many samples. */
   int32_t raw;
   float voxel_size;
   const double *workspace;
   double normals_radius;
   const double *sample_xyz;
   int32_t num_points_processed;
-  int32_t reserved2_;
+  int32_t num_samples_processed;
 } gpd_detect_job;
 
 /* detect_grasps over a batch of independent clouds (src/detect_grasps.cpp:20-86 called once per

@@ -232,3 +232,53 @@ def test_raw_krylon_through_the_batch_entry_matches_the_reference():
         assert jobs[1].status == 0 and jobs[1].num_hands > 0
     finally:
         ctx.close()
+
+
+def test_raw_job_cuts_the_samples_and_drops_nan_rows():
+    """ADVICE r5: preprocessPointCloud starts with Cloud::removeNans (candidates_generator.cpp:17) and Cloud::filterWorkspace cuts
+    the SAMPLES with the cloud (cloud.cpp:225-237, strict double comparisons).  A raw job whose samples straddle the workspace and
+    whose scan carries NaN / Inf rows (an organised sensor scan's missing depth) must equal the stepwise route on the cleaned scan
+    with the samples cut by hand — a sample just outside still finds neighbours, and its hand sets would shift every later set's
+    shadow stream."""
+    rng = np.random.RandomState(77)
+    cl = synth.make_cloud(640, 30000)
+    xyz = (cl["xyz"] + rng.uniform(-1e-3, 1e-3, cl["xyz"].shape)).astype(np.float32)
+    obj = np.flatnonzero(cl["is_object"])
+    pick = rng.choice(obj, 200, replace=False)
+    sm = cl["xyz"][pick].astype(np.float64)
+    # the cut runs through the middle of the sampled object along x; one sample sits exactly ON the bound (strict: dropped)
+    xcut = float(np.median(sm[:, 0]))
+    on_bound = int(np.argmin(np.abs(sm[:, 0] - xcut)))
+    xcut = float(sm[on_bound, 0])
+    ws = np.array([-1.0, xcut, -1.0, 1.0, -1.0, 1.0])
+    inside = (sm[:, 0] > ws[0]) & (sm[:, 0] < ws[1]) & (sm[:, 1] > ws[2]) & (sm[:, 1] < ws[3]) & (sm[:, 2] > ws[4]) & (sm[:, 2] < ws[5])
+    assert 40 < inside.sum() < 160 and not inside[on_bound]
+    # NaN / Inf rows scattered through the scan
+    dirty = xyz.copy()
+    bad = rng.choice(len(dirty), 500, replace=False)
+    dirty[bad[:300]] = np.nan
+    dirty[bad[300:400], 2] = np.inf
+    dirty[bad[400:], 0] = -np.inf
+    clean_rows = np.ones(len(dirty), bool)
+    clean_rows[bad] = False
+    cam = np.ones((1, len(xyz)), np.int32)
+    vp = np.zeros((1, 3))
+    w = synth.lenet_weights(15, real=dict(np.load(os.path.join(GOLD, "lenet15_params.npz"))), trained_magnitude=True)
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(w)
+        for ws_job in (ws, None):
+            keep_s = inside if ws_job is not None else np.ones(len(sm), bool)
+            want, n_vox, n_cand = _stepwise(ctx, dict(xyz=np.ascontiguousarray(xyz[clean_rows]), cam_source=cam[:, clean_rows], view_points=vp),
+                                            sm[keep_s], ws_job, 0.003, 0.03)
+            jobs, keep = ctx.raw_batch([dict(xyz=dirty, cam_source=cam, view_points=vp)], [sm], ws_job, 0.003, 0.03)
+            ctx._check(api.lib().gpd_hip_detect_batch(ctx._h, jobs, 1))
+            j = jobs[0]
+            assert j.status == 0 and j.num_samples_processed == int(keep_s.sum()) and j.num_points_processed == n_vox
+            assert j.num_candidates == n_cand and n_cand > 50
+            assert keep[0][5][: j.num_hands].tobytes() == want.tobytes()
+        # the standalone entry still refuses a non-finite cloud (it is filterWorkspace + voxelizeCloud, not removeNans)
+        with pytest.raises(api.GpdHipError):
+            ctx.preprocess_cloud(dirty, cam, None, 0.003)
+    finally:
+        ctx.close()
