@@ -69,7 +69,7 @@ def bind_host_thread(device):
 EXPORTS = ["gpd_hip_default_params", "gpd_hip_create", "gpd_hip_destroy", "gpd_hip_last_error",
            "gpd_hip_set_lenet_weights", "gpd_hip_score", "gpd_hip_upload_cloud", "gpd_hip_search",
            "gpd_hip_images", "gpd_hip_detect", "gpd_hip_last_stage_ms", "gpd_hip_replay", "gpd_hip_replay_times", "gpd_hip_last_images_stats", "gpd_hip_estimate_normals",
-           "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms",
+           "gpd_hip_search_samples", "gpd_hip_detect_samples", "gpd_hip_reevaluate", "gpd_hip_replay_kernel_ms", "gpd_hip_last_centre_chains",
            "gpd_hip_detect_select", "gpd_hip_detect_batch", "gpd_hip_detect_batch_multi", "gpd_hip_conv1_stats", "gpd_hip_last_fallbacks", "gpd_hip_preprocess_cloud", "gpd_hip_find_clusters", "gpd_hip_reserve", "gpd_hip_bind_host_thread",
            "gpd_hip_set_lenet_mode", "gpd_hip_lenet_debug", "gpd_hip_lenet_fast_tables", "gpd_hip_detect_sharded"]
 
@@ -108,6 +108,7 @@ def lib():
         L.gpd_hip_detect_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(DetectJob), C.c_int]
         L.gpd_hip_detect_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(DetectJob)]
         L.gpd_hip_last_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
+        L.gpd_hip_last_centre_chains.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.gpd_hip_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.gpd_hip_replay.argtypes = [C.c_void_p, C.c_int]
         L.gpd_hip_estimate_normals.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
@@ -390,6 +391,13 @@ class Context:
         self._check(lib().gpd_hip_last_fallbacks(self._h, _ptr(out)))
         return dict(neighbourhood_list_capacity=int(out[0]), large_shadow_kernel_candidates=int(out[1]),
                     large_points_kernel_candidates=int(out[2]), lenet_passes=int(out[3]))
+
+    def centre_chains(self):
+        """(sample, coordinate) pairs of the last search whose neighbourhood centre took the serial fp64 chain (the order-free sum
+        inside the neighbourhood kernel could not be certified exact)."""
+        out = C.c_longlong(0)
+        self._check(lib().gpd_hip_last_centre_chains(self._h, C.byref(out)))
+        return int(out.value)
 
     def find_clusters(self, hands, scores, min_inliers=1, remove_inliers=False):
         """Clustering::findClusters on the device -> (cluster records, scores f64, seed index)."""

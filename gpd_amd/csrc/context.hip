@@ -1702,6 +1702,22 @@ int gpd_hip_last_fallbacks(gpd_hip_ctx *ctx, long long out[4]) {
   return GPD_OK;
 }
 
+int gpd_hip_last_centre_chains(gpd_hip_ctx *ctx, long long *out) {
+  if (!ctx || !out) return GPD_ERR_INVALID;
+  HIP_TRY(hipSetDevice(ctx->device));
+  Lane &L = ctx->lane[0];
+  HIP_TRY(hipStreamSynchronize(L.stream));
+  *out = 0;
+  const int S = L.search.num_samples;
+  if (S <= 0 || !L.search.d_counts) return GPD_OK;
+  std::vector<int32_t> h((size_t)S * 8);
+  HIP_TRY(hipMemcpy(h.data(), L.search.d_counts, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  long long n = 0;
+  for (int i = 0; i < S; i++) n += __builtin_popcount((unsigned)h[(size_t)8 * i + 5] & 7u);
+  *out = n;
+  return GPD_OK;
+}
+
 int gpd_hip_last_stage_ms(gpd_hip_ctx *ctx, float ms[3]) {
   if (!ctx || !ms) return GPD_ERR_INVALID;
   for (int i = 0; i < 3; i++) ms[i] = ctx->lane[0].stage_ms[i];

@@ -494,6 +494,19 @@ __device__ void eigen3(double m00, double m10, double m11, double m20, double m2
 // ---------------------------------------------------------------------------
 // neighbourhood_kernel
 // ---------------------------------------------------------------------------
+// Is the fp64 sum of n floats exact in every order?  emin / emax: smallest / largest biased exponent among the non-zero addends
+// (denormals count as exponent 1; no non-zero addend: emin = 255 > emax = 0).  Every addend is a multiple of 2^(emin - 150) and
+// below 2^(emax - 126) in magnitude, so every partial sum of every subset is a multiple of the former below n 2^(emax - 126);
+// fp64 holds every multiple of 2^L below 2^(L + 53): exact when ceil(log2 n) + emax - 126 <= emin - 150 + 53.  One more bit is
+// left as margin; infinities / NaNs (emax = 255) never pass.
+__host__ __device__ inline bool centre_exact(int emin, int emax, int n) {
+  if (emax == 0) return true;  // nothing but zeros
+  if (emax >= 255) return false;
+  int lg = 0;
+  while ((1ll << lg) < (long long)n) lg++;
+  return lg + emax - emin <= 28;
+}
+
 struct NbParams {
   const float *px, *py, *pz, *nx, *ny, *nz;
   const float4 *pxyz, *pnrm;  // AoS copies: one 16-byte load per random access
@@ -577,6 +590,8 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   __shared__ int s_count;
   __shared__ int s_bounds[3];
   __shared__ int s_seen;
+  __shared__ double s_csum[NB_WAVES][3];  // centre of the image neighbourhood: the waves' partial sums ...
+  __shared__ int s_cexp[NB_WAVES][6];     // ... and the smallest / largest biased exponent among their non-zero addends
   __shared__ double s_hl_axis[4];  // height list: hand axis of slot 0 and the limit h + margin (published by the frame wave)
   __shared__ int s_hl_ready, s_hl_next, s_hl_count;
   __shared__ int s_ncrowd;
@@ -1185,6 +1200,27 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
   // then asks for the next points waits for its 14 store acknowledgements before it sees them.  The first camera's
   // flag comes with the coordinates (pxyz.w).
   constexpr int GT = NB_THREADS;  // every wave gathers
+  // Centre of the image neighbourhood (HandSet::calculateShadow, hand_set.cpp:131-133: points.rowwise().sum() / size; the oracle
+  // defines the sum sequentially in neighbour order, Eigen reduces in packets).  The addends are floats: when every addend is
+  // a multiple of 2^L and n x max|x| < 2^(L + 53), EVERY partial sum of EVERY summation order is exact in fp64 — the
+  // sequential chain, Eigen's, and the order-free one taken here on the way (each thread its entries, then the waves, then
+  // the workgroup).  The certificate is two exponents per coordinate (see centre_exact); a sample that fails it — a point within
+  // micrometres of a coordinate plane among points decimetres away — is flagged and gets its serial chain from centre_kernel.
+  // (That kernel used to walk all 3 S chains from the gathered rows: 93 MB read back, 0.12-0.13 ms on a side stream.)
+  double csum[3] = {0.0, 0.0, 0.0};
+  int cemin[3] = {255, 255, 255}, cemax[3] = {0, 0, 0};
+  auto centre_add = [&](const float4 &a) {
+    const float v[3] = {a.x, a.y, a.z};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      csum[c] += (double)v[c];
+      const int e = (int)((__float_as_uint(v[c]) >> 23) & 0xffu);
+      const bool nz = (__float_as_uint(v[c]) & 0x7fffffffu) != 0u;
+      const int el = e ? e : 1;  // a denormal's ulp is that of exponent 1
+      cemin[c] = nz && el < cemin[c] ? el : cemin[c];
+      cemax[c] = nz && el > cemax[c] ? el : cemax[c];
+    }
+  };
   struct Rnd {
     int t0, i0, i1, c0, c1;
     float4 a0, b0, a1, b1;
@@ -1211,7 +1247,10 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       on[3 * P.cap + t0] = r.b0.x;
       on[4 * P.cap + t0] = r.b0.y;
       on[5 * P.cap + t0] = r.b0.z;
-      if (t0 < n_img) seen |= (int)(r.c0 != 0);
+      if (t0 < n_img) {
+        seen |= (int)(r.c0 != 0);
+        centre_add(r.a0);
+      }
     }
     if (two) {
       on[0 * P.cap + t1] = r.a1.x;
@@ -1220,7 +1259,10 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
       on[3 * P.cap + t1] = r.b1.x;
       on[4 * P.cap + t1] = r.b1.y;
       on[5 * P.cap + t1] = r.b1.z;
-      if (t1 < n_img) seen |= (int)(r.c1 != 0);
+      if (t1 < n_img) {
+        seen |= (int)(r.c1 != 0);
+        centre_add(r.a1);
+      }
     }
     for (int cam = 1; cam < P.num_cams; cam++) {  // further cameras: not pipelined
       if (one && t0 < n_img) seen |= (int)((unsigned)(P.cam_source[(size_t)cam * P.num_points + r.i0] != 0) << cam);
@@ -1262,6 +1304,25 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     }
   }
   if (seen) atomicOr(&s_seen, seen);
+  {  // the wave's share of the centre sums (exact under the certificate, discarded otherwise)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        csum[c] += __shfl_xor(csum[c], o);
+        cemin[c] = min(cemin[c], __shfl_xor(cemin[c], o));
+        cemax[c] = max(cemax[c], __shfl_xor(cemax[c], o));
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        s_csum[tid >> 6][c] = csum[c];
+        s_cexp[tid >> 6][c] = cemin[c];
+        s_cexp[tid >> 6][3 + c] = cemax[c];
+      }
+    }
+  }
   NTICK(6);
   if (late) {
     // 5'. the frame from the sorted list (more than FCAP points inside the frame radius), then the height list as a pass
@@ -1303,18 +1364,34 @@ __global__ __launch_bounds__(NB_THREADS) void neighbourhood_kernel(NbParams P) {
     P.counts[8 * s + 4] = s_seen;
     if (P.hl) P.counts[8 * s + 6] = s_hl_count;
   }
+  if (tid < 3) {
+    double acc = 0.0;
+    int emin = 255, emax = 0;
+    for (int w = 0; w < NB_WAVES; w++) {
+      acc += s_csum[w][tid];
+      emin = min(emin, s_cexp[w][tid]);
+      emax = max(emax, s_cexp[w][tid + 3]);
+    }
+    const bool exact = centre_exact(emin, emax, n_img);
+    if (exact) P.centers[3 * (size_t)s + tid] = n_img > 0 ? acc / (double)n_img : 0.0;
+    // counts[8 s + 5]: bit c set -> coordinate c of the centre still needs its serial chain (centre_kernel)
+    const unsigned long long todo = __ballot(!exact);
+    if (tid == 0) P.counts[8 * s + 5] = (int)(todo & 7ull);
+  }
 #undef NTICK
 }
 
 // centre of the image neighbourhood (HandSet::calculateShadow, hand_set.cpp:131-133): sequential
 // fp64 sums in neighbour order.  The chain is serial, so one LANE per (sample, coordinate) walks it
 // and the whole batch runs side by side (inside neighbourhood_kernel the three chains of a sample
-// kept a 256-thread workgroup waiting: 390 of its 1320 us).
+// kept a 256-thread workgroup waiting: 390 of its 1320 us).  Since round 6 only for the (sample, coordinate) pairs whose
+// sum neighbourhood_kernel could not certify as exact in every order (counts[8 s + 5]): on the benchmark clouds none.
 __global__ __launch_bounds__(64) void centre_kernel(const float *__restrict__ nn, const int32_t *__restrict__ counts, int cap,
                                                     int num_samples, double *__restrict__ centers) {
   const int g = blockIdx.x * 64 + threadIdx.x;
   if (g >= 3 * num_samples) return;
   const int s = g / 3, c = g - 3 * s;
+  if (!((counts[8 * s + 5] >> c) & 1)) return;  // neighbourhood_kernel's order-free sum was exact: the centre is written
   const int n_img = counts[8 * s + 1];
   const float *row = nn + ((size_t)s * 6 + c) * cap;
   double acc = 0.0;

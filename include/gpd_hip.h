@@ -357,6 +357,13 @@ int gpd_hip_last_images_stats(gpd_hip_ctx *ctx, long long out[4]);
  * each).  Waits for the context's stream. */
 int gpd_hip_last_fallbacks(gpd_hip_ctx *ctx, long long out[4]);
 
+/* Of the last search's 3 x num_samples centre coordinates (the mean of a sample's image neighbourhood, hand_set.cpp:131-133):
+ * how many took the serial fp64 chain in neighbour order because the order-free sum taken inside the neighbourhood kernel could
+ * not be certified exact (a point within micrometres of a coordinate plane among points decimetres away).  Wherever the
+ * certificate holds the sum is the same in EVERY order — the oracle's sequential one and Eigen's packet reduction alike.
+ * Measurement / tests only.  Waits for the context's stream. */
+int gpd_hip_last_centre_chains(gpd_hip_ctx *ctx, long long *out);
+
 /* Re-run stage 3 (stages == 1: grasp images), stage 4 (2: LeNet) or both (3) on the
  * candidate list that the last gpd_hip_images / gpd_hip_detect left resident on the
  * device — what calling ImageGenerator::createImages + Classifier::classifyImages
