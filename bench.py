@@ -12,8 +12,8 @@ timed region: `detect_end_to_end` (one gpd_hip_detect call, host buffers in and 
 `batch_end_to_end` (gpd_hip_detect_batch over a few clouds per rank: upload + search + filter + images +
 LeNet + records back, two clouds in flight) — the product path, whole job over all ranks.
 
---config {2,3a,3b,4} selects the other single-GPU BASELINE configs (3a/3b: 3 / 12 channels on the same
-cloud, 4: 300k-point clutter cloud, 50000 candidates).
+--config {2,2o,3a,3b,4} selects the other single-GPU BASELINE configs (3a/3b: 3 / 12 channels on the same
+cloud, 4: 300k-point clutter cloud, 50000 candidates; 2o: configs[1]'s cloud with sensor-like, off-lattice coordinates).
 
 --mode batch: BASELINE configs[4] end to end — `--clouds` synthetic 30k-point clouds (default 256), cloud i ->
 rank i mod N, every cloud uploaded, searched, imaged, scored and its candidates returned to the host
@@ -124,6 +124,10 @@ CONFIGS = {  # BASELINE.json configs[1..3]
     "3a": dict(points=30000, candidates=5000, channels=3, clutter=False),
     "3b": dict(points=30000, candidates=5000, channels=12, clutter=False),
     "4": dict(points=300000, candidates=50000, channels=15, clutter=True),
+    # configs[1]'s scene with sensor-like coordinates (synth.off_lattice: every point moved by a seeded sub-voxel offset) — the side
+    # line on which the reference's unpinned third-party behaviours (FLANN's order among equal distances, ulp-level eigen-solver
+    # differences) do not decide outputs; pinned against the reference's own sources by ref_pin_offlattice_*.npz
+    "2o": dict(points=30000, candidates=5000, channels=15, clutter=False, off_lattice=True),
 }
 
 
@@ -355,6 +359,8 @@ def main():
 
     # --- replay mode.  Workload: one cloud per rank (seed 1234 + rank), first `candidates` valid hands
     cloud = synth.make_cloud(1234 + rank, points, clutter=clutter)
+    if preset.get("off_lattice"):
+        cloud = synth.off_lattice(cloud)
     ctx.upload_cloud(cloud["xyz"], cloud["normals"], cloud["cam_source"], cloud["view_points"])
     n_samples = min(int(candidates / 2.0) + 64, int(cloud["is_object"].sum()))
     si = synth.sample_indices(cloud, n_samples)
@@ -476,8 +482,9 @@ def main():
             "value": value, "unit": "candidates/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-            "config": {"workload": "single %dk-point synthetic %scloud per GPU (seed 1234+rank), first %d valid candidates, %d-channel LeNet"
-                       % (points // 1000, "clutter " if clutter else "", n_cand, C), "points": points, "candidates_per_gpu": n_cand,
+            "config": {"workload": "single %dk-point synthetic %scloud per GPU (seed 1234+rank%s), first %d valid candidates, %d-channel LeNet"
+                       % (points // 1000, "clutter " if clutter else "", ", coordinates moved off the 3 mm lattice by a seeded sub-voxel offset" if preset.get("off_lattice") else "",
+                          n_cand, C), "points": points, "candidates_per_gpu": n_cand,
                        "samples": int(n_samples), "channels": C, "sharding": "one cloud per GPU, no collective"},
             "roofline": roofline, "kernels": kernels, "pmc_traffic": traffic,
             "fallbacks": fallbacks,

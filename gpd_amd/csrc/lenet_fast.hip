@@ -346,41 +346,47 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
     __syncthreads();  // the pieces are complete, the raw region is free, s_nxt is visible
     const int nxt = s_nxt;
     const uint4 *nsrc = reinterpret_cast<const uint4 *>(pool1 + (size_t)(nxt < n ? nxt : img) * (784 * 20));
+    // the fragments of k-step ks live in a_buf[ks & 1]: the next step's are requested before this step's MFMAs — and behind a
+    // tile's last step the FIRST step of the wave's next tile (round 6: the tile used to start by asking for them and waiting,
+    // an LDS round trip per tile in which both waves of the SIMD, running in step, left the matrix pipe idle)
+    bf16x8 a_buf[2][3];
+    auto tile_base = [&](int tt) {
+      const int T = half * 18 + tt, rp = T / 3, xt = T - 3 * rp;
+      return s_img + (2 * rp) * F2_RS + (8 * xt) * 40;
+    };
+    // the two 8-byte reads of k-step ks for piece pc of the tile at `base`
+    auto frag = [&](const uint8_t *base, int ks, int pc) -> bf16x8 {
+      uint2 v[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int e = ks + 16 * h;
+        const uint8_t *a = e < 25 ? base + off_x + (e / 5) * F2_RS + (e % 5) * 8
+                           : e < 30 ? base + off_y + (e - 25) * 8
+                           : e == 30 ? base + off_z
+                                     : base + off_w;
+        // (volatile: keeps the two halves two ds_read_b64 — merged into ds_read2_b64 they run at half the LDS rate and on
+        //  the 32-bank rule, and their results have to be re-sorted into the operand registers)
+        typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
+        const unsigned long long t = *(lds_u64)(a + pc * F2_PP);
+        v[h] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
+      }
+      return as_bf16x8(make_uint4(v[0].x, v[0].y, v[1].x, v[1].y));
+    };
+#pragma unroll
+    for (int pc = 0; pc < 3; pc++) a_buf[0][pc] = frag(tile_base(0), 0, pc);
+#pragma unroll 1
     for (int tt = 0; tt < 18; tt++) {
       const int piece = tt * F2_THREADS + tid;
       const bool has_piece = nxt < n && piece < F2_RAW / 16;
       uint4 stage = make_uint4(0, 0, 0, 0);
       if (has_piece) stage = nsrc[piece];
       const int T = half * 18 + tt, rp = T / 3, xt = T - 3 * rp;
-      const uint8_t *base = s_img + (2 * rp) * F2_RS + (8 * xt) * 40;
-      // the two 8-byte reads of k-step ks for piece pc
-      auto frag = [&](int ks, int pc) -> bf16x8 {
-        uint2 v[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int e = ks + 16 * h;
-          const uint8_t *a = e < 25 ? base + off_x + (e / 5) * F2_RS + (e % 5) * 8
-                             : e < 30 ? base + off_y + (e - 25) * 8
-                             : e == 30 ? base + off_z
-                                       : base + off_w;
-          // (volatile: keeps the two halves two ds_read_b64 — merged into ds_read2_b64 they run at half the LDS rate and on
-          //  the 32-bank rule, and their results have to be re-sorted into the operand registers)
-          typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
-          const unsigned long long t = *(lds_u64)(a + pc * F2_PP);
-          v[h] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
-        }
-        return as_bf16x8(make_uint4(v[0].x, v[0].y, v[1].x, v[1].y));
-      };
+      const uint8_t *base = tile_base(tt), *base_next = tile_base(tt < 17 ? tt + 1 : tt);  // (the last tile re-reads itself: unused)
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // two chains (even / odd terms), added at the end
-      bf16x8 a_buf[2][3];  // the fragments of k-step ks live in a_buf[ks & 1]: the next step's are requested before this step's MFMAs
-#pragma unroll
-      for (int pc = 0; pc < 3; pc++) a_buf[0][pc] = frag(0, pc);
 #pragma unroll
       for (int ks = 0; ks < 16; ks++) {
-        if (ks + 1 < 16) {
 #pragma unroll
-          for (int pc = 0; pc < 3; pc++) a_buf[(ks + 1) & 1][pc] = frag(ks + 1, pc);
-        }
+        for (int pc = 0; pc < 3; pc++) a_buf[(ks + 1) & 1][pc] = ks + 1 < 16 ? frag(base, ks + 1, pc) : frag(base_next, 0, pc);
 #pragma unroll
         for (int term = 0; term < 6; term++) {
           // (activation piece, weight piece): l*h, h*l, m*m, m*h, h*m, h*h — small terms first

@@ -137,6 +137,18 @@ def sample_indices(cloud, num_samples, seed=None):
 TRAINED_IP1_DIVISOR = 128.0  # ip1 / 128: logits of the size a trained LeNet produces (|score| < 20) on real grasp images
 
 
+def off_lattice(cloud, seed=7, amplitude=0.0012):
+    """The same scene with sensor-like coordinates: every point of a lattice cloud moved by a seeded offset of up to
+    `amplitude` (< half a 3 mm voxel) per axis, float32.  On the lattice neighbours tie in distance by the hundred and points lie
+    exactly on the hand's decision planes, so bit-agreement with the real third-party libraries hangs on FLANN's order among
+    equal distances and on ulp-level eigen-solver differences (profiles/r05_thirdparty_sensitivity.txt); off the
+    lattice those boundaries stop deciding outputs.  Normals, cameras and the object mask are kept."""
+    rng = np.random.RandomState(seed)
+    out = dict(cloud)
+    out["xyz"] = (cloud["xyz"].astype(np.float64) + rng.uniform(-amplitude, amplitude, cloud["xyz"].shape)).astype(np.float32)
+    return out
+
+
 def lenet_weights(channels=15, seed=42, real=None, trained_magnitude=False):
     """LeNet parameters in the reference's file layouts (eigen_classifier.cpp:28-50).
     `real`: optional dict with the reference's conv1/conv2/ip2 parameters; ip1

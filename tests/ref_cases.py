@@ -79,19 +79,27 @@ VARIANTS = {
     "two_cameras": (15, {}, 2),
     "three_cameras": (15, {}, 3),
     "twelve_cameras": (15, {}, 12),  # the reference's camera_source has no bound on its rows (cloud.h); the kernels take 32
+    # (round 6) the same scene with sensor-like coordinates (synth.off_lattice: every point moved by a seeded sub-voxel offset): no
+    # distance ties, no point exactly on a decision plane — where the unpinned third-party behaviours (FLANN's tie order, ulp-level
+    # eigen-solver differences) stop deciding outputs (profiles/r05_thirdparty_sensitivity.txt)
+    "offlattice_c15": (15, {}, 1),
+    "offlattice_c3": (3, {}, 1),
+    "offlattice_two_cameras": (15, {}, 2),
+    "offlattice_three_axes": (15, dict(hand_axes=[0, 1, 2]), 1),
 }
-FULL_IMAGES = ("default_c15", "default_c12", "default_c3", "default_c1", "two_cameras")  # the others are pinned by digest
+FULL_IMAGES = ("default_c15", "default_c12", "default_c3", "default_c1", "two_cameras", "offlattice_c15")  # the others are pinned by digest
 
 
-def cloud():
-    return synth.make_cloud(CLOUD_SEED, CLOUD_POINTS)
+def cloud(name=""):
+    cl = synth.make_cloud(CLOUD_SEED, CLOUD_POINTS)
+    return synth.off_lattice(cl) if name.startswith("offlattice") else cl
 
 
 def case_inputs(name, default_params):
     """(params, cloud dict, sample indices, cam_source, view_points) of a variant; `default_params(channels)` builds the
     parameter block of whoever runs the case (oracle.default_params / api.default_params: same fields)."""
     C, over, ncam = VARIANTS[name]
-    cl = cloud()
+    cl = cloud(name)
     si = synth.sample_indices(cl, NUM_SAMPLES)
     p = set_params(default_params(C), **over)
     if ncam == 1:

@@ -45,6 +45,16 @@ def test_config2_30k_cloud_5000_candidates(oracle_mod, cloud30k):
     assert n > 4500
 
 
+def test_config2_off_lattice(oracle_mod, cloud30k):
+    """configs[1]'s scene with sensor-like coordinates (synth.off_lattice, bench.py --config 2o): every point off the 3 mm
+    lattice — no distance ties, no point exactly on a decision plane — ~5000 candidates, full oracle comparison.  The small
+    version of this cloud is pinned against the reference's own sources (ref_pin_offlattice_*.npz)."""
+    cl = synth.off_lattice(cloud30k)
+    si = synth.sample_indices(cl, 2200)
+    n, err = _full_compare(oracle_mod, cl, si, 15)
+    assert n > 4000
+
+
 @pytest.mark.parametrize("C", [1, 3, 12])
 def test_config3_other_image_geometries(oracle_mod, cloud30k, C):
     """configs[2]: 3- and 12-channel geometries on the same cloud."""
