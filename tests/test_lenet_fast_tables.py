@@ -76,7 +76,7 @@ def _pool(h):
     return h.reshape(F, H // 2, 2, W // 2, 2).max(axis=(2, 4))
 
 
-@pytest.mark.parametrize("channels", [15, 3])
+@pytest.mark.parametrize("channels", [15, 12, 3, 1])
 def test_conv1_tables_and_index_arithmetic(channels):
     rng = np.random.RandomState(5)
     w = synth.lenet_weights(channels, seed=7)
@@ -96,28 +96,58 @@ def test_conv1_tables_and_index_arithmetic(channels):
         assert corr[f] == 128.0 * Wi.sum()
     img = rng.randint(0, 256, (channels, 60, 60)).astype(np.uint8)
     img[:, 10:30, 5:50] = 0
-    img[2] = 255
-    # LDS image: pixel-major, 72 pixels per row, 16 bytes per pixel, x ^ 0x80
-    P = 72
-    hwc = np.zeros((60 * P * 16 + 4096,), np.int8)
+    img[min(2, channels - 1)] = 255
     v = (img.astype(np.int16) - 128).astype(np.int8)  # == x ^ 0x80 as int8
-    for c in range(channels):
-        for y in range(60):
-            hwc[(y * P + np.arange(60)) * 16 + c] = v[c, y]
     lanes = np.arange(64)
     j, q = lanes & 15, lanes >> 4
     m_row, m_x = (j >> 1) & 1, 2 * (j >> 2) + (j & 1)
-    kyg = np.array([0, 2, 1, 3])[q]
-    lane_off = (m_row * P + m_x) * 16
+    narrow = channels <= 4
+    if narrow:
+        # LDS image (round 6, C <= 4): four-byte pixels, 68 per row, FOUR copies, copy s shifted by s pixels; what lies beyond column 59
+        # (and the padding bytes) is never initialised by the kernel: poison it, its weights must be zero
+        P, COPY = 68, 60 * 68 * 4
+        hwc = np.full((4 * COPY + 4096,), 77, np.int8)
+        for sft in range(4):
+            for c in range(channels):
+                for y in range(60):
+                    hwc[sft * COPY + (y * P + np.arange(60) + sft) * 4 + c] = v[c, y]
+        n_shift = (4 - (m_x & 3)) & 3
+        lane_off = n_shift * COPY + (m_row * P + m_x + n_shift) * 4
+
+        def slot(ks, g):  # lenet_fast.hip f1n_slot
+            sl = 4 * ks + g
+            return 2 * sl if sl < 5 else (2 * (sl - 5) + 1 if sl < 10 else -1)
+        n_slot = np.zeros((3, 64), np.int64)
+        for ks in range(3):
+            for g in range(4):
+                sl = slot(ks, g)
+                n_slot[ks, q == g] = 0 if sl < 0 else ((sl >> 1) * P + 4 * (sl & 1)) * 4
+        assert (atab[3:] == 0).all()
+        n_ks = 3
+    else:
+        # LDS image: pixel-major, 72 pixels per row, 16 bytes per pixel, x ^ 0x80
+        P = 72
+        hwc = np.zeros((60 * P * 16 + 4096,), np.int8)
+        for c in range(channels):
+            for y in range(60):
+                hwc[(y * P + np.arange(60)) * 16 + c] = v[c, y]
+        kyg = np.array([0, 2, 1, 3])[q]
+        lane_off = (m_row * P + m_x) * 16
+        n_ks = 7
     out = np.zeros((28, 28, 20), np.float32)
     bias = w["c1b"]
     for t in range(196):
         trow, tcol = divmod(t, 7)
-        base = ((2 * trow) * P + 8 * tcol) * 16 + lane_off
-        pa, pb, pc = base + kyg * P * 16, base + 4 * P * 16 + q * 16, base + 4 * P * 16 + 64
-        addr = [pa + ks * 16 for ks in range(5)] + [pb, pc]
+        if narrow:
+            base = ((2 * trow) * P + 8 * tcol) * 4 + lane_off
+            assert (base % 16 == 0).all()  # every window is 16-byte aligned in the lane's copy
+            addr = [base + n_slot[ks] for ks in range(3)]
+        else:
+            base = ((2 * trow) * P + 8 * tcol) * 16 + lane_off
+            pa, pb, pc = base + kyg * P * 16, base + 4 * P * 16 + q * 16, base + 4 * P * 16 + 64
+            addr = [pa + ks * 16 for ks in range(5)] + [pb, pc]
         acc = np.zeros((5, 64, 4))
-        for ks in range(7):
+        for ks in range(n_ks):
             B = np.stack([hwc[a:a + 16] for a in addr[ks]])
             for mt in range(5):
                 acc[mt] += _mfma(atab[ks, mt], B)  # weights are the A operand (rows), pixels the B operand (columns)
