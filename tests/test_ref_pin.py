@@ -451,14 +451,13 @@ def _random_geometry(seed):
     return kw, rng
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_GEOMETRY", "4"))))
-def test_oracle_matches_live_reference_on_random_geometry(oracle_mod, seed):
-    """The reference's own code under arbitrary-double geometry (finger table, deepen steps, box extents, cell thresholds):
-    hands, filter, images of 1 / 3 / 12 / 15 channels.  GPD_REF_FUZZ_GEOMETRY=N widens the draw."""
+def _geometry_case(oracle_mod, seed, off_lattice):
     ref = _live()
     kw, rng = _random_geometry(seed)
     C = int(rng.choice([15, 15, 12, 3, 1]))
     cl = synth.make_cloud(3000 + seed, int(rng.randint(4000, 10000)), clutter=bool(rng.randint(2)))
+    if off_lattice:  # sensor-like coordinates: every point moved by a seeded offset of up to 0.2 - 1.4 mm per axis
+        cl = synth.off_lattice(cl, seed=seed, amplitude=float(rng.uniform(0.0002, 0.0014)))
     si = synth.sample_indices(cl, 24, seed=seed)
     p = rcs.set_params(oracle_mod.default_params(C), **kw)
     ncam = 1 + seed % 3
@@ -480,6 +479,21 @@ def test_oracle_matches_live_reference_on_random_geometry(oracle_mod, seed):
     finally:
         det.close()
         rc.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_GEOMETRY", "4"))))
+def test_oracle_matches_live_reference_on_random_geometry(oracle_mod, seed):
+    """The reference's own code under arbitrary-double geometry (finger table, deepen steps, box extents, cell thresholds):
+    hands, filter, images of 1 / 3 / 12 / 15 channels.  GPD_REF_FUZZ_GEOMETRY=N widens the draw."""
+    _geometry_case(oracle_mod, seed, False)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_OFFLATTICE", "3"))))
+def test_oracle_matches_live_reference_off_the_lattice(oracle_mod, seed):
+    """(round 6) The same draw on clouds with sensor-like coordinates (synth.off_lattice): no distance ties, no point exactly on a
+    decision plane — the regime in which the unpinned third-party behaviours stop deciding outputs.
+    GPD_REF_FUZZ_OFFLATTICE=N widens the draw."""
+    _geometry_case(oracle_mod, 500000 + seed, True)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_REF_FUZZ_ROWS", "3"))))
