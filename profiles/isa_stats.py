@@ -3,7 +3,7 @@
 (no GPU needed): VGPR / AGPR / SGPR counts, LDS bytes, scratch bytes, spills, the waves per SIMD those allow at the
 kernel's launch size, and how many matrix instructions of which kind the body holds.
 
-    python profiles/isa_stats.py > profiles/r05_isa_stats.txt        (after `make` in gpd_amd/csrc)
+    python profiles/isa_stats.py > profiles/r06_isa_stats.txt        (after `make` in gpd_amd/csrc)
 
 tests/test_isa_resources.py reads the same numbers: no kernel of the scoring path spills or touches scratch, the
 LDS budgets are the ones DESIGN.md states.

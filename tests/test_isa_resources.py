@@ -1,5 +1,5 @@
 """Static resources of the gfx950 kernels, read from the code objects the build leaves in gpd_amd/csrc/*.o (no GPU):
-what DESIGN.md says about registers, LDS and scratch is what the compiler produced, and profiles/r05_isa_stats.txt is the
+what DESIGN.md says about registers, LDS and scratch is what the compiler produced, and profiles/r06_isa_stats.txt is the
 listing of the sources as committed."""
 import importlib.util
 import io
@@ -39,7 +39,10 @@ def test_split_kernels_hold_the_matrix_instructions_the_bench_prices(isa):
     tile / k-step are the ones in the code objects (nothing unrolled twice, nothing dropped)."""
     _, k = isa
     for C in (15, 12, 3, 1):
-        assert k["gpd::conv1_i8_kernel<%d>" % C]["matrix"] == {"v_mfma_i32_16x16x64_i8": 7 * 5}  # F1_KS x F1_MT per tile
+        ks = 3 if C <= 4 else 7  # F1N_KS (four-byte pixels, round 6) / F1_KS k-steps x F1_MT row tiles per pixel tile
+        assert k["gpd::conv1_i8_kernel<%d>" % C]["matrix"] == {"v_mfma_i32_16x16x64_i8": ks * 5}
+        import bench
+        assert bench.lenet_mfma_work(C)["conv1_i8_kernel"]["executed"] == 196 * ks * 5 * 32768.0
     assert k["gpd::conv2_bf16_kernel"]["matrix"] == {"v_mfma_f32_16x16x32_bf16": 16 * 6}  # k-steps x piece products per pixel tile and wave
     for nt in (1, 2, 3, 4, 5):
         assert k["gpd::fc1_bf16_kernel<%d>" % nt]["matrix"] == {"v_mfma_f32_16x16x32_bf16": nt * 4 * 6}  # m-tiles x n-tiles x pieces per BK
@@ -62,5 +65,5 @@ def test_committed_listing_is_of_the_committed_sources(isa):
     buf = io.StringIO()
     with redirect_stdout(buf):
         mod.main()
-    want = open(os.path.join(ROOT, "profiles", "r05_isa_stats.txt")).read()
-    assert buf.getvalue() == want, "kernels changed: python profiles/isa_stats.py > profiles/r05_isa_stats.txt"
+    want = open(os.path.join(ROOT, "profiles", "r06_isa_stats.txt")).read()
+    assert buf.getvalue() == want, "kernels changed: python profiles/isa_stats.py > profiles/r06_isa_stats.txt"
