@@ -537,26 +537,15 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
       for (int i = 0; i < X_PT; i++) x2[pc * X_PT + i] = *reinterpret_cast<const u32x4 *>(xsrc[i] + pc * xs_plane + k0);
     }
   };
-  // one 16-byte store of the staged tile: piece pc, W load i (kind 0) or X load i (kind 1).  Branch-free where it matters (the
-  // 160-row tile): a thread without a row in the second X load writes its FIRST row's chunk once more, same bytes, same address.
-  auto stage_one = [&](int buf, int pc, int kind, int i, const u32x4(&w2)[3 * W_PT], const u32x4(&x2)[3 * X_PT]) {
-    uint8_t *b = smem + buf * STAGE + ldst;
-    if (kind == 0) {
-      *reinterpret_cast<u32x4 *>(b + 3 * XB + pc * WB + i * 128 * 64) = w2[pc * W_PT + i];
-    } else if (i == 0) {
-      if (BM >= 128 || lrow < BM) *reinterpret_cast<u32x4 *>(b + pc * XB) = x2[pc * X_PT];  // (BM >= 128: every thread has a first row)
-    } else {
-      const bool has = lrow + 128 * i < BM;
-      *reinterpret_cast<u32x4 *>(b + pc * XB + (has ? i : 0) * 128 * 64) = has ? x2[pc * X_PT + i] : x2[pc * X_PT];
-    }
-  };
   auto stage = [&](int buf, const u32x4(&w2)[3 * W_PT], const u32x4(&x2)[3 * X_PT]) {
+    uint8_t *b = smem + buf * STAGE + ldst;
 #pragma unroll
     for (int pc = 0; pc < 3; pc++) {
 #pragma unroll
-      for (int i = 0; i < W_PT; i++) stage_one(buf, pc, 0, i, w2, x2);
+      for (int i = 0; i < W_PT; i++) *reinterpret_cast<u32x4 *>(b + 3 * XB + pc * WB + i * 128 * 64) = w2[pc * W_PT + i];
 #pragma unroll
-      for (int i = 0; i < X_PT; i++) stage_one(buf, pc, 1, i, w2, x2);
+      for (int i = 0; i < X_PT; i++)
+        if (lrow + 128 * i < BM) *reinterpret_cast<u32x4 *>(b + pc * XB + i * 128 * 64) = x2[pc * X_PT + i];
     }
   };
   f32x4 acc[NT][4];
@@ -567,44 +556,25 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
   // fragment addresses inside a piece's tile: row * 64 + ((g ^ swizzle(row)) << 4); row & 15 = j for both operands
   const int foff = j * 64 + ((g ^ ((4 - (j >> 2)) & 3)) << 4);
   const int xoff = (wm * 16 * NT) * 64 + foff, woff = (wu * 64) * 64 + foff;
-  // One k-step: the six piece products of the current buffer — and, BETWEEN them, this thread's share of the next step's tile on
-  // its way from the registers into the other buffer, then the request for the step after next.  (Round 5 staged first and
-  // multiplied afterwards: right behind the barrier all eight waves wrote 98 KB into the LDS at ~80 B/clk — 1.2 kcycles in which
-  // no wave had anything to multiply — round 6's SQ pass: MfmaUtil 48.6 %.)
-  constexpr int N_ST = 3 * (W_PT + X_PT);  // 16-byte stores per thread and step
-  auto compute = [&](int buf, int next_step) {
+  auto compute = [&](int buf) {
     const uint8_t *b = smem + buf * STAGE;
     bf16x8 wb[3][4];
 #pragma unroll
     for (int pc = 0; pc < 3; pc++)
 #pragma unroll
       for (int c = 0; c < 4; c++) wb[pc][c] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + 3 * XB + pc * WB + woff + c * 16 * 64));
-    int st = 0;  // stores issued so far: two behind each of the six product groups' first tiles
-    auto some_stores = [&](int upto) {
-#pragma unroll
-      for (; st < upto && st < N_ST; st++) {
-        const int pc = st / (W_PT + X_PT), r = st % (W_PT + X_PT);
-        stage_one(buf ^ 1, pc, r < W_PT ? 0 : 1, r < W_PT ? r : r - W_PT, rw, rx);
-      }
-    };
     // by image piece, small terms first: l*h; m*m, m*h; h*l, h*m, h*h
-    int grp = 0;
 #pragma unroll
     for (int pa = 2; pa >= 0; pa--) {
       bf16x8 xa[NT];
 #pragma unroll
       for (int t = 0; t < NT; t++) xa[t] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + pa * XB + xoff + t * 16 * 64));
 #pragma unroll
-      for (int pw = 2 - pa; pw >= 0; pw--) {
+      for (int pw = 2 - pa; pw >= 0; pw--)
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
+        for (int t = 0; t < NT; t++)
 #pragma unroll
           for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t], wb[pw][c], acc[t][c], 0, 0, 0);
-          if (t == 0) some_stores((grp + 1) * ((N_ST + 3) / 4));  // all of them behind the first four groups
-        }
-        grp++;
-        if (grp == 4) fetch(next_step, rw, rx);  // the registers are free: the step after next, two thirds of a step ahead of its stores
-      }
     }
   };
   fetch(0, rw, rx);
@@ -614,7 +584,9 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
   for (int t = 0; t < F3_STEPS; t++) {
     // buffer (t + 1) & 1 was read in step t - 1, whose barrier is behind us; the registers hold step t + 1 (the last step
     // restages itself into the buffer nobody reads again — no condition, so the compiler counts the loads exactly)
-    compute(t & 1, min(t + 2, F3_STEPS - 1));
+    stage((t + 1) & 1, rw, rx);
+    fetch(min(t + 2, F3_STEPS - 1), rw, rx);
+    compute(t & 1);
     __syncthreads();
   }
   // the quarter's partial sums, transposed for ip2: a lane holds four consecutive images of one unit
