@@ -55,6 +55,10 @@ def test_default_line_assembles(oracle_mod):
     s = d["scores_timed_list"]
     assert s["images"] == n and s["within_1e-4"] is True and s["f32_chain_mode_bit_identical_to_oracle"] is True
     assert s["timed_scores_reproduced_by_gpd_hip_score"] is True and s["max_abs_oracle_chain_minus_float64"] < 1e-4
+    # (round 6) the same images under SURVEY 8d's own weight set: relative to max |score| (~1000: one f32 ulp is 6e-5 there)
+    v = s["survey_8d_weights"]
+    assert v["max_abs_score"] > 100 and v["max_rel_split_minus_float64"] < 1e-5 and v["max_rel_oracle_chain_minus_float64"] < 1e-5
+    assert v["f32_chain_mode_bit_identical_to_oracle"] is True
     assert d["detect_end_to_end"]["candidates"] > n and d["search"]["samples"] == d["config"]["samples"]
     assert d["preprocess"]["points"] == 120000 and 0 < d["preprocess"]["kept"] <= 120000
     c = d["cpu_baseline"]
@@ -90,6 +94,12 @@ def test_config_line_without_the_cpu_legs(oracle_mod):
     assert d["kernels"]["conv1_i8_kernel"]["algorithmic_flops"] == 2.0 * 20 * 25 * 12 * 56 * 56 * 100
 
 
+def test_off_lattice_side_config(oracle_mod):
+    """--config 2o: configs[1]'s scene with sensor-like coordinates; the workload says so."""
+    d = _run("--config", "2o", "--points", "5000", "--candidates", "100", "--steps", "1", "--warmup", "0", "--batch-clouds", "0", "--cpu-samples", "0")
+    assert "off the 3 mm lattice" in d["config"]["workload"] and d["config"]["channels"] == 15 and d["config"]["candidates_per_gpu"] == 100
+
+
 def test_accuracy_leg_is_bounded_on_a_long_list(oracle_mod):
     """configs[3] times 50 000 candidates; the score-accuracy leg then looks at the first ACCURACY_LEG_MAX of them only (here 100 of
     160): the images it asks for and the timed scores it compares them with are the same candidates, in the same order."""
@@ -107,6 +117,8 @@ def test_batch_mode_line(oracle_mod):
     b = d["batch_end_to_end"]
     assert b["clouds"] == 6 and d["value"] == b["cand_per_s"] and abs(d["ms_per_step"] - b["wall_s"] / 2 * 1e3) < 1e-9
     assert d["roofline"]["bound"] == "mfma" and _finite(d["roofline"]["frac"]) and d["config"]["clouds"] == 3
+    # (round 6) the stage is priced against the peaks of the pipes it runs on: a utilisation, never above 1
+    assert 0 < d["roofline"]["frac"] <= 1 and d["roofline"]["unit"] == "TOP/s" and d["roofline"]["peak"] > 2500
 
 
 def test_two_ranks_under_the_drivers_launcher(oracle_mod):
