@@ -131,6 +131,37 @@ def test_scores_on_every_reference_pin():
         ctx.close()
 
 
+def test_split_mode_on_the_unscaled_weight_set():
+    """SURVEY 8d's own weights (ip1 ~ N(0, 0.005^2): |score| ~ 1000, one f32 ulp = 6e-5, where an absolute 1e-4 cannot be
+    asked of ANY f32 summation order) through the default mode, held by a RELATIVE bound against the reference's own long-double
+    scores on every 15-channel pin with images: a few f32 ulps of the largest score, and no further than the f32 chain (which
+    reproduces the pins' fma scores bit for bit)."""
+    from gpd_amd import api
+    ctx = api.Context(api.default_params(15))
+    try:
+        ctx.set_lenet_weights(rcs.weights(15))  # unscaled
+        total = 0
+        for name in sorted(rcs.VARIANTS):
+            pin = rcs.load_pin(name)
+            if pin is None or "images" not in pin or pin["images"].shape[-1] != 15 or "scores_ld" not in pin:
+                continue
+            img, ld = pin["images"], pin["scores_ld"].astype(np.float64)
+            ctx.set_lenet_mode(api.LENET_SPLIT)
+            s = ctx.score(img)
+            ctx.set_lenet_mode(api.LENET_F32_CHAIN)
+            c = ctx.score(img)
+            assert np.array_equal(c, pin["scores_fma"]), name
+            scale = float(np.abs(ld).max())
+            ulp = float(np.spacing(np.float32(scale)))
+            e_split, e_chain, e_plain = (float(np.abs(x - ld).max()) for x in (s, c, pin["scores_plain"]))
+            assert scale > 100 and e_split <= 10 * ulp and e_split <= e_chain + ulp, (name, e_split, e_chain, ulp)  # (the pins hold the long double rounded to f32: half an ulp of its own)
+            assert np.abs(s - pin["scores_plain"]).max() <= e_plain + 8 * ulp, name  # within the reference's own distance from its long double
+            total += len(img)
+        assert total >= 100
+    finally:
+        ctx.close()
+
+
 def test_score_is_independent_of_the_batch():
     """Tile shapes of ip1 (16 .. 80 images), ragged tails, one image, two persistent rounds of the conv kernels: an image's
     score does not depend on its neighbours."""
