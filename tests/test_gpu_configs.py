@@ -1,5 +1,7 @@
 """BASELINE.json configs on the GPU against the oracle (configs[1..4]) plus edge cases and
 error behaviour of the C-ABI.  Run with -m gpu on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -53,6 +55,18 @@ def test_config2_off_lattice(oracle_mod, cloud30k):
     si = synth.sample_indices(cl, 2200)
     n, err = _full_compare(oracle_mod, cl, si, 15)
     assert n > 4000
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GPD_FULLSIZE_SEEDS", "1"))))
+def test_config2_other_scenes(oracle_mod, seed):
+    """configs[1]'s size on OTHER synthetic scenes (seed 7000 + k; odd seeds off the lattice): ~5000 candidates each, full oracle
+    comparison.  GPD_FULLSIZE_SEEDS=N widens the draw (12 soaked in round 6: profiles/r06_soak.txt)."""
+    cl = synth.make_cloud(7000 + seed, 30000, clutter=bool(seed % 4 == 2))
+    if seed % 2:
+        cl = synth.off_lattice(cl, seed=seed)
+    si = synth.sample_indices(cl, 2200, seed=seed)
+    n, err = _full_compare(oracle_mod, cl, si, 15)
+    assert n > 3000
 
 
 @pytest.mark.parametrize("C", [1, 3, 12])
