@@ -157,6 +157,7 @@ struct NormalsScratch {
   long long *d_big_off = nullptr;
   unsigned long long *d_arena = nullptr, *d_ctl = nullptr;
   float *d_out = nullptr;
+  double *d_cent = nullptr;         // [P][3] centroids certified by the list kernel (NaN: walk the chain)
   int last_queued = 0;             // of the last run: points that went through the large-neighbourhood kernel
 };
 void normals_free(NormalsScratch &s);

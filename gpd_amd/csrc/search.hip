@@ -1455,6 +1455,8 @@ struct NormalsParams {
   long long arena_cap;
   int32_t *status;                 // bit 0: the arena is too small (the host grows it and runs again)
   float *out;                      // AoS [P][3] by original index
+  double *cent;                    // [P][3] by cell-order position: the centroid of a point's list when its order-free sum is certified
+                                   // exact (centre_exact), NaN where it is not (normals_finish_kernel then walks the chain)
 };
 
 // the hits of one query among the cells around it, a wave at work: hit(is a hit, index, d2) for every candidate, 64 at a time
@@ -1588,12 +1590,39 @@ __device__ __forceinline__ void wave_sort_regs(double (&key)[K], int lane) {
 // the p-th point of a block of 64 points at [block][e][p], so that normals_finish_kernel — a lane per point — reads one
 // contiguous kilobyte per step and wave
 template <int K>
-__device__ __forceinline__ void normals_sort_store(const NormalsParams &P, const unsigned long long *keys, int n, int lane, int w) {
+__device__ __forceinline__ void normals_sort_store(const NormalsParams &P, const unsigned long long *keys, int n, int lane, int w, const float4 &q) {
   double key[K];
 #pragma unroll
   for (int r = 0; r < K; r++) key[r] = __longlong_as_double((long long)(lane * K + r < n ? keys[lane * K + r] : NL_PAD_KEY));
   wave_sort_regs<K>(key, lane);
   float4 *col = P.lists + (size_t)((w - P.w0) >> 6) * NL_CAP * 64 + (w & 63);
+  // (round 6) the centroid on the way: the coordinates pass through this wave's registers anyway.  The sum of floats in fp64 is
+  // the same in EVERY order when centre_exact's certificate holds (two exponents per coordinate), so the order-free sum taken
+  // here — a lane its entries, then the wave — is the sequential one of the oracle; normals_finish_kernel then reads the lists
+  // ONCE (covariance) instead of twice: it moved 447 MB per 30k points, 3.8 TB/s.  A list that fails the certificate (a neighbour
+  // micrometres from a coordinate plane) gets NaN and its chain is walked there, as before.
+  // The certificate's two exponents per coordinate: every neighbour lies within the search radius of the query, so when the
+  // query is farther than that from the coordinate plane (wave-uniform: three neighbourhoods in four on the benchmark clouds)
+  // |q| - r <= |x| <= |q| + r bounds them without looking at a single entry; only a neighbourhood that reaches a coordinate
+  // plane tracks its smallest non-zero and its largest |x| entry by entry (as unsigned bit patterns: |x| orders like its bits,
+  // and bits - 1 sends a zero to the far end of a minimum).
+  const float qv[3] = {q.x, q.y, q.z};
+  const float rad = sqrtf(P.r2) * 1.0001f;
+  const bool track = !(fabsf(qv[0]) > 2.f * rad && fabsf(qv[1]) > 2.f * rad && fabsf(qv[2]) > 2.f * rad);
+  double cs[3] = {0.0, 0.0, 0.0};
+  unsigned umax[3] = {0u, 0u, 0u}, umin[3] = {~0u, ~0u, ~0u};
+  auto take = [&](const float4 &v, bool on) {
+    const float x[3] = {on ? v.x : 0.f, on ? v.y : 0.f, on ? v.z : 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      cs[a] += (double)x[a];
+      if (track) {
+        const unsigned b = __float_as_uint(x[a]) & 0x7fffffffu;
+        umax[a] = max(umax[a], b);
+        umin[a] = min(umin[a], b - 1u);
+      }
+    }
+  };
 #pragma unroll
   for (int r0 = 0; r0 < K; r0 += 4) {  // four gathers in flight, then their four stores
     const int e = lane * K + r0;
@@ -1605,6 +1634,39 @@ __device__ __forceinline__ void normals_sort_store(const NormalsParams &P, const
     if (e + 1 < n) col[(size_t)(e + 1) * 64] = v1;
     if (e + 2 < n) col[(size_t)(e + 2) * 64] = v2;
     if (e + 3 < n) col[(size_t)(e + 3) * 64] = v3;
+    take(v0, e + 0 < n);
+    take(v1, e + 1 < n);
+    take(v2, e + 2 < n);
+    take(v3, e + 3 < n);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cs[a] += __shfl_xor(cs[a], o);
+      if (track) {
+        umax[a] = max(umax[a], (unsigned)__shfl_xor((int)umax[a], o));
+        umin[a] = min(umin[a], (unsigned)__shfl_xor((int)umin[a], o));
+      }
+    }
+  }
+  if (lane < 3) {
+    const double sum = lane == 0 ? cs[0] : (lane == 1 ? cs[1] : cs[2]);
+    auto bexp = [](unsigned bits) {  // biased exponent of |x| given as bits, a denormal's as 1 (its ulp is that of exponent 1)
+      const int e = (int)((bits >> 23) & 0xffu);
+      return e ? e : 1;
+    };
+    int emin, emax;
+    if (track) {
+      const unsigned hi = lane == 0 ? umax[0] : (lane == 1 ? umax[1] : umax[2]), lo = lane == 0 ? umin[0] : (lane == 1 ? umin[1] : umin[2]);
+      emax = hi ? bexp(hi) : 0;  // (no non-zero addend: emax = 0, the sum is exact)
+      emin = hi ? bexp(lo + 1u) : 255;
+    } else {
+      const float aq = fabsf(lane == 0 ? qv[0] : (lane == 1 ? qv[1] : qv[2]));
+      emax = bexp(__float_as_uint(aq + rad));       // |x| <= |q| + r: its exponent bounds every entry's from above ...
+      emin = bexp(__float_as_uint(aq - rad)) - 1;   // ... |x| >= |q| - r > r from below (one binade of slack for the float subtraction)
+    }
+    P.cent[3 * (size_t)w + lane] = centre_exact(emin, emax, n) ? sum / (double)n : __longlong_as_double(0x7ff8000000000000ll);
   }
 }
 
@@ -1638,11 +1700,11 @@ __global__ __launch_bounds__(64 * NL_WAVES) void normals_list_kernel(NormalsPara
   __threadfence_block();  // the keys were written by other lanes of this wave
   __builtin_amdgcn_wave_barrier();
   if (n <= 256)
-    normals_sort_store<4>(P, keys, n, lane, w);
+    normals_sort_store<4>(P, keys, n, lane, w, q4);
   else if (n <= 512)
-    normals_sort_store<8>(P, keys, n, lane, w);
+    normals_sort_store<8>(P, keys, n, lane, w, q4);
   else
-    normals_sort_store<16>(P, keys, n, lane, w);
+    normals_sort_store<16>(P, keys, n, lane, w, q4);
 }
 
 // The queued points: a workgroup each (a persistent launch walks the queue, whose length stays on the device).  The list
@@ -1783,14 +1845,24 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
   SUM(t0 + B, bb, MASKED);       \
   load(t0 + 4 * B, bb);          \
   SUM(t0 + 2 * B, bc, MASKED);
-    load(0, ba);
-    load(B, bb);
+    // (round 6) the centroid comes from normals_list_kernel, which summed it order-free under centre_exact's certificate; a lane
+    // whose list failed it holds NaN, and only a wave with such a lane walks the three centroid chains (this pass read 223 of
+    // the kernel's 447 MB per 30k points)
+    c0 = P.cent[3 * (size_t)w + 0];
+    c1 = P.cent[3 * (size_t)w + 1];
+    c2 = P.cent[3 * (size_t)w + 2];
     int t0 = 0;
-    for (; t0 < tfull; t0 += 3 * B) { NL_ROUND(sum0, false) }
-    for (; t0 < nmax; t0 += 3 * B) { NL_ROUND(sum0, true) }
-    c0 /= (double)n;
-    c1 /= (double)n;
-    c2 /= (double)n;
+    if (__builtin_amdgcn_ballot_w64(c0 != c0 || c1 != c1 || c2 != c2) != 0ull) {
+      const double k0 = c0, k1 = c1, k2 = c2;
+      c0 = c1 = c2 = 0.0;
+      load(0, ba);
+      load(B, bb);
+      for (; t0 < tfull; t0 += 3 * B) { NL_ROUND(sum0, false) }
+      for (; t0 < nmax; t0 += 3 * B) { NL_ROUND(sum0, true) }
+      c0 = k0 != k0 ? c0 / (double)n : k0;
+      c1 = k1 != k1 ? c1 / (double)n : k1;
+      c2 = k2 != k2 ? c2 / (double)n : k2;
+    }
     load(0, ba);
     load(B, bb);
     for (t0 = 0; t0 < tfull; t0 += 3 * B) { NL_ROUND(sum1, false) }
@@ -1858,7 +1930,7 @@ __global__ __launch_bounds__(64) void normals_finish_kernel(NormalsParams P) {
 }
 
 void normals_free(NormalsScratch &s) {
-  void *ptrs[] = {s.d_count, s.d_lists, s.d_big, s.d_big_off, s.d_arena, s.d_ctl, s.d_out};
+  void *ptrs[] = {s.d_count, s.d_lists, s.d_big, s.d_big_off, s.d_arena, s.d_ctl, s.d_out, s.d_cent};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   s = NormalsScratch();
@@ -1891,6 +1963,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     HIP_RET(hipMalloc(&s.d_big_off, (size_t)cap * sizeof(long long)));
     HIP_RET(hipMalloc(&s.d_ctl, 4 * sizeof(unsigned long long)));  // [0] arena top, [1] status
     HIP_RET(hipMalloc(&s.d_out, (size_t)cap * 3 * sizeof(float)));
+    HIP_RET(hipMalloc(&s.d_cent, (size_t)cap * 3 * sizeof(double)));
     s.cap_points = cap;
   }
   if (!s.d_arena) {
@@ -1915,6 +1988,7 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
   np.arena_top = s.d_ctl;
   np.status = reinterpret_cast<int32_t *>(s.d_ctl + 1);
   np.out = s.d_out;
+  np.cent = s.d_cent;
   struct {
     unsigned long long top, status;
   } h = {0, 0};
@@ -1943,6 +2017,13 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
         HIP_RET(hipMemcpyAsync(&h, s.d_ctl, sizeof(h), hipMemcpyDeviceToHost, stream));
         HIP_RET(hipMemcpyAsync(&tile_queued[(size_t)t], s.d_big, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         if (t == tiles - 1 && normals_out) HIP_RET(hipMemcpyAsync(normals_out, s.d_out, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        if (t == tiles - 1) {
+          // the device copy of the cloud (planes nx, ny, nz) behind the last tile, before the ONE wait of the call (round 6: it
+          // was a second launch + wait after this one); a run that has to be repeated for a larger arena rewrites it
+          split_soa_kernel<<<(P + 255) / 256, 256, 0, stream>>>(c.staging, s.d_out, c.cam_source, P, c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.pxyz,
+                                                                 c.pnrm);
+          HIP_RET(hipGetLastError());
+        }
         HIP_RET(hipStreamSynchronize(stream));  // (several tiles: the control words are the next tile's)
         top_max = std::max(top_max, h.top);
         status_any |= h.status;
@@ -1966,11 +2047,6 @@ int normals_run(Cloud &c, double radius, float *normals_out, hipStream_t stream)
     s.arena_cap = want;
   }
   s.last_queued = queued;
-  // keep the device copy of the cloud consistent: planes nx, ny, nz
-  split_soa_kernel<<<(P + 255) / 256, 256, 0, stream>>>(c.staging, s.d_out, c.cam_source, P, c.px, c.py, c.pz, c.nx, c.ny, c.nz, c.pxyz,
-                                                         c.pnrm);
-  HIP_RET(hipGetLastError());
-  HIP_RET(hipStreamSynchronize(stream));
   c.generation++;
   return GPD_OK;
 }
