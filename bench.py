@@ -55,7 +55,7 @@ def lenet_mfma_work(C):
     512 k, six piece products); ip1 512 units x 7296 k x six piece products."""
     # conv1: 7 k-steps of 4 taps x 16 channel bytes; since round 6 the narrow images (C <= 4: four-byte pixels) take 3 k-steps of
     # 4 row groups x (4 taps x 4 channel bytes): 15 instead of 35 MFMAs per tile
-    c1_mfmas = 15 if C <= 4 else 35
+    c1_mfmas = 15 if C <= 4 else (25 if C == 12 else 35)  # (12 channels: twelve-byte pixels, a kernel row of 5 taps per k-step: 5 k-steps)
     return {
         "conv1_i8_kernel": dict(pipe="i8", executed=196 * c1_mfmas * 32768.0, algorithmic_split=2.0 * 20 * 25 * C * 56 * 56 * 4,
                                 algorithmic=2.0 * 20 * 25 * C * 56 * 56),

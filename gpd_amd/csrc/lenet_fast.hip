@@ -66,6 +66,14 @@ __host__ __device__ constexpr int f1_tap(int ks, int g) {
 // in copy (-X) mod 4 — a constant of the lane (the lane's column inside its tile).  K-groups: (kernel row ky, taps kx 0..3) and
 // (ky, taps kx 4..7: only kx = 4 is real, the others carry zero weights) = 10 groups -> 3 k-steps of 4 lane groups (2 slots
 // empty): 15 MFMAs per tile instead of 35.
+// ---- TWELVE channels (cfg/image_geometry_12channels.cfg; round 6): a pixel is 12 bytes, so the five taps of a kernel row are 60
+// contiguous bytes = ONE k-step (4 padding bytes carry zero weights): 5 k-steps instead of 7, 25 MFMAs per tile instead of 35.  A
+// lane group's 16 bytes of that row start at 12 px + 16 g — 4-byte aligned only.  Four shifted copies (as for the narrow images) do
+// not fit; TWO do, shifted by 0 and 4 bytes: in the copy of its column's parity every fragment is 8-byte aligned and is read as
+// two ds_read_b64.
+constexpr int F1P_KS = 5;
+constexpr int F1P_ROWB = 736;                       // bytes per LDS row: 60 x 12 + the bytes a window reaches beyond pixel 59
+constexpr int F1P_COPY = kImg * F1P_ROWB;           // 44160 bytes per copy
 constexpr int F1N_KS = 3;
 constexpr int F1N_PITCH = 68;                       // pixels per row: 60 + 3 (shift) + 3 (window beyond column 59), multiple of 4
 constexpr int F1N_COPY = kImg * F1N_PITCH * 4;      // 16320 bytes per copy
@@ -100,8 +108,9 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
   constexpr int RAW = C * kPix, NV = RAW / 16;
   static_assert(RAW % 16 == 0 && C <= 16, "image bytes");
   constexpr bool NARROW = C <= 4;                       // four-byte pixels, four shifted copies (see f1n_slot)
-  constexpr int KS = NARROW ? F1N_KS : F1_KS;
-  __shared__ __attribute__((aligned(16))) uint8_t s_hwc[NARROW ? 4 * F1N_COPY : F1_HWC];
+  constexpr bool PACK12 = C == 12;                      // twelve-byte pixels, two shifted copies, a kernel row per k-step
+  constexpr int KS = NARROW ? F1N_KS : PACK12 ? F1P_KS : F1_KS;
+  __shared__ __attribute__((aligned(16))) uint8_t s_hwc[NARROW ? 4 * F1N_COPY : PACK12 ? 2 * F1P_COPY : F1_HWC];
   __shared__ __attribute__((aligned(16))) uint8_t s_raw[RAW];
   __shared__ int s_nxt;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -155,6 +164,38 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
       }
       return;
     }
+    if constexpr (PACK12) {
+      // raw planar [12][60][60] -> two copies of [60][736 B] twelve-byte pixels (x ^ 0x80), copy 1 shifted by 4 bytes; a task is four
+      // consecutive pixels = 48 contiguous bytes: three 16-byte stores into copy 0 (48 x0 / 4 is a multiple of 16), twelve 4-byte
+      // stores into copy 1
+      for (int task = tid; task < kImg * (kImg / 4); task += F1_THREADS) {
+        const int y = task / (kImg / 4), x0 = 4 * (task - y * (kImg / 4));
+        uint32_t o[4][3];  // [pixel][channel group]
+#pragma unroll
+        for (int cg = 0; cg < 3; cg++) {
+          uint32_t r[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) r[c] = *reinterpret_cast<const uint32_t *>(s_raw + (4 * cg + c) * kPix + y * kImg + x0);
+          const uint32_t t0 = __builtin_amdgcn_perm(r[1], r[0], 0x05010400u), t1 = __builtin_amdgcn_perm(r[1], r[0], 0x07030602u);
+          const uint32_t t2 = __builtin_amdgcn_perm(r[3], r[2], 0x05010400u), t3 = __builtin_amdgcn_perm(r[3], r[2], 0x07030602u);
+          o[0][cg] = __builtin_amdgcn_perm(t2, t0, 0x05040100u) ^ 0x80808080u;
+          o[1][cg] = __builtin_amdgcn_perm(t2, t0, 0x07060302u) ^ 0x80808080u;
+          o[2][cg] = __builtin_amdgcn_perm(t3, t1, 0x05040100u) ^ 0x80808080u;
+          o[3][cg] = __builtin_amdgcn_perm(t3, t1, 0x07060302u) ^ 0x80808080u;
+        }
+        uint8_t *d = s_hwc + y * F1P_ROWB + 12 * x0;
+        uint4 *d4 = reinterpret_cast<uint4 *>(d);
+        d4[0] = make_uint4(o[0][0], o[0][1], o[0][2], o[1][0]);
+        d4[1] = make_uint4(o[1][1], o[1][2], o[2][0], o[2][1]);
+        d4[2] = make_uint4(o[2][2], o[3][0], o[3][1], o[3][2]);
+        uint32_t *e = reinterpret_cast<uint32_t *>(d + F1P_COPY + 4);
+#pragma unroll
+        for (int px = 0; px < 4; px++)
+#pragma unroll
+          for (int cg = 0; cg < 3; cg++) e[3 * px + cg] = o[px][cg];
+      }
+      return;
+    }
     for (int task = tid; task < kImg * (kImg / 4); task += F1_THREADS) {
       const int y = task / (kImg / 4), x0 = 4 * (task - y * (kImg / 4));
       uint32_t r[16];
@@ -184,7 +225,10 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
   const int kyg = q == 0 ? 0 : q == 1 ? 2 : q == 2 ? 1 : 3;
   // (narrow: the lane's copy is the one in which its windows are aligned: tile columns start at multiples of 8)
   const int n_shift = (4 - (m_x & 3)) & 3;
-  const int lane_off = NARROW ? n_shift * F1N_COPY + (m_row * F1N_PITCH + m_x + n_shift) * 4 : (m_row * F1_PITCH + m_x) * 16;
+  // (twelve channels: the copy of the column's parity, shifted by four bytes for the odd columns)
+  const int lane_off = NARROW   ? n_shift * F1N_COPY + (m_row * F1N_PITCH + m_x + n_shift) * 4
+                       : PACK12 ? (m_x & 1) * (F1P_COPY + 4) + m_row * F1P_ROWB + 12 * m_x + 16 * q
+                                : (m_row * F1_PITCH + m_x) * 16;
   // narrow: the byte offsets of the lane group's three slots (an empty slot reads slot 0's window: its weights are zero)
   int n_slot[F1N_KS];
 #pragma unroll
@@ -212,6 +256,8 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
       const int trow = tc / 7, tcol = tc - 7 * trow;
       if constexpr (NARROW) {
         pa = pb = pc = s_hwc + ((2 * trow) * F1N_PITCH + 8 * tcol) * 4 + lane_off;
+      } else if constexpr (PACK12) {
+        pa = pb = pc = s_hwc + (2 * trow) * F1P_ROWB + 12 * (8 * tcol) + lane_off;
       } else {
         const uint8_t *base = s_hwc + ((2 * trow) * F1_PITCH + 8 * tcol) * 16 + lane_off;
         pa = base + kyg * F1_ROWB;
@@ -221,6 +267,11 @@ __global__ __launch_bounds__(F1_THREADS) void conv1_i8_kernel(const uint8_t *__r
     };
     auto frag_b = [&](int ks, const uint8_t *pa, const uint8_t *pb, const uint8_t *pc) {
       if constexpr (NARROW) return *reinterpret_cast<const i32x4 *>(pa + n_slot[ks < F1N_KS ? ks : 0]);
+      else if constexpr (PACK12) {  // kernel row ks: two 8-byte reads (the window is 8-byte aligned in the lane's copy)
+        typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
+        const unsigned long long lo = *(lds_u64)(pa + ks * F1P_ROWB), hi = *(lds_u64)(pa + ks * F1P_ROWB + 8);
+        return i32x4{(int)(uint32_t)lo, (int)(uint32_t)(lo >> 32), (int)(uint32_t)hi, (int)(uint32_t)(hi >> 32)};
+      }
       else return *reinterpret_cast<const i32x4 *>(ks < 5 ? pa + ks * 16 : ks == 5 ? pb : pc);
     };
     i32x4 B[KS];
@@ -670,7 +721,8 @@ void lenet_fast_conv1_tables(int channels, const float *w, std::vector<uint8_t> 
     return d;
   };
   const bool narrow = channels <= 4;  // conv1_i8_kernel's NARROW layout: byte 4 i + c of a slot = tap kx = 4 half + i, channel c
-  for (int ks = 0; ks < (narrow ? F1N_KS : F1_KS); ks++)
+  const bool pack12 = channels == 12; // ... PACK12: k-step = kernel row, byte 16 g + b of it = tap kx = (16 g + b) / 12, channel (16 g + b) % 12
+  for (int ks = 0; ks < (narrow ? F1N_KS : pack12 ? F1P_KS : F1_KS); ks++)
     for (int mt = 0; mt < F1_MT; mt++)
       for (int lane = 0; lane < 64; lane++) {
         const int i = lane & 15, g = lane >> 4;
@@ -684,6 +736,14 @@ void lenet_fast_conv1_tables(int channels, const float *w, std::vector<uint8_t> 
             const int kx = 4 * half + px;
             if (kx > 4) continue;
             for (int c = 0; c < channels; c++) row[4 * px + c] = (uint8_t)(int8_t)digit_of(W[(size_t)f * K + c * 25 + ky * 5 + kx], digit);
+          }
+          continue;
+        }
+        if (pack12) {
+          for (int b = 0; b < 16; b++) {
+            const int kb = 16 * g + b;
+            if (kb >= 60) continue;
+            row[b] = (uint8_t)(int8_t)digit_of(W[(size_t)f * K + (kb % 12) * 25 + ks * 5 + kb / 12], digit);
           }
           continue;
         }

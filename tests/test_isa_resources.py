@@ -39,7 +39,7 @@ def test_split_kernels_hold_the_matrix_instructions_the_bench_prices(isa):
     tile / k-step are the ones in the code objects (nothing unrolled twice, nothing dropped)."""
     _, k = isa
     for C in (15, 12, 3, 1):
-        ks = 3 if C <= 4 else 7  # F1N_KS (four-byte pixels, round 6) / F1_KS k-steps x F1_MT row tiles per pixel tile
+        ks = 3 if C <= 4 else (5 if C == 12 else 7)  # F1N_KS (four-byte pixels) / F1P_KS (twelve-byte pixels, round 6) / F1_KS k-steps x F1_MT row tiles per pixel tile
         assert k["gpd::conv1_i8_kernel<%d>" % C]["matrix"] == {"v_mfma_i32_16x16x64_i8": ks * 5}
         import bench
         assert bench.lenet_mfma_work(C)["conv1_i8_kernel"]["executed"] == 196 * ks * 5 * 32768.0

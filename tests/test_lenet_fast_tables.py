@@ -102,6 +102,7 @@ def test_conv1_tables_and_index_arithmetic(channels):
     j, q = lanes & 15, lanes >> 4
     m_row, m_x = (j >> 1) & 1, 2 * (j >> 2) + (j & 1)
     narrow = channels <= 4
+    pack12 = channels == 12
     if narrow:
         # LDS image (round 6, C <= 4): four-byte pixels, 68 per row, FOUR copies, copy s shifted by s pixels; what lies beyond column 59
         # (and the padding bytes) is never initialised by the kernel: poison it, its weights must be zero
@@ -124,6 +125,18 @@ def test_conv1_tables_and_index_arithmetic(channels):
                 n_slot[ks, q == g] = 0 if sl < 0 else ((sl >> 1) * P + 4 * (sl & 1)) * 4
         assert (atab[3:] == 0).all()
         n_ks = 3
+    elif pack12:
+        # LDS image (round 6, C = 12): twelve-byte pixels, 736 bytes per row, TWO copies, copy 1 shifted by 4 bytes; a k-step is a kernel
+        # row: 5 taps x 12 channels = 60 bytes + 4 that must carry zero weights (poisoned here)
+        ROWB, COPY = 736, 60 * 736
+        hwc = np.full((2 * COPY + 4096,), 77, np.int8)
+        for sft in range(2):
+            for c in range(12):
+                for y in range(60):
+                    hwc[sft * COPY + y * ROWB + 12 * np.arange(60) + c + 4 * sft] = v[c, y]
+        lane_off = (m_x & 1) * (COPY + 4) + m_row * ROWB + 12 * m_x + 16 * q
+        assert (atab[5:] == 0).all()
+        n_ks = 5
     else:
         # LDS image: pixel-major, 72 pixels per row, 16 bytes per pixel, x ^ 0x80
         P = 72
@@ -142,6 +155,10 @@ def test_conv1_tables_and_index_arithmetic(channels):
             base = ((2 * trow) * P + 8 * tcol) * 4 + lane_off
             assert (base % 16 == 0).all()  # every window is 16-byte aligned in the lane's copy
             addr = [base + n_slot[ks] for ks in range(3)]
+        elif pack12:
+            base = (2 * trow) * ROWB + 12 * (8 * tcol) + lane_off
+            assert (base % 8 == 0).all()  # every fragment is two 8-byte aligned reads in the lane's copy
+            addr = [base + ks * ROWB for ks in range(5)]
         else:
             base = ((2 * trow) * P + 8 * tcol) * 16 + lane_off
             pa, pb, pc = base + kyg * P * 16, base + 4 * P * 16 + q * 16, base + 4 * P * 16 + 64
