@@ -548,6 +548,10 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
 constexpr int F3_THREADS = 512, F3_BN = 256, F3_BK = 32, F3_KQ = 4;
 constexpr int F3_KLEN = F2_XLD / F3_KQ, F3_STEPS = F3_KLEN / F3_BK;  // 1824, 57
 static_assert(F2_XLD % (F3_KQ * F3_BK) == 0 && F2_XLD >= kFc1In, "K quarters");
+static_assert(F3_STEPS % 2 == 1, "the step loop below runs in pairs + one");
+
+typedef const __attribute__((address_space(1))) void *glds_src_t;
+typedef __attribute__((address_space(3))) void *glds_dst_t;
 
 template <int NT>
 __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned short *__restrict__ xs, size_t xs_plane,
@@ -556,7 +560,9 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
   constexpr int BM = 32 * NT;
   constexpr int XB = BM * 64, WB = F3_BN * 64;  // bytes of one piece's tile
   constexpr int STAGE = 3 * (XB + WB);
-  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];
+  // two stages as two objects: the DMA into one and the fragment reads of the other are provably apart
+  __shared__ __attribute__((aligned(16))) uint8_t smem_a[STAGE];
+  __shared__ __attribute__((aligned(16))) uint8_t smem_b[STAGE];
   static_assert(2 * STAGE <= 160 * 1024, "LDS");
   const int tid = threadIdx.x;
   const int L = blockIdx.x;
@@ -568,36 +574,35 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wm = wave >> 2, wu = wave & 3;
   const int g = lane >> 4, j = lane & 15;
-  // loader roles: a 16-byte chunk per thread and load, 4 consecutive lanes cover one row's 64 bytes; thread -> (row tid >> 2
-  // + 128 i, chunk tid & 3): the row's swizzle does not depend on i
-  constexpr int W_PT = F3_BN / 128, X_PT = (BM + 127) / 128;  // loads per piece
-  const int lrow = tid >> 2, lch = tid & 3;
-  const unsigned short *wsrc = wt + (size_t)(u0 + lrow) * F2_XLD + k_base + lch * 8;
-  const int ldst = lrow * 64 + ((lch ^ ((4 - (lrow >> 2)) & 3)) << 4);
-  const unsigned short *xsrc[X_PT];
+  // Loader: the tiles go from global memory straight into the LDS (global_load_lds_dwordx4: no staging registers, no
+  // ds_write pass — the register-staged version of round 5 spent a third of a step moving 98 KB from VGPRs into the LDS,
+  // 13 cycles per ds_write_b128, which the matrix instructions of the same SIMD do not overlap).  One instruction fills
+  // 1 KB = 16 tile rows of 64 bytes, lane l -> row l >> 2, 16-byte slot l & 3; the LDS image is lane-linear, so the XOR
+  // swizzle sits on the SOURCE: the lane fetches the k chunk that belongs into its slot.  W: 16 row blocks x 3 pieces, a
+  // wave takes blocks wave and wave + 8 of every piece; X: 2 NT row blocks x 3 pieces dealt round robin.
+  const int lr = lane >> 2, lch = (lane & 3) ^ ((4 - (lr >> 2)) & 3);
+  constexpr int XBLK = 6 * NT, X_PW = (XBLK + 7) / 8;
+  const unsigned short *wsrc[2];
 #pragma unroll
-  for (int i = 0; i < X_PT; i++) xsrc[i] = xs + (size_t)min(m0 + lrow + 128 * i, n - 1) * F2_XLD + k_base + lch * 8;
-  u32x4 rw[3 * W_PT], rx[3 * X_PT];
-  auto fetch = [&](int step, u32x4(&w2)[3 * W_PT], u32x4(&x2)[3 * X_PT]) {
+  for (int i = 0; i < 2; i++) wsrc[i] = wt + (size_t)(u0 + 16 * (wave + 8 * i) + lr) * F2_XLD + k_base + lch * 8;
+  const unsigned short *xsrc[X_PW];
+  int xdst[X_PW];
+#pragma unroll
+  for (int i = 0; i < X_PW; i++) {
+    const int e = min(wave + 8 * i, XBLK - 1), rb = e / 3, pc = e - 3 * rb;
+    xsrc[i] = xs + pc * xs_plane + (size_t)min(m0 + 16 * rb + lr, n - 1) * F2_XLD + k_base + lch * 8;
+    xdst[i] = pc * XB + rb * 1024;
+  }
+  auto fetch = [&](int step, uint8_t *b) {
     const int k0 = step * F3_BK;
 #pragma unroll
-    for (int pc = 0; pc < 3; pc++) {
+    for (int pc = 0; pc < 3; pc++)
 #pragma unroll
-      for (int i = 0; i < W_PT; i++) w2[pc * W_PT + i] = *reinterpret_cast<const u32x4 *>(wsrc + pc * wt_plane + (size_t)i * 128 * F2_XLD + k0);
+      for (int i = 0; i < 2; i++)
+        __builtin_amdgcn_global_load_lds((glds_src_t)(wsrc[i] + pc * wt_plane + k0), (glds_dst_t)(b + 3 * XB + pc * WB + (wave + 8 * i) * 1024), 16, 0, 0);
 #pragma unroll
-      for (int i = 0; i < X_PT; i++) x2[pc * X_PT + i] = *reinterpret_cast<const u32x4 *>(xsrc[i] + pc * xs_plane + k0);
-    }
-  };
-  auto stage = [&](int buf, const u32x4(&w2)[3 * W_PT], const u32x4(&x2)[3 * X_PT]) {
-    uint8_t *b = smem + buf * STAGE + ldst;
-#pragma unroll
-    for (int pc = 0; pc < 3; pc++) {
-#pragma unroll
-      for (int i = 0; i < W_PT; i++) *reinterpret_cast<u32x4 *>(b + 3 * XB + pc * WB + i * 128 * 64) = w2[pc * W_PT + i];
-#pragma unroll
-      for (int i = 0; i < X_PT; i++)
-        if (lrow + 128 * i < BM) *reinterpret_cast<u32x4 *>(b + pc * XB + i * 128 * 64) = x2[pc * X_PT + i];
-    }
+    for (int i = 0; i < X_PW; i++)
+      if (wave + 8 * i < XBLK) __builtin_amdgcn_global_load_lds((glds_src_t)(xsrc[i] + k0), (glds_dst_t)(b + xdst[i]), 16, 0, 0);
   };
   f32x4 acc[NT][4];
 #pragma unroll
@@ -607,41 +612,59 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
   // fragment addresses inside a piece's tile: row * 64 + ((g ^ swizzle(row)) << 4); row & 15 = j for both operands
   const int foff = j * 64 + ((g ^ ((4 - (j >> 2)) & 3)) << 4);
   const int xoff = (wm * 16 * NT) * 64 + foff, woff = (wu * 64) * 64 + foff;
-  auto compute = [&](int buf) {
-    const uint8_t *b = smem + buf * STAGE;
-    bf16x8 wb[3][4];
-#pragma unroll
-    for (int pc = 0; pc < 3; pc++)
+  auto compute = [&](const uint8_t *b) {
+    bf16x8 wb[3][4], xa[2][NT];
+    auto ldw = [&](int pc) {
 #pragma unroll
       for (int c = 0; c < 4; c++) wb[pc][c] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + 3 * XB + pc * WB + woff + c * 16 * 64));
-    // by image piece, small terms first: l*h; m*m, m*h; h*l, h*m, h*h
+    };
+    auto ldx = [&](int s, int pa) {
 #pragma unroll
-    for (int pa = 2; pa >= 0; pa--) {
-      bf16x8 xa[NT];
+      for (int t = 0; t < NT; t++) xa[s][t] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + pa * XB + xoff + t * 16 * 64));
+    };
+    auto mul = [&](int s, int pw) {
 #pragma unroll
-      for (int t = 0; t < NT; t++) xa[t] = as_bf16x8(*reinterpret_cast<const uint4 *>(b + pa * XB + xoff + t * 16 * 64));
+      for (int t = 0; t < NT; t++)
 #pragma unroll
-      for (int pw = 2 - pa; pw >= 0; pw--)
-#pragma unroll
-        for (int t = 0; t < NT; t++)
-#pragma unroll
-          for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[t], wb[pw][c], acc[t][c], 0, 0, 0);
-    }
+        for (int c = 0; c < 4; c++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[s][t], wb[pw][c], acc[t][c], 0, 0, 0);
+    };
+    // by image piece, small terms first: l*h; m*m, m*h; h*l, h*m, h*h; the fragments of a group are requested a group ahead
+    ldw(0);
+    ldx(0, 2);
+    ldw(1);
+    ldx(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    ldw(2);
+    ldx(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(1, 1);
+    mul(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(0, 2);
+    mul(0, 1);
+    mul(0, 0);
   };
-  fetch(0, rw, rx);
-  stage(0, rw, rx);
-  fetch(1, rw, rx);
+  // Step t multiplies stage t & 1 while the DMA fills the other one with step t + 1; __syncthreads() waits for the wave's own
+  // DMA (vmcnt(0): an LDS-DMA is a pending LDS write) before the barrier, so behind it every wave's part of the next stage
+  // is in place, and the stage just read is free for step t + 2.
+  fetch(0, smem_a);
   __syncthreads();
-  for (int t = 0; t < F3_STEPS; t++) {
-    // buffer (t + 1) & 1 was read in step t - 1, whose barrier is behind us; the registers hold step t + 1 (the last step
-    // restages itself into the buffer nobody reads again — no condition, so the compiler counts the loads exactly)
-    stage((t + 1) & 1, rw, rx);
-    fetch(min(t + 2, F3_STEPS - 1), rw, rx);
-    compute(t & 1);
+  for (int t = 0; t < F3_STEPS - 1; t += 2) {
+    fetch(t + 1, smem_b);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(smem_a);
+    __syncthreads();
+    fetch(t + 2, smem_a);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(smem_b);
     __syncthreads();
   }
+  compute(smem_a);
   // the quarter's partial sums, transposed for ip2: a lane holds four consecutive images of one unit
   float *outq = out_p + kq * out_plane;
+  const bool vec = (ld_out & 3) == 0;
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int u = u0 + 64 * wu + 16 * c + j;
@@ -650,9 +673,13 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
     for (int t = 0; t < NT; t++) {
       const int m = m0 + 16 * NT * wm + 16 * t + 4 * g;
       float *o = outq + (size_t)u * ld_out + m;
+      if (vec && m + 3 < n) {
+        *reinterpret_cast<f32x4 *>(o) = acc[t][c];
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (m + r < n) o[r] = acc[t][c][r];
+        for (int r = 0; r < 4; r++)
+          if (m + r < n) o[r] = acc[t][c][r];
+      }
     }
   }
 }
