@@ -787,9 +787,10 @@ int gpd_hip_lenet_debug(gpd_hip_ctx *ctx, int which, int n, void *out) {
   if (which == 0) {
     HIP_TRY(hipMemcpy(out, s.pool1, (size_t)n * 15680 * sizeof(float), hipMemcpyDeviceToHost));
   } else if (which == 1) {
-    for (int pc = 0; pc < 3; pc++)
-      HIP_TRY(hipMemcpy2D(static_cast<char *>(out) + (size_t)pc * n * 7200 * 2, 7200 * 2, s.xs + (size_t)pc * s.capacity * kLenetXld, kLenetXld * 2, 7200 * 2, n,
-                          hipMemcpyDeviceToHost));
+    const size_t rows = ((size_t)n + 15) & ~(size_t)15;
+    std::vector<unsigned short> blocked(3 * rows * kLenetXld);
+    HIP_TRY(hipMemcpy(blocked.data(), s.xs, blocked.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
+    lenet_fast_unblock_x(blocked.data(), n, static_cast<unsigned short *>(out));
   } else if (which == 2) {
     HIP_TRY(hipMemcpy2D(out, (size_t)n * sizeof(float), s.fc1t, (size_t)s.capacity * sizeof(float), (size_t)n * sizeof(float), kFc1Out,
                         hipMemcpyDeviceToHost));

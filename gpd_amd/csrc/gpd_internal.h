@@ -30,9 +30,10 @@ struct LeNetFast {
   double *c1corr = nullptr;        // [20] 128 * sum of the filter's fixed-point weights (the x - 128 shift of the inputs)
   int *c1shift = nullptr;          // [20] fixed-point position s of the filter: value = integer * 2^-s
   uint4 *c2b = nullptr;            // conv2 B fragments [2][2][3 pieces][16 k-steps][64 lanes] x 8 bf16
-  unsigned short *f1wt = nullptr;  // ip1 [3 pieces][512 units][7296 k] bf16
+  unsigned short *f1wt = nullptr;  // ip1's weights as bf16 pieces, blocked [32 unit blocks][228 k steps][3 pieces][16 units][32 k] (lenet_fast.hip f3_blocked)
 };
 void lenet_fast_free(LeNetFast &f);
+void lenet_fast_unblock_x(const unsigned short *blocked, int n, unsigned short *planes);  // test hook: [3][n][7200] from the blocked X
 hipError_t lenet_fast_prepare(LeNetFast &f, int channels, const float *c1w, const float *c2w, const float *f1w);
 
 struct LeNetWeights {
@@ -50,7 +51,7 @@ struct LeNetScratch {
   float *pool1 = nullptr;  // f32 chain: [cap][20][784], planes in conv1's chunk order (whole-line stores, lenet.hip P1_PLANE);
                            // split path: [cap][784][20], pixel-major
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
-  unsigned short *xs = nullptr;  // split path: flat as three bf16 planes [3][cap][7296] (k >= 7200: zeros, written once at allocation)
+  unsigned short *xs = nullptr;  // split path: flat as three bf16 pieces, blocked like ip1's weights [cap / 16][228][3][16][32] (k >= 7200: zeros, written once at allocation)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
   float *fc1p = nullptr;   // split path: ip1's partial sums over the four K quarters [4][500][cap]
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)

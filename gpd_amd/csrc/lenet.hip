@@ -765,8 +765,9 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   if ((e = hipMalloc(&s.pool1, (size_t)n * P1_IMG * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.flat, (size_t)n * kFc1In * sizeof(float))) != hipSuccess) return e;
   constexpr size_t kXld = kLenetXld;  // 7200 + 96 zeros, which no kernel ever writes
-  if ((e = hipMalloc(&s.xs, (size_t)3 * n * kXld * sizeof(unsigned short))) != hipSuccess) return e;
-  if ((e = hipMemset(s.xs, 0, (size_t)3 * n * kXld * sizeof(unsigned short))) != hipSuccess) return e;
+  const size_t xs_rows = ((size_t)n + 15) & ~(size_t)15;  // whole 16-image blocks (lenet_fast.hip f3_blocked)
+  if ((e = hipMalloc(&s.xs, 3 * xs_rows * kXld * sizeof(unsigned short))) != hipSuccess) return e;
+  if ((e = hipMemset(s.xs, 0, 3 * xs_rows * kXld * sizeof(unsigned short))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1p, (size_t)4 * n * kFc1Out * sizeof(float))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.c1_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return e;

@@ -401,6 +401,17 @@ constexpr int F2_IMG = 28 * F2_RS;     // 94080
 constexpr int F2_RAW = 784 * 20 * 4;   // 62720
 constexpr int F2_XLD = kLenetXld;      // row length of the flat bf16 planes: 7200 + 96 zeros (ip1 walks four K quarters in steps of 32)
 
+// ip1's operands — X (the flattened pool2 of every image, written by conv2) and W (its weights, unit-major) — are kept BLOCKED
+// the way ip1's loader takes them: 1 KB blocks [row block r / 16][k step k / 32 (228)][piece (3)] of 16 rows x 64 bytes, a
+// row's four 16-byte k chunks XOR-swizzled as the LDS tile wants them.  One global_load_lds_dwordx4 copies one block, 1 KB of
+// consecutive addresses = eight whole cache lines (rows of 7296 k, 64 bytes of each per instruction, measured 0.18 ms for ip1
+// against 0.14 with blocks), and the blocks a workgroup streams for a row block lie behind one another.
+constexpr int F3_KSTEPS = F2_XLD / 32;  // 228
+__host__ __device__ inline size_t f3_blocked(int r, int k, int pc) {  // byte offset of (row r, element k, piece pc)
+  const int rr = r & 15;
+  return ((((size_t)(r >> 4) * F3_KSTEPS + (k >> 5)) * 3 + pc) << 10) + rr * 64 + ((((k >> 3) & 3) ^ ((4 - (rr >> 2)) & 3)) << 4) + (k & 7) * 2;
+}
+
 // (tap = ky * 5 + kx, channel group) of k-slot entry e for lane group g; tap -1: empty
 __host__ __device__ constexpr int f2_slot_tap(int e, int g) {
   return e < 25 ? (e / 5) * 5 + g : e < 30 ? g * 5 + 4 : e == 30 ? 24 : (g == 0 ? 24 : -1);
@@ -409,7 +420,7 @@ __host__ __device__ constexpr int f2_slot_cg(int e, int g) { return e < 25 ? e %
 
 __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__restrict__ pool1, const uint4 *__restrict__ btab,
                                                                 const float *__restrict__ bias, unsigned short *__restrict__ xs,
-                                                                size_t xs_plane, int n, int *__restrict__ queue) {
+                                                                int n, int *__restrict__ queue) {
   __shared__ __attribute__((aligned(16))) uint8_t s_img[F2_IMG];
   __shared__ __attribute__((aligned(16))) uint8_t s_raw[F2_RAW];
   __shared__ int s_nxt;
@@ -506,17 +517,17 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
           acc[term & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_buf[ks & 1][pa], W[pw][ks], acc[term & 1], 0, 0, 0);
         }
       }
-      // pool over the lane's four registers, bias, split for ip1, store: flat index = pixel * 50 + filter (eigen_classifier.cpp:103-107)
+      // pool over the lane's four registers, bias, split for ip1, store: flat index = pixel * 50 + filter (eigen_classifier.cpp:103-107), blocked (f3_blocked)
       const int prow = rp, pcol = 4 * xt + q;
       {
         const f32x4 t = acc[0] + acc[1];
         const float v = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])) + k_bias;
         if (f_own < 50) {
           const Bf3 sp = bf16_split3(v);
-          unsigned short *o = xs + (size_t)img * F2_XLD + (prow * 12 + pcol) * 50 + f_own;
-          o[0] = sp.h;
-          o[xs_plane] = sp.m;
-          o[2 * xs_plane] = sp.l;
+          uint8_t *o = reinterpret_cast<uint8_t *>(xs) + f3_blocked(img, (prow * 12 + pcol) * 50 + f_own, 0);
+          *reinterpret_cast<unsigned short *>(o) = sp.h;
+          *reinterpret_cast<unsigned short *>(o + 1024) = sp.m;
+          *reinterpret_cast<unsigned short *>(o + 2048) = sp.l;
         }
       }
       if (has_piece) reinterpret_cast<uint4 *>(s_raw)[piece] = stage;
@@ -530,8 +541,8 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ip1 on the bf16 matrix pipe: D[image][unit] = sum_k X[image][k] W[k][unit], six piece products per k.
-//   X: three bf16 planes [n][7296] written by conv2 (k = pixel * 50 + filter, then 96 zeros), W: three bf16 planes
-//   [512][7296], unit-major (k contiguous), built once at gpd_hip_set_lenet_weights.
+//   X: the flattened pool2 of every image as three bf16 pieces, written by conv2 (k = pixel * 50 + filter, then 96 zeros);
+//   W: the weights' three pieces, unit-major, built once at gpd_hip_set_lenet_weights; both BLOCKED (f3_blocked above).
 //   A (images): lane (row l & 15, k group l >> 4) = 16 contiguous bytes; B (units) likewise; D: lane (unit l & 15),
 //   register r = image 4 (l >> 4) + r.
 // The GEMM is small against the chip (5000 x 512 x 7200) and its operands are fat (six bytes per element): with one
@@ -541,9 +552,9 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
 // every batch size), + bias, ReLU.  Tile traffic halves (1.15 GB), and workgroup L runs on XCD L % 8 = (unit half, quarter):
 // every XCD's L2 holds ITS 2.8 MB slice of W for the whole launch.
 // Eight waves, two per SIMD, as 2 (images) x 4 (units): a wave owns 16 NT images x 64 units = 4 NT accumulators.  K in steps
-// of 32: two LDS buffers of 3 x (32 NT + 256) rows x 64 bytes, the four 16-byte chunks of a row XOR-swizzled by
-// (4 - (row >> 2)) & 3: every ds_read_b128 of a fragment is bank-conflict free.  global -> registers one step ahead,
-// registers -> LDS while the other buffer is multiplied.
+// of 32: two LDS stages of 3 x (32 NT + 256) rows x 64 bytes, the four 16-byte chunks of a row XOR-swizzled by
+// (4 - (row >> 2)) & 3: every ds_read_b128 of a fragment is bank-conflict free.  Round 6: the stages are filled by LDS-DMA
+// from the blocked operands, one step ahead (what the time was made of, by ablation: profiles/NOTES.md §I).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int F3_THREADS = 512, F3_BN = 256, F3_BK = 32, F3_KQ = 4;
 constexpr int F3_KLEN = F2_XLD / F3_KQ, F3_STEPS = F3_KLEN / F3_BK;  // 1824, 57
@@ -554,8 +565,7 @@ typedef const __attribute__((address_space(1))) void *glds_src_t;
 typedef __attribute__((address_space(3))) void *glds_dst_t;
 
 template <int NT>
-__global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned short *__restrict__ xs, size_t xs_plane,
-                                                             const unsigned short *__restrict__ wt, size_t wt_plane,
+__global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned short *__restrict__ xs, const unsigned short *__restrict__ wt,
                                                              float *__restrict__ out_p, size_t out_plane, int n, int ld_out) {
   constexpr int BM = 32 * NT;
   constexpr int XB = BM * 64, WB = F3_BN * 64;  // bytes of one piece's tile
@@ -576,33 +586,34 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
   const int g = lane >> 4, j = lane & 15;
   // Loader: the tiles go from global memory straight into the LDS (global_load_lds_dwordx4: no staging registers, no
   // ds_write pass — the register-staged version of round 5 spent a third of a step moving 98 KB from VGPRs into the LDS,
-  // 13 cycles per ds_write_b128, which the matrix instructions of the same SIMD do not overlap).  One instruction fills
-  // 1 KB = 16 tile rows of 64 bytes, lane l -> row l >> 2, 16-byte slot l & 3; the LDS image is lane-linear, so the XOR
-  // swizzle sits on the SOURCE: the lane fetches the k chunk that belongs into its slot.  W: 16 row blocks x 3 pieces, a
-  // wave takes blocks wave and wave + 8 of every piece; X: 2 NT row blocks x 3 pieces dealt round robin.
-  const int lr = lane >> 2, lch = (lane & 3) ^ ((4 - (lr >> 2)) & 3);
+  // 13 cycles per ds_write_b128, which the matrix instructions of the same SIMD do not overlap).  One instruction copies
+  // one 1 KB block of the blocked operands (f3_blocked) = 16 tile rows of 64 bytes, swizzle included: source and LDS image are
+  // both lane-linear.  W: 16 row blocks x 3 pieces, a wave takes blocks wave and wave + 8 of every piece; X: 2 NT row blocks
+  // x 3 pieces dealt round robin (row blocks past the last image re-read the last one: their sums are not stored).
   constexpr int XBLK = 6 * NT, X_PW = (XBLK + 7) / 8;
-  const unsigned short *wsrc[2];
+  constexpr size_t ROWBLK = (size_t)F3_KSTEPS * 3 * 1024;  // bytes of one row block
+  const uint8_t *wsrc[2];
 #pragma unroll
-  for (int i = 0; i < 2; i++) wsrc[i] = wt + (size_t)(u0 + 16 * (wave + 8 * i) + lr) * F2_XLD + k_base + lch * 8;
-  const unsigned short *xsrc[X_PW];
+  for (int i = 0; i < 2; i++)
+    wsrc[i] = reinterpret_cast<const uint8_t *>(wt) + (size_t)(u0 / 16 + wave + 8 * i) * ROWBLK + (size_t)(k_base / 32) * 3072 + lane * 16;
+  const uint8_t *xsrc[X_PW];
   int xdst[X_PW];
 #pragma unroll
   for (int i = 0; i < X_PW; i++) {
     const int e = min(wave + 8 * i, XBLK - 1), rb = e / 3, pc = e - 3 * rb;
-    xsrc[i] = xs + pc * xs_plane + (size_t)min(m0 + 16 * rb + lr, n - 1) * F2_XLD + k_base + lch * 8;
+    xsrc[i] = reinterpret_cast<const uint8_t *>(xs) + (size_t)min(m0 / 16 + rb, (n - 1) / 16) * ROWBLK + (size_t)(k_base / 32) * 3072 + pc * 1024 + lane * 16;
     xdst[i] = pc * XB + rb * 1024;
   }
   auto fetch = [&](int step, uint8_t *b) {
-    const int k0 = step * F3_BK;
+    const int so = step * 3072;
 #pragma unroll
     for (int pc = 0; pc < 3; pc++)
 #pragma unroll
       for (int i = 0; i < 2; i++)
-        __builtin_amdgcn_global_load_lds((glds_src_t)(wsrc[i] + pc * wt_plane + k0), (glds_dst_t)(b + 3 * XB + pc * WB + (wave + 8 * i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glds_src_t)(wsrc[i] + so + pc * 1024), (glds_dst_t)(b + 3 * XB + pc * WB + (wave + 8 * i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < X_PW; i++)
-      if (wave + 8 * i < XBLK) __builtin_amdgcn_global_load_lds((glds_src_t)(xsrc[i] + k0), (glds_dst_t)(b + xdst[i]), 16, 0, 0);
+      if (wave + 8 * i < XBLK) __builtin_amdgcn_global_load_lds((glds_src_t)(xsrc[i] + so), (glds_dst_t)(b + xdst[i]), 16, 0, 0);
   };
   f32x4 acc[NT][4];
 #pragma unroll
@@ -806,16 +817,22 @@ void lenet_fast_conv2_tables(const float *w, std::vector<unsigned short> &btab) 
 // ip1: the reference's file layout is column-major 500 x 7200 == row-major [7200][500] (dense_layer.cpp:7); here unit-major
 // bf16 planes [3][512][7232], zero beyond unit 499 / k 7199
 void lenet_fast_ip1_tables(const float *w, std::vector<unsigned short> &wt) {
-  const size_t plane = (size_t)512 * F2_XLD;
-  wt.assign(3 * plane, 0);
+  wt.assign((size_t)3 * 512 * F2_XLD, 0);  // units 500..511 and k 7200..7295: zeros
+  uint8_t *base = reinterpret_cast<uint8_t *>(wt.data());
   for (int k = 0; k < kFc1In; k++)
     for (int u = 0; u < kFc1Out; u++) {
       const Bf3 sp = bf16_split3(w[(size_t)k * kFc1Out + u]);
-      const size_t o = (size_t)u * F2_XLD + k;
-      wt[o] = sp.h;
-      wt[plane + o] = sp.m;
-      wt[2 * plane + o] = sp.l;
+      const unsigned short pcs[3] = {sp.h, sp.m, sp.l};
+      for (int pc = 0; pc < 3; pc++) memcpy(base + f3_blocked(u, k, pc), &pcs[pc], 2);
     }
+}
+
+// test hook: the blocked X operand (n images) back as three planes [3][n][7200]
+void lenet_fast_unblock_x(const unsigned short *blocked, int n, unsigned short *planes) {
+  const uint8_t *base = reinterpret_cast<const uint8_t *>(blocked);
+  for (int pc = 0; pc < 3; pc++)
+    for (int m = 0; m < n; m++)
+      for (int k = 0; k < kFc1In; k++) memcpy(planes + ((size_t)pc * n + m) * kFc1In + k, base + f3_blocked(m, k, pc), 2);
 }
 
 }  // namespace gpd
@@ -865,8 +882,7 @@ hipError_t lenet_fast_prepare(LeNetFast &f, int channels, const float *c1w, cons
 template <int NT>
 static void fc1f_launch(const LeNetWeights &w, LeNetScratch &s, int n, hipStream_t stream) {
   const int m_tiles = (n + 32 * NT - 1) / (32 * NT);
-  const size_t xs_plane = (size_t)s.capacity * F2_XLD, wt_plane = (size_t)512 * F2_XLD;
-  fc1_bf16_kernel<NT><<<m_tiles * 8, F3_THREADS, 0, stream>>>(s.xs, xs_plane, w.fast.f1wt, wt_plane, s.fc1p, (size_t)kFc1Out * s.capacity, n, s.capacity);
+  fc1_bf16_kernel<NT><<<m_tiles * 8, F3_THREADS, 0, stream>>>(s.xs, w.fast.f1wt, s.fc1p, (size_t)kFc1Out * s.capacity, n, s.capacity);
 }
 // image-tile height 32 NT: the smallest (at most 160: two LDS buffers) whose tiles (8 workgroups each: 2 unit halves x 4 K
 // quarters) fill the chip's 256 CUs in r whole rounds, r as small as possible
@@ -889,7 +905,7 @@ hipError_t lenet_forward_fast(const LeNetWeights &w, LeNetScratch &s, const uint
     default: return hipErrorInvalidValue;
   }
   if (kernel_events) (void)hipEventRecord(kernel_events[0], stream);
-  conv2_bf16_kernel<<<grid, F2_THREADS, 0, stream>>>(s.pool1, w.fast.c2b, w.c2b, s.xs, (size_t)s.capacity * F2_XLD, m, queue + 1);
+  conv2_bf16_kernel<<<grid, F2_THREADS, 0, stream>>>(s.pool1, w.fast.c2b, w.c2b, s.xs, m, queue + 1);
   if (kernel_events) (void)hipEventRecord(kernel_events[1], stream);
   switch (fc1f_pick_nt(m)) {
     case 1: fc1f_launch<1>(w, s, m, stream); break;
