@@ -112,7 +112,7 @@ def lenet_stage_roofline(C, n_images, stage_s):
     work = lenet_mfma_work(C)
     ops = sum(v["executed"] for v in work.values()) * n_images
     t_peak = sum(v["executed"] * n_images / ((I8_PEAK_TOPS if v["pipe"] == "i8" else BF16_PEAK_TFLOPS) * 1e12) for v in work.values())
-    return {"kernel": "LeNet stage of the batch (conv1_i8 + conv2_bf16 + fc1_bf16 + combine + ip2), rank 0", "bound": "mfma",
+    return {"kernel": "LeNet stage of the batch (conv1_i8 + conv2_bf16 + fc1_bf16 + ip2, which adds ip1's K quarters), rank 0", "bound": "mfma",
             "achieved": ops / stage_s / 1e12, "peak": ops / t_peak / 1e12, "unit": "TOP/s", "frac": t_peak / stage_s, "traffic": None,
             "executed_ops": ops, "stage_ms": stage_s * 1e3,
             "f32_equivalent_TFLOPs": LENET_MFLOP[C] * 1e6 * n_images / stage_s / 1e12,
@@ -408,7 +408,7 @@ def main():
     for _ in range(args.steps):
         ctx.replay(3)
     img_ms, net_ms, launches, timed_scores = ctx.replay_times(n_scores=n_cand)  # the scores of the last timed step come back with the times
-    kernel_ms = ctx.replay_kernel_ms()              # conv1, conv2, ip1 (+ its combine pass), ip2 summed over the timed steps
+    kernel_ms = ctx.replay_kernel_ms()              # conv1, conv2, ip1, ip2 (which adds ip1's four K quarters first) summed over the timed steps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:

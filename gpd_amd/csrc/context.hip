@@ -791,6 +791,18 @@ int gpd_hip_lenet_debug(gpd_hip_ctx *ctx, int which, int n, void *out) {
     std::vector<unsigned short> blocked(3 * rows * kLenetXld);
     HIP_TRY(hipMemcpy(blocked.data(), s.xs, blocked.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
     lenet_fast_unblock_x(blocked.data(), n, static_cast<unsigned short *>(out));
+  } else if (which == 2 && ctx->lenet.mode == GPD_LENET_SPLIT) {
+    // the split path keeps ip1's output as four partial sums (they meet inside ip2's kernel): added here as there, in order
+    const size_t rows = ((size_t)n + 31) & ~(size_t)31;
+    std::vector<float> part(rows * 4 * kFc1Out), b1(kFc1Out);
+    HIP_TRY(hipMemcpy(part.data(), s.fc1p, part.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b1.data(), ctx->lenet.f1b, b1.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float *o = static_cast<float *>(out);
+    for (int u = 0; u < kFc1Out; u++)
+      for (int m = 0; m < n; m++) {
+        const float v = ((part[fc1p_index(m, 0, u)] + part[fc1p_index(m, 1, u)]) + part[fc1p_index(m, 2, u)]) + part[fc1p_index(m, 3, u)] + b1[u];
+        o[(size_t)u * n + m] = v > 0.f ? v : 0.f;
+      }
   } else if (which == 2) {
     HIP_TRY(hipMemcpy2D(out, (size_t)n * sizeof(float), s.fc1t, (size_t)s.capacity * sizeof(float), (size_t)n * sizeof(float), kFc1Out,
                         hipMemcpyDeviceToHost));

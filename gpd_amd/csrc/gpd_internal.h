@@ -20,6 +20,8 @@ constexpr int kImg = 60;            // image_size (eigen_classifier.cpp:12)
 constexpr int kPix = kImg * kImg;   // 3600
 constexpr int kFc1In = 7200;        // 50 * 12 * 12
 constexpr int kFc1Out = 500;
+// split path: where ip1 leaves the partial sum of (image m, K quarter kq, unit u) for ip2's kernel (floats)
+__host__ __device__ inline size_t fc1p_index(int m, int kq, int u) { return (((size_t)(m >> 5) * 4 + kq) * kFc1Out + u) * 32 + (m & 31); }
 constexpr int kLenetXld = 7296;     // row length of the split path's flat bf16 planes: 7200 + 96 zeros = 4 K quarters x 57 steps of 32 (lenet_fast.hip)
 
 // ---- LeNet (lenet.hip) ----------------------------------------------------
@@ -53,7 +55,7 @@ struct LeNetScratch {
   float *flat = nullptr;   // [cap][7200]  (pixel-major, channel-minor)
   unsigned short *xs = nullptr;  // split path: flat as three bf16 pieces, blocked like ip1's weights [cap / 16][228][3][16][32] (k >= 7200: zeros, written once at allocation)
   float *fc1t = nullptr;   // [500][cap]   (transposed, ReLU applied)
-  float *fc1p = nullptr;   // split path: ip1's partial sums over the four K quarters [4][500][cap]
+  float *fc1p = nullptr;   // split path: ip1's partial sums over the four K quarters, blocked [cap / 32][4][500][32] (fc1p_index)
   int num_cus = 0;         // compute units of the context's device (grid of the persistent conv2)
   unsigned long long *c1_stats = nullptr;  // device: [0] (chunk, channel) pairs conv1 executed, [1] pairs it looked at — summed
                                            // over its launches since the last gpd_hip_conv1_stats(reset); [2] != 0: a launch gave up

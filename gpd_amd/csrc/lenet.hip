@@ -735,19 +735,45 @@ static int fc1_pick_nt(int n) {
 
 // FC2 + score (dense_layer.cpp:6-15 with 2 units; eigen_classifier.cpp:74: score = y1 - y0).  Each logit is ONE fmaf
 // chain over the 500 ip1 units in ascending order — the definition the oracle and the reference pins share — so it
-// cannot be folded into ip1's epilogue as partial sums over ip1's four u-tiles (that changes the rounding).  What can be
-// spread is everything else: the two logits of an image are two lanes (a lane pair), the images of a workgroup are only
-// 32, so that n = 5000 fills 157 CUs instead of 20; reads of fc1t stay coalesced over the images.
-constexpr int FC2_THREADS = 64;
-__global__ __launch_bounds__(FC2_THREADS) void fc2_score_kernel(const float *__restrict__ fc1t, const float *__restrict__ w,
+// cannot be folded into ip1's epilogue as partial sums over ip1's u-tiles (that changes the rounding).  What can be
+// spread is everything else.  32 images per workgroup; phase 1, all 512 threads: the images' 500 ip1 outputs into the LDS,
+// many loads in flight per thread (the one-wave version of rounds 1-5 walked its chain straight off global memory, ten
+// loads at a time: 29 us per 5000 images for 10 MFLOP) — on the split path this is also where ip1's four K quarters meet:
+// ((q0 + q1) + q2) + q3 + bias, ReLU (eigen_classifier.cpp:113; a kernel of its own until round 6, 9 us), read as 16-byte
+// pieces from ONE contiguous 256 KB (fc1p_index: ip1 writes its partial sums blocked by 32 images); phase 2, one wave: the
+// two logits of an image are a lane pair, the chain reads the LDS.
+constexpr int FC2_THREADS = 512, FC2_IMGS = 32;
+template <bool COMBINE>
+__global__ __launch_bounds__(FC2_THREADS) void fc2_score_kernel(const float *__restrict__ fc1p, const float *__restrict__ b1,
+                                                               const float *__restrict__ fc1t, const float *__restrict__ w,
                                                                const float *__restrict__ b, float *__restrict__ scores, int n, int ld) {
-  const int lane = threadIdx.x;
-  const int which = lane >> 5;                      // logit 0 in lanes 0..31, logit 1 in lanes 32..63
-  const int m = blockIdx.x * 32 + (lane & 31);
-  const int mc = m < n ? m : n - 1;
+  __shared__ __attribute__((aligned(16))) float hs[kFc1Out][FC2_IMGS];
+  __shared__ float ws[2 * kFc1Out];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * kFc1Out; i += FC2_THREADS) ws[i] = w[i];
+  if constexpr (COMBINE) {
+    const float4 *q = reinterpret_cast<const float4 *>(fc1p + fc1p_index(blockIdx.x * FC2_IMGS, 0, 0));
+    constexpr int PLANE4 = kFc1Out * FC2_IMGS / 4;  // float4s of one quarter
+#pragma unroll 4
+    for (int i = tid; i < PLANE4; i += FC2_THREADS) {
+      const float4 a = q[i], c = q[PLANE4 + i], d = q[2 * PLANE4 + i], e = q[3 * PLANE4 + i];
+      const float bu = b1[i >> 3];
+      reinterpret_cast<float4 *>(&hs[0][0])[i] = make_float4(fmaxf(((a.x + c.x) + d.x) + e.x + bu, 0.f), fmaxf(((a.y + c.y) + d.y) + e.y + bu, 0.f),
+                                                             fmaxf(((a.z + c.z) + d.z) + e.z + bu, 0.f), fmaxf(((a.w + c.w) + d.w) + e.w + bu, 0.f));
+    }
+  } else {
+    const int mi = tid & (FC2_IMGS - 1);
+    const int m = blockIdx.x * FC2_IMGS + mi, mc = m < n ? m : n - 1;
+#pragma unroll 8
+    for (int j = tid / FC2_IMGS; j < kFc1Out; j += FC2_THREADS / FC2_IMGS) hs[j][mi] = fc1t[(size_t)j * ld + mc];
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  const int which = tid >> 5;  // logit 0 in lanes 0..31, logit 1 in lanes 32..63
+  const int mi = tid & 31, m = blockIdx.x * FC2_IMGS + mi;
   float y = 0.f;
-#pragma unroll 10
-  for (int j = 0; j < kFc1Out; j++) y = __builtin_fmaf(w[2 * j + which], fc1t[(size_t)j * ld + mc], y);
+#pragma unroll 20
+  for (int j = 0; j < kFc1Out; j++) y = __builtin_fmaf(ws[2 * j + which], hs[j][mi], y);
   y += b[which];
   const float other = __shfl_xor(y, 32);
   if (which == 1 && m < n) scores[m] = y - other;  // y1 - y0
@@ -769,7 +795,7 @@ hipError_t lenet_scratch_reserve(LeNetScratch &s, int n) {
   if ((e = hipMalloc(&s.xs, 3 * xs_rows * kXld * sizeof(unsigned short))) != hipSuccess) return e;
   if ((e = hipMemset(s.xs, 0, 3 * xs_rows * kXld * sizeof(unsigned short))) != hipSuccess) return e;
   if ((e = hipMalloc(&s.fc1t, (size_t)n * kFc1Out * sizeof(float))) != hipSuccess) return e;
-  if ((e = hipMalloc(&s.fc1p, (size_t)4 * n * kFc1Out * sizeof(float))) != hipSuccess) return e;
+  if ((e = hipMalloc(&s.fc1p, (((size_t)n + 31) & ~(size_t)31) * 4 * kFc1Out * sizeof(float))) != hipSuccess) return e;  // whole 32-image blocks (fc1p_index)
   if ((e = hipMalloc(&s.c1_stats, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
   if ((e = hipMemset(s.c1_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return e;
   s.capacity = n;
@@ -850,7 +876,10 @@ hipError_t lenet_forward(const LeNetWeights &w, LeNetScratch &s, const uint8_t *
     }
     if (kernel_events && off == 0) (void)hipEventRecord(kernel_events[2], stream);
     }
-    fc2_score_kernel<<<(m + 31) / 32, FC2_THREADS, 0, stream>>>(s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
+    if (w.mode == GPD_LENET_SPLIT)
+      fc2_score_kernel<true><<<(m + FC2_IMGS - 1) / FC2_IMGS, FC2_THREADS, 0, stream>>>(s.fc1p, w.f1b, nullptr, w.f2w, w.f2b, d_scores + off, m, s.capacity);
+    else
+      fc2_score_kernel<false><<<(m + FC2_IMGS - 1) / FC2_IMGS, FC2_THREADS, 0, stream>>>(nullptr, nullptr, s.fc1t, w.f2w, w.f2b, d_scores + off, m, s.capacity);
   }
   return hipGetLastError();
 }

@@ -14,7 +14,7 @@
 //   conv2,  f32 activations x f32 weights: each operand is the sum of three bf16 pieces (round to nearest, residual, again:
 //   ip1     a = h + m + l to 2^-24 and better); h*h + h*m + m*h + h*l + l*h + m*m on v_mfma_f32_16x16x32_bf16 with f32
 //           accumulation: every product exact, what is dropped (m*l, l*m, l*l) is below 2^-24 of the product.
-//   ip2     two 500-long f32 chains, as before (lenet.hip fc2_score_kernel).
+//   ip2     two 500-long f32 chains, as before (lenet.hip fc2_score_kernel), which also adds ip1's four K quarters in order.
 //
 // Measured against float64 on the reference pins the scores of this path are closer than the f32 chain's
 // (tests/test_gpu_lenet_fast.py), and within 1e-4 of the reference's plain-float Eigen path on every pin.
@@ -566,7 +566,7 @@ typedef __attribute__((address_space(3))) void *glds_dst_t;
 
 template <int NT>
 __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned short *__restrict__ xs, const unsigned short *__restrict__ wt,
-                                                             float *__restrict__ out_p, size_t out_plane, int n, int ld_out) {
+                                                             float *__restrict__ out_p, int n) {
   constexpr int BM = 32 * NT;
   constexpr int XB = BM * 64, WB = F3_BN * 64;  // bytes of one piece's tile
   constexpr int STAGE = 3 * (XB + WB);
@@ -673,9 +673,9 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
     __syncthreads();
   }
   compute(smem_a);
-  // the quarter's partial sums, transposed for ip2: a lane holds four consecutive images of one unit
-  float *outq = out_p + kq * out_plane;
-  const bool vec = (ld_out & 3) == 0;
+  // the quarter's partial sums for ip2's kernel, blocked [32 images][quarter][unit][32]: a lane holds four consecutive images
+  // of one unit (16 bytes), the 16 units of a tile column are 16 consecutive rows of 128 bytes — and a workgroup of ip2
+  // (32 images) reads ONE contiguous 256 KB (rows of the plain [unit][n] transpose lay 4 n bytes apart: 24 us for ip2)
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int u = u0 + 64 * wu + 16 * c + j;
@@ -683,34 +683,8 @@ __global__ __launch_bounds__(F3_THREADS) void fc1_bf16_kernel(const unsigned sho
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       const int m = m0 + 16 * NT * wm + 16 * t + 4 * g;
-      float *o = outq + (size_t)u * ld_out + m;
-      if (vec && m + 3 < n) {
-        *reinterpret_cast<f32x4 *>(o) = acc[t][c];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (m + r < n) o[r] = acc[t][c][r];
-      }
+      if (m < n) *reinterpret_cast<f32x4 *>(out_p + fc1p_index(m, kq, u)) = acc[t][c];  // (rows past n inside the block: never read back)
     }
-  }
-}
-
-// ip1's epilogue: unit u of image m = relu(q0 + q1 + q2 + q3 + bias) over the four K quarters in this order (eigen_classifier.cpp:113),
-// transposed [500][ld] for ip2 (lenet.hip fc2_score_kernel).  Four images per thread.
-__global__ __launch_bounds__(256) void fc1_combine_kernel(const float *__restrict__ fc1p, size_t plane, const float *__restrict__ b1,
-                                                          float *__restrict__ fc1t, int n, int ld) {
-  const int m = 4 * (blockIdx.x * 256 + threadIdx.x), u = blockIdx.y;
-  if (m >= n) return;
-  const float *q = fc1p + (size_t)u * ld + m;
-  float *o = fc1t + (size_t)u * ld + m;
-  const float bu = b1[u];
-  if (m + 3 < n && (ld & 3) == 0) {
-    const float4 a = *reinterpret_cast<const float4 *>(q), b = *reinterpret_cast<const float4 *>(q + plane),
-                 c = *reinterpret_cast<const float4 *>(q + 2 * plane), d = *reinterpret_cast<const float4 *>(q + 3 * plane);
-    *reinterpret_cast<float4 *>(o) = make_float4(fmaxf(((a.x + b.x) + c.x) + d.x + bu, 0.f), fmaxf(((a.y + b.y) + c.y) + d.y + bu, 0.f),
-                                                 fmaxf(((a.z + b.z) + c.z) + d.z + bu, 0.f), fmaxf(((a.w + b.w) + c.w) + d.w + bu, 0.f));
-  } else {
-    for (int r = 0; r < 4 && m + r < n; r++) o[r] = fmaxf(((q[r] + q[plane + r]) + q[2 * plane + r]) + q[3 * plane + r] + bu, 0.f);
   }
 }
 
@@ -882,7 +856,7 @@ hipError_t lenet_fast_prepare(LeNetFast &f, int channels, const float *c1w, cons
 template <int NT>
 static void fc1f_launch(const LeNetWeights &w, LeNetScratch &s, int n, hipStream_t stream) {
   const int m_tiles = (n + 32 * NT - 1) / (32 * NT);
-  fc1_bf16_kernel<NT><<<m_tiles * 8, F3_THREADS, 0, stream>>>(s.xs, w.fast.f1wt, s.fc1p, (size_t)kFc1Out * s.capacity, n, s.capacity);
+  fc1_bf16_kernel<NT><<<m_tiles * 8, F3_THREADS, 0, stream>>>(s.xs, w.fast.f1wt, s.fc1p, n);
 }
 // image-tile height 32 NT: the smallest (at most 160: two LDS buffers) whose tiles (8 workgroups each: 2 unit halves x 4 K
 // quarters) fill the chip's 256 CUs in r whole rounds, r as small as possible
@@ -914,7 +888,7 @@ hipError_t lenet_forward_fast(const LeNetWeights &w, LeNetScratch &s, const uint
     case 4: fc1f_launch<4>(w, s, m, stream); break;
     default: fc1f_launch<5>(w, s, m, stream); break;
   }
-  fc1_combine_kernel<<<dim3((m + 1023) / 1024, kFc1Out), 256, 0, stream>>>(s.fc1p, (size_t)kFc1Out * s.capacity, w.f1b, s.fc1t, m, s.capacity);
+  // (the four K quarters are added, in order, by ip2's kernel: lenet.hip fc2_score_kernel<true>)
   if (kernel_events) (void)hipEventRecord(kernel_events[2], stream);
   return hipGetLastError();
 }
