@@ -51,15 +51,16 @@ DTYPE = ("f64 geometry / u8 images / LeNet f32-equivalent by exact operand split
 def lenet_mfma_work(C):
     """What the split path's three matrix kernels EXECUTE per image (padding included) and what that is algorithmically
     (gpd_amd/csrc/lenet_fast.hip): conv1 196 tiles x 35 v_mfma_i32_16x16x64_i8 (20 filters x 4 digits = 80 rows, 7 k-steps of 4 taps x
-    16 channels for 25 taps x C channels); conv2 36 tiles x 4 column tiles x 96 v_mfma_f32_16x16x32_bf16 (50 -> 64 filters, 500 ->
-    512 k, six piece products); ip1 512 units x 7296 k x six piece products."""
+    16 channels for 25 taps x C channels); conv2 36 tiles x 3 column tiles x 96 v_mfma_f32_16x16x32_bf16 (48 filters, 500 -> 512 k, six piece
+    products) + 24 units x 48 for filters 48 and 49 (round 6: rows = (filter, kernel column), k = 5 kernel rows x 24 channel slots ->
+    128; until then a fourth column tile, 14 of its 16 columns zero); ip1 512 units x 7296 k x six piece products."""
     # conv1: 7 k-steps of 4 taps x 16 channel bytes; since round 6 the narrow images (C <= 4: four-byte pixels) take 3 k-steps of
     # 4 row groups x (4 taps x 4 channel bytes): 15 instead of 35 MFMAs per tile
     c1_mfmas = 15 if C <= 4 else (25 if C == 12 else 35)  # (12 channels: twelve-byte pixels, a kernel row of 5 taps per k-step: 5 k-steps)
     return {
         "conv1_i8_kernel": dict(pipe="i8", executed=196 * c1_mfmas * 32768.0, algorithmic_split=2.0 * 20 * 25 * C * 56 * 56 * 4,
                                 algorithmic=2.0 * 20 * 25 * C * 56 * 56),
-        "conv2_bf16_kernel": dict(pipe="bf16", executed=36 * 4 * 96 * 16384.0, algorithmic_split=2.0 * 50 * 500 * 24 * 24 * 6,
+        "conv2_bf16_kernel": dict(pipe="bf16", executed=(3 * 36 * 96 + 24 * 48) * 16384.0, algorithmic_split=2.0 * 50 * 500 * 24 * 24 * 6,
                                   algorithmic=2.0 * 50 * 500 * 24 * 24),
         "fc1_bf16_kernel": dict(pipe="bf16", executed=2.0 * 512 * 7296 * 6, algorithmic_split=2.0 * 500 * 7200 * 6, algorithmic=2.0 * 500 * 7200),
     }

@@ -31,7 +31,7 @@ struct LeNetFast {
   uint4 *c1a = nullptr;            // conv1 A fragments [7 k-steps][5 row tiles][64 lanes] x 16 int8
   double *c1corr = nullptr;        // [20] 128 * sum of the filter's fixed-point weights (the x - 128 shift of the inputs)
   int *c1shift = nullptr;          // [20] fixed-point position s of the filter: value = integer * 2^-s
-  uint4 *c2b = nullptr;            // conv2 B fragments [2][2][3 pieces][16 k-steps][64 lanes] x 8 bf16
+  uint4 *c2b = nullptr;            // conv2 fragments [4 slots][3 pieces][16 k-steps][64 lanes] x 8 bf16 (slot 3: the A fragments of filters 48, 49)
   unsigned short *f1wt = nullptr;  // ip1's weights as bf16 pieces, blocked [32 unit blocks][228 k steps][3 pieces][16 units][32 k] (lenet_fast.hip f3_blocked)
 };
 void lenet_fast_free(LeNetFast &f);

@@ -399,6 +399,7 @@ constexpr int F2_PP = 28 * 40;         // bytes of one piece row: 28 pixels x 20
 constexpr int F2_RS = 3 * F2_PP;       // bytes of one image row (three pieces)
 constexpr int F2_IMG = 28 * F2_RS;     // 94080
 constexpr int F2_RAW = 784 * 20 * 4;   // 62720
+constexpr int F2_LUNITS = 24;         // work units of the wave that computes filters 48, 49: 12 row pairs x 2 column halves
 constexpr int F2_XLD = kLenetXld;      // row length of the flat bf16 planes: 7200 + 96 zeros (ip1 walks four K quarters in steps of 32)
 
 // ip1's operands — X (the flattened pool2 of every image, written by conv2) and W (its weights, unit-major) — are kept BLOCKED
@@ -426,18 +427,11 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
   __shared__ int s_nxt;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = wave & 3, half = wave >> 2;
   const int j = lane & 15, q = lane >> 4;
-  int img = blockIdx.x;
-  if (img >= n) return;
-  // the weight fragments of the wave's 16 filters: [piece][k-step]
-  bf16x8 W[3][16];
-#pragma unroll
-  for (int pc = 0; pc < 3; pc++)
-#pragma unroll
-    for (int ks = 0; ks < 16; ks++) W[pc][ks] = as_bf16x8(btab[((nt * 3 + pc) * 16 + ks) * 64 + lane]);
+  const int img0 = blockIdx.x;
+  if (img0 >= n) return;
   {  // the first image, by everybody
-    const uint4 *src = reinterpret_cast<const uint4 *>(pool1 + (size_t)img * (784 * 20));
+    const uint4 *src = reinterpret_cast<const uint4 *>(pool1 + (size_t)img0 * (784 * 20));
     uint4 *dst = reinterpret_cast<uint4 *>(s_raw);
     for (int i = tid; i < F2_RAW / 16; i += F2_THREADS) dst[i] = src[i];
   }
@@ -456,87 +450,185 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
     }
   };
   split();
+  // one pooled value (+ bias) as its three pieces into ip1's blocked X: flat index = pixel * 50 + filter (eigen_classifier.cpp:103-107)
+  auto store_x = [&](int img, int pixel, int f, float v) {
+    const Bf3 sp = bf16_split3(v);
+    uint8_t *o = reinterpret_cast<uint8_t *>(xs) + f3_blocked(img, pixel * 50 + f, 0);
+    *reinterpret_cast<unsigned short *>(o) = sp.h;
+    *reinterpret_cast<unsigned short *>(o + 1024) = sp.m;
+    *reinterpret_cast<unsigned short *>(o + 2048) = sp.l;
+  };
+  // the frame every role runs per image: `passes` loop passes (at least eight: each carries 16 bytes per thread of the next
+  // image's raw rows from global memory into the LDS), two barriers
+  auto image_loop = [&](int passes, auto &&work) {
+    int img = img0;
+    for (;;) {
+      if (tid == 0) s_nxt = (int)gridDim.x + atomicAdd(queue, 1);
+      __syncthreads();  // the pieces are complete, the raw region is free, s_nxt is visible
+      const int nxt = s_nxt;
+      const uint4 *nsrc = reinterpret_cast<const uint4 *>(pool1 + (size_t)(nxt < n ? nxt : img) * (784 * 20));
+#pragma unroll 1
+      for (int tt = 0; tt < passes; tt++) {
+        const int piece = tt * F2_THREADS + tid;
+        const bool has_piece = nxt < n && piece < F2_RAW / 16;
+        uint4 stage = make_uint4(0, 0, 0, 0);
+        if (has_piece) stage = nsrc[piece];
+        work(img, tt);
+        if (has_piece) reinterpret_cast<uint4 *>(s_raw)[piece] = stage;
+      }
+      __syncthreads();  // every tile of the image is done, the next image's raw rows are in LDS
+      if (nxt >= n) break;
+      split();
+      img = nxt;
+    }
+  };
+  // Roles (round 6).  50 filters are three column tiles of 16 and two left over; until round 6 a fourth column tile carried the
+  // two (14 of its 16 columns zero: a quarter of the kernel's matrix instructions for 4 % of its filters).  Now seven waves
+  // share the 3 x 36 pixel tiles of the three full groups and the eighth computes filters 48 and 49 by another route;
+  // waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically), so every SIMD gets 2880 MFMAs per image:
+  //   waves 0-3: group 1 + wave / 2, half wave & 1 (18 tiles x 96);  waves 4-6: group 0, a third each (12 tiles x 96);
+  //   wave 7: the two filters (24 units x 48).  The two roles are two copies of the image loop, so that the eighth wave's
+  //   registers are not those of a full group's weights.
+  if (wave == 7) {
+    // Filters 48 and 49 as a 16 x 16 tile of (filter, kernel column kx) rows x 16 INPUT columns of one conv row:
+    //   D[(f, kx)][x] = sum over (ky, c) of W[f][c][ky][kx] * pool1[y + ky][x][c]        (K = 5 kernel rows x 20 channels)
+    //   conv[f][y][x] = sum over kx of D[(f, kx)][x + kx]                                  (five shifted rows, added across lanes)
+    // 16 input columns give 12 outputs, so a conv row is two such tiles; K is laid out as 15 chunks of 8 = (ky, 8 channels)
+    // with the third chunk of a kernel row half empty (channels 16..19 + 4 zero weights): four k-steps of 32.  A work unit =
+    // a pair of conv rows x 12 columns = 6 pooled pixels of both filters: 2 x 4 k-steps x 6 piece products = 48 MFMAs; 24
+    // units per image = 1152 against the 3456 of a padded column tile.  The weights are the A operand here (rows (f, kx):
+    // lane group 0 holds (48, kx 0..3) in its four registers, group 1 (49, kx 0..3), group 2 (48, 4), group 3 (49, 4)).
+    __builtin_amdgcn_s_setprio(3);  // its chain of short steps is the longest of the SIMD's two: the pipe when it is ready (0.735 -> 0.68 ms)
+    bf16x8 LW[3][4];
+#pragma unroll
+    for (int pc = 0; pc < 3; pc++)
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) LW[pc][ks] = as_bf16x8(btab[((3 * 3 + pc) * 16 + ks) * 64 + lane]);
+    int l_lo[4], l_hi[4];  // the lane's two 8-byte reads of k-step ks, relative to (conv row, first input column) of piece 0
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const int idx = min(4 * ks + q, 14), ky = idx / 3, c8 = idx - 3 * ky;  // (chunk 15 is empty: zero weights, any finite data will do)
+      l_lo[ks] = ky * F2_RS + j * 40 + c8 * 16;
+      l_hi[ks] = c8 == 2 ? l_lo[ks] : l_lo[ks] + 8;  // (channels 20..23 do not exist: zero weights against a second copy of 16..19)
+    }
+    const int f_own = 48 + (q & 1);
+    const float k_bias = bias[f_own];
+    auto unit_base = [&](int u) { return s_img + (2 * (u >> 1)) * F2_RS + (12 * (u & 1)) * 40; };
+    auto lfrag = [&](const uint8_t *ubase, int step, int pc) -> bf16x8 {  // step = conv row of the pair * 4 + k-step
+      typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
+      const uint8_t *a = ubase + (step >> 2) * F2_RS + pc * F2_PP;
+      const unsigned long long lo = *(lds_u64)(a + l_lo[step & 3]), hi = *(lds_u64)(a + l_hi[step & 3]);
+      return as_bf16x8(make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
+    };
+    // a ring of four fragment sets, three steps ahead of the products — across the units too (the image's last unit asks for
+    // its own first steps again: the same addresses the next image's first unit needs, requested anew behind the barriers)
+    bf16x8 b_buf[4][3];
+    auto shl = [](float v, auto n) {  // lane i of a row of 16 <- lane i + n (0 past the row's end)
+      return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + decltype(n)::value, 0xf, 0xf, true));
+    };
+    image_loop(F2_LUNITS, [&](int img, int tt) {
+      const uint8_t *ubase = unit_base(tt), *unext = unit_base(tt < F2_LUNITS - 1 ? tt + 1 : tt);
+      if (tt == 0) {
+#pragma unroll
+        for (int st = 0; st < 3; st++)
+#pragma unroll
+          for (int pc = 0; pc < 3; pc++) b_buf[st][pc] = lfrag(ubase, st, pc);
+      }
+      f32x4 lacc[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll
+      for (int step = 0; step < 8; step++) {
+#pragma unroll
+        for (int pc = 0; pc < 3; pc++) b_buf[(step + 3) & 3][pc] = step + 3 < 8 ? lfrag(ubase, step + 3, pc) : lfrag(unext, step + 3 - 8, pc);
+#pragma unroll
+        for (int term = 0; term < 6; term++) {
+          const int pa = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
+          const int pw = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+          lacc[step >> 2][term & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(LW[pw][step & 3], b_buf[step & 3][pa], lacc[step >> 2][term & 1], 0, 0, 0);
+        }
+      }
+      // the five shifted rows meet: lane (column x, group f) takes kx = 0..3 from its own registers' rows, shifted inside its
+      // row of 16 lanes (DPP), and kx = 4 from group f + 2 (the upper half of the wave comes down through a permute)
+      float conv_row[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; rr++) {
+        const f32x4 t = lacc[rr][0] + lacc[rr][1];
+        const float v = ((t[0] + shl(t[1], std::integral_constant<int, 1>())) + shl(t[2], std::integral_constant<int, 2>())) + shl(t[3], std::integral_constant<int, 3>());
+        // (ds_bpermute for the move between the wave's halves: v_permlane32_swap gave wrong sums here on the device, the same
+        //  arithmetic with the permute passes — not pursued, the step is two instructions per unit)
+        conv_row[rr] = v + __shfl(shl(t[0], std::integral_constant<int, 4>()), (lane + 32) & 63);
+      }
+      float pv = fmaxf(conv_row[0], conv_row[1]);
+      pv = fmaxf(pv, shl(pv, std::integral_constant<int, 1>())) + k_bias;
+      if (q < 2 && (j & 1) == 0 && j < 12) store_x(img, (tt >> 1) * 12 + 6 * (tt & 1) + (j >> 1), f_own, pv);
+    });
+    return;
+  }
+  const int grp = wave < 4 ? 1 + (wave >> 1) : 0;
+  const int t0 = wave < 4 ? 18 * (wave & 1) : 12 * (wave - 4), tcnt = wave < 4 ? 18 : 12;
+  // the weight fragments of the wave's 16 filters: [piece][k-step]
+  bf16x8 W[3][16];
+#pragma unroll
+  for (int pc = 0; pc < 3; pc++)
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) W[pc][ks] = as_bf16x8(btab[((grp * 3 + pc) * 16 + ks) * 64 + lane]);
   const int m_row = (j >> 1) & 1, m_x = 2 * (j >> 2) + (j & 1);
   const int lane_off = m_row * F2_RS + m_x * 40;
   // the four address patterns of the k-slot table (see above): + 40 g (columns), + g rows, + 8 g (channel groups), none
   const int off_x = lane_off + 40 * q, off_y = lane_off + q * F2_RS + 4 * 40, off_z = lane_off + 4 * F2_RS + 4 * 40 + 8 * q,
             off_w = lane_off + 4 * F2_RS + 4 * 40 + 32;
-  const int f_own = 16 * nt + j;  // the lane's filter (50..63: padding)
-  const float k_bias = f_own < 50 ? bias[f_own] : 0.f;
-  for (;;) {
-    if (tid == 0) s_nxt = (int)gridDim.x + atomicAdd(queue, 1);
-    __syncthreads();  // the pieces are complete, the raw region is free, s_nxt is visible
-    const int nxt = s_nxt;
-    const uint4 *nsrc = reinterpret_cast<const uint4 *>(pool1 + (size_t)(nxt < n ? nxt : img) * (784 * 20));
-    // the fragments of k-step ks live in a_buf[ks & 1]: the next step's are requested before this step's MFMAs — and behind a
-    // tile's last step the FIRST step of the wave's next tile (round 6: the tile used to start by asking for them and waiting,
-    // an LDS round trip per tile in which both waves of the SIMD, running in step, left the matrix pipe idle)
-    bf16x8 a_buf[2][3];
-    auto tile_base = [&](int tt) {
-      const int T = half * 18 + tt, rp = T / 3, xt = T - 3 * rp;
-      return s_img + (2 * rp) * F2_RS + (8 * xt) * 40;
-    };
-    // the two 8-byte reads of k-step ks for piece pc of the tile at `base`
-    auto frag = [&](const uint8_t *base, int ks, int pc) -> bf16x8 {
-      uint2 v[2];
+  const int f_own = 16 * grp + j;  // the lane's filter
+  const float k_bias = bias[f_own];
+  auto tile_base = [&](int tt) {
+    const int T = t0 + tt, rp = T / 3, xt = T - 3 * rp;
+    return s_img + (2 * rp) * F2_RS + (8 * xt) * 40;
+  };
+  // the two 8-byte reads of k-step ks for piece pc of the tile at `base`
+  auto frag = [&](const uint8_t *base, int ks, int pc) -> bf16x8 {
+    uint2 v[2];
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int e = ks + 16 * h;
-        const uint8_t *a = e < 25 ? base + off_x + (e / 5) * F2_RS + (e % 5) * 8
-                           : e < 30 ? base + off_y + (e - 25) * 8
-                           : e == 30 ? base + off_z
-                                     : base + off_w;
-        // (volatile: keeps the two halves two ds_read_b64 — merged into ds_read2_b64 they run at half the LDS rate and on
-        //  the 32-bank rule, and their results have to be re-sorted into the operand registers)
-        typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
-        const unsigned long long t = *(lds_u64)(a + pc * F2_PP);
-        v[h] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
-      }
-      return as_bf16x8(make_uint4(v[0].x, v[0].y, v[1].x, v[1].y));
-    };
-#pragma unroll
-    for (int pc = 0; pc < 3; pc++) a_buf[0][pc] = frag(tile_base(0), 0, pc);
-#pragma unroll 1
-    for (int tt = 0; tt < 18; tt++) {
-      const int piece = tt * F2_THREADS + tid;
-      const bool has_piece = nxt < n && piece < F2_RAW / 16;
-      uint4 stage = make_uint4(0, 0, 0, 0);
-      if (has_piece) stage = nsrc[piece];
-      const int T = half * 18 + tt, rp = T / 3, xt = T - 3 * rp;
-      const uint8_t *base = tile_base(tt), *base_next = tile_base(tt < 17 ? tt + 1 : tt);  // (the last tile re-reads itself: unused)
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // two chains (even / odd terms), added at the end
-#pragma unroll
-      for (int ks = 0; ks < 16; ks++) {
-#pragma unroll
-        for (int pc = 0; pc < 3; pc++) a_buf[(ks + 1) & 1][pc] = ks + 1 < 16 ? frag(base, ks + 1, pc) : frag(base_next, 0, pc);
-#pragma unroll
-        for (int term = 0; term < 6; term++) {
-          // (activation piece, weight piece): l*h, h*l, m*m, m*h, h*m, h*h — small terms first
-          const int pa = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
-          const int pw = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
-          acc[term & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_buf[ks & 1][pa], W[pw][ks], acc[term & 1], 0, 0, 0);
-        }
-      }
-      // pool over the lane's four registers, bias, split for ip1, store: flat index = pixel * 50 + filter (eigen_classifier.cpp:103-107), blocked (f3_blocked)
-      const int prow = rp, pcol = 4 * xt + q;
-      {
-        const f32x4 t = acc[0] + acc[1];
-        const float v = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])) + k_bias;
-        if (f_own < 50) {
-          const Bf3 sp = bf16_split3(v);
-          uint8_t *o = reinterpret_cast<uint8_t *>(xs) + f3_blocked(img, (prow * 12 + pcol) * 50 + f_own, 0);
-          *reinterpret_cast<unsigned short *>(o) = sp.h;
-          *reinterpret_cast<unsigned short *>(o + 1024) = sp.m;
-          *reinterpret_cast<unsigned short *>(o + 2048) = sp.l;
-        }
-      }
-      if (has_piece) reinterpret_cast<uint4 *>(s_raw)[piece] = stage;
+    for (int h = 0; h < 2; h++) {
+      const int e = ks + 16 * h;
+      const uint8_t *a = e < 25 ? base + off_x + (e / 5) * F2_RS + (e % 5) * 8
+                         : e < 30 ? base + off_y + (e - 25) * 8
+                         : e == 30 ? base + off_z
+                                   : base + off_w;
+      // (volatile: keeps the two halves two ds_read_b64 — merged into ds_read2_b64 they run at half the LDS rate and on
+      //  the 32-bank rule, and their results have to be re-sorted into the operand registers)
+      typedef const volatile __attribute__((address_space(3))) unsigned long long *lds_u64;
+      const unsigned long long t = *(lds_u64)(a + pc * F2_PP);
+      v[h] = make_uint2((uint32_t)t, (uint32_t)(t >> 32));
     }
-    __syncthreads();  // every tile of the image is done, the next image's raw rows are in LDS
-    if (nxt >= n) break;
-    split();
-    img = nxt;
-  }
+    return as_bf16x8(make_uint4(v[0].x, v[0].y, v[1].x, v[1].y));
+  };
+  // the fragments of k-step ks live in a_buf[ks & 1]: the next step's are requested before this step's MFMAs — and behind a
+  // tile's last step the FIRST step of the wave's next tile (an LDS round trip per tile otherwise, in which both waves of
+  // the SIMD, running in step, leave the matrix pipe idle); the image's last tile asks for its own first step again, which is
+  // what the next image's first tile needs: same addresses, other data — so the request is repeated behind the barriers
+  bf16x8 a_buf[2][3];
+  image_loop(tcnt, [&](int img, int tt) {
+    if (tt == 0) {
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) a_buf[0][pc] = frag(tile_base(0), 0, pc);
+    }
+    const int T = t0 + tt, rp = T / 3, xt = T - 3 * rp;
+    const uint8_t *base = tile_base(tt), *base_next = tile_base(tt < tcnt - 1 ? tt + 1 : tt);  // (the last tile re-reads itself: unused)
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // two chains (even / odd terms), added at the end
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) {
+#pragma unroll
+      for (int pc = 0; pc < 3; pc++) a_buf[(ks + 1) & 1][pc] = ks + 1 < 16 ? frag(base, ks + 1, pc) : frag(base_next, 0, pc);
+#pragma unroll
+      for (int term = 0; term < 6; term++) {
+        // (activation piece, weight piece): l*h, h*l, m*m, m*h, h*m, h*h — small terms first
+        const int pa = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
+        const int pw = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+        acc[term & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_buf[ks & 1][pa], W[pw][ks], acc[term & 1], 0, 0, 0);
+      }
+    }
+    // pool over the lane's four registers, bias, split for ip1, store
+    const f32x4 t = acc[0] + acc[1];
+    store_x(img, rp * 12 + 4 * xt + q, f_own, fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])) + k_bias);
+  });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -765,27 +857,36 @@ void lenet_fast_conv1_tables(int channels, const float *w, std::vector<uint8_t> 
       }
 }
 
-// conv2: the three bf16 pieces of every weight as the MFMA B fragments of conv2_bf16_kernel:
-// [wave pair np][column tile nt][piece][k-step][lane] x 8 bf16; filter 32 np + 16 nt + (lane & 15), filters >= 50 are zero
+// conv2: the three bf16 pieces of every weight as the MFMA fragments of conv2_bf16_kernel: [slot][piece][k-step][lane] x 8 bf16.
+// Slots 0..2: the B fragments of filters 16 slot + (lane & 15).  Slot 3, k-steps 0..3: the A fragments of the wave that computes
+// filters 48 and 49 — row lane & 15 = (filter, kernel column): 0..3 (48, kx), 4..7 (49, kx - 4), 8 (48, 4), 12 (49, 4), the
+// rest zero; the lane's 8 k = chunk 4 ks + (lane >> 4) = (kernel row ky = chunk / 3, channels 8 (chunk % 3) ..+7), zero from
+// channel 20 on and in chunk 15
 void lenet_fast_conv2_tables(const float *w, std::vector<unsigned short> &btab) {
-  btab.assign((size_t)2 * 2 * 3 * 16 * 64 * 8, 0);
-  for (int np = 0; np < 2; np++)
-    for (int nt = 0; nt < 2; nt++)
-      for (int ks = 0; ks < 16; ks++)
-        for (int lane = 0; lane < 64; lane++) {
-          const int f = 32 * np + 16 * nt + (lane & 15), g = lane >> 4;
-          if (f >= 50) continue;
-          for (int h = 0; h < 2; h++) {
-            const int e = ks + 16 * h, tap = f2_slot_tap(e, g), cg = f2_slot_cg(e, g);
-            if (tap < 0) continue;
-            for (int c = 0; c < 4; c++) {
-              const Bf3 sp = bf16_split3(w[(size_t)f * 500 + (4 * cg + c) * 25 + tap]);
-              const unsigned short pcs[3] = {sp.h, sp.m, sp.l};
-              for (int pc = 0; pc < 3; pc++)
-                btab[((((size_t)(np * 2 + nt) * 3 + pc) * 16 + ks) * 64 + lane) * 8 + 4 * h + c] = pcs[pc];
-            }
-          }
+  btab.assign((size_t)4 * 3 * 16 * 64 * 8, 0);
+  auto put = [&](int slot, int ks, int lane, int e, float v) {
+    const Bf3 sp = bf16_split3(v);
+    const unsigned short pcs[3] = {sp.h, sp.m, sp.l};
+    for (int pc = 0; pc < 3; pc++) btab[((((size_t)slot * 3 + pc) * 16 + ks) * 64 + lane) * 8 + e] = pcs[pc];
+  };
+  for (int slot = 0; slot < 3; slot++)
+    for (int ks = 0; ks < 16; ks++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int f = 16 * slot + (lane & 15), g = lane >> 4;
+        for (int h = 0; h < 2; h++) {
+          const int e = ks + 16 * h, tap = f2_slot_tap(e, g), cg = f2_slot_cg(e, g);
+          if (tap < 0) continue;
+          for (int c = 0; c < 4; c++) put(slot, ks, lane, 4 * h + c, w[(size_t)f * 500 + (4 * cg + c) * 25 + tap]);
         }
+      }
+  for (int ks = 0; ks < 4; ks++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int row = lane & 15, chunk = 4 * ks + (lane >> 4);
+      if ((row > 8 && row != 12) || chunk > 14) continue;
+      const int f = row < 8 ? 48 + (row >> 2) : 48 + ((row - 8) >> 2), kx = row < 8 ? (row & 3) : 4;
+      const int ky = chunk / 3, c0 = 8 * (chunk % 3);
+      for (int e = 0; e < 8 && c0 + e < 20; e++) put(3, ks, lane, e, w[(size_t)f * 500 + (c0 + e) * 25 + ky * 5 + kx]);
+    }
 }
 
 // ip1: the reference's file layout is column-major 500 x 7200 == row-major [7200][500] (dense_layer.cpp:7); here unit-major

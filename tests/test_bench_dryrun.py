@@ -50,7 +50,7 @@ def test_default_line_assembles(oracle_mod):
     for name in ("grasp_image_kernel", "lenet_forward", "conv1_i8_kernel", "conv2_bf16_kernel", "fc1_bf16_kernel", "fc2_score_kernel", "search"):
         assert _finite(d["kernels"][name]["ms"]) and d["kernels"][name]["ms"] > 0, name
     # the stand-in's stage times are the committed line's, scaled to the list: the same fractions come out
-    assert abs(r["frac"] - 36 * 4 * 96 * 16384.0 * 5000 / 0.72e-3 / 1e12 / 2500.0) < 1e-9
+    assert abs(r["frac"] - (3 * 36 * 96 + 24 * 48) * 16384.0 * 5000 / 0.72e-3 / 1e12 / 2500.0) < 1e-9
     # the legs around the headline
     s = d["scores_timed_list"]
     assert s["images"] == n and s["within_1e-4"] is True and s["f32_chain_mode_bit_identical_to_oracle"] is True

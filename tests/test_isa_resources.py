@@ -43,7 +43,8 @@ def test_split_kernels_hold_the_matrix_instructions_the_bench_prices(isa):
         assert k["gpd::conv1_i8_kernel<%d>" % C]["matrix"] == {"v_mfma_i32_16x16x64_i8": ks * 5}
         import bench
         assert bench.lenet_mfma_work(C)["conv1_i8_kernel"]["executed"] == 196 * ks * 5 * 32768.0
-    assert k["gpd::conv2_bf16_kernel"]["matrix"] == {"v_mfma_f32_16x16x32_bf16": 16 * 6}  # k-steps x piece products per pixel tile and wave
+    assert k["gpd::conv2_bf16_kernel"]["matrix"] == {"v_mfma_f32_16x16x32_bf16": 16 * 6 + 8 * 6}  # k-steps x piece products per pixel tile and wave + the work unit of the wave that computes filters 48, 49 (2 conv rows x 4 k-steps)
+    assert bench.lenet_mfma_work(15)["conv2_bf16_kernel"]["executed"] == (3 * 36 * 16 * 6 + 24 * 8 * 6) * 16384.0
     for nt in (1, 2, 3, 4, 5):
         assert k["gpd::fc1_bf16_kernel<%d>" % nt]["matrix"] == {"v_mfma_f32_16x16x32_bf16": 3 * nt * 4 * 6}  # m-tiles x n-tiles x pieces per BK; the step's body stands three times (the loop runs over pairs of steps, one stage each, + the last step)
     # LDS budgets of DESIGN.md section 4

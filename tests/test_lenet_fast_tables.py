@@ -23,7 +23,7 @@ def _tables(channels, w):
     atab = np.zeros((7, 5, 64, 16), np.int8)
     corr = np.zeros(20, np.float64)
     shift = np.zeros(20, np.int32)
-    btab = np.zeros((2, 2, 3, 16, 64, 8), np.uint16)
+    btab = np.zeros((4, 3, 16, 64, 8), np.uint16)  # [slot][piece][k-step][lane][8]
     c1w = np.ascontiguousarray(w["c1w"], np.float32)
     c2w = np.ascontiguousarray(w["c2w"], np.float32)
     rc = L.gpd_hip_lenet_fast_tables(channels, c1w.ctypes.data, c2w.ctypes.data, atab.ctypes.data, corr.ctypes.data, shift.ctypes.data,
@@ -216,34 +216,64 @@ def test_conv2_tables_and_index_arithmetic():
     lane_off = m_row * RS + m_x * 40
     off_x, off_y = lane_off + 40 * q, lane_off + q * RS + 160
     off_z, off_w = lane_off + 4 * RS + 160 + 8 * q, lane_off + 4 * RS + 160 + 32 + 0 * q
-    flat = np.zeros((144, 50), np.float64)
+    flat = np.full((144, 50), np.nan, np.float64)
     terms = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]
-    for np_ in range(2):
-        for half in range(2):
-            for tt in range(18):
-                T = half * 18 + tt
-                rp, xt = divmod(T, 3)
-                base = (2 * rp) * RS + (8 * xt) * 40
-                acc = np.zeros((2, 64, 4))
-                for ks in range(16):
-                    frag = []
-                    for pc in range(3):
-                        halves = []
-                        for h in range(2):
-                            e = ks + 16 * h
-                            a = (base + off_x + (e // 5) * RS + (e % 5) * 8) if e < 25 else (base + off_y + (e - 25) * 8) if e < 30 else \
-                                (base + off_z) if e == 30 else (base + off_w)
-                            a = (a + pc * PP) // 2
-                            halves.append(np.stack([lds[x:x + 4] for x in a]))
-                        frag.append(_bf16_to_f32(np.concatenate(halves, 1)))
-                    for pa, pw in terms:
-                        for nt in range(2):
-                            acc[nt] += _mfma(frag[pa], _bf16_to_f32(btab[np_, nt, pw, ks]))  # pixels are the A operand, filters B
-                for nt in range(2):
-                    f = 32 * np_ + 16 * nt + j
-                    v = acc[nt].max(axis=1)
-                    ok = f < 50
-                    flat[(rp * 12 + 4 * xt + q)[ok], f[ok]] = v[ok]
+    # the seven waves of the full filter groups (round 6 roles: waves 0-3 group 1 + wave / 2, a half each; waves 4-6 group 0,
+    # a third each): every (group, tile) pair exactly once
+    roles = [(1 + (w >> 1), 18 * (w & 1), 18) for w in range(4)] + [(0, 12 * (w - 4), 12) for w in range(4, 7)]
+    seen = set()
+    for grp, t0, tcnt in roles:
+        for tt in range(tcnt):
+            T = t0 + tt
+            assert (grp, T) not in seen
+            seen.add((grp, T))
+            rp, xt = divmod(T, 3)
+            base = (2 * rp) * RS + (8 * xt) * 40
+            acc = np.zeros((64, 4))
+            for ks in range(16):
+                frag = []
+                for pc in range(3):
+                    halves = []
+                    for h in range(2):
+                        e = ks + 16 * h
+                        a = (base + off_x + (e // 5) * RS + (e % 5) * 8) if e < 25 else (base + off_y + (e - 25) * 8) if e < 30 else \
+                            (base + off_z) if e == 30 else (base + off_w)
+                        a = (a + pc * PP) // 2
+                        halves.append(np.stack([lds[x:x + 4] for x in a]))
+                    frag.append(_bf16_to_f32(np.concatenate(halves, 1)))
+                for pa, pw in terms:
+                    acc += _mfma(frag[pa], _bf16_to_f32(btab[grp, pw, ks]))  # pixels are the A operand, filters B
+            flat[rp * 12 + 4 * xt + q, 16 * grp + j] = acc.max(axis=1)
+    assert len(seen) == 3 * 36
+    # the eighth wave: filters 48 and 49 as (filter, kernel column) rows x 16 input columns of a conv row, the five shifted
+    # rows added across lanes — the lane arithmetic of conv2_bf16_kernel's second role
+    for unit in range(24):
+        yp, xh = unit >> 1, unit & 1
+        ubase = (2 * yp) * RS + (12 * xh) * 40
+        conv_row = []
+        for rr in range(2):
+            acc = np.zeros((64, 4))
+            for ks in range(4):
+                idx = np.minimum(4 * ks + q, 14)
+                ky, c8 = idx // 3, idx % 3
+                lo = ky * RS + j * 40 + c8 * 16
+                hi = np.where(c8 == 2, lo, lo + 8)
+                frag = []
+                for pc in range(3):
+                    a = ubase + rr * RS + pc * PP
+                    frag.append(_bf16_to_f32(np.concatenate([np.stack([lds[(a + x) // 2:(a + x) // 2 + 4] for x in lo]),
+                                                             np.stack([lds[(a + x) // 2:(a + x) // 2 + 4] for x in hi])], 1)))
+                for pa, pw in terms:
+                    acc += _mfma(_bf16_to_f32(btab[3, pw, ks]), frag[pa])  # weights are the A operand here
+            shl = lambda v, n: np.where((lanes & 15) + n < 16, v[np.minimum(lanes + n, 63)], 0.0)  # DPP row_shl:n, bound_ctrl
+            v = ((acc[:, 0] + shl(acc[:, 1], 1)) + shl(acc[:, 2], 2)) + shl(acc[:, 3], 3)
+            e4 = shl(acc[:, 0], 4)
+            conv_row.append(v + e4[(lanes + 32) & 63])  # lanes 0..31 <- lanes 32..63 (the upper lanes' sums are not used)
+        pv = np.maximum(conv_row[0], conv_row[1])
+        pv = np.maximum(pv, shl(pv, 1))
+        ok = (q < 2) & (j % 2 == 0) & (j < 12)
+        flat[(yp * 12 + 6 * xh + (j >> 1))[ok], (48 + (q & 1))[ok]] = pv[ok]
+    assert not np.isnan(flat).any()
     # reference: the same six piece products, summed in float64
     wp = [_bf16_to_f32(p).astype(np.float64) for p in _split3(c2w)]
     xp = [np.transpose(_bf16_to_f32(p).astype(np.float64), (2, 0, 1)) for p in pieces]
