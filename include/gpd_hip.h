@@ -388,10 +388,12 @@ int gpd_hip_replay_kernel_ms(gpd_hip_ctx *ctx, float ms[4]);
  * Measurement only: no reference counterpart. */
 int gpd_hip_conv1_stats(gpd_hip_ctx *ctx, unsigned long long pairs[2], int reset);
 /* test hook: intermediate tensors of the last gpd_hip_score pass (n images) — which = 0: pool1 f32 [n][15680] (layout of the
- * mode), 1: the three bf16 planes of the flattened pool2 [3][n][7200] (GPD_LENET_SPLIT), 2: ip1 after ReLU, transposed f32 [500][n] */
+ * mode), 1: the three bf16 planes of the flattened pool2 [3][n][7200] (GPD_LENET_SPLIT; un-blocked on the host), 2: ip1 after ReLU, transposed f32 [500][n]
+ * (GPD_LENET_SPLIT: the four K-quarter partial sums added on the host as ip2's kernel adds them) */
 int gpd_hip_lenet_debug(gpd_hip_ctx *ctx, int which, int n, void *out);
 /* test hook, host only: the operand tables of the split path's conv kernels as uploaded — atab: conv1's int8 digit
- * fragments [7][5][64][16], corr / shift [20], btab: conv2's bf16 fragments [2][2][3][16][64][8] */
+ * fragments [7][5][64][16], corr / shift [20], btab: conv2's bf16 fragments [4 slots][3][16][64][8] (slots 0-2: filters 16 slot + lane % 16; slot 3, k-steps 0-3: the
+ * (filter, kernel column) rows of filters 48 and 49) */
 int gpd_hip_lenet_fast_tables(int channels, const float *conv1_w, const float *conv2_w, uint8_t *atab, double *corr, int *shift,
                               unsigned short *btab);
 
