@@ -24,11 +24,12 @@ def test_executed_mfma_work_matches_the_kernels_constants():
     """bench.py prices the split path's kernels by the MFMA operations they execute: the tile / step counts it multiplies
     are the kernels' own constants."""
     src = open(os.path.join(ROOT, "gpd_amd", "csrc", "lenet_fast.hip")).read()
-    for needle in ("F1_TILES = 28 * 7", "F1_KS = 7, F1_MT = 5", "for (int tt = 0; tt < 18; tt++)", "for (int ks = 0; ks < 16; ks++)", "kLenetXld"):
+    for needle in ("F1_TILES = 28 * 7", "F1_KS = 7, F1_MT = 5", "tcnt = wave < 4 ? 18 : 12", "F2_LUNITS = 24", "for (int step = 0; step < 8; step++)", "for (int ks = 0; ks < 16; ks++)", "kLenetXld"):
         assert needle in src, needle
     w = bench.lenet_mfma_work(15)
     assert w["conv1_i8_kernel"]["executed"] == 196 * 7 * 5 * 16 * 16 * 64 * 2
-    assert w["conv2_bf16_kernel"]["executed"] == 2 * 18 * 4 * 16 * 6 * 16 * 16 * 32 * 2  # halves x tiles x column tiles x k-steps x pieces
+    # (round 6) waves 0-3: 18 pixel tiles, waves 4-6: 12, each x 16 k-steps x 6 piece products; wave 7: 24 units x 8 steps x 6
+    assert w["conv2_bf16_kernel"]["executed"] == ((4 * 18 + 3 * 12) * 16 * 6 + 24 * 8 * 6) * 16 * 16 * 32 * 2
     assert w["fc1_bf16_kernel"]["executed"] == 2.0 * 512 * 7296 * 6
     for v in w.values():
         assert 0.7 < v["algorithmic_split"] / v["executed"] <= 1.0
@@ -150,15 +151,15 @@ def test_float64_reference_of_the_score_leg_is_chunk_independent(lenet15_real, o
 
 def test_roofline_object_reproduces_the_committed_line():
     """lenet_kernel_entry / lenet_roofline (the functions bench.py's main builds `kernels` and `roofline` with) fed the launch
-    time of the committed round-5 line give that line's numbers, and the f32-equivalent block carries both peaks."""
-    line = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    time of the committed line of the final round-6 kernels give that line's numbers, and the f32-equivalent block carries both peaks."""
+    line = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")))
     rf, n = line["roofline"], line["config"]["candidates_per_gpu"]
     dom = rf["kernel"]
     work = bench.lenet_mfma_work(15)
     kd = bench.lenet_kernel_entry(rf["launch_ms"] / 1e3, work[dom]["algorithmic"], n, work[dom])
     for k in ("ms", "algorithmic_flops", "achieved_TFLOPs", "frac_f32", "executed_ops", "executed_Tops", "frac_pipe"):
         assert kd[k] == pytest.approx(line["kernels"][dom][k], rel=1e-12), k
-    got = bench.lenet_roofline(dom, kd, work[dom], None)
+    got = bench.lenet_roofline(dom, kd, work[dom], rf["traffic"])
     for k in ("kernel", "bound", "peak", "unit", "pipe", "traffic"):
         assert got[k] == rf[k], k
     for k in ("achieved", "frac", "ops_per_launch", "launch_ms", "algorithmic_flops_per_launch", "useful_share_of_executed"):

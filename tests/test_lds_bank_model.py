@@ -79,7 +79,8 @@ def test_conv2_activation_fragments():
 
 
 def test_ip1_fragments_and_the_swizzle():
-    assert "((g ^ ((4 - (j >> 2)) & 3)) << 4)" in SRC and "((lch ^ ((4 - (lrow >> 2)) & 3)) << 4)" in SRC
+    # the reader's swizzle, and (round 6: the tiles arrive by LDS-DMA from blocked operands) the same one where the blocks are built
+    assert "((g ^ ((4 - (j >> 2)) & 3)) << 4)" in SRC and "((((k >> 3) & 3) ^ ((4 - (rr >> 2)) & 3)) << 4)" in SRC
     for swz, want in ((True, 4), (False, 8)):
         addrs = []
         for l in range(64):
