@@ -68,3 +68,28 @@ def test_committed_listing_is_of_the_committed_sources(isa):
         mod.main()
     want = open(os.path.join(ROOT, "profiles", "r06_isa_stats.txt")).read()
     assert buf.getvalue() == want, "kernels changed: python profiles/isa_stats.py > profiles/r06_isa_stats.txt"
+
+
+def test_ip1_waits_for_its_lds_dma_before_every_barrier(isa):
+    """fc1_bf16_kernel fills its LDS stages by global_load_lds_dwordx4: the data of a wave's DMA is ordered for the other waves'
+    ds_reads only by that wave's vmcnt wait followed by the barrier.  The source relies on __syncthreads() emitting the wait
+    (an LDS-DMA is a pending LDS write on the VM counter); this holds the compiler to it — every s_barrier of the kernel has
+    an s_waitcnt vmcnt(0) right before it, and nothing stages through registers any more (no ds_write in the kernel)."""
+    import subprocess
+    import tempfile
+    mod, _ = isa
+    with tempfile.TemporaryDirectory() as tmp:
+        co = mod.code_object("lenet_fast", tmp)
+        dis = subprocess.run([mod.LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    body, on = [], False
+    for line in dis.splitlines():
+        if line[:1].isalnum() and line.rstrip().endswith(">:"):
+            on = "fc1_bf16_kernelILi5" in line
+            continue
+        if on and line.startswith("\t"):
+            body.append(line.split("//")[0].strip())
+    assert any(l.startswith("global_load_lds_dwordx4") for l in body) and not any(l.startswith("ds_write") for l in body)
+    barriers = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
+    assert len(barriers) >= 3
+    for i in barriers:
+        assert body[i - 1].startswith("s_waitcnt") and "vmcnt(0)" in body[i - 1], (i, body[i - 3:i + 1])
