@@ -382,11 +382,12 @@ __host__ __device__ inline Bf3 bf16_split3(float a) {
 //   v_mfma_f32_16x16x32_bf16: A (pixels): lane (pixel m = l & 15, k group g = l >> 4) holds 8 k = two 4-channel groups of
 //   8 bytes; B (weights): lane (filter l & 15, k group g); D: lane (filter l & 15), register r = pixel 4 (l >> 4) + r — a tile
 //   is 8 x 2 conv pixels = four pool windows, pixel m = 4 window + position, so the pool is a max over the lane's registers.
-// Eight waves per workgroup, two per SIMD: wave (nt, half) keeps the three bf16 planes of 16 filters (3 pieces x 16 k-steps
-// x 4 VGPRs = 192 registers) for the whole launch and walks the 18 pixel tiles of its half of the image; the activations of a
-// k-step (3 pieces x 2 reads of 8 bytes) feed 6 MFMAs on two alternating accumulators.  (Round 5's first version ran four
-// waves with 32 filters each in 512 registers, one per SIMD: every stall of the single wave idled the SIMD's matrix pipe,
-// MfmaUtil 63 %.)
+// Eight waves per workgroup, two per SIMD: a wave keeps the three bf16 planes of 16 filters (3 pieces x 16 k-steps x 4 VGPRs
+// = 192 registers) for the whole launch and walks pixel tiles of the image; the activations of a k-step (3 pieces x 2 reads of
+// 8 bytes) feed 6 MFMAs on two alternating accumulators.  Seven waves share the 3 x 36 tiles of filters 0..47, the eighth
+// computes filters 48 and 49 by another route (the roles: in the kernel; until round 6 every wave had 18 tiles of one of FOUR
+// column tiles, the fourth 14 / 16 zeros).  (Round 5's first version ran four waves with 32 filters each in 512 registers, one
+// per SIMD: every stall of the single wave idled the SIMD's matrix pipe, MfmaUtil 63 %.)
 // LDS: the image as bf16 pieces [row 28][piece 3][column 28][channel 20] (94 080 B) + the next image's raw f32 rows (62 720 B),
 // which arrive one 16-byte piece per thread and tile and are split between two barriers.
 // The 128 four-channel k-slots of the 16 k-steps hold the 125 (tap, channel group) pairs so that the two lane groups of a
