@@ -459,9 +459,9 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
     *reinterpret_cast<unsigned short *>(o + 1024) = sp.m;
     *reinterpret_cast<unsigned short *>(o + 2048) = sp.l;
   };
-  // the frame every role runs per image: `passes` loop passes (at least eight: each carries 16 bytes per thread of the next
-  // image's raw rows from global memory into the LDS), two barriers
-  auto image_loop = [&](int passes, auto &&work) {
+  // the frame every role runs per image: `passes` loop passes (the seven waves of the full groups: at least nine, each carries
+  // 16 bytes per thread of the next image's raw rows from global memory into the LDS), two barriers
+  auto image_loop = [&](int passes, auto carries, auto &&work) {  // carries: whether the role takes part in fetching the next image
     int img = img0;
     for (;;) {
       if (tid == 0) s_nxt = (int)gridDim.x + atomicAdd(queue, 1);
@@ -470,8 +470,10 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
       const uint4 *nsrc = reinterpret_cast<const uint4 *>(pool1 + (size_t)(nxt < n ? nxt : img) * (784 * 20));
 #pragma unroll 1
       for (int tt = 0; tt < passes; tt++) {
-        const int piece = tt * F2_THREADS + tid;
-        const bool has_piece = nxt < n && piece < F2_RAW / 16;
+        // (waves 0-6 carry the next image, 448 pieces a pass, nine passes; the eighth wave's passes are too short for a global
+        //  load to land in one: it waited for its pieces, and — gfx9 counts stores on vmcnt too — for its own stores)
+        const int piece = tt * (7 * 64) + tid;
+        const bool has_piece = decltype(carries)::value && nxt < n && piece < F2_RAW / 16;
         uint4 stage = make_uint4(0, 0, 0, 0);
         if (has_piece) stage = nsrc[piece];
         work(img, tt);
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
   // two (14 of its 16 columns zero: a quarter of the kernel's matrix instructions for 4 % of its filters).  Now seven waves
   // share the 3 x 36 pixel tiles of the three full groups and the eighth computes filters 48 and 49 by another route;
   // waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically), so every SIMD gets 2880 MFMAs per image:
-  //   waves 0-3: group 1 + wave / 2, half wave & 1 (18 tiles x 96);  waves 4-6: group 0, a third each (12 tiles x 96);
+  //   waves 0-3: group 1 + wave / 2, half wave & 1 (18 tiles x 96; group 2: 20 + 16);  waves 4-6: group 0, a third each (12 x 96);
   //   wave 7: the two filters (24 units x 48).  The two roles are two copies of the image loop, so that the eighth wave's
   //   registers are not those of a full group's weights.
   if (wave == 7) {
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
     auto shl = [](float v, auto n) {  // lane i of a row of 16 <- lane i + n (0 past the row's end)
       return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + decltype(n)::value, 0xf, 0xf, true));
     };
-    image_loop(F2_LUNITS, [&](int img, int tt) {
+    asm volatile("" ::"v"(k_bias));  // (its load is waited for HERE, not by a vmcnt(0) in every unit)
+    image_loop(F2_LUNITS, std::false_type(), [&](int img, int tt) {
       const uint8_t *ubase = unit_base(tt), *unext = unit_base(tt < F2_LUNITS - 1 ? tt + 1 : tt);
       if (tt == 0) {
 #pragma unroll
@@ -565,7 +568,10 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
     return;
   }
   const int grp = wave < 4 ? 1 + (wave >> 1) : 0;
-  const int t0 = wave < 4 ? 18 * (wave & 1) : 12 * (wave - 4), tcnt = wave < 4 ? 18 : 12;
+  // (group 2 is cut 20 : 16, not 18 : 18: the SIMD that hosts the eighth wave runs its 2880 MFMAs ~11 % slower than the others
+  //  — measured: without that wave's MFMAs, or with half its units, the kernel drops to the others' time — so its full-group
+  //  wave gets two tiles fewer; 19 : 17 and 21 : 15 measured worse)
+  const int t0 = wave == 3 ? 20 : wave < 4 ? 18 * (wave & 1) : 12 * (wave - 4), tcnt = wave == 2 ? 20 : wave == 3 ? 16 : wave < 4 ? 18 : 12;
   // the weight fragments of the wave's 16 filters: [piece][k-step]
   bf16x8 W[3][16];
 #pragma unroll
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(F2_THREADS) void conv2_bf16_kernel(const float *__r
   // the SIMD, running in step, leave the matrix pipe idle); the image's last tile asks for its own first step again, which is
   // what the next image's first tile needs: same addresses, other data — so the request is repeated behind the barriers
   bf16x8 a_buf[2][3];
-  image_loop(tcnt, [&](int img, int tt) {
+  image_loop(tcnt, std::true_type(), [&](int img, int tt) {
     if (tt == 0) {
 #pragma unroll
       for (int pc = 0; pc < 3; pc++) a_buf[0][pc] = frag(tile_base(0), 0, pc);

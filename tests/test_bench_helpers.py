@@ -24,11 +24,11 @@ def test_executed_mfma_work_matches_the_kernels_constants():
     """bench.py prices the split path's kernels by the MFMA operations they execute: the tile / step counts it multiplies
     are the kernels' own constants."""
     src = open(os.path.join(ROOT, "gpd_amd", "csrc", "lenet_fast.hip")).read()
-    for needle in ("F1_TILES = 28 * 7", "F1_KS = 7, F1_MT = 5", "tcnt = wave < 4 ? 18 : 12", "F2_LUNITS = 24", "for (int step = 0; step < 8; step++)", "for (int ks = 0; ks < 16; ks++)", "kLenetXld"):
+    for needle in ("F1_TILES = 28 * 7", "F1_KS = 7, F1_MT = 5", "wave < 4 ? 18 : 12;", "F2_LUNITS = 24", "for (int step = 0; step < 8; step++)", "for (int ks = 0; ks < 16; ks++)", "kLenetXld"):
         assert needle in src, needle
     w = bench.lenet_mfma_work(15)
     assert w["conv1_i8_kernel"]["executed"] == 196 * 7 * 5 * 16 * 16 * 64 * 2
-    # (round 6) waves 0-3: 18 pixel tiles, waves 4-6: 12, each x 16 k-steps x 6 piece products; wave 7: 24 units x 8 steps x 6
+    # (round 6) waves 0-3: 18 pixel tiles (group 2: 20 + 16), waves 4-6: 12, each x 16 k-steps x 6 piece products; wave 7: 24 units x 8 steps x 6
     assert w["conv2_bf16_kernel"]["executed"] == ((4 * 18 + 3 * 12) * 16 * 6 + 24 * 8 * 6) * 16 * 16 * 32 * 2
     assert w["fc1_bf16_kernel"]["executed"] == 2.0 * 512 * 7296 * 6
     for v in w.values():

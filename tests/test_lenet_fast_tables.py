@@ -218,9 +218,9 @@ def test_conv2_tables_and_index_arithmetic():
     off_z, off_w = lane_off + 4 * RS + 160 + 8 * q, lane_off + 4 * RS + 160 + 32 + 0 * q
     flat = np.full((144, 50), np.nan, np.float64)
     terms = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]
-    # the seven waves of the full filter groups (round 6 roles: waves 0-3 group 1 + wave / 2, a half each; waves 4-6 group 0,
-    # a third each): every (group, tile) pair exactly once
-    roles = [(1 + (w >> 1), 18 * (w & 1), 18) for w in range(4)] + [(0, 12 * (w - 4), 12) for w in range(4, 7)]
+    # the seven waves of the full filter groups (round 6 roles: waves 0-3 group 1 + wave / 2, a half each — group 2 cut 20 : 16 —;
+    # waves 4-6 group 0, a third each): every (group, tile) pair exactly once
+    roles = [(1, 0, 18), (1, 18, 18), (2, 0, 20), (2, 20, 16)] + [(0, 12 * (w - 4), 12) for w in range(4, 7)]
     seen = set()
     for grp, t0, tcnt in roles:
         for tt in range(tcnt):
